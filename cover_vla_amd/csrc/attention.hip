@@ -1,0 +1,252 @@
+// Flash-style attention for gfx950, one wave per 16 query rows, no LDS in the main loop.
+//
+// Both products run on v_mfma_f32_16x16x32_bf16 with SWAPPED operands so that the query index is lane&15 in
+// every accumulator (softmax row state is per lane, replicated over the 4 lane groups):
+//   S^T[key][q] = K-fragment (rows = keys, contraction over d)  x  Q-fragment
+//   O^T[d][q]   = V^T-fragment (rows = d, contraction over keys) x  P-fragment
+// The key order inside a 32-key tile is permuted (key_of(X,i) = t0 + 8*(i>>2) + 4*X + (i&3)) so that the eight
+// probabilities a lane holds after QK^T are exactly the eight contraction elements the PV MFMA expects from
+// that lane: P never leaves registers, no shuffles, no LDS. V is read from a TRANSPOSED cache [d][t] so its
+// operand is one 16-byte load per lane as well.
+//
+// Masks come from lengths (COVER_MASK_LEN / CAUSAL / VISLEN), never from a materialised [T,T] tensor
+// (make_att_2d_masks, modeling_pi0.py:98-128). Masked keys get probability exactly 0, as in the reference
+// where exp(-2.38e38 - max) underflows to 0 (paligemma_with_expert.py:418-423).
+//
+// Query rows of a tile enumerate (token, q-head-within-kv-group) pairs so that GQA/MQA heads sharing one
+// kv head share K/V loads (pi0: 8 q heads x 1 kv head; decode: 5 suffix tokens x 8 heads = 40 rows = 3 waves).
+// KSPLIT mode (few query rows, e.g. single-token decode): the 4 waves of a block split the key tiles and merge
+// their (m, l, O) partial states through LDS.
+#include "common.h"
+#include "kernels.h"
+
+struct SegDev {
+    const bf16_t* k;
+    const bf16_t* vt;
+    long long k_slot, k_t, k_h, vt_slot, vt_h, vt_d;
+    const int* slot_of_batch;
+    const int* len_of_batch;
+    const int* vis_len;
+    int len, mode, causal_off;
+};
+struct AttnDev {
+    const bf16_t* q;
+    bf16_t* out;
+    long long q_b, q_t, q_h, o_b, o_t, o_h;
+    int B, Tq, Hq, Hkv, G, R;
+    float scale_log2e;
+    int n_seg;
+    SegDev seg[3];
+};
+
+template <int D, bool KSPLIT>
+__global__ __launch_bounds__(256) void attn_kernel(AttnDev a) {
+    constexpr int KS = D / 32;  // k-steps of QK^T
+    constexpr int DB = D / 16;  // 16-row d blocks of O^T
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nw = blockDim.x >> 6;
+    const int b = blockIdx.z, kvh = blockIdx.y;
+    const int tile = KSPLIT ? blockIdx.x : blockIdx.x * nw + w;
+    const int r = lane & 15, g = lane >> 4;
+
+    const int qi = tile * 16 + r;
+    const bool q_ok = qi < a.R;
+    const int qc = q_ok ? qi : 0;
+    const int t = qc / a.G, gh = qc - t * a.G;
+    const int h = kvh * a.G + gh;
+    if (!KSPLIT && tile * 16 >= a.R) return;  // whole wave idle (no barriers in this mode)
+
+    // Q fragments
+    bf16x8 qf[KS];
+    {
+        const bf16_t* qp = a.q + (long long)b * a.q_b + (long long)t * a.q_t + (long long)h * a.q_h + g * 8;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) qf[ks] = as_bf16x8(*(const uint4*)(qp + ks * 32));
+    }
+
+    float m_run = -INFINITY, l_run = 0.f;
+    f32x4 oacc[DB];
+#pragma unroll
+    for (int db = 0; db < DB; ++db) oacc[db] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // largest token index in this tile (wave-uniform) for causal early exit
+    int t_hi = (tile * 16 + 15) / a.G;
+    t_hi = t_hi < a.Tq ? t_hi : a.Tq - 1;
+
+    int tile_counter = 0;
+    for (int si = 0; si < a.n_seg; ++si) {
+        const SegDev& sg = a.seg[si];
+        const int slot = sg.slot_of_batch ? sg.slot_of_batch[b] : b;
+        const int len = sg.len_of_batch ? sg.len_of_batch[b] : sg.len;
+        int kend = len;
+        if (sg.mode == COVER_MASK_CAUSAL) kend = min(kend, t_hi + sg.causal_off + 1);
+        int vis = len;  // per-lane visible key bound (exclusive)
+        if (sg.mode == COVER_MASK_CAUSAL) vis = min(len, t + sg.causal_off + 1);
+        else if (sg.mode == COVER_MASK_VISLEN) vis = min(len, sg.vis_len[t]);
+        const bf16_t* kb = sg.k + (long long)slot * sg.k_slot + (long long)kvh * sg.k_h + g * 8;
+        const bf16_t* vb = sg.vt + (long long)slot * sg.vt_slot + (long long)kvh * sg.vt_h + (long long)r * sg.vt_d + g * 8;
+
+        for (int t0 = 0; t0 < kend; t0 += 32, ++tile_counter) {
+            if (KSPLIT && (tile_counter & (nw - 1)) != w) continue;
+            // ---- S^T = K . Q^T for two 16-key blocks ----
+            f32x4 s0 = (f32x4){0.f, 0.f, 0.f, 0.f}, s1 = s0;
+            {
+                int key0 = t0 + 8 * (r >> 2) + (r & 3);
+                int key1 = key0 + 4;
+                key0 = key0 < len ? key0 : len - 1;
+                key1 = key1 < len ? key1 : len - 1;
+                const bf16_t* k0p = kb + (long long)key0 * sg.k_t;
+                const bf16_t* k1p = kb + (long long)key1 * sg.k_t;
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const bf16x8 kf0 = as_bf16x8(*(const uint4*)(k0p + ks * 32));
+                    const bf16x8 kf1 = as_bf16x8(*(const uint4*)(k1p + ks * 32));
+                    s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf0, qf[ks], s0, 0, 0, 0);
+                    s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf1, qf[ks], s1, 0, 0, 0);
+                }
+            }
+            // lane (q = r, g) holds keys t0 + 8g + e, e = 0..7 (s0 -> e 0..3, s1 -> e 4..7)
+            float sc[8];
+            float tmax = -INFINITY;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float v = (e < 4 ? s0[e] : s1[e - 4]) * a.scale_log2e;
+                const int key = t0 + 8 * g + e;
+                sc[e] = (key < vis) ? v : -INFINITY;
+                tmax = fmaxf(tmax, sc[e]);
+            }
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 16));
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+            const float m_new = fmaxf(m_run, tmax);
+            float alpha = 1.f, psum = 0.f;
+            float p[8];
+            if (m_new == -INFINITY) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) p[e] = 0.f;
+            } else {
+                alpha = exp2f(m_run - m_new);  // m_run = -inf -> 0
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    p[e] = exp2f(sc[e] - m_new);  // masked -> exp2(-inf) = 0
+                    psum += p[e];
+                }
+            }
+            psum += __shfl_xor(psum, 16);
+            psum += __shfl_xor(psum, 32);
+            l_run = l_run * alpha + psum;
+            m_run = m_new;
+            uint4 pp;
+            pp.x = pack_bf2(p[0], p[1]);
+            pp.y = pack_bf2(p[2], p[3]);
+            pp.z = pack_bf2(p[4], p[5]);
+            pp.w = pack_bf2(p[6], p[7]);
+            const bf16x8 pf = as_bf16x8(pp);
+            // ---- O^T += V^T . P ----
+            const bf16_t* vp = vb + t0;
+#pragma unroll
+            for (int db = 0; db < DB; ++db) {
+                const bf16x8 vf = as_bf16x8(*(const uint4*)(vp + (long long)(db * 16) * sg.vt_d));
+                f32x4 o = oacc[db];
+                o[0] *= alpha; o[1] *= alpha; o[2] *= alpha; o[3] *= alpha;
+                oacc[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, o, 0, 0, 0);
+            }
+        }
+    }
+
+    if (KSPLIT) {
+        // merge the nw partial states: LDS layout per wave: [DB*4 floats per lane][64 lanes] + m[16] + l[16]
+        float* so = (float*)smem;
+        constexpr int OW = DB * 4 * 64;
+        float* sm = so + 4 * OW;
+        float* sl = sm + 4 * 16;
+#pragma unroll
+        for (int db = 0; db < DB; ++db)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) so[w * OW + (db * 4 + e) * 64 + lane] = oacc[db][e];
+        if (g == 0) {
+            sm[w * 16 + r] = m_run;
+            sl[w * 16 + r] = l_run;
+        }
+        __syncthreads();
+        if (w != 0) return;
+        float mx = -INFINITY;
+        for (int i = 0; i < nw; ++i) mx = fmaxf(mx, sm[i * 16 + r]);
+        float lt = 0.f;
+        float f[4];
+        for (int i = 0; i < nw; ++i) {
+            const float mi = sm[i * 16 + r];
+            f[i] = (mi == -INFINITY) ? 0.f : exp2f(mi - mx);
+            lt += sl[i * 16 + r] * f[i];
+        }
+#pragma unroll
+        for (int db = 0; db < DB; ++db)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float acc = 0.f;
+                for (int i = 0; i < nw; ++i) acc += so[i * OW + (db * 4 + e) * 64 + lane] * f[i];
+                oacc[db][e] = acc;
+            }
+        l_run = lt;
+    }
+
+    if (!q_ok) return;
+    const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
+    bf16_t* op = a.out + (long long)b * a.o_b + (long long)t * a.o_t + (long long)h * a.o_h + 4 * g;
+#pragma unroll
+    for (int db = 0; db < DB; ++db) {
+        uint2 v;
+        v.x = pack_bf2(oacc[db][0] * inv, oacc[db][1] * inv);
+        v.y = pack_bf2(oacc[db][2] * inv, oacc[db][3] * inv);
+        *(uint2*)(op + db * 16) = v;
+    }
+}
+
+template <int D>
+static hipError_t launch_d(const AttnDev& a, hipStream_t st) {
+    const int tiles = (a.R + 15) / 16;
+    if (tiles <= 2) {
+        // few query rows: split keys over 4 waves
+        const size_t lds = (size_t)(4 * (D / 16) * 4 * 64 + 2 * 4 * 16) * sizeof(float);
+        dim3 grid(tiles, a.Hkv, a.B), block(256);
+        hipLaunchKernelGGL((attn_kernel<D, true>), grid, block, lds, st, a);
+    } else {
+        const int nw = tiles >= 4 ? 4 : tiles;
+        dim3 grid((tiles + nw - 1) / nw, a.Hkv, a.B), block(64 * nw);
+        hipLaunchKernelGGL((attn_kernel<D, false>), grid, block, 0, st, a);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_attention_bf16(const cover_attn_args* x, hipStream_t st) {
+    if (x->n_seg < 1 || x->n_seg > 3 || x->Hq % x->Hkv != 0) return hipErrorInvalidValue;
+    AttnDev a;
+    a.q = (const bf16_t*)x->q;
+    a.out = (bf16_t*)x->out;
+    a.q_b = x->q_b_stride; a.q_t = x->q_t_stride; a.q_h = x->q_h_stride;
+    a.o_b = x->o_b_stride; a.o_t = x->o_t_stride; a.o_h = x->o_h_stride;
+    a.B = x->B; a.Tq = x->Tq; a.Hq = x->Hq; a.Hkv = x->Hkv;
+    a.G = x->Hq / x->Hkv;
+    a.R = x->Tq * a.G;
+    a.scale_log2e = x->scale * 1.4426950408889634f;
+    a.n_seg = x->n_seg;
+    for (int i = 0; i < x->n_seg; ++i) {
+        const cover_kv_segment& s = x->seg[i];
+        SegDev& d = a.seg[i];
+        d.k = (const bf16_t*)s.k; d.vt = (const bf16_t*)s.vt;
+        d.k_slot = s.k_slot_stride; d.k_t = s.k_t_stride; d.k_h = s.k_h_stride;
+        d.vt_slot = s.vt_slot_stride; d.vt_h = s.vt_h_stride; d.vt_d = s.vt_d_stride;
+        d.slot_of_batch = s.slot_of_batch; d.len_of_batch = s.len_of_batch; d.vis_len = s.vis_len;
+        d.len = s.len; d.mode = s.mask_mode; d.causal_off = s.causal_offset;
+        if (d.mode == COVER_MASK_VISLEN && d.vis_len == nullptr) return hipErrorInvalidValue;
+    }
+    if (a.B <= 0 || a.R <= 0) return hipSuccess;
+    switch (x->D) {
+        case 64: return launch_d<64>(a, st);
+        case 96: return launch_d<96>(a, st);
+        case 128: return launch_d<128>(a, st);
+        case 256: return launch_d<256>(a, st);
+        default: return hipErrorInvalidValue;
+    }
+}

@@ -1,0 +1,454 @@
+// extern "C" surface of libcover_hip (include/cover_hip.h) + the composite tower / decoder forwards.
+// Host code only; kernels live in the sibling .hip files.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <string.h>
+#include <string>
+#include "kernels.h"
+
+static thread_local std::string g_err;
+static int fail(int code, const char* what, hipError_t e = hipSuccess) {
+    char buf[512];
+    if (e != hipSuccess) snprintf(buf, sizeof buf, "%s: %s", what, hipGetErrorString(e));
+    else snprintf(buf, sizeof buf, "%s", what);
+    g_err = buf;
+    return code;
+}
+#define HIPCHK(call, what)                                  \
+    do {                                                    \
+        hipError_t _e = (call);                             \
+        if (_e != hipSuccess) return fail(_e == hipErrorInvalidValue ? COVER_EINVAL : COVER_EHIP, what, _e); \
+    } while (0)
+#define ST(s) ((hipStream_t)(s))
+
+extern "C" {
+
+int cover_abi_version(void) { return COVER_ABI_VERSION; }
+const char* cover_last_error(void) { return g_err.c_str(); }
+
+int cover_device_info(int dev, int* n_cu, size_t* total_mem, char* name, int name_len) {
+    hipDeviceProp_t p;
+    HIPCHK(hipGetDeviceProperties(&p, dev), "hipGetDeviceProperties");
+    if (n_cu) *n_cu = p.multiProcessorCount;
+    if (total_mem) *total_mem = p.totalGlobalMem;
+    if (name && name_len > 0) {
+        strncpy(name, p.gcnArchName, name_len - 1);
+        name[name_len - 1] = 0;
+    }
+    return COVER_OK;
+}
+
+int cover_packed_k(int K) { return (K + 127) / 128 * 128; }
+size_t cover_packed_weight_bytes(int N, int K) {
+    return (size_t)((N + 15) / 16) * 16 * (size_t)cover_packed_k(K) * 2;
+}
+int cover_pack_weight_bf16(const void* W, int ldw, int N, int K, void* Wp, int glu, void* stream) {
+    if (!W || !Wp || N <= 0 || K <= 0) return fail(COVER_EINVAL, "cover_pack_weight_bf16: bad arguments");
+    if (glu && ((N / 2) % 16 != 0 || (N & 1))) return fail(COVER_EINVAL, "cover_pack_weight_bf16: glu needs N/2 % 16 == 0");
+    HIPCHK(launch_pack_weight_bf16((const bf16_t*)W, ldw, N, K, (bf16_t*)Wp, cover_packed_k(K), glu, ST(stream)),
+           "pack_weight");
+    return COVER_OK;
+}
+size_t cover_gemm_workspace_bytes(int M, int N, int K) { return gemm_workspace_bytes(M, N, K); }
+int cover_gemm_bf16(const void* A, int lda, const void* Wp, void* C, int ldc, int M, int N, int K,
+                    const cover_gemm_epi* epi, void* ws, size_t ws_bytes, int variant, void* stream) {
+    if (!A || !Wp || !C) return fail(COVER_EINVAL, "cover_gemm_bf16: null pointer");
+    if (lda % 8) return fail(COVER_EINVAL, "cover_gemm_bf16: lda must be a multiple of 8 elements");
+    if (lda < cover_packed_k(K)) return fail(COVER_EINVAL, "cover_gemm_bf16: lda < padded K");
+    if (epi && epi->glu && (N % 32)) return fail(COVER_EINVAL, "cover_gemm_bf16: glu needs N % 32 == 0");
+    HIPCHK(launch_gemm_bf16((const bf16_t*)A, lda, (const bf16_t*)Wp, C, ldc, M, N, K, epi, (float*)ws, ws_bytes, variant,
+                            ST(stream)),
+           "gemm_bf16");
+    return COVER_OK;
+}
+
+int cover_attention_bf16(const cover_attn_args* a, void* stream) {
+    if (!a) return fail(COVER_EINVAL, "cover_attention_bf16: null args");
+    HIPCHK(launch_attention_bf16(a, ST(stream)), "attention_bf16 (D must be 64/96/128/256, 1..3 segments)");
+    return COVER_OK;
+}
+
+int cover_layernorm_bf16(const void* x, int ldx, const float* w, const float* b, void* y, int ldy, int rows, int dim,
+                         float eps, void* stream) {
+    HIPCHK(launch_layernorm_bf16((const bf16_t*)x, ldx, w, b, (bf16_t*)y, ldy, rows, dim, eps, ST(stream)), "layernorm_bf16");
+    return COVER_OK;
+}
+int cover_rmsnorm_bf16(const void* x, int x_f32, int ldx, const float* w, float w_offset, int style, void* y, int ldy,
+                       int rows, int dim, float eps, void* stream) {
+    HIPCHK(launch_rmsnorm(x, x_f32, ldx, w, w_offset, style, (bf16_t*)y, ldy, rows, dim, eps, ST(stream)), "rmsnorm_bf16");
+    return COVER_OK;
+}
+int cover_rope_kv_write(const cover_rope_args* a, void* stream) {
+    if (!a) return fail(COVER_EINVAL, "cover_rope_kv_write: null args");
+    HIPCHK(launch_rope_kv_write(a, ST(stream)), "rope_kv_write");
+    return COVER_OK;
+}
+int cover_embed_gather(const void* table, int dim, const int64_t* ids, int n, float scale, void* out, int ldo,
+                       void* stream) {
+    HIPCHK(launch_embed_gather((const bf16_t*)table, dim, ids, n, scale, (bf16_t*)out, ldo, ST(stream)), "embed_gather");
+    return COVER_OK;
+}
+int cover_patchify(const cover_patchify_args* a, void* stream) {
+    if (!a || a->patch <= 0 || a->H % a->patch || a->W % a->patch || a->ld_out < 3 * a->patch * a->patch)
+        return fail(COVER_EINVAL, "cover_patchify: bad geometry");
+    HIPCHK(launch_patchify(a, ST(stream)), "patchify");
+    return COVER_OK;
+}
+int cover_copy_rows_bf16(const void* src, int ld_src, void* dst, int ld_dst, int rows, int cols, const int* sidx,
+                         const int* didx, void* stream) {
+    HIPCHK(launch_copy_rows_bf16((const bf16_t*)src, ld_src, (bf16_t*)dst, ld_dst, rows, cols, sidx, didx, ST(stream)),
+           "copy_rows");
+    return COVER_OK;
+}
+int cover_add_rows_bf16(void* x, int ldx, const void* add, int ld_add, int rows, int cols, int add_rows, void* stream) {
+    if (add_rows <= 0) return fail(COVER_EINVAL, "cover_add_rows_bf16: add_rows <= 0");
+    HIPCHK(launch_add_bias_rows_bf16((bf16_t*)x, ldx, (const bf16_t*)add, ld_add, rows, cols, add_rows, ST(stream)), "add_rows");
+    return COVER_OK;
+}
+int cover_scale_bf16(void* x, int ldx, int rows, int cols, float pre_div, float post_mul, void* stream) {
+    HIPCHK(launch_scale_bf16((bf16_t*)x, ldx, rows, cols, pre_div, post_mul, ST(stream)), "scale_bf16");
+    return COVER_OK;
+}
+int cover_cast_f32_to_bf16(const float* x, int ldx, void* y, int ldy, int rows, int cols, void* stream) {
+    HIPCHK(launch_cast_f32_to_bf16(x, ldx, (bf16_t*)y, ldy, rows, cols, ST(stream)), "cast_f32_to_bf16");
+    return COVER_OK;
+}
+int cover_cast_bf16_to_f32(const void* x, int ldx, float* y, int ldy, int rows, int cols, void* stream) {
+    HIPCHK(launch_cast_bf16_to_f32((const bf16_t*)x, ldx, y, ldy, rows, cols, ST(stream)), "cast_bf16_to_f32");
+    return COVER_OK;
+}
+
+int cover_gemm_f32(const cover_gemm_f32_args* a, void* stream) {
+    if (!a || !a->A || !a->B || !a->C) return fail(COVER_EINVAL, "cover_gemm_f32: null pointer");
+    HIPCHK(launch_gemm_f32(a, ST(stream)), "gemm_f32");
+    return COVER_OK;
+}
+int cover_layernorm_f32(const float* x, int ldx, const float* w, const float* b, float* y, int ldy, int rows, int dim,
+                        float eps, void* stream) {
+    HIPCHK(launch_layernorm_f32(x, ldx, w, b, y, ldy, rows, dim, eps, ST(stream)), "layernorm_f32");
+    return COVER_OK;
+}
+int cover_softmax_rows_f32(float* x, int ldx, int rows, int cols, float scale, void* stream) {
+    HIPCHK(launch_softmax_rows_f32(x, ldx, rows, cols, scale, ST(stream)), "softmax_rows_f32");
+    return COVER_OK;
+}
+int cover_l2norm_rows_f32(const float* x, int ldx, float* y, int ldy, int rows, int cols, void* stream) {
+    HIPCHK(launch_l2norm_rows_f32(x, ldx, y, ldy, rows, cols, ST(stream)), "l2norm_rows_f32");
+    return COVER_OK;
+}
+int cover_add_f32(const float* a, int lda, const float* b, int ldb, float* y, int ldy, int rows, int cols, int b_rows,
+                  void* stream) {
+    if (b_rows <= 0) return fail(COVER_EINVAL, "cover_add_f32: b_rows <= 0");
+    HIPCHK(launch_add_f32(a, lda, b, ldb, y, ldy, rows, cols, b_rows, ST(stream)), "add_f32");
+    return COVER_OK;
+}
+int cover_mha_f32(const cover_mha_f32_args* a, void* stream) {
+    if (!a) return fail(COVER_EINVAL, "cover_mha_f32: null args");
+    HIPCHK(launch_mha_f32(a, ST(stream)), "mha_f32 (Tq*Tk <= 8192)");
+    return COVER_OK;
+}
+int cover_masked_mean_f32(const float* x, const uint8_t* pad, float* y, int B, int T, int D, void* stream) {
+    HIPCHK(launch_masked_mean_f32(x, pad, y, B, T, D, ST(stream)), "masked_mean_f32");
+    return COVER_OK;
+}
+int cover_sincos_time_embed(const float* time, int B, int dim, double min_period, double max_period, void* out, int ldo,
+                            void* stream) {
+    if (dim % 2) return fail(COVER_EINVAL, "cover_sincos_time_embed: dimension must be divisible by 2");
+    HIPCHK(launch_sincos_time_embed(time, B, dim, min_period, max_period, (bf16_t*)out, ldo, ST(stream)), "sincos_time_embed");
+    return COVER_OK;
+}
+
+int cover_token_select(const cover_token_select_args* a, void* stream) {
+    if (!a) return fail(COVER_EINVAL, "cover_token_select: null args");
+    HIPCHK(launch_token_select(a, ST(stream)), "token_select (sampling width <= 4096, temperature > 0)");
+    return COVER_OK;
+}
+int cover_score_select(const cover_score_select_args* a, void* stream) {
+    if (!a) return fail(COVER_EINVAL, "cover_score_select: null args");
+    HIPCHK(launch_score_select(a, ST(stream)), "score_select (N % group_size == 0, fused_*_out required)");
+    return COVER_OK;
+}
+int cover_group_argmax(const float* scores, int N, int group_size, int* result_out, float* best_out, void* stream) {
+    HIPCHK(launch_group_argmax(scores, N, group_size, result_out, best_out, ST(stream)), "group_argmax");
+    return COVER_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// composite forwards
+// ---------------------------------------------------------------------------------------------------
+static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+struct Carver {
+    char* base;
+    size_t cap, off;
+    void* take(size_t bytes) {
+        off = align_up(off, 256);
+        void* p = base ? base + off : nullptr;
+        off += bytes;
+        return p;
+    }
+};
+
+static size_t vit_ws(const cover_vit_desc* d, int n_seq, int T, Carver* c, void** h, void** qkv, void** attn, void** mlp,
+                     void** vt, void** sk, size_t* sk_bytes, int* tcap) {
+    const size_t R = (size_t)n_seq * T;
+    const int HD = d->heads * d->head_dim_p;
+    *tcap = (T + 31) / 32 * 32;
+    Carver tmp{nullptr, 0, 0};
+    Carver& cc = c ? *c : tmp;
+    void* p;
+    p = cc.take(R * d->dim * 2); if (h) *h = p;
+    p = cc.take(R * 3 * HD * 2); if (qkv) *qkv = p;
+    p = cc.take(R * HD * 2); if (attn) *attn = p;
+    p = cc.take(R * d->mlp_p * 2); if (mlp) *mlp = p;
+    p = cc.take((size_t)n_seq * HD * (*tcap) * 2); if (vt) *vt = p;
+    size_t skb = 0;
+    if (R <= 64) {
+        const int ns[4] = {3 * HD, d->dim, d->mlp_p, d->dim};
+        const int ks[4] = {d->dim, HD, d->dim, d->mlp_p};
+        for (int i = 0; i < 4; ++i) {
+            size_t b = gemm_workspace_bytes((int)R, ns[i], ks[i]);
+            skb = b > skb ? b : skb;
+        }
+    }
+    p = cc.take(skb); if (sk) *sk = p;
+    if (sk_bytes) *sk_bytes = skb;
+    return cc.off + 256;
+}
+size_t cover_vit_workspace_bytes(const cover_vit_desc* d, int n_seq, int T) {
+    int tcap;
+    return vit_ws(d, n_seq, T, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, &tcap);
+}
+
+int cover_vit_forward(const cover_vit_desc* d, void* x, int n_seq, int T, void* attn_out, cover_workspace ws, int variant,
+                      void* stream) {
+    if (!d || !x || !d->layers_host) return fail(COVER_EINVAL, "cover_vit_forward: null pointer");
+    if (d->last_attn_only && !attn_out) return fail(COVER_EINVAL, "cover_vit_forward: last_attn_only needs attn_out");
+    hipStream_t st = ST(stream);
+    Carver c{(char*)ws.ptr, ws.bytes, 0};
+    void *h, *qkv, *attn, *mlp, *vt, *sk;
+    size_t skb;
+    int tcap;
+    const size_t need = vit_ws(d, n_seq, T, &c, &h, &qkv, &attn, &mlp, &vt, &sk, &skb, &tcap);
+    if (!ws.ptr || ws.bytes < need) return fail(COVER_EWORKSPACE, "cover_vit_forward: workspace too small");
+    const int R = n_seq * T, dim = d->dim, H = d->heads, Dp = d->head_dim_p, HD = H * Dp;
+    // the transposed-V scratch must be finite where keys >= T are read under a zero probability
+    if (tcap != T) HIPCHK(hipMemsetAsync(vt, 0, (size_t)n_seq * HD * tcap * 2, st), "memset vt");
+
+    for (int l = 0; l < d->n_layers; ++l) {
+        const cover_vit_layer& L = d->layers_host[l];
+        HIPCHK(launch_layernorm_bf16((const bf16_t*)x, dim, L.ln1_w, L.ln1_b, (bf16_t*)h, dim, R, dim, d->ln_eps, st), "vit ln1");
+        cover_gemm_epi e;
+        memset(&e, 0, sizeof e);
+        e.out_scale = 1.0f;
+        e.bias = L.qkv_b;
+        HIPCHK(launch_gemm_bf16((const bf16_t*)h, dim, (const bf16_t*)L.qkv_w, qkv, 3 * HD, R, 3 * HD, dim, &e, (float*)sk, skb, variant, st), "vit qkv");
+        cover_rope_args ra;
+        memset(&ra, 0, sizeof ra);
+        ra.qkv = qkv; ra.ld_qkv = 3 * HD; ra.B = n_seq; ra.T = T; ra.Hq = H; ra.Hkv = H; ra.D = Dp; ra.rope_mode = 0;
+        ra.vt_cache = vt; ra.vt_slot_stride = (long long)HD * tcap; ra.vt_h_stride = (long long)Dp * tcap; ra.vt_d_stride = tcap;
+        HIPCHK(launch_rope_kv_write(&ra, st), "vit v-transpose");
+        cover_attn_args aa;
+        memset(&aa, 0, sizeof aa);
+        aa.q = qkv; aa.q_b_stride = (long long)T * 3 * HD; aa.q_t_stride = 3 * HD; aa.q_h_stride = Dp;
+        aa.out = attn; aa.o_b_stride = (long long)T * HD; aa.o_t_stride = HD; aa.o_h_stride = Dp;
+        aa.B = n_seq; aa.Tq = T; aa.Hq = H; aa.Hkv = H; aa.D = Dp; aa.scale = d->attn_scale; aa.n_seg = 1;
+        aa.seg[0].k = (const bf16_t*)qkv + HD; aa.seg[0].k_slot_stride = (long long)T * 3 * HD; aa.seg[0].k_t_stride = 3 * HD; aa.seg[0].k_h_stride = Dp;
+        aa.seg[0].vt = vt; aa.seg[0].vt_slot_stride = (long long)HD * tcap; aa.seg[0].vt_h_stride = (long long)Dp * tcap; aa.seg[0].vt_d_stride = tcap;
+        aa.seg[0].len = T; aa.seg[0].mask_mode = COVER_MASK_LEN;
+        HIPCHK(launch_attention_bf16(&aa, st), "vit attention");
+        const bool last_attn = d->last_attn_only && l == d->n_layers - 1;
+        memset(&e, 0, sizeof e);
+        e.out_scale = 1.0f;
+        e.bias = L.proj_b;
+        if (last_attn) {
+            HIPCHK(launch_gemm_bf16((const bf16_t*)attn, HD, (const bf16_t*)L.proj_w, attn_out, dim, R, dim, HD, &e, (float*)sk, skb, variant, st), "vit proj (tap)");
+            break;
+        }
+        e.residual = x; e.ld_residual = dim; e.layer_scale = L.ls1;
+        HIPCHK(launch_gemm_bf16((const bf16_t*)attn, HD, (const bf16_t*)L.proj_w, x, dim, R, dim, HD, &e, (float*)sk, skb, variant, st), "vit proj");
+        HIPCHK(launch_layernorm_bf16((const bf16_t*)x, dim, L.ln2_w, L.ln2_b, (bf16_t*)h, dim, R, dim, d->ln_eps, st), "vit ln2");
+        memset(&e, 0, sizeof e);
+        e.out_scale = 1.0f;
+        e.bias = L.fc1_b; e.act = d->act;
+        HIPCHK(launch_gemm_bf16((const bf16_t*)h, dim, (const bf16_t*)L.fc1_w, mlp, d->mlp_p, R, d->mlp_p, dim, &e, (float*)sk, skb, variant, st), "vit fc1");
+        memset(&e, 0, sizeof e);
+        e.out_scale = 1.0f;
+        e.bias = L.fc2_b; e.residual = x; e.ld_residual = dim; e.layer_scale = L.ls2;
+        HIPCHK(launch_gemm_bf16((const bf16_t*)mlp, d->mlp_p, (const bf16_t*)L.fc2_w, x, dim, R, dim, d->mlp_p, &e, (float*)sk, skb, variant, st), "vit fc2");
+    }
+    return COVER_OK;
+}
+
+static size_t dec_ws(const cover_dec_desc* d, int rows, Carver* c, void** h, void** qkv, void** attn, void** mlp, void** sk,
+                     size_t* sk_bytes) {
+    Carver tmp{nullptr, 0, 0};
+    Carver& cc = c ? *c : tmp;
+    const int nqkv = (d->Hq + 2 * d->Hkv) * d->D;
+    void* p;
+    p = cc.take((size_t)rows * d->dim * 2); if (h) *h = p;
+    p = cc.take((size_t)rows * nqkv * 2); if (qkv) *qkv = p;
+    p = cc.take((size_t)rows * d->Hq * d->D * 2); if (attn) *attn = p;
+    p = cc.take((size_t)rows * d->mlp * 2); if (mlp) *mlp = p;
+    size_t skb = 0;
+    if (rows <= 64) {
+        const int ns[4] = {nqkv, d->dim, 2 * d->mlp, d->dim};
+        const int ks[4] = {d->dim, d->Hq * d->D, d->dim, d->mlp};
+        for (int i = 0; i < 4; ++i) {
+            size_t b = gemm_workspace_bytes(rows, ns[i], ks[i]);
+            skb = b > skb ? b : skb;
+        }
+    }
+    p = cc.take(skb); if (sk) *sk = p;
+    if (sk_bytes) *sk_bytes = skb;
+    return cc.off + 256;
+}
+size_t cover_decoder_workspace_bytes(const cover_dec_desc* d, int rows) {
+    return dec_ws(d, rows, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+}
+
+int cover_decoder_forward(const cover_dec_desc* d, const cover_dec_pass* p, void* x, cover_workspace ws, int variant,
+                          void* stream) {
+    if (!d || !p || !x || !d->layers_host) return fail(COVER_EINVAL, "cover_decoder_forward: null pointer");
+    if (p->n_groups < 1 || p->n_groups > 2) return fail(COVER_EINVAL, "cover_decoder_forward: 1 or 2 groups");
+    hipStream_t st = ST(stream);
+    int rows = 0, row0[2] = {0, 0};
+    for (int g = 0; g < p->n_groups; ++g) {
+        const cover_dec_group& G = p->groups[g];
+        if (G.n_seg < 1 || G.n_seg > 3 || G.write_seg < 0 || G.write_seg >= G.n_seg)
+            return fail(COVER_EINVAL, "cover_decoder_forward: bad segment description");
+        row0[g] = rows;
+        rows += G.B * G.T;
+    }
+    Carver c{(char*)ws.ptr, ws.bytes, 0};
+    void *h, *qkv, *attn, *mlp, *sk;
+    size_t skb;
+    const size_t need = dec_ws(d, rows, &c, &h, &qkv, &attn, &mlp, &sk, &skb);
+    if (!ws.ptr || ws.bytes < need) return fail(COVER_EWORKSPACE, "cover_decoder_forward: workspace too small");
+    const int dim = d->dim, Hq = d->Hq, Hkv = d->Hkv, D = d->D, nqkv = (Hq + 2 * Hkv) * D, HD = Hq * D;
+
+    for (int l = 0; l < d->n_layers; ++l) {
+        const cover_dec_layer& L = d->layers_host[l];
+        const bool first_f32 = (l == 0 && p->x_f32 != nullptr);
+        HIPCHK(launch_rmsnorm(first_f32 ? (const void*)p->x_f32 : (const void*)x, first_f32 ? 1 : 0, dim, L.in_norm_w,
+                              d->norm_w_offset, d->norm_style, (bf16_t*)h, dim, rows, dim, d->norm_eps, st), "dec in_norm");
+        cover_gemm_epi e;
+        memset(&e, 0, sizeof e);
+        e.out_scale = 1.0f;
+        e.bias = L.qkv_b;
+        HIPCHK(launch_gemm_bf16((const bf16_t*)h, dim, (const bf16_t*)L.qkv_w, qkv, nqkv, rows, nqkv, dim, &e, (float*)sk, skb, variant, st), "dec qkv");
+        for (int g = 0; g < p->n_groups; ++g) {
+            const cover_dec_group& G = p->groups[g];
+            if (G.B * G.T == 0) continue;
+            bf16_t* gq = (bf16_t*)qkv + (size_t)row0[g] * nqkv;
+            const cover_kv_segment& W = G.segs[G.write_seg];
+            cover_rope_args ra;
+            memset(&ra, 0, sizeof ra);
+            ra.qkv = gq; ra.ld_qkv = nqkv; ra.B = G.B; ra.T = G.T; ra.Hq = Hq; ra.Hkv = Hkv; ra.D = D;
+            ra.positions = G.positions; ra.cos_table = d->cos_table; ra.sin_table = d->sin_table; ra.n_pos = d->n_pos;
+            ra.rope_mode = d->rope_mode;
+            ra.k_cache = (bf16_t*)L.k_cache + G.seg_k_offset[G.write_seg];
+            ra.k_slot_stride = W.k_slot_stride; ra.k_t_stride = W.k_t_stride; ra.k_h_stride = W.k_h_stride;
+            ra.vt_cache = (bf16_t*)L.vt_cache + G.seg_vt_offset[G.write_seg];
+            ra.vt_slot_stride = W.vt_slot_stride; ra.vt_h_stride = W.vt_h_stride; ra.vt_d_stride = W.vt_d_stride;
+            ra.slot_of_batch = G.write_slot_of_batch; ra.t_offset_of_batch = G.write_t_offset_of_batch; ra.t_offset = G.write_t_offset;
+            HIPCHK(launch_rope_kv_write(&ra, st), "dec rope/kv");
+            cover_attn_args aa;
+            memset(&aa, 0, sizeof aa);
+            aa.q = gq; aa.q_b_stride = (long long)G.T * nqkv; aa.q_t_stride = nqkv; aa.q_h_stride = D;
+            aa.out = (bf16_t*)attn + (size_t)row0[g] * HD; aa.o_b_stride = (long long)G.T * HD; aa.o_t_stride = HD; aa.o_h_stride = D;
+            aa.B = G.B; aa.Tq = G.T; aa.Hq = Hq; aa.Hkv = Hkv; aa.D = D; aa.scale = d->attn_scale; aa.n_seg = G.n_seg;
+            for (int s = 0; s < G.n_seg; ++s) {
+                aa.seg[s] = G.segs[s];
+                aa.seg[s].k = (const bf16_t*)L.k_cache + G.seg_k_offset[s];
+                aa.seg[s].vt = (const bf16_t*)L.vt_cache + G.seg_vt_offset[s];
+            }
+            HIPCHK(launch_attention_bf16(&aa, st), "dec attention");
+        }
+        memset(&e, 0, sizeof e);
+        e.out_scale = 1.0f;
+        e.residual = first_f32 ? (const void*)p->x_f32 : (const void*)x; e.residual_f32 = first_f32 ? 1 : 0; e.ld_residual = dim;
+        HIPCHK(launch_gemm_bf16((const bf16_t*)attn, HD, (const bf16_t*)L.o_w, x, dim, rows, dim, HD, &e, (float*)sk, skb, variant, st), "dec o_proj");
+        HIPCHK(launch_rmsnorm(x, 0, dim, L.post_norm_w, d->norm_w_offset, d->norm_style, (bf16_t*)h, dim, rows, dim, d->norm_eps, st), "dec post_norm");
+        memset(&e, 0, sizeof e);
+        e.out_scale = 1.0f;
+        e.act = d->act; e.glu = 1;
+        HIPCHK(launch_gemm_bf16((const bf16_t*)h, dim, (const bf16_t*)L.gate_up_w, mlp, d->mlp, rows, 2 * d->mlp, dim, &e, (float*)sk, skb, variant, st), "dec gate_up");
+        memset(&e, 0, sizeof e);
+        e.out_scale = 1.0f;
+        e.residual = x; e.ld_residual = dim;
+        HIPCHK(launch_gemm_bf16((const bf16_t*)mlp, d->mlp, (const bf16_t*)L.down_w, x, dim, rows, dim, d->mlp, &e, (float*)sk, skb, variant, st), "dec down");
+    }
+    if (p->final_norm)
+        HIPCHK(launch_rmsnorm(x, 0, dim, d->final_norm_w, d->norm_w_offset, d->norm_style, (bf16_t*)x, dim, rows, dim, d->norm_eps, st), "dec final_norm");
+    return COVER_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// graphs, timers
+// ---------------------------------------------------------------------------------------------------
+int cover_graph_begin(void* stream) {
+    HIPCHK(hipStreamBeginCapture(ST(stream), hipStreamCaptureModeThreadLocal), "hipStreamBeginCapture");
+    return COVER_OK;
+}
+int cover_graph_end(void* stream, void** out) {
+    hipGraph_t g = nullptr;
+    HIPCHK(hipStreamEndCapture(ST(stream), &g), "hipStreamEndCapture");
+    hipGraphExec_t ge = nullptr;
+    hipError_t e = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(g);
+    HIPCHK(e, "hipGraphInstantiate");
+    *out = (void*)ge;
+    return COVER_OK;
+}
+int cover_graph_launch(void* ge, void* stream) {
+    HIPCHK(hipGraphLaunch((hipGraphExec_t)ge, ST(stream)), "hipGraphLaunch");
+    return COVER_OK;
+}
+int cover_graph_destroy(void* ge) {
+    HIPCHK(hipGraphExecDestroy((hipGraphExec_t)ge), "hipGraphExecDestroy");
+    return COVER_OK;
+}
+
+struct Timer { hipEvent_t a, b; };
+int cover_timer_create(void** out) {
+    Timer* t = new Timer;
+    hipError_t e = hipEventCreate(&t->a);
+    if (e == hipSuccess) e = hipEventCreate(&t->b);
+    if (e != hipSuccess) { delete t; return fail(COVER_EHIP, "hipEventCreate", e); }
+    *out = t;
+    return COVER_OK;
+}
+int cover_timer_start(void* timer, void* stream) {
+    HIPCHK(hipEventRecord(((Timer*)timer)->a, ST(stream)), "hipEventRecord");
+    return COVER_OK;
+}
+int cover_timer_stop(void* timer, void* stream, float* ms) {
+    Timer* t = (Timer*)timer;
+    HIPCHK(hipEventRecord(t->b, ST(stream)), "hipEventRecord");
+    HIPCHK(hipEventSynchronize(t->b), "hipEventSynchronize");
+    HIPCHK(hipEventElapsedTime(ms, t->a, t->b), "hipEventElapsedTime");
+    return COVER_OK;
+}
+int cover_timer_destroy(void* timer) {
+    Timer* t = (Timer*)timer;
+    (void)hipEventDestroy(t->a);
+    (void)hipEventDestroy(t->b);
+    delete t;
+    return COVER_OK;
+}
+int cover_stream_sync(void* stream) {
+    HIPCHK(hipStreamSynchronize(ST(stream)), "hipStreamSynchronize");
+    return COVER_OK;
+}
+
+size_t cover_sizeof(const char* n) {
+#define SZ(T) if (!strcmp(n, #T)) return sizeof(T)
+    SZ(cover_gemm_epi); SZ(cover_kv_segment); SZ(cover_attn_args); SZ(cover_rope_args); SZ(cover_patchify_args);
+    SZ(cover_gemm_f32_args); SZ(cover_mha_f32_args); SZ(cover_token_select_args); SZ(cover_score_select_args);
+    SZ(cover_workspace); SZ(cover_vit_layer); SZ(cover_vit_desc); SZ(cover_dec_layer); SZ(cover_dec_desc);
+    SZ(cover_dec_group); SZ(cover_dec_pass);
+#undef SZ
+    return 0;
+}
+
+}  // extern "C"

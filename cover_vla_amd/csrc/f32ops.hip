@@ -1,0 +1,268 @@
+// fp32 kernels for the parts of the path the reference keeps in float32: the verifier heads
+// (bridge_verifier/ensemble_eval/model.py:7-112, efficient_ensemble_merged.py:194-247) and the pi0 suffix
+// projections / Euler update (modeling_pi0.py:569-629,748-751,713-714).
+// The GEMM runs on v_mfma_f32_16x16x4_f32 (exact fp32 FMA chain, k-ordered), everything else is VALU.
+#include "common.h"
+#include "kernels.h"
+
+// ---------------------------------------------------------------------------------------------------
+// C[m,n] = residual + alpha * act(sum_k A[m,k] B[n,k] + bias[n])     (generic strides, optional batch)
+// 64x64 tile, BK = 32, 4 waves each a 32x32 sub-tile of 2x2 MFMA fragments.
+// ---------------------------------------------------------------------------------------------------
+#define FT 64
+#define FK 32
+__global__ __launch_bounds__(256) void gemm_f32_k(cover_gemm_f32_args a) {
+    __shared__ float As[FT][FK + 1];
+    __shared__ float Bs[FT][FK + 1];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wm = w >> 1, wn = w & 1;
+    const int m0 = blockIdx.y * FT, n0 = blockIdx.x * FT;
+    const int bz = blockIdx.z;
+    const float* A = a.A + (size_t)bz * a.a_batch_stride;
+    const float* B = a.B + (size_t)bz * a.b_batch_stride;
+    float* C = a.C + (size_t)bz * a.c_batch_stride;
+
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // tile loader: pick the thread->element map that makes the unit-stride axis contiguous across threads
+    auto load_tile = [&](float(&S)[FT][FK + 1], const float* P, long long rs, long long ks, int r0, int R, int k0) {
+        if (rs == 1 && ks != 1) {
+            const int row = tid & 63, kb = (tid >> 6) * 8;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int k = k0 + kb + e, rr = r0 + row;
+                S[row][kb + e] = (rr < R && k < a.K) ? P[(size_t)rr * rs + (size_t)k * ks] : 0.f;
+            }
+        } else {
+            const int row = tid >> 2, kb = (tid & 3) * 8;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int k = k0 + kb + e, rr = r0 + row;
+                S[row][kb + e] = (rr < R && k < a.K) ? P[(size_t)rr * rs + (size_t)k * ks] : 0.f;
+            }
+        }
+    };
+
+    const int r = lane & 15, g = lane >> 4;
+    for (int k0 = 0; k0 < a.K; k0 += FK) {
+        __syncthreads();
+        load_tile(As, A, a.a_row_stride, a.a_k_stride, m0, a.M, k0);
+        load_tile(Bs, B, a.b_row_stride, a.b_k_stride, n0, a.N, k0);
+        __syncthreads();
+#pragma unroll
+        for (int k4 = 0; k4 < FK / 4; ++k4) {
+            float af[2], bf[2];
+#pragma unroll
+            for (int f = 0; f < 2; ++f) {
+                af[f] = As[wm * 32 + f * 16 + r][k4 * 4 + g];
+                bf[f] = Bs[wn * 32 + f * 16 + r][k4 * 4 + g];
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    // D[row = 4g + e][col = r]
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int m = m0 + wm * 32 + i * 16 + 4 * g + e;
+                const int n = n0 + wn * 32 + j * 16 + r;
+                if (m < a.M && n < a.N) {
+                    float v = acc[i][j][e];
+                    if (a.bias) v += a.bias[n];
+                    v = act_apply(v, a.act);
+                    v *= a.alpha;
+                    if (a.residual) v += a.residual[(size_t)bz * a.c_batch_stride + (size_t)m * a.ld_residual + n];
+                    C[(size_t)m * a.c_row_stride + n] = v;
+                }
+            }
+}
+hipError_t launch_gemm_f32(const cover_gemm_f32_args* a, hipStream_t st) {
+    if (a->M <= 0 || a->N <= 0) return hipSuccess;
+    const int nb = a->batch > 0 ? a->batch : 1;
+    dim3 grid((a->N + FT - 1) / FT, (a->M + FT - 1) / FT, nb);
+    hipLaunchKernelGGL(gemm_f32_k, grid, dim3(256), 0, st, *a);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// row kernels (fp32)
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void layernorm_f32_k(const float* __restrict__ x, int ldx, const float* __restrict__ w,
+                                                       const float* __restrict__ b, float* __restrict__ y, int ldy,
+                                                       int dim, float eps) {
+    __shared__ float red[16];
+    const float* xr = x + (size_t)blockIdx.x * ldx;
+    float s = 0.f;
+    for (int c = threadIdx.x; c < dim; c += 256) s += xr[c];
+    const float mean = block_sum(s, red) / dim;
+    float q = 0.f;
+    for (int c = threadIdx.x; c < dim; c += 256) {
+        const float d = xr[c] - mean;
+        q += d * d;
+    }
+    const float rstd = rsqrtf(block_sum(q, red) / dim + eps);
+    float* yr = y + (size_t)blockIdx.x * ldy;
+    for (int c = threadIdx.x; c < dim; c += 256) yr[c] = (xr[c] - mean) * rstd * (w ? w[c] : 1.f) + (b ? b[c] : 0.f);
+}
+hipError_t launch_layernorm_f32(const float* x, int ldx, const float* w, const float* b, float* y, int ldy, int rows,
+                                int dim, float eps, hipStream_t st) {
+    if (rows <= 0) return hipSuccess;
+    hipLaunchKernelGGL(layernorm_f32_k, dim3(rows), dim3(256), 0, st, x, ldx, w, b, y, ldy, dim, eps);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void softmax_rows_f32_k(float* __restrict__ x, int ldx, int cols, float scale) {
+    __shared__ float red[16];
+    float* xr = x + (size_t)blockIdx.x * ldx;
+    float m = -INFINITY;
+    for (int c = threadIdx.x; c < cols; c += 256) m = fmaxf(m, xr[c] * scale);
+    m = block_max(m, red);
+    float s = 0.f;
+    for (int c = threadIdx.x; c < cols; c += 256) {
+        const float e = expf(xr[c] * scale - m);
+        xr[c] = e;
+        s += e;
+    }
+    const float inv = 1.f / block_sum(s, red);
+    for (int c = threadIdx.x; c < cols; c += 256) xr[c] *= inv;
+}
+hipError_t launch_softmax_rows_f32(float* x, int ldx, int rows, int cols, float scale, hipStream_t st) {
+    if (rows <= 0) return hipSuccess;
+    hipLaunchKernelGGL(softmax_rows_f32_k, dim3(rows), dim3(256), 0, st, x, ldx, cols, scale);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void l2norm_rows_f32_k(const float* __restrict__ x, int ldx, float* __restrict__ y,
+                                                         int ldy, int cols) {
+    __shared__ float red[16];
+    const float* xr = x + (size_t)blockIdx.x * ldx;
+    float q = 0.f;
+    for (int c = threadIdx.x; c < cols; c += 256) q += xr[c] * xr[c];
+    const float nrm = sqrtf(block_sum(q, red));
+    float* yr = y + (size_t)blockIdx.x * ldy;
+    for (int c = threadIdx.x; c < cols; c += 256) yr[c] = xr[c] / nrm;
+}
+hipError_t launch_l2norm_rows_f32(const float* x, int ldx, float* y, int ldy, int rows, int cols, hipStream_t st) {
+    if (rows <= 0) return hipSuccess;
+    hipLaunchKernelGGL(l2norm_rows_f32_k, dim3(rows), dim3(256), 0, st, x, ldx, y, ldy, cols);
+    return hipGetLastError();
+}
+
+__global__ void add_f32_k(const float* __restrict__ a, int lda, const float* __restrict__ b, int ldb,
+                          float* __restrict__ y, int ldy, int cols, int b_rows) {
+    const int r = blockIdx.x;
+    for (int c = threadIdx.x; c < cols; c += blockDim.x)
+        y[(size_t)r * ldy + c] = a[(size_t)r * lda + c] + b[(size_t)(r % b_rows) * ldb + c];
+}
+hipError_t launch_add_f32(const float* a, int lda, const float* b, int ldb, float* y, int ldy, int rows, int cols,
+                          int b_rows, hipStream_t st) {
+    if (rows <= 0) return hipSuccess;
+    hipLaunchKernelGGL(add_f32_k, dim3(rows), dim3(256), 0, st, a, lda, b, ldb, y, ldy, cols, b_rows);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// small multi-head attention: one block per (batch, head); Tq*Tk <= 4096, Dh <= 128
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mha_f32_k(cover_mha_f32_args a) {
+    extern __shared__ float sc[];  // [Tq][Tk]
+    const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
+    const float* q = a.q + (size_t)b * a.q_b_stride + (size_t)h * a.Dh;
+    const float* k = a.k + (size_t)b * a.k_b_stride + (size_t)h * a.Dh;
+    const float* v = a.v + (size_t)b * a.v_b_stride + (size_t)h * a.Dh;
+    const uint8_t* pad = a.key_pad ? a.key_pad + (size_t)b * a.Tk : nullptr;
+    const int n = a.Tq * a.Tk;
+    for (int idx = threadIdx.x; idx < n; idx += 256) {
+        const int i = idx / a.Tk, j = idx - i * a.Tk;
+        const float* qi = q + (size_t)i * a.q_t_stride;
+        const float* kj = k + (size_t)j * a.k_t_stride;
+        float s = 0.f;
+        for (int d = 0; d < a.Dh; ++d) s += (qi[d] * a.scale) * kj[d];
+        sc[idx] = (pad && pad[j]) ? -INFINITY : s;
+    }
+    __syncthreads();
+    // softmax per query row: one wave per row
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int i = w; i < a.Tq; i += 4) {
+        float m = -INFINITY;
+        for (int j = lane; j < a.Tk; j += 64) m = fmaxf(m, sc[i * a.Tk + j]);
+        m = wave_max(m);
+        float s = 0.f;
+        for (int j = lane; j < a.Tk; j += 64) {
+            const float e = (m == -INFINITY) ? 0.f : expf(sc[i * a.Tk + j] - m);
+            sc[i * a.Tk + j] = e;
+            s += e;
+        }
+        s = wave_sum(s);
+        const float inv = 1.f / s;  // all-masked row -> NaN, as torch
+        for (int j = lane; j < a.Tk; j += 64) sc[i * a.Tk + j] *= inv;
+    }
+    __syncthreads();
+    float* o = a.out + (size_t)b * a.o_b_stride + (size_t)h * a.Dh;
+    for (int idx = threadIdx.x; idx < a.Tq * a.Dh; idx += 256) {
+        const int i = idx / a.Dh, d = idx - i * a.Dh;
+        float acc = 0.f;
+        for (int j = 0; j < a.Tk; ++j) acc += sc[i * a.Tk + j] * v[(size_t)j * a.v_t_stride + d];
+        o[(size_t)i * a.o_t_stride + d] = acc;
+    }
+}
+hipError_t launch_mha_f32(const cover_mha_f32_args* a, hipStream_t st) {
+    if (a->B <= 0) return hipSuccess;
+    if ((long long)a->Tq * a->Tk > 8192) return hipErrorInvalidValue;
+    const size_t lds = (size_t)a->Tq * a->Tk * sizeof(float);
+    hipLaunchKernelGGL(mha_f32_k, dim3(a->B * a->H), dim3(256), lds, st, *a);
+    return hipGetLastError();
+}
+
+__global__ void masked_mean_f32_k(const float* __restrict__ x, const uint8_t* __restrict__ pad, float* __restrict__ y,
+                                  int T, int D) {
+    const int b = blockIdx.x;
+    float cnt = 0.f;
+    for (int t = 0; t < T; ++t) cnt += (pad && pad[(size_t)b * T + t]) ? 0.f : 1.f;
+    cnt = fmaxf(cnt, 1e-9f);
+    for (int d = threadIdx.x; d < D; d += blockDim.x) {
+        float s = 0.f;
+        for (int t = 0; t < T; ++t) {
+            const float mk = (pad && pad[(size_t)b * T + t]) ? 0.f : 1.f;
+            s += x[((size_t)b * T + t) * D + d] * mk;
+        }
+        y[(size_t)b * D + d] = s / cnt;
+    }
+}
+hipError_t launch_masked_mean_f32(const float* x, const uint8_t* pad, float* y, int B, int T, int D, hipStream_t st) {
+    if (B <= 0) return hipSuccess;
+    hipLaunchKernelGGL(masked_mean_f32_k, dim3(B), dim3(256), 0, st, x, pad, y, T, D);
+    return hipGetLastError();
+}
+
+// create_sinusoidal_pos_embedding (modeling_pi0.py:71-89) in float64, cast to bf16 (embed_suffix :593-596)
+__global__ void sincos_time_embed_k(const float* __restrict__ time, int dim, double min_period, double max_period,
+                                    bf16_t* __restrict__ out, int ldo) {
+    const int b = blockIdx.x, half = dim >> 1;
+    const double tt = (double)time[b];
+    for (int i = threadIdx.x; i < half; i += blockDim.x) {
+        const double fraction = half > 1 ? (double)i / (double)(half - 1) : 0.0;
+        const double period = min_period * pow(max_period / min_period, fraction);
+        const double arg = 1.0 / period * 2.0 * 3.141592653589793 * tt;
+        out[(size_t)b * ldo + i] = f2bf((float)sin(arg));
+        out[(size_t)b * ldo + half + i] = f2bf((float)cos(arg));
+    }
+}
+hipError_t launch_sincos_time_embed(const float* time, int B, int dim, double min_period, double max_period, bf16_t* out,
+                                    int ldo, hipStream_t st) {
+    if (B <= 0) return hipSuccess;
+    hipLaunchKernelGGL(sincos_time_embed_k, dim3(B), dim3(256), 0, st, time, dim, min_period, max_period,
+                       out, ldo);
+    return hipGetLastError();
+}

@@ -1,0 +1,503 @@
+// bf16 GEMM kernels for gfx950: C[M,N] = epi(A[M,K] . W[N,K]^T), fp32 accumulate on v_mfma_f32_16x16x32_bf16.
+//
+// Weight layout (cover_pack_weight_bf16): Wp[nb = n/16][kb = k/32][lane = (n%16) + 16*((k%32)/8)][8 bf16]
+//   -> one 16x32 block = 1 KiB contiguous = exactly the MFMA operand of one wave, lane-linear.
+// Operands are SWAPPED (first MFMA operand = weight fragment, second = activation fragment), so the
+// accumulator of lane (r = lane&15, g = lane>>4) holds C[m = r][n = 4g .. 4g+3]: four consecutive output
+// columns per lane -> 8/16-byte epilogue stores, bias/residual loads are vector loads too.
+//
+// Two kernels:
+//   gemm_tiled   128x128x64 tile, 4 waves (2x2), LDS double buffer. A tile staged with an XOR chunk swizzle
+//                (conflict-free ds_read_b128), W tile staged lane-linear straight from the packed layout.
+//                Staging either async global->LDS (global_load_lds, 16 B/lane) or through registers.
+//   gemm_skinny  M <= 64 (decode / denoise steps): HBM-bound weight streaming. The activation K-chunk lives in
+//                LDS in fragment-major form, every wave streams whole 1 KiB weight blocks straight into VGPRs
+//                (no LDS round trip for the streamed operand), split-K over grid.y with fp32 partials that a
+//                small reduce kernel folds together with the epilogue.
+#include "common.h"
+#include "kernels.h"
+
+struct EpiDev {
+    const float* bias;
+    const void* residual;
+    const float* lscale;
+    int ldr, res_f32, act, glu, out_f32;
+    float out_scale;
+};
+
+// val[4] are 4 consecutive columns n0..n0+3 of row m. Handles bias/act/residual/scale + store.
+__device__ __forceinline__ void epi_store4(const EpiDev& e, void* C, int ldc, int m, int n0, int N, float v[4]) {
+    if (n0 >= N) return;
+    const bool full = (n0 + 3 < N);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float x = v[i];
+        if (e.bias && (full || n0 + i < N)) x += e.bias[n0 + i];
+        x = bfround(x);                       // nn.Linear output rounding point
+        if (e.act != ACT_NONE) x = bfround(act_apply(x, e.act));
+        v[i] = x;
+    }
+    if (e.lscale) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (full || n0 + i < N) v[i] = bfround(v[i] * e.lscale[n0 + i]);
+    }
+    if (e.residual) {
+        if (e.res_f32) {
+            const float* r = (const float*)e.residual + (size_t)m * e.ldr + n0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (full || n0 + i < N) v[i] = v[i] + r[i];
+        } else {
+            const bf16_t* r = (const bf16_t*)e.residual + (size_t)m * e.ldr + n0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (full || n0 + i < N) v[i] = v[i] + bf2f(r[i]);
+        }
+    }
+    if (e.out_scale != 1.0f) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] *= e.out_scale;
+    }
+    if (e.out_f32) {
+        float* o = (float*)C + (size_t)m * ldc + n0;
+        if (full && ((((uintptr_t)o) & 15) == 0)) {
+            *(float4*)o = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+            for (int i = 0; i < 4; ++i)
+                if (n0 + i < N) o[i] = v[i];
+        }
+    } else {
+        bf16_t* o = (bf16_t*)C + (size_t)m * ldc + n0;
+        if (full && ((((uintptr_t)o) & 7) == 0)) {
+            uint2 p;
+            p.x = pack_bf2(v[0], v[1]);
+            p.y = pack_bf2(v[2], v[3]);
+            *(uint2*)o = p;
+        } else {
+            for (int i = 0; i < 4; ++i)
+                if (n0 + i < N) o[i] = f2bf(v[i]);
+        }
+    }
+}
+
+// GLU epilogue: g[4] = gate columns, u[4] = matching up columns; output column j0 (N_out = N/2 columns).
+__device__ __forceinline__ void epi_store4_glu(const EpiDev& e, void* C, int ldc, int m, int j0, int Nout, float g[4],
+                                               float u[4]) {
+    if (j0 >= Nout) return;
+    float v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float gg = bfround(g[i]), uu = bfround(u[i]);
+        gg = bfround(act_apply(gg, e.act));
+        v[i] = bfround(gg * uu);
+    }
+    if (e.out_f32) {
+        float* o = (float*)C + (size_t)m * ldc + j0;
+        for (int i = 0; i < 4; ++i)
+            if (j0 + i < Nout) o[i] = v[i];
+    } else {
+        bf16_t* o = (bf16_t*)C + (size_t)m * ldc + j0;
+        if (j0 + 3 < Nout && ((((uintptr_t)o) & 7) == 0)) {
+            uint2 p;
+            p.x = pack_bf2(v[0], v[1]);
+            p.y = pack_bf2(v[2], v[3]);
+            *(uint2*)o = p;
+        } else {
+            for (int i = 0; i < 4; ++i)
+                if (j0 + i < Nout) o[i] = f2bf(v[i]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Tiled kernel
+// ---------------------------------------------------------------------------------------------------
+#define BM 128
+#define BN 128
+#define BK 64
+#define TILE_BYTES (BM * BK * 2)  // 16 KiB per operand per buffer
+
+template <bool GLDS>
+__global__ __launch_bounds__(256) void gemm_tiled(const bf16_t* __restrict__ A, int lda,
+                                                     const bf16_t* __restrict__ Wp, void* C, int ldc, int M, int N,
+                                                     int K, int Kp, EpiDev epi, int tiles_m, int tiles_n) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // layout: [A buf0][A buf1][B buf0][B buf1]
+    char* As = smem;
+    char* Bs = smem + 2 * TILE_BYTES;
+
+    // XCD-aware bijective remap of the linear block id: blocks dispatched round-robin over the 8 XCDs get a
+    // contiguous range of tiles each, so the m-tiles that share one weight tile hit the same L2.
+    const int nwg = tiles_m * tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+        const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+        bid = base + (bid >> 3);
+    }
+    const int tn = bid / tiles_m, tm = bid % tiles_m;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = w >> 1, wn = w & 1;
+    const int K32 = Kp >> 5;
+    const int N16 = (N + 15) >> 4;
+    const int nk = Kp / BK;
+
+    // ---- staging addresses (4 x 16 B per thread per operand per tile) ----
+    // A: LDS chunk position p = j*64 + lane (j = w*4+i): row = p>>3, c = p&7 holds global chunk c ^ (row&7)
+    const bf16_t* a_src[4];
+    const bf16_t* b_src[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int j = w * 4 + i;
+        const int row = j * 8 + (lane >> 3), c = lane & 7;
+        int gr = m0 + row;
+        gr = gr < M ? gr : M - 1;
+        a_src[i] = A + (size_t)gr * lda + ((c ^ (row & 7)) << 3);
+        const int nbi = j >> 1, kbi = j & 1;
+        int nb = (n0 >> 4) + nbi;
+        nb = nb < N16 ? nb : N16 - 1;
+        b_src[i] = Wp + ((size_t)nb * K32 + kbi) * 512 + lane * 8;
+    }
+
+    f32x4 acc[4][4];  // [n-block b][m-frag f]
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int f = 0; f < 4; ++f) acc[b][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    uint4 ra[4], rb[4];
+    auto stage_glds = [&](int buf, int kt) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int j = w * 4 + i;
+            glds16(a_src[i] + kt * BK, As + buf * TILE_BYTES + j * 1024);
+            glds16(b_src[i] + (size_t)kt * 2 * 512, Bs + buf * TILE_BYTES + j * 1024);
+        }
+    };
+    auto stage_load = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            ra[i] = *(const uint4*)(a_src[i] + kt * BK);
+            rb[i] = *(const uint4*)(b_src[i] + (size_t)kt * 2 * 512);
+        }
+    };
+    auto stage_write = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int j = w * 4 + i;
+            *(uint4*)(As + buf * TILE_BYTES + j * 1024 + lane * 16) = ra[i];
+            *(uint4*)(Bs + buf * TILE_BYTES + j * 1024 + lane * 16) = rb[i];
+        }
+    };
+    const int r = lane & 15, g = lane >> 4;
+    auto compute = [&](int buf) {
+        const char* Ab = As + buf * TILE_BYTES;
+        const char* Bb = Bs + buf * TILE_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 xf[4], wf[4];
+#pragma unroll
+            for (int f = 0; f < 4; ++f) {
+                const int row = wm * 64 + f * 16 + r;
+                const int c = (ks * 4 + g) ^ (row & 7);
+                xf[f] = as_bf16x8(*(const uint4*)(Ab + (row * 8 + c) * 16));
+            }
+#pragma unroll
+            for (int b = 0; b < 4; ++b) wf[b] = as_bf16x8(*(const uint4*)(Bb + (((wn * 4 + b) * 2 + ks) * 64 + lane) * 16));
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+#pragma unroll
+                for (int f = 0; f < 4; ++f)
+                    acc[b][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[b], xf[f], acc[b][f], 0, 0, 0);
+        }
+    };
+
+    if (GLDS) {
+        stage_glds(0, 0);
+        for (int kt = 0; kt < nk; ++kt) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (kt + 1 < nk) stage_glds((kt + 1) & 1, kt + 1);
+            compute(kt & 1);
+        }
+    } else {
+        stage_load(0);
+        stage_write(0);
+        for (int kt = 0; kt < nk; ++kt) {
+            __syncthreads();
+            if (kt + 1 < nk) stage_load(kt + 1);
+            compute(kt & 1);
+            if (kt + 1 < nk) stage_write((kt + 1) & 1);
+        }
+    }
+
+    // ---- epilogue ----
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+        const int m = m0 + wm * 64 + f * 16 + r;
+        if (m >= M) continue;
+        if (epi.glu) {
+#pragma unroll
+            for (int b = 0; b < 4; b += 2) {
+                const int nblk = (n0 >> 4) + wn * 4 + b;  // even block = gate, odd = up
+                float gv[4] = {acc[b][f][0], acc[b][f][1], acc[b][f][2], acc[b][f][3]};
+                float uv[4] = {acc[b + 1][f][0], acc[b + 1][f][1], acc[b + 1][f][2], acc[b + 1][f][3]};
+                epi_store4_glu(epi, C, ldc, m, (nblk >> 1) * 16 + 4 * g, N >> 1, gv, uv);
+            }
+        } else {
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                float v[4] = {acc[b][f][0], acc[b][f][1], acc[b][f][2], acc[b][f][3]};
+                epi_store4(epi, C, ldc, m, n0 + wn * 64 + b * 16 + 4 * g, N, v);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Weight-streaming kernel (M <= 64)
+// ---------------------------------------------------------------------------------------------------
+// grid = (ceil(N16 / nb_per_block), S); block = 512 threads (8 waves). LDS = MF*16 rows x KC x 2 B, fragment-major:
+//   xs[ks][f][lane][16 B].  partial[s][m][n] fp32.
+template <int MF>
+__global__ __launch_bounds__(512) void gemm_skinny(const bf16_t* __restrict__ A, int lda,
+                                                   const bf16_t* __restrict__ Wp, float* __restrict__ partial, int M,
+                                                   int N, int Kp, int KC, int nb_per_block) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int s = blockIdx.y;
+    const int k0 = s * KC;
+    const int kc = min(KC, Kp - k0);  // multiple of 128
+    const int K32 = Kp >> 5;
+    const int N16 = (N + 15) >> 4;
+
+    // ---- stage the activation chunk: coalesced 16-B reads along k, scattered into fragment-major LDS ----
+    {
+        const int cpr = kc >> 3;  // 16-B chunks per row
+        const int total = MF * 16 * cpr;
+        for (int c = tid; c < total; c += 512) {
+            const int row = c / cpr, kc8 = c - row * cpr;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (row < M) v = *(const uint4*)(A + (size_t)row * lda + k0 + kc8 * 8);
+            const int ks = kc8 >> 2, gg = kc8 & 3, f = row >> 4, rr = row & 15;
+            *(uint4*)(smem + (((ks * MF + f) * 64) + rr + 16 * gg) * 16) = v;
+        }
+    }
+    __syncthreads();
+
+    const int nb_begin = blockIdx.x * nb_per_block;
+    const int nb_end = min(N16, nb_begin + nb_per_block);
+    const int nbatch = kc >> 7;  // batches of 4 k-steps (128 k)
+    const int r = lane & 15, g = lane >> 4;
+
+    for (int nb = nb_begin + w; nb < nb_end; nb += 8) {
+        const u32x4* wsrc = (const u32x4*)(Wp + ((size_t)nb * K32 + (k0 >> 5)) * 512) + lane;  // +64 x 16 B per k-step
+        f32x4 acc[MF];
+#pragma unroll
+        for (int f = 0; f < MF; ++f) acc[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        u32x4 w0[4], w1[4];
+        auto load4 = [&](u32x4(&dst)[4], int b) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) dst[u] = __builtin_nontemporal_load(wsrc + (size_t)(b * 4 + u) * 64);
+        };
+        auto comp4 = [&](u32x4(&src)[4], int b) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int ks = b * 4 + u;
+                const bf16x8 wf = __builtin_bit_cast(bf16x8, src[u]);
+#pragma unroll
+                for (int f = 0; f < MF; ++f) {
+                    const bf16x8 xf = as_bf16x8(*(const uint4*)(smem + ((ks * MF + f) * 64 + lane) * 16));
+                    acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf, acc[f], 0, 0, 0);
+                }
+            }
+        };
+        load4(w0, 0);
+        for (int b = 0; b < nbatch; b += 2) {
+            if (b + 1 < nbatch) load4(w1, b + 1);
+            comp4(w0, b);
+            if (b + 1 < nbatch) {
+                if (b + 2 < nbatch) load4(w0, b + 2);
+                comp4(w1, b + 1);
+            }
+        }
+        // partial[s][m][n]: lane holds m = f*16 + r, n = nb*16 + 4g .. +3
+#pragma unroll
+        for (int f = 0; f < MF; ++f) {
+            const int m = f * 16 + r;
+            const int n = nb * 16 + 4 * g;
+            if (m < M && n < N) {
+                float* o = partial + ((size_t)s * M + m) * N + n;
+                if (n + 3 < N && ((((uintptr_t)o) & 15) == 0)) {
+                    *(float4*)o = make_float4(acc[f][0], acc[f][1], acc[f][2], acc[f][3]);
+                } else {
+                    for (int i = 0; i < 4; ++i)
+                        if (n + i < N) o[i] = acc[f][i];
+                }
+            }
+        }
+    }
+}
+
+// out = epi(sum_s partial[s]) ; one thread per 4 output columns
+__global__ __launch_bounds__(256) void splitk_reduce(const float* __restrict__ partial, int S, void* C, int ldc, int M,
+                                                     int N, EpiDev epi) {
+    const int Nout = epi.glu ? (N >> 1) : N;
+    const int groups = (Nout + 3) >> 2;
+    const long long total = (long long)M * groups;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const int m = (int)(idx / groups);
+        const int j0 = (int)(idx - (long long)m * groups) * 4;
+        if (epi.glu) {
+            const int ng = (j0 >> 4) * 32 + (j0 & 15);  // gate columns; up = +16
+            float gv[4] = {0, 0, 0, 0}, uv[4] = {0, 0, 0, 0};
+            for (int s = 0; s < S; ++s) {
+                const float* p = partial + ((size_t)s * M + m) * N + ng;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (j0 + i < Nout) {
+                        gv[i] += p[i];
+                        uv[i] += p[16 + i];
+                    }
+            }
+            epi_store4_glu(epi, C, ldc, m, j0, Nout, gv, uv);
+        } else {
+            float v[4] = {0, 0, 0, 0};
+            for (int s = 0; s < S; ++s) {
+                const float* p = partial + ((size_t)s * M + m) * N + j0;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (j0 + i < N) v[i] += p[i];
+            }
+            epi_store4(epi, C, ldc, m, j0, N, v);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Weight packing: W[N, ldw] row-major -> fragment-major. One thread per 16-B chunk of the packed image.
+// ---------------------------------------------------------------------------------------------------
+__global__ void pack_weight(const bf16_t* __restrict__ W, int ldw, int N, int K, bf16_t* __restrict__ Wp, int Kp,
+                            int glu) {
+    const int K32 = Kp >> 5;
+    const int N16 = (N + 15) >> 4;
+    const long long total = (long long)N16 * K32 * 64;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const int lane = (int)(idx & 63);
+        const long long blk = idx >> 6;
+        const int kb = (int)(blk % K32);
+        const int nb = (int)(blk / K32);
+        int n = nb * 16 + (lane & 15);
+        if (glu) {  // packed block 2i = gate rows [16i,16i+16), block 2i+1 = up rows N/2 + [16i,16i+16)
+            const int half = N >> 1;
+            const int i = nb >> 1;
+            n = ((nb & 1) ? half : 0) + i * 16 + (lane & 15);
+            if (i * 16 + (lane & 15) >= half) n = N;  // out of range -> zeros
+        }
+        const int k = kb * 32 + (lane >> 4) * 8;
+        bf16_t v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (n < N && k + e < K) ? W[(size_t)n * ldw + k + e] : (bf16_t)0;
+        *(uint4*)(Wp + idx * 8) = *(const uint4*)v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Host launchers
+// ---------------------------------------------------------------------------------------------------
+static EpiDev make_epi(const cover_gemm_epi* e) {
+    EpiDev d;
+    d.bias = e ? e->bias : nullptr;
+    d.residual = e ? e->residual : nullptr;
+    d.res_f32 = e ? e->residual_f32 : 0;
+    d.lscale = e ? e->layer_scale : nullptr;
+    d.ldr = e ? e->ld_residual : 0;
+    d.act = e ? e->act : 0;
+    d.glu = e ? e->glu : 0;
+    d.out_f32 = e ? e->out_f32 : 0;
+    d.out_scale = e ? e->out_scale : 1.0f;
+    if (d.out_scale == 0.0f) d.out_scale = 1.0f;
+    return d;
+}
+
+struct SkinnyPlan {
+    int MF, KC, S, nbpb, gx;
+    size_t lds, ws_bytes;
+};
+static SkinnyPlan plan_skinny(int M, int N, int Kp) {
+    SkinnyPlan p;
+    p.MF = (M + 15) / 16;
+    const int N16 = (N + 15) / 16;
+    p.nbpb = N16 >= 1024 ? 16 : 8;
+    p.gx = (N16 + p.nbpb - 1) / p.nbpb;
+    const int kc_max = (64 * 1024) / (p.MF * 16 * 2) / 128 * 128;  // LDS <= 64 KiB -> 2 blocks per CU
+    int S = (512 + p.gx - 1) / p.gx;
+    int kb = Kp / 128;
+    if (S > kb) S = kb;
+    if (S < 1) S = 1;
+    int KC = ((kb + S - 1) / S) * 128;
+    if (KC > kc_max) KC = kc_max;
+    p.KC = KC;
+    p.S = (Kp + KC - 1) / KC;
+    p.lds = (size_t)p.MF * 16 * KC * 2;
+    p.ws_bytes = (size_t)p.S * M * N * sizeof(float);
+    return p;
+}
+
+size_t gemm_workspace_bytes(int M, int N, int K) {
+    if (M > 64) return 0;
+    const int Kp = (K + 127) / 128 * 128;
+    return plan_skinny(M, N, Kp).ws_bytes;
+}
+
+hipError_t launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* Wp, void* C, int ldc, int M, int N, int K,
+                            const cover_gemm_epi* epi_in, float* ws, size_t ws_bytes, int variant, hipStream_t st) {
+    if (M <= 0 || N <= 0) return hipSuccess;
+    const int Kp = (K + 127) / 128 * 128;
+    EpiDev epi = make_epi(epi_in);
+    if (variant == 0) variant = (M <= 64 && ws != nullptr) ? 3 : 1;
+    if (variant == 3) {
+        if (M > 64) return hipErrorInvalidValue;
+        SkinnyPlan p = plan_skinny(M, N, Kp);
+        if (ws == nullptr || ws_bytes < p.ws_bytes) return hipErrorInvalidValue;
+        dim3 grid(p.gx, p.S), block(512);
+        switch (p.MF) {
+            case 1: hipLaunchKernelGGL(gemm_skinny<1>, grid, block, p.lds, st, A, lda, Wp, ws, M, N, Kp, p.KC, p.nbpb); break;
+            case 2: hipLaunchKernelGGL(gemm_skinny<2>, grid, block, p.lds, st, A, lda, Wp, ws, M, N, Kp, p.KC, p.nbpb); break;
+            case 3: hipLaunchKernelGGL(gemm_skinny<3>, grid, block, p.lds, st, A, lda, Wp, ws, M, N, Kp, p.KC, p.nbpb); break;
+            default: hipLaunchKernelGGL(gemm_skinny<4>, grid, block, p.lds, st, A, lda, Wp, ws, M, N, Kp, p.KC, p.nbpb); break;
+        }
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        const int Nout = epi.glu ? N / 2 : N;
+        const long long total = (long long)M * ((Nout + 3) / 4);
+        int rb = (int)((total + 255) / 256);
+        if (rb > 2048) rb = 2048;
+        hipLaunchKernelGGL(splitk_reduce, dim3(rb), dim3(256), 0, st, (const float*)ws, p.S, C, ldc, M, N, epi);
+        return hipGetLastError();
+    }
+    const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
+    const size_t lds = 4 * TILE_BYTES;
+    dim3 grid(tiles_m * tiles_n), block(256);
+    if (variant == 2)
+        hipLaunchKernelGGL(gemm_tiled<false>, grid, block, lds, st, A, lda, Wp, C, ldc, M, N, K, Kp, epi, tiles_m, tiles_n);
+    else
+        hipLaunchKernelGGL(gemm_tiled<true>, grid, block, lds, st, A, lda, Wp, C, ldc, M, N, K, Kp, epi, tiles_m, tiles_n);
+    return hipGetLastError();
+}
+
+hipError_t launch_pack_weight_bf16(const bf16_t* W, int ldw, int N, int K, bf16_t* Wp, int Kpad, int glu,
+                                   hipStream_t st) {
+    const long long total = (long long)((N + 15) / 16) * (Kpad / 32) * 64;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 65535) blocks = 65535;
+    hipLaunchKernelGGL(pack_weight, dim3(blocks), dim3(256), 0, st, W, ldw, N, K, Wp, Kpad, glu);
+    return hipGetLastError();
+}

@@ -1,0 +1,55 @@
+// Internal launch API of libcover_hip (host-side declarations). Every launcher is asynchronous on `st`
+// and returns a hipError_t; nothing here allocates. The extern "C" surface is include/cover_hip.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/cover_hip.h"
+
+typedef uint16_t bf16_t;
+
+// ---- gemm_bf16.hip -------------------------------------------------------------------------------
+// C[M,N] = epi(A[M,K] x W[N,K]^T); W pre-packed by cover_pack_weight_bf16 (fragment-major).
+hipError_t launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* Wp, void* C, int ldc, int M, int N, int K,
+                            const cover_gemm_epi* epi, float* splitk_ws, size_t splitk_ws_bytes, int variant,
+                            hipStream_t st);
+hipError_t launch_pack_weight_bf16(const bf16_t* W, int ldw, int N, int K, bf16_t* Wp, int Kpad, int glu_interleave,
+                                   hipStream_t st);
+
+// ---- attention.hip -------------------------------------------------------------------------------
+hipError_t launch_attention_bf16(const cover_attn_args* a, hipStream_t st);
+
+// ---- rowops.hip ----------------------------------------------------------------------------------
+hipError_t launch_layernorm_bf16(const bf16_t* x, int ldx, const float* w, const float* b, bf16_t* y, int ldy, int rows,
+                                 int dim, float eps, hipStream_t st);
+hipError_t launch_rmsnorm(const void* x, int x_f32, int ldx, const float* w, float w_offset, int style, bf16_t* y, int ldy,
+                          int rows, int dim, float eps, hipStream_t st);
+hipError_t launch_rope_kv_write(const cover_rope_args* a, hipStream_t st);
+hipError_t launch_embed_gather(const bf16_t* table, int dim, const int64_t* ids, int n, float scale, bf16_t* out,
+                               int ldo, hipStream_t st);
+hipError_t launch_patchify(const cover_patchify_args* a, hipStream_t st);
+hipError_t launch_copy_rows_bf16(const bf16_t* src, int lds_, bf16_t* dst, int ldd, int rows, int cols,
+                                 const int* src_row_idx, const int* dst_row_idx, hipStream_t st);
+hipError_t launch_add_bias_rows_bf16(bf16_t* x, int ldx, const bf16_t* add, int ld_add, int rows, int cols, int add_rows,
+                                     hipStream_t st);
+hipError_t launch_scale_bf16(bf16_t* x, int ldx, int rows, int cols, float pre_div, float post_mul, hipStream_t st);
+hipError_t launch_cast_f32_to_bf16(const float* x, int ldx, bf16_t* y, int ldy, int rows, int cols, hipStream_t st);
+hipError_t launch_cast_bf16_to_f32(const bf16_t* x, int ldx, float* y, int ldy, int rows, int cols, hipStream_t st);
+
+// ---- f32ops.hip ----------------------------------------------------------------------------------
+hipError_t launch_gemm_f32(const cover_gemm_f32_args* a, hipStream_t st);
+hipError_t launch_layernorm_f32(const float* x, int ldx, const float* w, const float* b, float* y, int ldy, int rows,
+                                int dim, float eps, hipStream_t st);
+hipError_t launch_softmax_rows_f32(float* x, int ldx, int rows, int cols, float scale, hipStream_t st);
+hipError_t launch_l2norm_rows_f32(const float* x, int ldx, float* y, int ldy, int rows, int cols, hipStream_t st);
+hipError_t launch_add_f32(const float* a, int lda, const float* b, int ldb, float* y, int ldy, int rows, int cols,
+                          int b_rows, hipStream_t st);
+hipError_t launch_mha_f32(const cover_mha_f32_args* a, hipStream_t st);
+hipError_t launch_masked_mean_f32(const float* x, const uint8_t* pad, float* y, int B, int T, int D, hipStream_t st);
+hipError_t launch_sincos_time_embed(const float* time, int B, int dim, double min_period, double max_period, bf16_t* out,
+                                    int ldo, hipStream_t st);
+
+// ---- select.hip ----------------------------------------------------------------------------------
+hipError_t launch_token_select(const cover_token_select_args* a, hipStream_t st);
+hipError_t launch_score_select(const cover_score_select_args* a, hipStream_t st);
+hipError_t launch_group_argmax(const float* scores, int N, int gs, int* result, float* best, hipStream_t st);
+size_t gemm_workspace_bytes(int M, int N, int K);

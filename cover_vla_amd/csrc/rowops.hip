@@ -1,0 +1,311 @@
+// HBM-bound row kernels: norms, RoPE + KV placement, gathers, patch extraction, casts.
+// All bf16 traffic is 16 bytes per lane; reductions are wave shuffles + one LDS hop per block.
+#include "common.h"
+#include "kernels.h"
+
+// ---------------------------------------------------------------------------------------------------
+// LayerNorm / RMSNorm: one 256-thread block per row, row cached in registers (dim <= 8192, dim % 8 == 0)
+// ---------------------------------------------------------------------------------------------------
+#define NORM_MAX_CHUNKS 4
+
+template <bool IN_F32>
+__device__ __forceinline__ void load_row8(const void* x, size_t off, float (&v)[8]) {
+    if (IN_F32) {
+        const float4 a = *(const float4*)((const float*)x + off);
+        const float4 b = *(const float4*)((const float*)x + off + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    } else {
+        const uint4 u = *(const uint4*)((const bf16_t*)x + off);
+        const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            v[2 * i] = __uint_as_float(w[i] << 16);
+            v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+        }
+    }
+}
+__device__ __forceinline__ void store_row8(bf16_t* y, size_t off, const float (&v)[8]) {
+    uint4 u;
+    u.x = pack_bf2(v[0], v[1]); u.y = pack_bf2(v[2], v[3]); u.z = pack_bf2(v[4], v[5]); u.w = pack_bf2(v[6], v[7]);
+    *(uint4*)(y + off) = u;
+}
+
+__global__ __launch_bounds__(256) void layernorm_bf16_k(const bf16_t* __restrict__ x, int ldx, const float* __restrict__ w,
+                                                        const float* __restrict__ b, bf16_t* __restrict__ y, int ldy,
+                                                        int dim, float eps) {
+    __shared__ float red[16];
+    const int row = blockIdx.x;
+    const int nch = dim >> 3;
+    float v[NORM_MAX_CHUNKS][8];
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < NORM_MAX_CHUNKS; ++c) {
+        const int ch = threadIdx.x + c * 256;
+        if (ch < nch) {
+            load_row8<false>(x, (size_t)row * ldx + ch * 8, v[c]);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) s += v[c][i];
+        }
+    }
+    const float mean = block_sum(s, red) / dim;
+    float q = 0.f;
+#pragma unroll
+    for (int c = 0; c < NORM_MAX_CHUNKS; ++c) {
+        const int ch = threadIdx.x + c * 256;
+        if (ch < nch) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float d = v[c][i] - mean;
+                q += d * d;
+            }
+        }
+    }
+    const float rstd = rsqrtf(block_sum(q, red) / dim + eps);
+#pragma unroll
+    for (int c = 0; c < NORM_MAX_CHUNKS; ++c) {
+        const int ch = threadIdx.x + c * 256;
+        if (ch < nch) {
+            float o[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int col = ch * 8 + i;
+                o[i] = (v[c][i] - mean) * rstd * w[col] + (b ? b[col] : 0.f);
+            }
+            store_row8(y, (size_t)row * ldy + ch * 8, o);
+        }
+    }
+}
+
+// style 0 (Gemma): y = bf16(x * rstd * (w_offset + w)) ; style 1 (Llama): y = bf16(w * bf16(x * rstd))
+template <bool IN_F32>
+__global__ __launch_bounds__(256) void rmsnorm_bf16_k(const void* __restrict__ x, int ldx, const float* __restrict__ w,
+                                                      float w_offset, int style, bf16_t* __restrict__ y, int ldy, int dim,
+                                                      float eps) {
+    __shared__ float red[16];
+    const int row = blockIdx.x;
+    const int nch = dim >> 3;
+    float v[NORM_MAX_CHUNKS][8];
+    float q = 0.f;
+#pragma unroll
+    for (int c = 0; c < NORM_MAX_CHUNKS; ++c) {
+        const int ch = threadIdx.x + c * 256;
+        if (ch < nch) {
+            load_row8<IN_F32>(x, (size_t)row * ldx + ch * 8, v[c]);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) q += v[c][i] * v[c][i];
+        }
+    }
+    const float rstd = rsqrtf(block_sum(q, red) / dim + eps);
+#pragma unroll
+    for (int c = 0; c < NORM_MAX_CHUNKS; ++c) {
+        const int ch = threadIdx.x + c * 256;
+        if (ch < nch) {
+            float o[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int col = ch * 8 + i;
+                const float ww = w ? w[col] : 0.f;
+                if (style == 1) o[i] = ww * bfround(v[c][i] * rstd);
+                else o[i] = v[c][i] * rstd * (w_offset + ww);
+            }
+            store_row8(y, (size_t)row * ldy + ch * 8, o);
+        }
+    }
+}
+
+hipError_t launch_layernorm_bf16(const bf16_t* x, int ldx, const float* w, const float* b, bf16_t* y, int ldy, int rows,
+                                 int dim, float eps, hipStream_t st) {
+    if (rows <= 0) return hipSuccess;
+    if (dim % 8 || dim > NORM_MAX_CHUNKS * 256 * 8) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(layernorm_bf16_k, dim3(rows), dim3(256), 0, st, x, ldx, w, b, y, ldy, dim, eps);
+    return hipGetLastError();
+}
+hipError_t launch_rmsnorm(const void* x, int x_f32, int ldx, const float* w, float w_offset, int style, bf16_t* y, int ldy,
+                          int rows, int dim, float eps, hipStream_t st) {
+    if (rows <= 0) return hipSuccess;
+    if (dim % 8 || dim > NORM_MAX_CHUNKS * 256 * 8) return hipErrorInvalidValue;
+    if (x_f32)
+        hipLaunchKernelGGL(rmsnorm_bf16_k<true>, dim3(rows), dim3(256), 0, st, x, ldx, w, w_offset, style, y, ldy, dim, eps);
+    else
+        hipLaunchKernelGGL(rmsnorm_bf16_k<false>, dim3(rows), dim3(256), 0, st, x, ldx, w, w_offset, style, y, ldy, dim, eps);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// RoPE + KV placement: one wave per (row, head) of the fused qkv buffer
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rope_kv_write_k(cover_rope_args a) {
+    const int lane = threadIdx.x & 63;
+    const int wid = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int nh = a.Hq + 2 * a.Hkv;
+    const int rows = a.B * a.T;
+    if (wid >= rows * nh) return;
+    const int row = wid / nh, hh = wid - row * nh;
+    const int b = row / a.T, t = row - b * a.T;
+    bf16_t* src = (bf16_t*)a.qkv + (size_t)row * a.ld_qkv + (size_t)hh * a.D;
+    const int half = a.D >> 1;
+    const int slot = a.slot_of_batch ? a.slot_of_batch[b] : b;
+    const int tt = a.t_offset + (a.t_offset_of_batch ? a.t_offset_of_batch[b] : 0) + t;
+
+    if (hh >= a.Hq + a.Hkv) {  // V head -> transposed cache
+        const int h = hh - a.Hq - a.Hkv;
+        bf16_t* dst = (bf16_t*)a.vt_cache + (size_t)slot * a.vt_slot_stride + (size_t)h * a.vt_h_stride + tt;
+        for (int d = lane; d < a.D; d += 64) dst[(size_t)d * a.vt_d_stride] = src[d];
+        return;
+    }
+    const bool is_k = hh >= a.Hq;
+    bf16_t* dst = src;  // q (and k without a cache) rotate in place
+    if (is_k && a.k_cache)
+        dst = (bf16_t*)a.k_cache + (size_t)slot * a.k_slot_stride + (size_t)tt * a.k_t_stride +
+              (size_t)(hh - a.Hq) * a.k_h_stride;
+    if (a.rope_mode == 0) {
+        if (dst != src)
+            for (int d = lane; d < a.D; d += 64) dst[d] = src[d];
+        return;
+    }
+    int pos = a.positions ? a.positions[row] : t;
+    pos = pos < 0 ? 0 : (pos >= a.n_pos ? a.n_pos - 1 : pos);
+    const float* ct = a.cos_table + (size_t)pos * half;
+    const float* stb = a.sin_table + (size_t)pos * half;
+    for (int i = lane; i < half; i += 64) {
+        const float x1 = bf2f(src[i]), x2 = bf2f(src[i + half]);
+        float c = ct[i], s = stb[i], o1, o2;
+        if (a.rope_mode == 2) {  // HF rotate_half in bf16 arithmetic
+            c = bfround(c); s = bfround(s);
+            o1 = bfround(bfround(x1 * c) + bfround(-x2 * s));
+            o2 = bfround(bfround(x2 * c) + bfround(x1 * s));
+        } else {  // apply_rope (paligemma_with_expert.py:34-57): fp32, one rounding
+            o1 = x1 * c - x2 * s;
+            o2 = x2 * c + x1 * s;
+        }
+        dst[i] = f2bf(o1);
+        dst[i + half] = f2bf(o2);
+    }
+}
+hipError_t launch_rope_kv_write(const cover_rope_args* a, hipStream_t st) {
+    const long long waves = (long long)a->B * a->T * (a->Hq + 2 * a->Hkv);
+    if (waves <= 0) return hipSuccess;
+    if (!a->vt_cache || (a->D & 1)) return hipErrorInvalidValue;
+    if (a->rope_mode != 0 && (!a->cos_table || !a->sin_table)) return hipErrorInvalidValue;
+    const int blocks = (int)((waves + 3) / 4);
+    hipLaunchKernelGGL(rope_kv_write_k, dim3(blocks), dim3(256), 0, st, *a);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// gathers / copies / casts
+// ---------------------------------------------------------------------------------------------------
+__global__ void embed_gather_k(const bf16_t* __restrict__ table, int dim, const int64_t* __restrict__ ids, float scale,
+                               bf16_t* __restrict__ out, int ldo) {
+    const int i = blockIdx.x;
+    const bf16_t* src = table + (size_t)ids[i] * dim;
+    for (int c = threadIdx.x; c < (dim >> 3); c += blockDim.x) {
+        float v[8];
+        load_row8<false>(src, (size_t)c * 8, v);
+        if (scale != 1.0f) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] *= scale;
+        }
+        store_row8(out, (size_t)i * ldo + c * 8, v);
+    }
+}
+hipError_t launch_embed_gather(const bf16_t* table, int dim, const int64_t* ids, int n, float scale, bf16_t* out, int ldo,
+                               hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    if (dim % 8) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(embed_gather_k, dim3(n), dim3(128), 0, st, table, dim, ids, scale, out, ldo);
+    return hipGetLastError();
+}
+
+__global__ void patchify_k(cover_patchify_args a) {
+    const int gw = a.W / a.patch, gh = a.H / a.patch;
+    const int np = gw * gh;
+    const int row = blockIdx.x;  // img * np + p
+    const int img = row / np, p = row - img * np;
+    const int py0 = (p / gw) * a.patch, px0 = (p % gw) * a.patch;
+    const int kk = 3 * a.patch * a.patch;
+    bf16_t* o = (bf16_t*)a.out + (size_t)row * a.ld_out;
+    for (int k = threadIdx.x; k < a.ld_out; k += blockDim.x) {
+        float v = 0.f;
+        if (k < kk) {
+            const int c = k / (a.patch * a.patch), rem = k - c * a.patch * a.patch;
+            const int y = py0 + rem / a.patch, x = px0 + rem % a.patch;
+            float pix;
+            if (a.in_u8_hwc) pix = (float)((const uint8_t*)a.img)[(size_t)img * a.img_stride + ((size_t)y * a.W + x) * 3 + c];
+            else pix = ((const float*)a.img)[(size_t)img * a.img_stride + ((size_t)c * a.H + y) * a.W + x];
+            v = pix * a.mul[c] + a.add[c];
+        }
+        o[k] = f2bf(v);
+    }
+}
+hipError_t launch_patchify(const cover_patchify_args* a, hipStream_t st) {
+    const int np = (a->W / a->patch) * (a->H / a->patch);
+    if (a->n_img <= 0) return hipSuccess;
+    hipLaunchKernelGGL(patchify_k, dim3(a->n_img * np), dim3(256), 0, st, *a);
+    return hipGetLastError();
+}
+
+__global__ void copy_rows_k(const bf16_t* __restrict__ src, int lds_, bf16_t* __restrict__ dst, int ldd, int cols,
+                            const int* __restrict__ sidx, const int* __restrict__ didx) {
+    const int i = blockIdx.x;
+    const bf16_t* s = src + (size_t)(sidx ? sidx[i] : i) * lds_;
+    bf16_t* d = dst + (size_t)(didx ? didx[i] : i) * ldd;
+    if ((cols & 7) == 0 && ((((uintptr_t)s) | ((uintptr_t)d)) & 15) == 0) {
+        for (int c = threadIdx.x; c < (cols >> 3); c += blockDim.x) ((uint4*)d)[c] = ((const uint4*)s)[c];
+    } else {
+        for (int c = threadIdx.x; c < cols; c += blockDim.x) d[c] = s[c];
+    }
+}
+hipError_t launch_copy_rows_bf16(const bf16_t* src, int lds_, bf16_t* dst, int ldd, int rows, int cols,
+                                 const int* sidx, const int* didx, hipStream_t st) {
+    if (rows <= 0) return hipSuccess;
+    hipLaunchKernelGGL(copy_rows_k, dim3(rows), dim3(128), 0, st, src, lds_, dst, ldd, cols, sidx, didx);
+    return hipGetLastError();
+}
+
+__global__ void add_rows_k(bf16_t* __restrict__ x, int ldx, const bf16_t* __restrict__ add, int ld_add, int cols,
+                           int add_rows) {
+    const int r = blockIdx.x;
+    bf16_t* xr = x + (size_t)r * ldx;
+    const bf16_t* ar = add + (size_t)(r % add_rows) * ld_add;
+    for (int c = threadIdx.x; c < cols; c += blockDim.x) xr[c] = f2bf(bf2f(xr[c]) + bf2f(ar[c]));
+}
+hipError_t launch_add_bias_rows_bf16(bf16_t* x, int ldx, const bf16_t* add, int ld_add, int rows, int cols, int add_rows,
+                                     hipStream_t st) {
+    if (rows <= 0) return hipSuccess;
+    hipLaunchKernelGGL(add_rows_k, dim3(rows), dim3(256), 0, st, x, ldx, add, ld_add, cols, add_rows);
+    return hipGetLastError();
+}
+
+__global__ void scale_bf16_k(bf16_t* __restrict__ x, int ldx, int cols, float pre_div, float post_mul) {
+    bf16_t* xr = x + (size_t)blockIdx.x * ldx;
+    for (int c = threadIdx.x; c < cols; c += blockDim.x) {
+        float v = bf2f(xr[c]);
+        if (pre_div != 1.0f) v = bfround(v / pre_div);
+        xr[c] = f2bf(v * post_mul);
+    }
+}
+hipError_t launch_scale_bf16(bf16_t* x, int ldx, int rows, int cols, float pre_div, float post_mul, hipStream_t st) {
+    if (rows <= 0) return hipSuccess;
+    hipLaunchKernelGGL(scale_bf16_k, dim3(rows), dim3(256), 0, st, x, ldx, cols, pre_div, post_mul);
+    return hipGetLastError();
+}
+
+__global__ void cast_f2b_k(const float* __restrict__ x, int ldx, bf16_t* __restrict__ y, int ldy, int cols) {
+    for (int c = threadIdx.x; c < cols; c += blockDim.x)
+        y[(size_t)blockIdx.x * ldy + c] = f2bf(x[(size_t)blockIdx.x * ldx + c]);
+}
+__global__ void cast_b2f_k(const bf16_t* __restrict__ x, int ldx, float* __restrict__ y, int ldy, int cols) {
+    for (int c = threadIdx.x; c < cols; c += blockDim.x)
+        y[(size_t)blockIdx.x * ldy + c] = bf2f(x[(size_t)blockIdx.x * ldx + c]);
+}
+hipError_t launch_cast_f32_to_bf16(const float* x, int ldx, bf16_t* y, int ldy, int rows, int cols, hipStream_t st) {
+    if (rows <= 0) return hipSuccess;
+    hipLaunchKernelGGL(cast_f2b_k, dim3(rows), dim3(256), 0, st, x, ldx, y, ldy, cols);
+    return hipGetLastError();
+}
+hipError_t launch_cast_bf16_to_f32(const bf16_t* x, int ldx, float* y, int ldy, int rows, int cols, hipStream_t st) {
+    if (rows <= 0) return hipSuccess;
+    hipLaunchKernelGGL(cast_b2f_k, dim3(rows), dim3(256), 0, st, x, ldx, y, ldy, cols);
+    return hipGetLastError();
+}

@@ -1,0 +1,178 @@
+// Selection kernels: action-token decode head and the verifier's fuse + score + grouped arg-max (K20).
+// Index results must be bit-exact against the oracle, so every reduction that decides an index runs in a
+// fixed order with "first maximum wins" ties (torch.max / np.argmax semantics).
+#include "common.h"
+#include "kernels.h"
+
+// (value, index) arg-max with smallest-index tie break
+__device__ __forceinline__ void argmax_combine(float& v, int& i, float ov, int oi) {
+    if (ov > v || (ov == v && oi < i)) {
+        v = ov;
+        i = oi;
+    }
+}
+__device__ __forceinline__ void block_argmax(float& v, int& i, float* sv, int* si) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(v, o);
+        const int oi = __shfl_xor(i, o);
+        argmax_combine(v, i, ov, oi);
+    }
+    const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) {
+        sv[w] = v;
+        si[w] = i;
+    }
+    __syncthreads();
+    v = sv[0];
+    i = si[0];
+    for (int k = 1; k < nw; ++k) argmax_combine(v, i, sv[k], si[k]);
+}
+
+// one block per row
+__global__ __launch_bounds__(256) void token_select_k(cover_token_select_args a) {
+    __shared__ float sv[16];
+    __shared__ int si[16];
+    __shared__ float probs[4096];
+    const int row = blockIdx.x;
+    const float* lg = a.logits + (size_t)row * a.ld;
+    float v = -INFINITY;
+    int idx = 0x7fffffff;
+    for (int c = a.lo + threadIdx.x; c < a.hi; c += 256) argmax_combine(v, idx, lg[c], c);
+    block_argmax(v, idx, sv, si);
+    if (a.uniform == nullptr) {
+        if (threadIdx.x == 0) {
+            a.token_out[row] = idx;
+            if (a.logit_out) a.logit_out[row] = v;
+        }
+        return;
+    }
+    // inverse-CDF sampling over [lo, hi) (width <= 4096): p_i = exp((l_i - max) / T), sequential fp32 cumsum in
+    // index order, pick the first i with cumsum_i > u * total (the oracle does the same arithmetic in numpy).
+    const int n = a.hi - a.lo;
+    const float inv_t = 1.0f / a.temperature;
+    for (int c = threadIdx.x; c < n; c += 256) probs[c] = expf((lg[a.lo + c] - v) * inv_t);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float total = 0.f;
+        for (int c = 0; c < n; ++c) total += probs[c];
+        const float target = a.uniform[row] * total;
+        float cs = 0.f;
+        int pick = n - 1;
+        for (int c = 0; c < n; ++c) {
+            cs += probs[c];
+            if (cs > target) {
+                pick = c;
+                break;
+            }
+        }
+        a.token_out[row] = a.lo + pick;
+        if (a.logit_out) a.logit_out[row] = lg[a.lo + pick];
+    }
+}
+hipError_t launch_token_select(const cover_token_select_args* a, hipStream_t st) {
+    if (a->rows <= 0) return hipSuccess;
+    if (a->hi <= a->lo) return hipErrorInvalidValue;
+    if (a->uniform && (a->hi - a->lo > 4096 || !(a->temperature > 0.f))) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(token_select_k, dim3(a->rows), dim3(256), 0, st, *a);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K20 (efficient_ensemble_merged.py:404-448): mean over members -> renormalise -> IT . ACT^T -> [G, S] ->
+// arg-max of group means -> arg-max within the group. Single block (N <= 4096 candidates).
+// ---------------------------------------------------------------------------------------------------
+__device__ void group_argmax_dev(const float* scores, int N, int gs, int* result, float* best, float* gmean_s,
+                                 float* sv, int* si) {
+    const int G = N / gs;
+    for (int gi = threadIdx.x; gi < G; gi += blockDim.x) {
+        float s = 0.f;
+        for (int j = 0; j < gs; ++j) s += scores[gi * gs + j];
+        gmean_s[gi] = s / (float)gs;
+    }
+    __syncthreads();
+    float v = -INFINITY;
+    int idx = 0x7fffffff;
+    for (int gi = threadIdx.x; gi < G; gi += blockDim.x) argmax_combine(v, idx, gmean_s[gi], gi);
+    block_argmax(v, idx, sv, si);
+    const int bg = idx;
+    const float bgm = v;
+    float v2 = -INFINITY;
+    int i2 = 0x7fffffff;
+    for (int j = threadIdx.x; j < gs; j += blockDim.x) argmax_combine(v2, i2, scores[bg * gs + j], j);
+    block_argmax(v2, i2, sv, si);
+    if (threadIdx.x == 0) {
+        result[0] = bg * gs + i2;
+        result[1] = bg;
+        result[2] = i2;
+        result[3] = 0;
+        best[0] = v2;
+        best[1] = bgm;
+    }
+}
+
+__global__ __launch_bounds__(256) void score_select_k(cover_score_select_args a, float* fit_ws, float* fact_ws) {
+    __shared__ float red[16];
+    __shared__ float sv[16];
+    __shared__ int si[16];
+    __shared__ float gmean[4096];
+    const int dim = a.dim;
+    // fused image-text embedding
+    {
+        float q = 0.f;
+        for (int d = threadIdx.x; d < dim; d += 256) {
+            float s = 0.f;
+            for (int m = 0; m < a.n_members; ++m) s += a.it[(size_t)m * dim + d];
+            s /= (float)a.n_members;
+            fit_ws[d] = s;
+            q += s * s;
+        }
+        const float nrm = sqrtf(block_sum(q, red));
+        for (int d = threadIdx.x; d < dim; d += 256) fit_ws[d] = fit_ws[d] / nrm;
+    }
+    __syncthreads();
+    // per candidate: fused action embedding + score (one wave per candidate)
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int n = w; n < a.N; n += 4) {
+        float q = 0.f;
+        for (int d = lane; d < dim; d += 64) {
+            float s = 0.f;
+            for (int m = 0; m < a.n_members; ++m) s += a.act[((size_t)m * a.N + n) * dim + d];
+            s /= (float)a.n_members;
+            fact_ws[(size_t)n * dim + d] = s;
+            q += s * s;
+        }
+        const float nrm = sqrtf(wave_sum(q));
+        float dot = 0.f;
+        for (int d = lane; d < dim; d += 64) {
+            const float f = fact_ws[(size_t)n * dim + d] / nrm;
+            fact_ws[(size_t)n * dim + d] = f;
+            dot += fit_ws[d] * f;
+        }
+        dot = wave_sum(dot);
+        if (lane == 0) a.scores_out[n] = dot;
+    }
+    __syncthreads();
+    __threadfence_block();
+    group_argmax_dev(a.scores_out, a.N, a.group_size, a.result_out, a.best_out, gmean, sv, si);
+}
+hipError_t launch_score_select(const cover_score_select_args* a, hipStream_t st) {
+    if (a->N <= 0 || a->group_size <= 0 || a->N % a->group_size != 0 || a->N / a->group_size > 4096)
+        return hipErrorInvalidValue;
+    if (!a->fused_it_out || !a->fused_act_out) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(score_select_k, dim3(1), dim3(256), 0, st, *a, a->fused_it_out, a->fused_act_out);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void group_argmax_k(const float* scores, int N, int gs, int* result, float* best) {
+    __shared__ float sv[16];
+    __shared__ int si[16];
+    __shared__ float gmean[4096];
+    group_argmax_dev(scores, N, gs, result, best, gmean, sv, si);
+}
+hipError_t launch_group_argmax(const float* scores, int N, int gs, int* result, float* best, hipStream_t st) {
+    if (N <= 0 || gs <= 0 || N % gs != 0 || N / gs > 4096) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(group_argmax_k, dim3(1), dim3(256), 0, st, scores, N, gs, result, best);
+    return hipGetLastError();
+}

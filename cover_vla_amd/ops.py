@@ -1,0 +1,425 @@
+"""Tensor-level wrappers over the C ABI (include/cover_hip.h).
+
+PyTorch-ROCm is plumbing here: it owns device memory and the stream; every arithmetic call below goes through
+libcover_hip.so. Nothing in this module computes on the CPU or through torch kernels.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional, Sequence
+
+import torch
+
+from . import _lib as L
+
+ACT = {"none": 0, "gelu_tanh": 1, "gelu_erf": 2, "silu": 3, "relu": 4}
+MASK_LEN, MASK_CAUSAL, MASK_VISLEN = 0, 1, 2
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _chk_dev(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise L.CoverError("cover_vla_amd ops need device tensors: there is no CPU path")
+
+
+# ------------------------------------------------------------------------------------------------ GEMM
+@dataclass
+class PackedLinear:
+    """nn.Linear weight in the MFMA fragment-major layout (+ fp32 bias)."""
+    wp: torch.Tensor            # packed bf16 storage
+    N: int                      # rows of the packed matrix (2*mlp for GLU)
+    K: int
+    bias: Optional[torch.Tensor] = None   # fp32 [N]
+    glu: bool = False
+
+    @property
+    def n_out(self) -> int:
+        return self.N // 2 if self.glu else self.N
+
+    @property
+    def kp(self) -> int:
+        return (self.K + 127) // 128 * 128
+
+
+def pack_linear(weight: torch.Tensor, bias: Optional[torch.Tensor] = None, glu: bool = False) -> PackedLinear:
+    """weight: [N, K] (nn.Linear layout) on the device; for glu=True weight = cat([gate, up], 0)."""
+    _chk_dev(weight)
+    w = weight.to(torch.bfloat16).contiguous()
+    N, K = w.shape
+    h = L.lib()
+    nbytes = h.cover_packed_weight_bytes(N, K)
+    wp = torch.empty(nbytes // 2, dtype=torch.bfloat16, device=w.device)
+    L.check(h.cover_pack_weight_bf16(w.data_ptr(), K, N, K, wp.data_ptr(), 1 if glu else 0, _stream()), "pack_weight")
+    b = None if bias is None else bias.detach().to(torch.float32).contiguous().to(w.device)
+    return PackedLinear(wp, N, K, b, glu)
+
+
+def gemm_workspace(M: int, N: int, K: int, device) -> Optional[torch.Tensor]:
+    n = L.lib().cover_gemm_workspace_bytes(M, N, K)
+    return torch.empty(max(n, 4) // 4, dtype=torch.float32, device=device) if n else None
+
+
+def gemm(a: torch.Tensor, lin: PackedLinear, *, act: str = "none", residual: Optional[torch.Tensor] = None,
+         layer_scale: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, out_f32: bool = False,
+         out_scale: float = 1.0, variant: int = 0, ws: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[M, n_out] = epi(a[M, K] @ W^T). `a` is bf16 with row stride >= padded K (zero padded)."""
+    _chk_dev(a, residual, out)
+    assert a.dtype == torch.bfloat16 and a.dim() == 2 and a.stride(1) == 1
+    M = a.shape[0]
+    h = L.lib()
+    if out is None:
+        out = torch.empty(M, lin.n_out, dtype=torch.float32 if out_f32 else torch.bfloat16, device=a.device)
+    e = L.GemmEpi()
+    e.bias = _ptr(lin.bias)
+    e.residual = _ptr(residual)
+    e.ld_residual = residual.stride(0) if residual is not None else 0
+    e.residual_f32 = 1 if (residual is not None and residual.dtype == torch.float32) else 0
+    e.layer_scale = _ptr(layer_scale)
+    e.act = ACT[act]
+    e.glu = 1 if lin.glu else 0
+    e.out_f32 = 1 if out.dtype == torch.float32 else 0
+    e.out_scale = out_scale
+    if ws is None and (variant == 3 or (variant == 0 and M <= 64)):
+        ws = gemm_workspace(M, lin.N, lin.K, a.device)
+    L.check(h.cover_gemm_bf16(a.data_ptr(), a.stride(0), lin.wp.data_ptr(), out.data_ptr(), out.stride(0), M, lin.N,
+                              lin.K, C.byref(e), _ptr(ws), ws.numel() * 4 if ws is not None else 0, variant,
+                              _stream()), "gemm_bf16")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ attention
+@dataclass
+class Segment:
+    k: torch.Tensor                 # any bf16 tensor; strides given explicitly (elements)
+    vt: torch.Tensor
+    k_strides: Sequence[int]        # (slot, t, h)
+    vt_strides: Sequence[int]       # (slot, h, d)
+    length: int = 0
+    len_of_batch: Optional[torch.Tensor] = None   # int32 [B]
+    slot_of_batch: Optional[torch.Tensor] = None  # int32 [B]
+    mask: int = MASK_LEN
+    causal_offset: int = 0
+    vis_len: Optional[torch.Tensor] = None        # int32 [Tq]
+    k_offset: int = 0               # element offsets added to the base pointers
+    vt_offset: int = 0
+
+
+def fill_segment(s: L.KvSegment, seg: Segment) -> None:
+    s.k = seg.k.data_ptr() + 2 * seg.k_offset
+    s.vt = seg.vt.data_ptr() + 2 * seg.vt_offset
+    s.k_slot_stride, s.k_t_stride, s.k_h_stride = seg.k_strides
+    s.vt_slot_stride, s.vt_h_stride, s.vt_d_stride = seg.vt_strides
+    s.slot_of_batch = _ptr(seg.slot_of_batch)
+    s.len_of_batch = _ptr(seg.len_of_batch)
+    s.vis_len = _ptr(seg.vis_len)
+    s.len = seg.length
+    s.mask_mode = seg.mask
+    s.causal_offset = seg.causal_offset
+
+
+def attention(q: torch.Tensor, q_strides: Sequence[int], out: torch.Tensor, o_strides: Sequence[int], B: int, Tq: int,
+              Hq: int, Hkv: int, D: int, scale: float, segments: Sequence[Segment]) -> torch.Tensor:
+    _chk_dev(q, out)
+    a = L.AttnArgs()
+    a.q, a.out = q.data_ptr(), out.data_ptr()
+    a.q_b_stride, a.q_t_stride, a.q_h_stride = q_strides
+    a.o_b_stride, a.o_t_stride, a.o_h_stride = o_strides
+    a.B, a.Tq, a.Hq, a.Hkv, a.D, a.scale = B, Tq, Hq, Hkv, D, scale
+    a.n_seg = len(segments)
+    for i, sg in enumerate(segments):
+        fill_segment(a.seg[i], sg)
+    L.check(L.lib().cover_attention_bf16(C.byref(a), _stream()), "attention_bf16")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ row kernels
+def layernorm(x, w, b, eps, out=None):
+    _chk_dev(x, w)
+    out = torch.empty_like(x) if out is None else out
+    L.check(L.lib().cover_layernorm_bf16(x.data_ptr(), x.stride(0), w.data_ptr(), _ptr(b), out.data_ptr(), out.stride(0),
+                                         x.shape[0], x.shape[1], eps, _stream()), "layernorm_bf16")
+    return out
+
+
+def rmsnorm(x, w, eps, w_offset=0.0, style=0, out=None):
+    _chk_dev(x, w)
+    if out is None:
+        out = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    L.check(L.lib().cover_rmsnorm_bf16(x.data_ptr(), 1 if x.dtype == torch.float32 else 0, x.stride(0), _ptr(w), w_offset,
+                                       style, out.data_ptr(), out.stride(0), x.shape[0], x.shape[1], eps, _stream()),
+            "rmsnorm_bf16")
+    return out
+
+
+def rope_kv_write(qkv, B, T, Hq, Hkv, D, *, positions=None, cos=None, sin=None, rope_mode=0, k_cache=None,
+                  k_strides=(0, 0, 0), k_offset=0, vt_cache=None, vt_strides=(0, 0, 0), vt_offset=0, slot_of_batch=None,
+                  t_offset_of_batch=None, t_offset=0):
+    _chk_dev(qkv, vt_cache)
+    a = L.RopeArgs()
+    a.qkv, a.ld_qkv = qkv.data_ptr(), qkv.stride(0)
+    a.B, a.T, a.Hq, a.Hkv, a.D = B, T, Hq, Hkv, D
+    a.positions = _ptr(positions)
+    a.cos_table, a.sin_table = _ptr(cos), _ptr(sin)
+    a.n_pos = cos.shape[0] if cos is not None else 0
+    a.rope_mode = rope_mode
+    a.k_cache = None if k_cache is None else k_cache.data_ptr() + 2 * k_offset
+    a.k_slot_stride, a.k_t_stride, a.k_h_stride = k_strides
+    a.vt_cache = vt_cache.data_ptr() + 2 * vt_offset
+    a.vt_slot_stride, a.vt_h_stride, a.vt_d_stride = vt_strides
+    a.slot_of_batch = _ptr(slot_of_batch)
+    a.t_offset_of_batch = _ptr(t_offset_of_batch)
+    a.t_offset = t_offset
+    L.check(L.lib().cover_rope_kv_write(C.byref(a), _stream()), "rope_kv_write")
+
+
+def embed_gather(table, ids, scale=1.0, out=None):
+    _chk_dev(table, ids)
+    n, dim = ids.numel(), table.shape[1]
+    if out is None:
+        out = torch.empty(n, dim, dtype=torch.bfloat16, device=table.device)
+    L.check(L.lib().cover_embed_gather(table.data_ptr(), dim, ids.data_ptr(), n, scale, out.data_ptr(), out.stride(0),
+                                       _stream()), "embed_gather")
+    return out
+
+
+def patchify(img, patch, mul, add, ld_out, out=None):
+    """img: uint8 [n,H,W,3] or fp32 [n,3,H,W] -> bf16 [n*nP, ld_out] rows (k = c*p*p + py*p + px)."""
+    _chk_dev(img)
+    a = L.PatchifyArgs()
+    if img.dtype == torch.uint8:
+        n, H, W, _ = img.shape
+        a.in_u8_hwc = 1
+    else:
+        assert img.dtype == torch.float32
+        n, _, H, W = img.shape
+        a.in_u8_hwc = 0
+    img = img.contiguous()
+    a.img, a.H, a.W, a.patch, a.n_img, a.img_stride = img.data_ptr(), H, W, patch, n, 3 * H * W
+    for i in range(3):
+        a.mul[i], a.add[i] = float(mul[i]), float(add[i])
+    rows = n * (H // patch) * (W // patch)
+    if out is None:
+        out = torch.empty(rows, ld_out, dtype=torch.bfloat16, device=img.device)
+    a.out, a.ld_out = out.data_ptr(), out.stride(0)
+    L.check(L.lib().cover_patchify(C.byref(a), _stream()), "patchify")
+    return out
+
+
+def copy_rows(src, dst, rows, cols, src_idx=None, dst_idx=None):
+    _chk_dev(src, dst)
+    L.check(L.lib().cover_copy_rows_bf16(src.data_ptr(), src.stride(0), dst.data_ptr(), dst.stride(0), rows, cols,
+                                         _ptr(src_idx), _ptr(dst_idx), _stream()), "copy_rows")
+
+
+def add_rows(x, add):
+    _chk_dev(x, add)
+    L.check(L.lib().cover_add_rows_bf16(x.data_ptr(), x.stride(0), add.data_ptr(), add.stride(0), x.shape[0], x.shape[1],
+                                        add.shape[0], _stream()), "add_rows")
+    return x
+
+
+def scale_bf16(x, pre_div, post_mul):
+    _chk_dev(x)
+    L.check(L.lib().cover_scale_bf16(x.data_ptr(), x.stride(0), x.shape[0], x.shape[1], pre_div, post_mul, _stream()),
+            "scale_bf16")
+    return x
+
+
+def cast_f32_to_bf16(x, out=None):
+    _chk_dev(x)
+    if out is None:
+        out = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    L.check(L.lib().cover_cast_f32_to_bf16(x.data_ptr(), x.stride(0), out.data_ptr(), out.stride(0), x.shape[0],
+                                           x.shape[1], _stream()), "cast")
+    return out
+
+
+def cast_bf16_to_f32(x, out=None):
+    _chk_dev(x)
+    if out is None:
+        out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    L.check(L.lib().cover_cast_bf16_to_f32(x.data_ptr(), x.stride(0), out.data_ptr(), out.stride(0), x.shape[0],
+                                           x.shape[1], _stream()), "cast")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ fp32 kernels
+def gemm_f32(a, b, *, bias=None, act="none", alpha=1.0, residual=None, out=None, b_is_kn=False, batch=1,
+             a_bs=0, b_bs=0, c_bs=0, M=None, N=None, K=None):
+    """C[m,n] = residual + alpha*act(sum_k a[m,k] b[n,k] + bias[n]). b_is_kn: b given as [K, N] (k-major)."""
+    _chk_dev(a, b)
+    g = L.GemmF32Args()
+    M = a.shape[-2] if M is None else M
+    K = a.shape[-1] if K is None else K
+    if N is None:
+        N = b.shape[-1] if b_is_kn else b.shape[-2]
+    g.A, g.a_row_stride, g.a_k_stride = a.data_ptr(), a.stride(-2), a.stride(-1)
+    g.B = b.data_ptr()
+    if b_is_kn:
+        g.b_row_stride, g.b_k_stride = b.stride(-1), b.stride(-2)
+    else:
+        g.b_row_stride, g.b_k_stride = b.stride(-2), b.stride(-1)
+    if out is None:
+        shape = (batch, M, N) if batch > 1 else (M, N)
+        out = torch.empty(shape, dtype=torch.float32, device=a.device)
+    g.C, g.c_row_stride = out.data_ptr(), out.stride(-2)
+    g.bias, g.residual = _ptr(bias), _ptr(residual)
+    g.ld_residual = residual.stride(-2) if residual is not None else 0
+    g.M, g.N, g.K, g.act, g.alpha = M, N, K, ACT[act], alpha
+    g.batch, g.a_batch_stride, g.b_batch_stride, g.c_batch_stride = batch, a_bs, b_bs, c_bs
+    L.check(L.lib().cover_gemm_f32(C.byref(g), _stream()), "gemm_f32")
+    return out
+
+
+def layernorm_f32(x, w, b, eps=1e-5, out=None):
+    _chk_dev(x)
+    out = torch.empty_like(x) if out is None else out
+    L.check(L.lib().cover_layernorm_f32(x.data_ptr(), x.stride(0), _ptr(w), _ptr(b), out.data_ptr(), out.stride(0),
+                                        x.shape[0], x.shape[1], eps, _stream()), "layernorm_f32")
+    return out
+
+
+def softmax_rows_f32(x, scale=1.0):
+    _chk_dev(x)
+    L.check(L.lib().cover_softmax_rows_f32(x.data_ptr(), x.stride(0), x.shape[0], x.shape[1], scale, _stream()), "softmax")
+    return x
+
+
+def l2norm_rows_f32(x, out=None):
+    _chk_dev(x)
+    out = torch.empty_like(x) if out is None else out
+    L.check(L.lib().cover_l2norm_rows_f32(x.data_ptr(), x.stride(0), out.data_ptr(), out.stride(0), x.shape[0],
+                                          x.shape[1], _stream()), "l2norm")
+    return out
+
+
+def add_f32(a, b, out=None):
+    _chk_dev(a, b)
+    out = torch.empty_like(a) if out is None else out
+    L.check(L.lib().cover_add_f32(a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), out.data_ptr(), out.stride(0),
+                                  a.shape[0], a.shape[1], b.shape[0], _stream()), "add_f32")
+    return out
+
+
+def mha_f32(q, k, v, B, Tq, Tk, H, Dh, q_strides, k_strides, v_strides, key_pad=None, out=None, o_strides=None):
+    """strides = (batch, token) in elements; heads are contiguous blocks of Dh inside a token row."""
+    _chk_dev(q, k, v)
+    if out is None:
+        out = torch.empty(B, Tq, H * Dh, dtype=torch.float32, device=q.device)
+        o_strides = (Tq * H * Dh, H * Dh)
+    a = L.MhaF32Args()
+    a.q, a.q_b_stride, a.q_t_stride = q.data_ptr(), q_strides[0], q_strides[1]
+    a.k, a.k_b_stride, a.k_t_stride = k.data_ptr(), k_strides[0], k_strides[1]
+    a.v, a.v_b_stride, a.v_t_stride = v.data_ptr(), v_strides[0], v_strides[1]
+    a.out, a.o_b_stride, a.o_t_stride = out.data_ptr(), o_strides[0], o_strides[1]
+    a.key_pad = _ptr(key_pad)
+    a.B, a.Tq, a.Tk, a.H, a.Dh, a.scale = B, Tq, Tk, H, Dh, Dh ** -0.5
+    L.check(L.lib().cover_mha_f32(C.byref(a), _stream()), "mha_f32")
+    return out
+
+
+def masked_mean_f32(x, pad, B, T, D):
+    _chk_dev(x)
+    out = torch.empty(B, D, dtype=torch.float32, device=x.device)
+    L.check(L.lib().cover_masked_mean_f32(x.data_ptr(), _ptr(pad), out.data_ptr(), B, T, D, _stream()), "masked_mean")
+    return out
+
+
+def sincos_time_embed(time, dim, min_period, max_period, out=None):
+    _chk_dev(time)
+    B = time.shape[0]
+    if out is None:
+        out = torch.empty(B, dim, dtype=torch.bfloat16, device=time.device)
+    L.check(L.lib().cover_sincos_time_embed(time.data_ptr(), B, dim, min_period, max_period, out.data_ptr(), out.stride(0),
+                                            _stream()), "sincos_time_embed")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ selection
+def token_select(logits, lo, hi, uniform=None, temperature=1.0):
+    _chk_dev(logits)
+    rows = logits.shape[0]
+    tok = torch.empty(rows, dtype=torch.int64, device=logits.device)
+    lg = torch.empty(rows, dtype=torch.float32, device=logits.device)
+    a = L.TokenSelectArgs()
+    a.logits, a.ld, a.rows, a.lo, a.hi = logits.data_ptr(), logits.stride(0), rows, lo, hi
+    a.uniform, a.temperature = _ptr(uniform), temperature
+    a.token_out, a.logit_out = tok.data_ptr(), lg.data_ptr()
+    L.check(L.lib().cover_token_select(C.byref(a), _stream()), "token_select")
+    return tok, lg
+
+
+def score_select(it, act, group_size):
+    """it [members, dim], act [members, N, dim] fp32 -> (scores [N], result int32[4], best f32[2], fused_it, fused_act)."""
+    _chk_dev(it, act)
+    m, N, dim = act.shape
+    dev = it.device
+    scores = torch.empty(N, dtype=torch.float32, device=dev)
+    result = torch.empty(4, dtype=torch.int32, device=dev)
+    best = torch.empty(2, dtype=torch.float32, device=dev)
+    fit = torch.empty(dim, dtype=torch.float32, device=dev)
+    fact = torch.empty(N, dim, dtype=torch.float32, device=dev)
+    a = L.ScoreSelectArgs()
+    a.it, a.act = it.contiguous().data_ptr(), act.contiguous().data_ptr()
+    a.n_members, a.N, a.dim, a.group_size = m, N, dim, group_size
+    a.scores_out, a.result_out, a.best_out = scores.data_ptr(), result.data_ptr(), best.data_ptr()
+    a.fused_it_out, a.fused_act_out = fit.data_ptr(), fact.data_ptr()
+    L.check(L.lib().cover_score_select(C.byref(a), _stream()), "score_select")
+    return scores, result, best, fit, fact
+
+
+def group_argmax(scores, group_size):
+    _chk_dev(scores)
+    result = torch.empty(4, dtype=torch.int32, device=scores.device)
+    best = torch.empty(2, dtype=torch.float32, device=scores.device)
+    L.check(L.lib().cover_group_argmax(scores.data_ptr(), scores.numel(), group_size, result.data_ptr(), best.data_ptr(),
+                                       _stream()), "group_argmax")
+    return result, best
+
+
+# ------------------------------------------------------------------------------------------------ graphs / timers
+class Graph:
+    """hipGraph captured from whatever runs on the current stream inside the `with` block."""
+
+    def __init__(self):
+        self.handle = C.c_void_p()
+        self.stream = None
+
+    def __enter__(self):
+        self.stream = _stream()
+        L.check(L.lib().cover_graph_begin(self.stream), "graph_begin")
+        return self
+
+    def __exit__(self, et, ev, tb):
+        rc = L.lib().cover_graph_end(self.stream, C.byref(self.handle))
+        if et is None:
+            L.check(rc, "graph_end")
+        return False
+
+    def launch(self):
+        L.check(L.lib().cover_graph_launch(self.handle, _stream()), "graph_launch")
+
+
+class Timer:
+    """hipEvent pair recorded on the current stream."""
+
+    def __init__(self):
+        self.h = C.c_void_p()
+        L.check(L.lib().cover_timer_create(C.byref(self.h)), "timer_create")
+
+    def start(self):
+        L.check(L.lib().cover_timer_start(self.h, _stream()), "timer_start")
+
+    def stop(self) -> float:
+        ms = C.c_float()
+        L.check(L.lib().cover_timer_stop(self.h, _stream(), C.byref(ms)), "timer_stop")
+        return ms.value

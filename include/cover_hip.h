@@ -1,0 +1,346 @@
+/*
+ * libcover_hip — C ABI of the MI355X (gfx950) kernels behind CoVer's candidate-sampling-and-verification
+ * hot path.
+ *
+ * The reference (cover-vla/cover-vla) has NO FFI / plugin interface: its boundary is two Python classes
+ * (PI0Policy.select_action, lerobot_custom/lerobot/common/policies/pi0/modeling_pi0.py:263-307, and
+ * EfficientEnsembleMerged.compute_max_similarity_scores_batch,
+ * bridge_verifier/ensemble_eval/efficient_ensemble_merged.py:309-454) whose arithmetic is eager PyTorch.
+ * This header is therefore the set of entry points a ctypes binding UNDER those two classes needs
+ * (INTEGRATION.md shows the binding); every entry cites the reference arithmetic it replaces.
+ *
+ * Conventions
+ *   - every pointer is a raw DEVICE pointer unless the name ends in _host; the caller owns all buffers
+ *   - bf16 tensors are uint16 storage ("bf16" in comments); fp32 tensors are float
+ *   - leading dimensions / strides are in ELEMENTS
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*); none synchronises or allocates
+ *   - return value: 0 = ok, negative = cover_status; cover_last_error() gives the message (thread-local)
+ *   - not thread-safe per stream; one process per GPU
+ */
+#ifndef COVER_HIP_H
+#define COVER_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define COVER_ABI_VERSION 1
+
+enum cover_status { COVER_OK = 0, COVER_EINVAL = -1, COVER_EHIP = -2, COVER_EWORKSPACE = -3, COVER_EUNSUPPORTED = -4 };
+enum cover_act { COVER_ACT_NONE = 0, COVER_ACT_GELU_TANH = 1, COVER_ACT_GELU_ERF = 2, COVER_ACT_SILU = 3, COVER_ACT_RELU = 4 };
+
+int cover_abi_version(void);
+const char* cover_last_error(void);
+/* number of devices visible / properties of device `dev` (CU count, total memory): plumbing for bench + tests */
+int cover_device_info(int dev, int* n_cu, size_t* total_mem, char* name, int name_len);
+
+/* ------------------------------------------------------------------------------------------------
+ * bf16 GEMM on MFMA (v_mfma_f32_16x16x32_bf16), fp32 accumulate.
+ * Replaces every nn.Linear on the path: q/k/v/o projections and gated MLPs
+ * (paligemma_with_expert.py:273-276,327-341), SigLIP/DINOv2/SigLIP2 ViT linears (un-vendored HF/timm
+ * modules called at paligemma_with_expert.py:229-230 and finetune_trajectory_bridge_ddp.py:314-316),
+ * multimodal projector, lm_head.
+ *
+ * Weights are packed once (cover_pack_weight_bf16) into the MFMA fragment-major layout
+ *   Wp[n/16][k/32][lane = (n%16) + 16*((k%32)/8)][8]        (1 KiB per 16x32 block, K padded to Kpad)
+ * so that both the LDS-tiled kernel and the weight-streaming (M <= 64) kernel read 1 KiB fully
+ * coalesced per wave instruction.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct cover_gemm_epi {
+    const float* bias;        /* [N] fp32 or NULL */
+    const void* residual;     /* bf16 [M, ld_residual] or NULL: out = residual + (layer_scale *) val */
+    const float* layer_scale; /* [N] fp32 or NULL (DINOv2 LayerScale) */
+    int ld_residual;
+    int residual_f32;         /* 1: residual is fp32 [M, ld_residual] (pi0 expert layer 0: the un-rounded suffix
+                                 embedding is the residual, paligemma_with_expert.py:319-332) */
+    int act;                  /* cover_act, applied after bias */
+    int glu;                  /* 1: weight rows interleaved gate/up in 16-row blocks (pack with glu_interleave=1):
+                                 out[m, j] = act(gate[m, j]) * up[m, j], output has N/2 columns */
+    int out_f32;              /* 0: bf16 output, 1: fp32 output */
+    float out_scale;          /* final multiply (1.0f = none) */
+} cover_gemm_epi;
+
+/* bytes needed for the packed form of an [N, K] weight (K padded to a multiple of 128, N to 16) */
+size_t cover_packed_weight_bytes(int N, int K);
+int cover_packed_k(int K);
+/* W: bf16 [N, ldw] row-major (PyTorch nn.Linear layout) -> Wp. glu_interleave=1 expects W = [gate(N/2 rows); up(N/2 rows)]
+ * and emits 16-row blocks gate0,up0,gate1,up1,... */
+int cover_pack_weight_bf16(const void* W, int ldw, int N, int K, void* Wp, int glu_interleave, void* stream);
+
+/* variant: 0 = auto, 1 = LDS-tiled with async global->LDS (global_load_lds), 2 = LDS-tiled register-staged,
+ *          3 = weight-streaming split-K (requires M <= 64).  K = TRUE reduction length (A has >= cover_packed_k(K)
+ *          readable, zero-padded columns when K is not a multiple of 128).
+ * splitk_ws: fp32 scratch (cover_gemm_workspace_bytes) used by variant 3. */
+size_t cover_gemm_workspace_bytes(int M, int N, int K);
+int cover_gemm_bf16(const void* A, int lda, const void* Wp, void* C, int ldc, int M, int N, int K,
+                    const cover_gemm_epi* epi, void* splitk_ws, size_t splitk_ws_bytes, int variant, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Flash-style attention on MFMA, fp32 softmax, over up to 3 KV segments per query row.
+ * Replaces eager_attention_forward (paligemma_with_expert.py:376-434: fp32 QK^T, scale after the matmul,
+ * masked positions get zero probability, probabilities rounded to bf16 before PV) and the HF/timm ViT
+ * attention inside the towers. Masks are generated from lengths, never materialised
+ * (make_att_2d_masks, modeling_pi0.py:98-128).
+ * K is read row-major [slot][t][h][d]; V is read TRANSPOSED [slot][h][d][t] (written by cover_rope_kv_write),
+ * so both MFMA operands are 16-byte contiguous per lane with no LDS transpose.
+ * ------------------------------------------------------------------------------------------------ */
+enum cover_mask_mode { COVER_MASK_LEN = 0, COVER_MASK_CAUSAL = 1, COVER_MASK_VISLEN = 2 };
+typedef struct cover_kv_segment {
+    const void* k;  /* bf16 */
+    const void* vt; /* bf16, t contiguous */
+    long long k_slot_stride, k_t_stride, k_h_stride;
+    long long vt_slot_stride, vt_h_stride, vt_d_stride;
+    const int* slot_of_batch; /* [B] or NULL (slot = b) */
+    const int* len_of_batch;  /* [B] or NULL (use len) */
+    const int* vis_len;       /* [Tq] for COVER_MASK_VISLEN: keys [0, vis_len[t]) visible to query token t */
+    int len;
+    int mask_mode;
+    int causal_offset;        /* COVER_MASK_CAUSAL: key j visible iff j <= t + causal_offset */
+    int _pad;
+} cover_kv_segment;
+
+typedef struct cover_attn_args {
+    const void* q; /* bf16 [B][Tq][Hq][D] via strides */
+    void* out;     /* bf16 [B][Tq][Hq][D] via strides */
+    long long q_b_stride, q_t_stride, q_h_stride;
+    long long o_b_stride, o_t_stride, o_h_stride;
+    int B, Tq, Hq, Hkv, D;
+    float scale;
+    int n_seg;
+    int _pad;
+    cover_kv_segment seg[3];
+} cover_attn_args;
+int cover_attention_bf16(const cover_attn_args* args, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Row kernels (HBM-bound, wave-shuffle reductions, 16-byte vector access)
+ * ------------------------------------------------------------------------------------------------ */
+/* nn.LayerNorm in fp32 math, bf16 in/out (ViT blocks) */
+int cover_layernorm_bf16(const void* x, int ldx, const float* w, const float* b, void* y, int ldy, int rows, int dim,
+                         float eps, void* stream);
+/* RMSNorm: y = x * rsqrt(mean(x^2)+eps) * (w_offset + w); Gemma uses w_offset=1 (HF GemmaRMSNorm, called at
+ * paligemma_with_expert.py:268,335,355), Llama w_offset=0. */
+/* style 0: y = bf16(x*rstd*(w_offset+w)) (Gemma); style 1: y = bf16(w * bf16(x*rstd)) (HF LlamaRMSNorm).
+ * x_f32 = 1: x is fp32 (pi0 suffix embeddings enter the expert's first norm un-rounded). */
+int cover_rmsnorm_bf16(const void* x, int x_f32, int ldx, const float* w, float w_offset, int style, void* y, int ldy,
+                       int rows, int dim, float eps, void* stream);
+
+/* RoPE + KV placement. Replaces apply_rope (paligemma_with_expert.py:34-57) and the dict/concat KV cache
+ * (:288-308) with in-place appends into a static cache. qkv rows = [B*T][ (Hq+2*Hkv)*D ].
+ * cos/sin: fp32 [n_pos][D/2] tables built on the host with the reference's own expressions.
+ * rope_mode 0: no rotation (ViT: only V^T is produced); 1: fp32 rotate, one rounding (pi0);
+ *           2: bf16 cos/sin and bf16 intermediate roundings (HF Llama rotate_half arithmetic). */
+typedef struct cover_rope_args {
+    void* qkv; int ld_qkv;       /* bf16; q is rotated IN PLACE */
+    int B, T, Hq, Hkv, D;
+    const int* positions;        /* [B*T] position ids or NULL */
+    const float* cos_table; const float* sin_table; int n_pos;
+    int rope_mode;
+    void* k_cache;               /* bf16 [slot][t][Hkv][D] or NULL (leave K in the qkv buffer, rotated in place) */
+    long long k_slot_stride, k_t_stride, k_h_stride;
+    void* vt_cache;              /* bf16 [slot][Hkv][D][t_cap] (required) */
+    long long vt_slot_stride, vt_h_stride, vt_d_stride;
+    const int* slot_of_batch;    /* [B] or NULL */
+    const int* t_offset_of_batch;/* [B] or NULL */
+    int t_offset;
+    int _pad;
+} cover_rope_args;
+int cover_rope_kv_write(const cover_rope_args* args, void* stream);
+
+/* token embedding gather (K4: modeling_pi0.py:549-553): out[i] = bf16(table[ids[i]] * scale) */
+int cover_embed_gather(const void* table, int dim, const int64_t* ids, int n, float scale, void* out, int ldo,
+                       void* stream);
+
+/* image -> patch rows for the patch-embedding GEMM (im2col-free conv, K1): out[p][c*ps*ps+py*ps+px] =
+ * bf16(pix*mul[c]+add[c]), zero padded to ld_out columns. in_u8_hwc=1: uint8 [H][W][3]; 0: fp32 [3][H][W] */
+typedef struct cover_patchify_args {
+    const void* img; int in_u8_hwc; int H, W, patch; int n_img; long long img_stride;
+    float mul[3]; float add[3];
+    void* out; int ld_out;
+} cover_patchify_args;
+int cover_patchify(const cover_patchify_args* args, void* stream);
+
+/* row gather/scatter copy: dst[dst_row_idx[i]] = src[src_row_idx[i]] (NULL idx = identity) */
+int cover_copy_rows_bf16(const void* src, int ld_src, void* dst, int ld_dst, int rows, int cols, const int* src_row_idx,
+                         const int* dst_row_idx, void* stream);
+/* x[r] += add[r % add_rows] (position embeddings) with bf16 rounding */
+int cover_add_rows_bf16(void* x, int ldx, const void* add, int ld_add, int rows, int cols, int add_rows, void* stream);
+/* x = bf16(bf16(x / pre_div) * post_mul): the image-token double rounding of modeling_pi0.py:534-538 (Appendix A.3) */
+int cover_scale_bf16(void* x, int ldx, int rows, int cols, float pre_div, float post_mul, void* stream);
+int cover_cast_f32_to_bf16(const float* x, int ldx, void* y, int ldy, int rows, int cols, void* stream);
+int cover_cast_bf16_to_f32(const void* x, int ldx, float* y, int ldy, int rows, int cols, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * fp32 kernels: verifier heads (model.py:7-112, efficient_ensemble_merged.py:194-247) and the pi0 suffix
+ * projections (modeling_pi0.py:569-629,748-751), which the reference keeps in fp32.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct cover_gemm_f32_args {
+    const float* A; long long a_row_stride, a_k_stride;   /* A[m,k] */
+    const float* B; long long b_row_stride, b_k_stride;   /* B[n,k]  (nn.Linear weight: row stride K, k stride 1) */
+    float* C; long long c_row_stride;                     /* C[m,n] */
+    const float* bias;      /* [N] or NULL */
+    const float* residual;  /* [M, c_row_stride-compatible ld_residual] or NULL: C = residual + val */
+    long long ld_residual;
+    int M, N, K;
+    int act;
+    float alpha;            /* C = residual + alpha * act(A.B^T + bias) */
+    int batch; long long a_batch_stride, b_batch_stride, c_batch_stride;
+} cover_gemm_f32_args;
+int cover_gemm_f32(const cover_gemm_f32_args* args, void* stream);
+int cover_layernorm_f32(const float* x, int ldx, const float* w, const float* b, float* y, int ldy, int rows, int dim,
+                        float eps, void* stream);
+/* in place: x[r] = softmax(x[r] * scale) */
+int cover_softmax_rows_f32(float* x, int ldx, int rows, int cols, float scale, void* stream);
+/* y[r] = x[r] / ||x[r]||_2  (finetune_trajectory_bridge_ddp.py:329-330,352-354; efficient_ensemble_merged.py:223,245) */
+int cover_l2norm_rows_f32(const float* x, int ldx, float* y, int ldy, int rows, int cols, void* stream);
+/* y = a + b[r % b_rows] */
+int cover_add_f32(const float* a, int lda, const float* b, int ldb, float* y, int ldy, int rows, int cols, int b_rows,
+                  void* stream);
+/* small multi-head attention in fp32 (nn.MultiheadAttention core, after the in-projections):
+ * q [B][Tq][H*Dh], k/v [B][Tk][H*Dh] via strides, optional key padding mask (1 = ignore key) [B][Tk] */
+typedef struct cover_mha_f32_args {
+    const float* q; long long q_b_stride, q_t_stride;
+    const float* k; long long k_b_stride, k_t_stride;
+    const float* v; long long v_b_stride, v_t_stride;
+    float* out; long long o_b_stride, o_t_stride;
+    const uint8_t* key_pad; /* [B][Tk] or NULL */
+    int B, Tq, Tk, H, Dh;
+    float scale;
+} cover_mha_f32_args;
+int cover_mha_f32(const cover_mha_f32_args* args, void* stream);
+/* masked mean over T (efficient_ensemble_merged.py:236-240): y[b] = sum_t x[b,t]*(1-pad) / max(sum(1-pad), 1e-9) */
+int cover_masked_mean_f32(const float* x, const uint8_t* pad, float* y, int B, int T, int D, void* stream);
+/* create_sinusoidal_pos_embedding (modeling_pi0.py:71-89) evaluated in float64 on the device, cast to bf16 */
+int cover_sincos_time_embed(const float* time, int B, int dim, double min_period, double max_period, void* out, int ldo,
+                            void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Selection kernels
+ * ------------------------------------------------------------------------------------------------ */
+/* Action-token decode head (OpenVLA profile; the 256-bin arithmetic the reference carries at
+ * INT-ACT/src/experiments/policies/policy_wrapper.py:259-266). logits fp32 [rows][ld]; greedy: first arg-max over
+ * [lo, hi); sampling: softmax((logits - max)/temperature) over [lo, hi), inverse CDF in index order with the
+ * host-supplied uniform u[row]. */
+typedef struct cover_token_select_args {
+    const float* logits; long long ld; int rows; int lo, hi;
+    const float* uniform;   /* [rows] in [0,1) or NULL for greedy */
+    float temperature;
+    int64_t* token_out;     /* [rows] */
+    float* logit_out;       /* [rows] selected logit (optional, may be NULL) */
+} cover_token_select_args;
+int cover_token_select(const cover_token_select_args* args, void* stream);
+
+/* K20: fuse + score + grouped arg-max (efficient_ensemble_merged.py:404-448). it: [n_members][512] image-text
+ * embeddings (unit rows), act: [n_members][N][512]; scores_out [N]; result_out int32 [4] =
+ * {global_idx, group_idx, idx_in_group, 0}; best_out float [2] = {max_score, best_group_mean}. First index wins ties
+ * (torch.max semantics). */
+typedef struct cover_score_select_args {
+    const float* it; const float* act;
+    int n_members, N, dim, group_size;
+    float* scores_out; int* result_out; float* best_out;
+    float* fused_it_out;   /* [dim] optional */
+    float* fused_act_out;  /* [N][dim] optional */
+} cover_score_select_args;
+int cover_score_select(const cover_score_select_args* args, void* stream);
+/* grouped arg-max over already-computed (e.g. all-gathered) scores: same selection rule as above */
+int cover_group_argmax(const float* scores, int N, int group_size, int* result_out, float* best_out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Composite forwards: the per-layer Python loops of the reference (18-layer loop in
+ * paligemma_with_expert.py:258-349, HF/timm encoder loops) run here in C++ so that a whole tower / prefill /
+ * decode step is one call (and one hipGraph when captured). Weight tables are plain HOST arrays of device
+ * pointers filled by the Python host.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct cover_workspace { void* ptr; size_t bytes; } cover_workspace;
+
+typedef struct cover_vit_layer {
+    const float *ln1_w, *ln1_b, *ln2_w, *ln2_b;
+    const void* qkv_w; const float* qkv_b;   /* packed [3*H*Dp, dim] */
+    const void* proj_w; const float* proj_b; /* packed [dim, H*Dp] */
+    const void* fc1_w; const float* fc1_b;   /* packed [mlp_p, dim] */
+    const void* fc2_w; const float* fc2_b;   /* packed [dim, mlp_p] */
+    const float *ls1, *ls2;                  /* LayerScale or NULL */
+} cover_vit_layer;
+typedef struct cover_vit_desc {
+    int dim, heads, head_dim_p, mlp_p, n_layers, act; /* head_dim_p / mlp_p = zero-padded sizes (72->96, 4304->4352) */
+    float ln_eps, attn_scale;                         /* attn_scale = TRUE head_dim ** -0.5 */
+    const cover_vit_layer* layers_host;               /* HOST array [n_layers] */
+    int last_attn_only; /* 1: the LAST listed block stops after its attention out-projection and that (pre-residual)
+                           tensor is written to attn_out: the forward-hook feature of
+                           finetune_trajectory_bridge_ddp.py:272-274 */
+    int _pad;
+} cover_vit_desc;
+/* x: bf16 [n_seq*T, dim] token embeddings, updated in place through the blocks; attn_out bf16 [n_seq*T, dim]
+ * (only with last_attn_only). */
+size_t cover_vit_workspace_bytes(const cover_vit_desc* d, int n_seq, int T);
+int cover_vit_forward(const cover_vit_desc* d, void* x, int n_seq, int T, void* attn_out, cover_workspace ws,
+                      int gemm_variant, void* stream);
+
+typedef struct cover_dec_layer {
+    const float* in_norm_w; const float* post_norm_w;
+    const void* qkv_w; const float* qkv_b;   /* packed [(Hq+2Hkv)*D, dim] */
+    const void* o_w;                          /* packed [dim, Hq*D] */
+    const void* gate_up_w;                    /* packed, glu-interleaved [2*mlp, dim] */
+    const void* down_w;                       /* packed [dim, mlp] */
+    void* k_cache; void* vt_cache;            /* this layer's cache bases (bf16) */
+} cover_dec_layer;
+typedef struct cover_dec_desc {
+    int dim, Hq, Hkv, D, mlp, n_layers, act;  /* act: COVER_ACT_GELU_TANH (Gemma) / COVER_ACT_SILU (Llama) */
+    int norm_style;                           /* cover_rmsnorm_bf16 style */
+    float norm_eps, norm_w_offset, attn_scale;
+    int rope_mode; int n_pos; int _pad;
+    const float* cos_table; const float* sin_table;
+    const float* final_norm_w;
+    const cover_dec_layer* layers_host;       /* HOST array [n_layers] */
+} cover_dec_desc;
+/* A pass pushes up to two GROUPS of rows through all layers with ONE read of the weights. Group g holds
+ * B x T new tokens laid out [b][t]; rows of group 1 follow group 0 in x. Per layer, each group's K/V are
+ * appended to segment `write_seg` of the layer cache (slot = write_slot_of_batch[b] or b,
+ * t = write_t_offset (+ write_t_offset_of_batch[b]) + t) and its queries attend its `segs` in order.
+ * The k/vt pointers inside `segs` are IGNORED: per layer they are layer.k_cache + seg_k_offset[i] /
+ * layer.vt_cache + seg_vt_offset[i] (element offsets), so one description serves every layer.
+ * pi0 denoise steps attend their own suffix K/V without keeping it (paligemma_with_expert.py:305-308): give
+ * them a scratch segment that the next step overwrites. */
+typedef struct cover_dec_group {
+    int B, T;
+    const int* positions;  /* [B*T] */
+    int n_seg; int write_seg;
+    cover_kv_segment segs[3];
+    long long seg_k_offset[3], seg_vt_offset[3];
+    const int* write_slot_of_batch; const int* write_t_offset_of_batch;
+    int write_t_offset; int _pad;
+} cover_dec_group;
+typedef struct cover_dec_pass {
+    int n_groups; int final_norm;      /* final_norm: apply final_norm_w to x at the end */
+    const float* x_f32;                /* optional fp32 [rows, dim] layer-0 input (norm input AND first residual) */
+    cover_dec_group groups[2];
+} cover_dec_pass;
+size_t cover_decoder_workspace_bytes(const cover_dec_desc* d, int rows);
+/* x: bf16 [rows, dim] input embeddings, overwritten with the output hidden states */
+int cover_decoder_forward(const cover_dec_desc* d, const cover_dec_pass* p, void* x, cover_workspace ws,
+                          int gemm_variant, void* stream);
+
+/* hipGraph capture helpers: everything launched on `stream` between begin/end becomes one replayable graph */
+int cover_graph_begin(void* stream);
+int cover_graph_end(void* stream, void** graph_exec_out);
+int cover_graph_launch(void* graph_exec, void* stream);
+int cover_graph_destroy(void* graph_exec);
+
+/* Timing on the stream the kernels run on (torch.cuda.Event only sees torch's current stream): opaque hipEvent
+ * pairs. cover_timer_stop synchronises the stop event and returns elapsed milliseconds. */
+int cover_timer_create(void** timer_out);
+int cover_timer_start(void* timer, void* stream);
+int cover_timer_stop(void* timer, void* stream, float* ms_out);
+int cover_timer_destroy(void* timer);
+int cover_stream_sync(void* stream);
+
+/* sizeof() of every struct above by name ("cover_attn_args", ...): lets a foreign-language binding check its
+ * mirrored layouts at load time. Returns 0 for unknown names. */
+size_t cover_sizeof(const char* struct_name);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

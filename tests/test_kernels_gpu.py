@@ -1,0 +1,410 @@
+"""Kernel-level parity: every HIP kernel (through the C ABI, via cover_vla_amd.ops) against a plain fp32 PyTorch
+restatement of the same op on the CPU. bf16 kernels: inputs are rounded to bf16 first, the reference computes in
+fp32 and the comparison allows bf16 output rounding. fp32 kernels: atol/rtol 2e-5. Index outputs: exact."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from cover_vla_amd import ops  # noqa: E402
+
+
+def bf(x):
+    return x.to(torch.bfloat16)
+
+
+def rel_l2(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return ((a - b).norm() / (b.norm() + 1e-12)).item()
+
+
+ACT_REF = {
+    "none": lambda x: x,
+    "gelu_tanh": lambda x: torch.nn.functional.gelu(x, approximate="tanh"),
+    "gelu_erf": lambda x: torch.nn.functional.gelu(x),
+    "silu": torch.nn.functional.silu,
+    "relu": torch.relu,
+}
+
+
+# ------------------------------------------------------------------------------------------------ bf16 GEMM
+@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("M,N,K", [(200, 256, 256), (333, 1152, 640), (128, 384, 1024), (1, 128, 128), (257, 136, 384)])
+def test_gemm_tiled(dev, variant, M, N, K):
+    g = torch.Generator().manual_seed(M * 7 + N)
+    a = bf(torch.randn(M, K, generator=g))
+    w = bf(torch.randn(N, K, generator=g) * 0.05)
+    bias = torch.randn(N, generator=g)
+    lin = ops.pack_linear(w.to(dev), bias.to(dev))
+    out = ops.gemm(a.to(dev), lin, variant=variant)
+    ref = a.float() @ w.float().T + bias
+    assert rel_l2(out, ref) < 6e-3
+    assert torch.allclose(out.float().cpu(), ref, atol=0.05, rtol=2e-2)
+
+
+def test_gemm_transpose_detecting(dev):
+    # A = I with an asymmetric W: out must equal W^T exactly (bf16 values are exact here)
+    K = N = 256
+    a = bf(torch.eye(K))
+    w = bf(torch.arange(N * K, dtype=torch.float32).reshape(N, K) % 251 - 125)
+    lin = ops.pack_linear(w.to(dev))
+    for variant in (1, 2):
+        out = ops.gemm(a.to(dev), lin, variant=variant)
+        assert torch.equal(out.float().cpu(), w.float().T)
+
+
+@pytest.mark.parametrize("M", [1, 5, 16, 32, 40, 64])
+@pytest.mark.parametrize("N,K", [(512, 1024), (4096, 512), (264, 128), (1376, 2176)])
+def test_gemm_skinny(dev, M, N, K):
+    g = torch.Generator().manual_seed(M * 131 + N + K)
+    a = bf(torch.randn(M, K, generator=g))
+    w = bf(torch.randn(N, K, generator=g) * 0.05)
+    bias = torch.randn(N, generator=g)
+    lin = ops.pack_linear(w.to(dev), bias.to(dev))
+    out = ops.gemm(a.to(dev), lin, variant=3)
+    ref = a.float() @ w.float().T + bias
+    assert rel_l2(out, ref) < 6e-3
+    out32 = ops.gemm(a.to(dev), lin, variant=3, out_f32=True)
+    assert torch.allclose(out32.cpu(), bf(ref).float(), atol=0.05, rtol=2e-2)
+
+
+@pytest.mark.parametrize("variant,M", [(1, 150), (2, 150), (3, 32)])
+@pytest.mark.parametrize("act", ["gelu_tanh", "gelu_erf", "silu", "relu"])
+def test_gemm_epilogues(dev, variant, M, act):
+    N, K = 384, 256
+    g = torch.Generator().manual_seed(11)
+    a = bf(torch.randn(M, K, generator=g))
+    w = bf(torch.randn(N, K, generator=g) * 0.08)
+    bias = torch.randn(N, generator=g) * 0.5
+    res = bf(torch.randn(M, N, generator=g))
+    ls = torch.rand(N, generator=g)
+    lin = ops.pack_linear(w.to(dev), bias.to(dev))
+    lin0 = ops.pack_linear(w.to(dev))
+    y = a.float() @ w.float().T
+    # activation
+    out = ops.gemm(a.to(dev), lin, act=act, variant=variant)
+    assert rel_l2(out, ACT_REF[act](y + bias)) < 8e-3
+    # residual + layer scale
+    out = ops.gemm(a.to(dev), lin, residual=res.to(dev), layer_scale=ls.to(dev), variant=variant)
+    assert rel_l2(out, res.float() + ls * (y + bias)) < 8e-3
+    # fp32 residual, fp32 output
+    res32 = torch.randn(M, N, generator=g)
+    out = ops.gemm(a.to(dev), lin0, residual=res32.to(dev), out_f32=True, variant=variant)
+    assert rel_l2(out, res32 + y) < 8e-3
+    # in-place residual (out aliases residual), as the decoder uses it
+    x = res.clone().to(dev)
+    ops.gemm(a.to(dev), lin0, residual=x, out=x, variant=variant)
+    assert rel_l2(x, res.float() + y) < 8e-3
+    # GLU: W = [gate; up]
+    wg = bf(torch.randn(2 * N, K, generator=g) * 0.08)
+    ling = ops.pack_linear(wg.to(dev), glu=True)
+    out = ops.gemm(a.to(dev), ling, act=act, variant=variant)
+    yy = a.float() @ wg.float().T
+    assert out.shape == (M, N)
+    assert rel_l2(out, ACT_REF[act](yy[:, :N]) * yy[:, N:]) < 1e-2
+
+
+# ------------------------------------------------------------------------------------------------ attention
+def attn_ref(q, segs, scale):
+    """q [B,Tq,Hq,D]; segs: list of (k [B,Tk,Hkv,D], v [B,Tk,Hkv,D], vis bool [B,Tq,Tk])."""
+    B, Tq, Hq, D = q.shape
+    k = torch.cat([s[0] for s in segs], 1).float()
+    v = torch.cat([s[1] for s in segs], 1).float()
+    vis = torch.cat([s[2] for s in segs], 2)
+    G = Hq // k.shape[2]
+    k = k.repeat_interleave(G, 2)
+    v = v.repeat_interleave(G, 2)
+    s = torch.einsum("bqhd,bkhd->bhqk", q.float(), k) * scale
+    s = s.masked_fill(~vis[:, None], float("-inf"))
+    p = torch.softmax(s, -1)
+    p = torch.nan_to_num(p, nan=0.0)
+    return torch.einsum("bhqk,bkhd->bqhd", p, v)
+
+
+def make_cache(k, v, dev, tcap=None):
+    """k, v [S, T, Hkv, D] -> device K cache [S][T][Hkv][D] and V^T cache [S][Hkv][D][tcap] + strides."""
+    S, T, Hkv, D = k.shape
+    tcap = tcap or (T + 31) // 32 * 32
+    kc = k.contiguous().to(dev)
+    vt = torch.zeros(S, Hkv, D, tcap, dtype=torch.bfloat16)
+    vt[..., :T] = v.permute(0, 2, 3, 1)
+    return kc, vt.to(dev), (T * Hkv * D, Hkv * D, D), (Hkv * D * tcap, D * tcap, tcap)
+
+
+@pytest.mark.parametrize("D", [64, 96, 128, 256])
+@pytest.mark.parametrize("Tq,Tk,Hq,Hkv", [(50, 77, 4, 4), (1, 300, 8, 8), (5, 40, 8, 1), (130, 130, 2, 1)])
+def test_attention_len_mask(dev, D, Tq, Tk, Hq, Hkv):
+    B = 3
+    g = torch.Generator().manual_seed(D + Tq)
+    q = bf(torch.randn(B, Tq, Hq, D, generator=g))
+    k = bf(torch.randn(B, Tk, Hkv, D, generator=g))
+    v = bf(torch.randn(B, Tk, Hkv, D, generator=g))
+    lens = torch.tensor([Tk, max(1, Tk // 2), max(1, Tk - 3)], dtype=torch.int32)
+    vis = (torch.arange(Tk)[None, None, :] < lens[:, None, None]).expand(B, Tq, Tk)
+    ref = attn_ref(q, [(k, v, vis)], D ** -0.5)
+    kc, vt, ks, vs = make_cache(k, v, dev)
+    out = torch.empty(B, Tq, Hq, D, dtype=torch.bfloat16, device=dev)
+    seg = ops.Segment(kc, vt, ks, vs, length=Tk, len_of_batch=lens.to(dev))
+    ops.attention(q.to(dev), (Tq * Hq * D, Hq * D, D), out, (Tq * Hq * D, Hq * D, D), B, Tq, Hq, Hkv, D, D ** -0.5, [seg])
+    assert rel_l2(out, ref) < 1.2e-2
+    assert torch.allclose(out.float().cpu(), ref, atol=3e-2, rtol=3e-2)
+
+
+@pytest.mark.parametrize("Tq", [1, 4, 37])
+def test_attention_three_segments(dev, Tq):
+    # shared prefix (one slot for every batch row) + per-prompt segment via slot map + own causal segment
+    B, Hq, Hkv, D = 6, 4, 2, 128
+    T0, T1, T2 = 70, 45, Tq + 3
+    g = torch.Generator().manual_seed(5 + Tq)
+    q = bf(torch.randn(B, Tq, Hq, D, generator=g))
+    k0, v0 = bf(torch.randn(1, T0, Hkv, D, generator=g)), bf(torch.randn(1, T0, Hkv, D, generator=g))
+    k1, v1 = bf(torch.randn(2, T1, Hkv, D, generator=g)), bf(torch.randn(2, T1, Hkv, D, generator=g))
+    k2, v2 = bf(torch.randn(B, T2, Hkv, D, generator=g)), bf(torch.randn(B, T2, Hkv, D, generator=g))
+    slot1 = torch.tensor([0, 0, 0, 1, 1, 1], dtype=torch.int32)
+    len1 = torch.tensor([45, 45, 45, 30, 30, 30], dtype=torch.int32)
+    zero = torch.zeros(B, dtype=torch.int32)
+    vis0 = torch.ones(B, Tq, T0, dtype=torch.bool)
+    vis1 = (torch.arange(T1)[None, None, :] < len1[:, None, None]).expand(B, Tq, T1)
+    vis2 = (torch.arange(T2)[None, None, :] <= (torch.arange(Tq)[None, :, None] + 3)).expand(B, Tq, T2)
+    ref = attn_ref(q, [(k0.expand(B, -1, -1, -1), v0.expand(B, -1, -1, -1), vis0), (k1[slot1.long()], v1[slot1.long()], vis1),
+                       (k2, v2, vis2)], 0.11)
+    c0 = make_cache(k0, v0, dev)
+    c1 = make_cache(k1, v1, dev)
+    c2 = make_cache(k2, v2, dev)
+    segs = [ops.Segment(c0[0], c0[1], c0[2], c0[3], length=T0, slot_of_batch=zero.to(dev)),
+            ops.Segment(c1[0], c1[1], c1[2], c1[3], length=T1, slot_of_batch=slot1.to(dev), len_of_batch=len1.to(dev)),
+            ops.Segment(c2[0], c2[1], c2[2], c2[3], length=T2, mask=ops.MASK_CAUSAL, causal_offset=3)]
+    out = torch.empty(B, Tq, Hq, D, dtype=torch.bfloat16, device=dev)
+    ops.attention(q.to(dev), (Tq * Hq * D, Hq * D, D), out, (Tq * Hq * D, Hq * D, D), B, Tq, Hq, Hkv, D, 0.11, segs)
+    assert rel_l2(out, ref) < 1.2e-2
+
+
+def test_attention_vislen_pi0_suffix(dev):
+    # pi0 denoise step: 5 suffix tokens x 8 q heads over 1 kv head; prefix by length + suffix block mask [1,5,5,5,5]
+    B, Tq, Hq, Hkv, D, Tp = 4, 5, 8, 1, 256, 90
+    g = torch.Generator().manual_seed(9)
+    q = bf(torch.randn(B, Tq, Hq, D, generator=g))
+    kp, vp = bf(torch.randn(2, Tp, Hkv, D, generator=g)), bf(torch.randn(2, Tp, Hkv, D, generator=g))
+    ks_, vs_ = bf(torch.randn(B, Tq, Hkv, D, generator=g)), bf(torch.randn(B, Tq, Hkv, D, generator=g))
+    slot = torch.tensor([0, 0, 1, 1], dtype=torch.int32)
+    plen = torch.tensor([80, 80, 61, 61], dtype=torch.int32)
+    vl = torch.tensor([1, 5, 5, 5, 5], dtype=torch.int32)
+    visp = (torch.arange(Tp)[None, None, :] < plen[:, None, None]).expand(B, Tq, Tp)
+    viss = (torch.arange(Tq)[None, None, :] < vl[None, :, None]).expand(B, Tq, Tq)
+    ref = attn_ref(q, [(kp[slot.long()], vp[slot.long()], visp), (ks_, vs_, viss)], D ** -0.5)
+    cp = make_cache(kp, vp, dev)
+    cs = make_cache(ks_, vs_, dev)
+    segs = [ops.Segment(cp[0], cp[1], cp[2], cp[3], length=Tp, slot_of_batch=slot.to(dev), len_of_batch=plen.to(dev)),
+            ops.Segment(cs[0], cs[1], cs[2], cs[3], length=Tq, mask=ops.MASK_VISLEN, vis_len=vl.to(dev))]
+    out = torch.empty(B, Tq, Hq, D, dtype=torch.bfloat16, device=dev)
+    ops.attention(q.to(dev), (Tq * Hq * D, Hq * D, D), out, (Tq * Hq * D, Hq * D, D), B, Tq, Hq, Hkv, D, D ** -0.5, segs)
+    assert rel_l2(out, ref) < 1.2e-2
+
+
+def test_attention_spike_forces_rescale(dev):
+    # one key far above the rest late in the sequence: exercises the online-softmax rescale branch
+    B, Tq, H, D, Tk = 1, 16, 1, 64, 200
+    g = torch.Generator().manual_seed(3)
+    q = bf(torch.randn(B, Tq, H, D, generator=g))
+    k = bf(torch.randn(B, Tk, H, D, generator=g) * 0.1)
+    v = bf(torch.randn(B, Tk, H, D, generator=g))
+    k[0, 170, 0] = q[0, 3, 0] * 4
+    vis = torch.ones(B, Tq, Tk, dtype=torch.bool)
+    ref = attn_ref(q, [(k, v, vis)], 1.0)
+    kc, vt, ks, vs = make_cache(k, v, dev)
+    out = torch.empty(B, Tq, H, D, dtype=torch.bfloat16, device=dev)
+    ops.attention(q.to(dev), (Tq * H * D, H * D, D), out, (Tq * H * D, H * D, D), B, Tq, H, H, D, 1.0,
+                  [ops.Segment(kc, vt, ks, vs, length=Tk)])
+    assert torch.allclose(out.float().cpu(), ref, atol=3e-2, rtol=3e-2)
+
+
+# ------------------------------------------------------------------------------------------------ row kernels
+@pytest.mark.parametrize("dim", [1024, 1152, 4096])
+def test_norms(dev, dim):
+    g = torch.Generator().manual_seed(dim)
+    x = bf(torch.randn(37, dim, generator=g) * 3 + 0.5)
+    w, b = torch.randn(dim, generator=g), torch.randn(dim, generator=g)
+    ref = torch.nn.functional.layer_norm(x.float(), (dim,), w, b, 1e-6)
+    out = ops.layernorm(x.to(dev), w.to(dev), b.to(dev), 1e-6)
+    assert torch.allclose(out.float().cpu(), ref, atol=2e-2, rtol=1e-2)
+    xf = x.float()
+    rstd = torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-6)
+    out = ops.rmsnorm(x.to(dev), w.to(dev), 1e-6, w_offset=1.0, style=0)  # Gemma
+    assert torch.allclose(out.float().cpu(), bf(xf * rstd * (1 + w)).float(), atol=2e-2, rtol=1e-2)
+    out = ops.rmsnorm(x.to(dev), w.to(dev), 1e-6, w_offset=0.0, style=1)  # Llama
+    assert torch.allclose(out.float().cpu(), bf(w * bf(xf * rstd).float()).float(), atol=2e-2, rtol=1e-2)
+    x32 = torch.randn(5, dim, generator=g)
+    rstd = torch.rsqrt(x32.pow(2).mean(-1, keepdim=True) + 1e-6)
+    out = ops.rmsnorm(x32.to(dev), w.to(dev), 1e-6, w_offset=1.0, style=0)
+    assert torch.allclose(out.float().cpu(), bf(x32 * rstd * (1 + w)).float(), atol=2e-2, rtol=1e-2)
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_rope_kv_write(dev, mode):
+    B, T, Hq, Hkv, D, tcap, npos = 2, 7, 4, 2, 128, 32, 64
+    g = torch.Generator().manual_seed(mode)
+    qkv = bf(torch.randn(B * T, (Hq + 2 * Hkv) * D, generator=g))
+    pos = torch.randint(0, npos, (B * T,), generator=g, dtype=torch.int32)
+    half = D // 2
+    inv = 1.0 / (10000.0 ** (torch.arange(0, D, 2).float() / D))
+    ang = torch.arange(npos).float()[:, None] * inv[None]
+    cos, sin = ang.cos(), ang.sin()
+    kc = torch.zeros(3, 16, Hkv, D, dtype=torch.bfloat16, device=dev)
+    vt = torch.zeros(3, Hkv, D, tcap, dtype=torch.bfloat16, device=dev)
+    slot = torch.tensor([2, 0], dtype=torch.int32)
+    toff = torch.tensor([1, 4], dtype=torch.int32)
+    d_qkv = qkv.clone().to(dev)
+    ops.rope_kv_write(d_qkv, B, T, Hq, Hkv, D, positions=pos.to(dev), cos=cos.to(dev), sin=sin.to(dev), rope_mode=mode,
+                      k_cache=kc, k_strides=(16 * Hkv * D, Hkv * D, D), vt_cache=vt, vt_strides=(Hkv * D * tcap, D * tcap, tcap),
+                      slot_of_batch=slot.to(dev), t_offset_of_batch=toff.to(dev), t_offset=2)
+    x = qkv.float().reshape(B, T, Hq + 2 * Hkv, D)
+    c = cos[pos.long()].reshape(B, T, 1, half)
+    s = sin[pos.long()].reshape(B, T, 1, half)
+
+    def rot(x):
+        x1, x2 = x[..., :half], x[..., half:]
+        if mode == 0:
+            return x
+        if mode == 1:
+            return torch.cat([x1 * c - x2 * s, x2 * c + x1 * s], -1)
+        cb, sb = bf(c).float(), bf(s).float()
+        return torch.cat([bf(bf(x1 * cb).float() + bf(-x2 * sb).float()).float(), bf(bf(x2 * cb).float() + bf(x1 * sb).float()).float()], -1)
+
+    got = d_qkv.float().cpu().reshape(B, T, Hq + 2 * Hkv, D)
+    assert torch.equal(got[:, :, :Hq], bf(rot(x[:, :, :Hq])).float())
+    kref = bf(rot(x[:, :, Hq:Hq + Hkv])).float()
+    for b in range(B):
+        t0 = 2 + toff[b].item()
+        assert torch.equal(kc[slot[b].item(), t0:t0 + T].float().cpu(), kref[b])
+        assert torch.equal(vt[slot[b].item(), :, :, t0:t0 + T].float().cpu(), x[b, :, Hq + Hkv:].permute(1, 2, 0))
+
+
+def test_small_row_kernels(dev):
+    g = torch.Generator().manual_seed(0)
+    table = bf(torch.randn(100, 256, generator=g))
+    ids = torch.randint(0, 100, (17,), generator=g)
+    sc = math.sqrt(256)
+    out = ops.embed_gather(table.to(dev), ids.to(dev), sc)
+    assert torch.equal(out.float().cpu(), bf(table[ids].float() * torch.tensor(sc, dtype=torch.float32)).float())
+    # patchify: uint8 HWC and fp32 CHW agree with unfold
+    img = torch.randint(0, 256, (2, 28, 42, 3), generator=g, dtype=torch.uint8)
+    mul, add = [1 / 255 / 0.5] * 3, [-1.0] * 3
+    p = ops.patchify(img.to(dev), 14, mul, add, 640)
+    x = img.float().permute(0, 3, 1, 2) * (1 / 255 / 0.5) - 1.0
+    ref = torch.nn.functional.unfold(x, 14, stride=14).transpose(1, 2).reshape(-1, 588)
+    assert torch.allclose(p[:, :588].float().cpu(), bf(ref).float(), atol=1e-2)
+    assert p[:, 588:].abs().max().item() == 0
+    p2 = ops.patchify(x.contiguous().to(dev), 14, [1.0] * 3, [0.0] * 3, 640)
+    assert torch.equal(p2[:, :588].float().cpu(), bf(ref).float())
+    # add_rows / scale / casts / copy_rows
+    xx = bf(torch.randn(12, 64, generator=g))
+    pe = bf(torch.randn(4, 64, generator=g))
+    o = ops.add_rows(xx.clone().to(dev), pe.to(dev))
+    assert torch.equal(o.float().cpu(), bf(xx.float() + pe.float().repeat(3, 1)).float())
+    o = ops.scale_bf16(xx.clone().to(dev), float(bf(torch.tensor(8.0))), float(bf(torch.tensor(8.0))))
+    assert torch.equal(o.float().cpu(), bf(bf(xx.float() / 8).float() * 8).float())
+    f = torch.randn(5, 40, generator=g)
+    assert torch.equal(ops.cast_f32_to_bf16(f.to(dev)).float().cpu(), bf(f).float())
+    assert torch.equal(ops.cast_bf16_to_f32(xx.to(dev)).cpu(), xx.float())
+    dst = torch.zeros(12, 64, dtype=torch.bfloat16, device=dev)
+    si = torch.tensor([3, 1, 7], dtype=torch.int32)
+    di = torch.tensor([0, 5, 11], dtype=torch.int32)
+    ops.copy_rows(xx.to(dev), dst, 3, 64, si.to(dev), di.to(dev))
+    assert torch.equal(dst[di.long()].float().cpu(), xx[si.long()].float())
+
+
+# ------------------------------------------------------------------------------------------------ fp32 kernels
+@pytest.mark.parametrize("M,N,K", [(64, 576, 1024), (1, 512, 512), (320, 512, 7), (70, 1024, 576), (33, 32, 1024)])
+def test_gemm_f32(dev, M, N, K):
+    g = torch.Generator().manual_seed(M + N + K)
+    a, w, bias = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) * 0.1, torch.randn(N, generator=g)
+    res = torch.randn(M, N, generator=g)
+    out = ops.gemm_f32(a.to(dev), w.to(dev), bias=bias.to(dev), act="gelu_erf", alpha=-0.1, residual=res.to(dev))
+    ref = res + -0.1 * torch.nn.functional.gelu((a.double() @ w.double().T).float() + bias)
+    assert torch.allclose(out.cpu(), ref, atol=2e-5, rtol=2e-5)
+    # k-major B operand ("NN"): C = A @ Bkn
+    bkn = torch.randn(K, N, generator=g)
+    out = ops.gemm_f32(a.to(dev), bkn.to(dev), b_is_kn=True)
+    assert torch.allclose(out.cpu(), (a.double() @ bkn.double()).float(), atol=1e-4, rtol=2e-5)
+
+
+def test_mha_f32_and_rows(dev):
+    g = torch.Generator().manual_seed(1)
+    B, Tq, Tk, H, Dh = 5, 10, 10, 8, 64
+    q, k, v = (torch.randn(B, t, H * Dh, generator=g) for t in (Tq, Tk, Tk))
+    pad = torch.zeros(B, Tk, dtype=torch.bool)
+    pad[0, :6] = True
+    pad[3, :2] = True
+    out = ops.mha_f32(q.to(dev), k.to(dev), v.to(dev), B, Tq, Tk, H, Dh, (Tq * H * Dh, H * Dh), (Tk * H * Dh, H * Dh),
+                      (Tk * H * Dh, H * Dh), key_pad=pad.to(torch.uint8).to(dev))
+    qh, kh, vh = (t.reshape(B, -1, H, Dh).transpose(1, 2) for t in (q, k, v))
+    s = (qh * Dh ** -0.5) @ kh.transpose(-1, -2)
+    s = s.masked_fill(pad[:, None, None, :], float("-inf"))
+    ref = (torch.softmax(s, -1) @ vh).transpose(1, 2).reshape(B, Tq, H * Dh)
+    assert torch.allclose(out.cpu(), ref, atol=2e-5, rtol=2e-5)
+    x = torch.randn(9, 576, generator=g)
+    assert torch.allclose(ops.softmax_rows_f32(x.clone().to(dev), 1 / 0.07).cpu(), torch.softmax(x / 0.07, -1), atol=1e-6, rtol=1e-4)
+    assert torch.allclose(ops.l2norm_rows_f32(x.to(dev)).cpu(), x / x.norm(dim=-1, keepdim=True), atol=1e-6, rtol=1e-5)
+    w, b = torch.randn(576, generator=g), torch.randn(576, generator=g)
+    assert torch.allclose(ops.layernorm_f32(x.to(dev), w.to(dev), b.to(dev)).cpu(),
+                          torch.nn.functional.layer_norm(x, (576,), w, b), atol=1e-5, rtol=1e-5)
+    assert torch.allclose(ops.add_f32(x.to(dev), x[:3].contiguous().to(dev)).cpu(), x + x[:3].repeat(3, 1))
+    xm = torch.randn(B, Tk, 512, generator=g)
+    mm = ops.masked_mean_f32(xm.to(dev), pad.to(torch.uint8).to(dev), B, Tk, 512)
+    keep = (~pad).float()[..., None]
+    assert torch.allclose(mm.cpu(), (xm * keep).sum(1) / keep.sum(1).clamp(min=1e-9), atol=1e-6, rtol=1e-5)
+    t = torch.tensor([1.0, 0.9, 0.5, 0.1])
+    emb = ops.sincos_time_embed(t.to(dev), 1024, 4e-3, 4.0)
+    fr = torch.linspace(0.0, 1.0, 512, dtype=torch.float64)
+    per = 4e-3 * (4.0 / 4e-3) ** fr
+    arg = (1.0 / per * 2 * math.pi)[None] * t.double()[:, None]
+    ref = torch.cat([arg.sin(), arg.cos()], 1).to(torch.bfloat16)
+    assert torch.allclose(emb.float().cpu(), ref.float(), atol=8e-3)
+    assert (emb.cpu() != ref).float().mean().item() < 0.01  # bf16 rounding of values computed in float64
+
+
+# ------------------------------------------------------------------------------------------------ selection
+def test_token_select(dev):
+    g = torch.Generator().manual_seed(2)
+    logits = torch.randn(9, 32064, generator=g)
+    logits[4, 100] = logits[4, 31999] = 50.0  # exact tie -> first index
+    tok, lg = ops.token_select(logits.to(dev), 0, 32000)
+    assert torch.equal(tok.cpu(), logits[:, :32000].argmax(-1))
+    assert tok[4].item() == 100
+    u = torch.rand(9, generator=g)
+    tok, _ = ops.token_select(logits.to(dev), 31744, 32000, uniform=u.to(dev), temperature=0.7)
+    sub = logits[:, 31744:32000].numpy()
+    for r in range(9):
+        p = np.exp(((sub[r] - sub[r].max()) / np.float32(0.7)).astype(np.float32)).astype(np.float32)
+        cs = np.cumsum(p, dtype=np.float32)
+        pick = int(np.argmax(cs > np.float32(u[r].item()) * cs[-1]))
+        assert abs(tok[r].item() - (31744 + pick)) <= 0  # same arithmetic -> same index
+
+
+def test_score_select(dev):
+    g = torch.Generator().manual_seed(4)
+    M, N, dim, gs = 3, 40, 512, 5
+    it = torch.nn.functional.normalize(torch.randn(M, dim, generator=g), dim=-1)
+    act = torch.nn.functional.normalize(torch.randn(M, N, dim, generator=g), dim=-1)
+    scores, result, best, fit, fact = ops.score_select(it.to(dev), act.to(dev), gs)
+    f_it = it.mean(0)
+    f_it = f_it / f_it.norm()
+    f_act = act.mean(0)
+    f_act = f_act / f_act.norm(dim=-1, keepdim=True)
+    ref = f_act @ f_it
+    assert torch.allclose(scores.cpu(), ref, atol=1e-6)
+    gm = ref.view(N // gs, gs).mean(1)
+    bg = gm.argmax().item()
+    bi = ref.view(N // gs, gs)[bg].argmax().item()
+    assert result.cpu().tolist()[:3] == [bg * gs + bi, bg, bi]
+    assert abs(best[0].item() - ref[bg * gs + bi].item()) < 1e-6
+    # ties: first maximum wins at both levels
+    s = torch.zeros(12)
+    r, _ = ops.group_argmax(s.to(dev), 3)
+    assert r.cpu().tolist()[:3] == [0, 0, 0]
+    s[7] = s[10] = 1.0
+    r, _ = ops.group_argmax(s.to(dev), 3)
+    assert r.cpu().tolist()[:3] == [7, 2, 1]
