@@ -1,0 +1,178 @@
+"""Deterministic synthetic checkpoints in the reference's own on-disk key layouts.
+
+There is no network and no real checkpoint offline, so parity tests and bench.py run on seeded random weights
+(SURVEY.md §8d). The dictionaries produced here use the SAME keys the reference loads:
+  * verifier: merged checkpoint {"ensemble_components": [ {text_aware_visual_extraction, vision_poolings,
+    text_pooling, input_projection, single_step_action_encoder, trajectory_encoder, action_padding_value} ]}
+    (bridge_verifier/ensemble_eval/efficient_ensemble_merged.py:37-53,94-184)
+  * pi0: model.safetensors keys without the leading "model." (modeling_pi0.py:486-494; HF PaliGemma / Gemma names)
+so that the golden-vector generator can `load_state_dict` them straight into the reference's modules.
+All tensors are CPU fp32 unless stated; `nontrivial=True` also randomises biases and norm weights so every
+epilogue path is numerically exercised.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict
+
+import torch
+
+Tensor = torch.Tensor
+
+
+class _G:
+    def __init__(self, seed: int, nontrivial: bool = True, std: float = 0.02):
+        self.g = torch.Generator().manual_seed(seed)
+        self.nontrivial = nontrivial
+        self.std = std
+
+    def w(self, *shape, std=None) -> Tensor:
+        return torch.randn(*shape, generator=self.g) * (self.std if std is None else std)
+
+    def b(self, n) -> Tensor:
+        return torch.randn(n, generator=self.g) * 0.02 if self.nontrivial else torch.zeros(n)
+
+    def ln_w(self, n) -> Tensor:
+        return 1.0 + torch.randn(n, generator=self.g) * 0.1 if self.nontrivial else torch.ones(n)
+
+    def rms_w(self, n, base=0.0) -> Tensor:
+        return base + torch.randn(n, generator=self.g) * 0.1 if self.nontrivial else torch.full((n,), base)
+
+
+def sincos_position_embedding(seq_len: int, dim: int) -> Tensor:
+    """Same expression as bridge_verifier/ensemble_eval/model.py:40-47 (a registered buffer of the checkpoint)."""
+    pos = torch.arange(seq_len).float()
+    inv_freq = 1.0 / (10000 ** (torch.arange(0, dim, 2).float() / dim))
+    s = torch.einsum("i,j->ij", pos, inv_freq)
+    return torch.cat((s.sin(), s.cos()), dim=-1)
+
+
+# ------------------------------------------------------------------------------------------------ verifier
+def _pooling_sd(g: _G, input_dim: int, dim: int, layers: int, std: float) -> Dict[str, Tensor]:
+    sd = {"query": torch.randn(1, 1, dim, generator=g.g), "layer_norm.weight": g.ln_w(dim), "layer_norm.bias": g.b(dim)}
+    for i in range(layers):
+        p = f"blocks.{i}."
+        sd[p + "attention.q_proj_weight"] = g.w(dim, dim, std=std)
+        sd[p + "attention.k_proj_weight"] = g.w(dim, input_dim, std=std)
+        sd[p + "attention.v_proj_weight"] = g.w(dim, input_dim, std=std)
+        sd[p + "attention.in_proj_bias"] = g.b(3 * dim)
+        sd[p + "attention.out_proj.weight"] = g.w(dim, dim, std=std)
+        sd[p + "attention.out_proj.bias"] = g.b(dim)
+        sd[p + "mlp.fc1.weight"] = g.w(dim, dim, std=std)
+        sd[p + "mlp.fc1.bias"] = g.b(dim)
+        sd[p + "mlp.fc2.weight"] = g.w(dim, dim, std=std)
+        sd[p + "mlp.fc2.bias"] = g.b(dim)
+        sd[p + "q_layer_norm.weight"] = g.ln_w(dim)
+        sd[p + "q_layer_norm.bias"] = g.b(dim)
+        sd[p + "layer_norm.weight"] = g.ln_w(dim)
+        sd[p + "layer_norm.bias"] = g.b(dim)
+    return sd
+
+
+def _traj_sd(g: _G, d: int, ff: int, layers: int, std: float) -> Dict[str, Tensor]:
+    sd = {}
+    for i in range(layers):
+        p = f"layers.{i}."
+        sd[p + "self_attn.in_proj_weight"] = g.w(3 * d, d, std=std)
+        sd[p + "self_attn.in_proj_bias"] = g.b(3 * d)
+        sd[p + "self_attn.out_proj.weight"] = g.w(d, d, std=std)
+        sd[p + "self_attn.out_proj.bias"] = g.b(d)
+        sd[p + "linear1.weight"] = g.w(ff, d, std=std)
+        sd[p + "linear1.bias"] = g.b(ff)
+        sd[p + "linear2.weight"] = g.w(d, ff, std=std)
+        sd[p + "linear2.bias"] = g.b(d)
+        sd[p + "norm1.weight"] = g.ln_w(d)
+        sd[p + "norm1.bias"] = g.b(d)
+        sd[p + "norm2.weight"] = g.ln_w(d)
+        sd[p + "norm2.bias"] = g.b(d)
+    return sd
+
+
+def verifier_checkpoint(n_members: int = 3, seed: int = 1234, num_patches: int = 576, vision_dim: int = 1024,
+                        text_dim: int = 1024, dim: int = 512, action_dim: int = 7, pooling_layers: int = 4,
+                        traj_layers: int = 4, nontrivial: bool = True, std: float = 0.05) -> dict:
+    """Merged verifier checkpoint (weights-only flavour: only `ensemble_components`)."""
+    comps = []
+    for m in range(n_members):
+        g = _G(seed + 1000 * m, nontrivial)
+        comps.append({
+            "text_aware_visual_extraction": {"temperature": torch.tensor(0.07),
+                                             "pos_emb": sincos_position_embedding(num_patches, vision_dim)},
+            "vision_poolings": _pooling_sd(g, vision_dim, dim, pooling_layers, std),
+            "text_pooling": _pooling_sd(g, text_dim, dim, pooling_layers, std),
+            "input_projection": {"weight": g.w(dim, 2 * dim, std=std), "bias": g.b(dim)},
+            "single_step_action_encoder": {"weight": g.w(dim, action_dim, std=0.5), "bias": g.b(dim)},
+            "trajectory_encoder": _traj_sd(g, dim, 2 * dim, traj_layers, std),
+            "action_padding_value": -5.0,
+        })
+    return {"ensemble_components": comps}
+
+
+def verifier_inputs(n_candidates: int, seed: int = 7, num_patches: int = 576, num_tokens: int = 64, dim: int = 1024,
+                    min_hist: int = 4, hist_len: int = 10):
+    """Unit-norm patch / text features (what extract_features returns) + candidate action histories in the
+    verifier format (dims 0-5 small reals, gripper in {0,1}), ragged lengths in [min_hist, hist_len]."""
+    g = torch.Generator().manual_seed(seed)
+    pf = torch.nn.functional.normalize(torch.randn(1, num_patches, dim, generator=g), dim=-1)
+    tf = torch.nn.functional.normalize(torch.randn(1, num_tokens, dim, generator=g), dim=-1)
+    hists = []
+    for i in range(n_candidates):
+        n = min_hist + (i * 3) % (hist_len - min_hist + 1)
+        h = torch.randn(n, 7, generator=g) * 0.02
+        h[:, 6] = (torch.rand(n, generator=g) > 0.5).float()
+        hists.append(h.double().numpy())
+    return pf, tf, hists
+
+
+# ------------------------------------------------------------------------------------------------ transformers
+def vit_state(g: _G, *, dim: int, layers: int, heads: int, mlp: int, patch: int, n_pos: int, layerscale: bool = False,
+              prefix_tokens: int = 0, post_ln: bool = True) -> Dict[str, Tensor]:
+    """Generic pre-LN ViT encoder in neutral names (used for SigLIP, SigLIP2, DINOv2 towers):
+    patch.weight [dim, 3*p*p] (conv kernel flattened c,py,px), patch.bias, pos [n_pos, dim], optional
+    prefix [prefix_tokens, dim] (CLS/register tokens), blocks.i.{ln1,ln2}.{weight,bias}, blocks.i.{q,k,v,o}.{weight,bias},
+    blocks.i.{fc1,fc2}.{weight,bias}, optional blocks.i.{ls1,ls2}, post_ln.{weight,bias}."""
+    sd = {"patch.weight": g.w(dim, 3 * patch * patch), "patch.bias": g.b(dim), "pos": g.w(n_pos, dim)}
+    if prefix_tokens:
+        sd["prefix"] = g.w(prefix_tokens, dim)
+    for i in range(layers):
+        p = f"blocks.{i}."
+        for n in ("ln1", "ln2"):
+            sd[p + n + ".weight"] = g.ln_w(dim)
+            sd[p + n + ".bias"] = g.b(dim)
+        for n in ("q", "k", "v", "o"):
+            sd[p + n + ".weight"] = g.w(dim, dim)
+            sd[p + n + ".bias"] = g.b(dim)
+        sd[p + "fc1.weight"] = g.w(mlp, dim)
+        sd[p + "fc1.bias"] = g.b(mlp)
+        sd[p + "fc2.weight"] = g.w(dim, mlp)
+        sd[p + "fc2.bias"] = g.b(dim)
+        if layerscale:
+            sd[p + "ls1"] = torch.full((dim,), 1.0) + (torch.randn(dim, generator=g.g) * 0.1 if g.nontrivial else 0)
+            sd[p + "ls2"] = torch.full((dim,), 1.0) + (torch.randn(dim, generator=g.g) * 0.1 if g.nontrivial else 0)
+    if post_ln:
+        sd["post_ln.weight"] = g.ln_w(dim)
+        sd["post_ln.bias"] = g.b(dim)
+    return sd
+
+
+def decoder_state(g: _G, *, dim: int, layers: int, Hq: int, Hkv: int, D: int, mlp: int, rms_base: float,
+                  vocab: int = 0) -> Dict[str, Tensor]:
+    """Gemma/Llama-style decoder in HF names: layers.i.{input_layernorm,post_attention_layernorm}.weight,
+    layers.i.self_attn.{q,k,v,o}_proj.weight, layers.i.mlp.{gate,up,down}_proj.weight, norm.weight,
+    optional embed_tokens.weight."""
+    sd = {}
+    for i in range(layers):
+        p = f"layers.{i}."
+        sd[p + "input_layernorm.weight"] = g.rms_w(dim, rms_base)
+        sd[p + "post_attention_layernorm.weight"] = g.rms_w(dim, rms_base)
+        sd[p + "self_attn.q_proj.weight"] = g.w(Hq * D, dim)
+        sd[p + "self_attn.k_proj.weight"] = g.w(Hkv * D, dim)
+        sd[p + "self_attn.v_proj.weight"] = g.w(Hkv * D, dim)
+        sd[p + "self_attn.o_proj.weight"] = g.w(dim, Hq * D)
+        sd[p + "mlp.gate_proj.weight"] = g.w(mlp, dim)
+        sd[p + "mlp.up_proj.weight"] = g.w(mlp, dim)
+        sd[p + "mlp.down_proj.weight"] = g.w(dim, mlp)
+    sd["norm.weight"] = g.rms_w(dim, rms_base)
+    if vocab:
+        sd["embed_tokens.weight"] = g.w(vocab, dim)
+    return sd

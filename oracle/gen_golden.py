@@ -1,0 +1,217 @@
+#!/usr/bin/env python3
+"""Golden-vector generator: runs the REFERENCE's own modules (imported from /root/reference, read-only, in THIS
+container only) on seeded synthetic weights/inputs and writes small input/output fixtures to tests/golden/.
+
+Nothing here travels to the GPU box except the .npz data it writes. The reference cannot be imported as-is
+(missing pip deps: draccus, open_clip, timm, cv2, ...), so this harness installs sys.modules SHELLS/STUBS for the
+packages the reference imports at module scope but that play no role in the arithmetic being pinned
+(SURVEY.md §8c lists them). No reference source is copied: modules are imported from where they lie.
+
+Usage:  PYTHONDONTWRITEBYTECODE=1 python oracle/gen_golden.py [verifier] [adapter] [pi0] [hf]
+"""
+from __future__ import annotations
+
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+os.environ.setdefault("PYTHONDONTWRITEBYTECODE", "1")
+sys.dont_write_bytecode = True
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+GOLD = os.path.join(ROOT, "tests", "golden")
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+from cover_vla_amd import synth  # noqa: E402
+
+
+def _shell(name, path=None, **attrs):
+    m = types.ModuleType(name)
+    if path is not None:
+        m.__path__ = [path]
+    for k, v in attrs.items():
+        setattr(m, k, v)
+    sys.modules[name] = m
+    return m
+
+
+def save(name, **arrays):
+    os.makedirs(GOLD, exist_ok=True)
+    out = {}
+    for k, v in arrays.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu()
+            v = v.float().numpy() if v.dtype == torch.bfloat16 else v.numpy()
+        out[k] = np.asarray(v)
+    path = os.path.join(GOLD, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"wrote {path} ({os.path.getsize(path) / 1024:.1f} KiB)")
+
+
+# ======================================================================================== verifier (P1)
+def import_reference_verifier():
+    """bridge_verifier/ensemble_eval/{model,efficient_ensemble_merged}.py with stubbed open_clip / timm / ijson."""
+    class Mlp(torch.nn.Module):  # timm.layers.mlp.Mlp defaults: fc1 -> exact GELU -> fc2 (drop = 0)
+        def __init__(self, in_features, hidden_features=None, out_features=None):
+            super().__init__()
+            self.fc1 = torch.nn.Linear(in_features, hidden_features or in_features)
+            self.act = torch.nn.GELU()
+            self.fc2 = torch.nn.Linear(hidden_features or in_features, out_features or in_features)
+
+        def forward(self, x):
+            return self.fc2(self.act(self.fc1(x)))
+
+    _shell("timm")
+    _shell("timm.layers")
+    _shell("timm.layers.mlp", Mlp=Mlp)
+    _shell("open_clip", create_model_from_pretrained=None, get_tokenizer=None, create_model_and_transforms=None)
+    _shell("ijson")
+    if "tqdm" not in sys.modules:
+        try:
+            import tqdm  # noqa: F401
+        except Exception:
+            _shell("tqdm", tqdm=lambda x, **k: x)
+    _shell("bridge_verifier", os.path.join(REF, "bridge_verifier"))
+    _shell("bridge_verifier.ensemble_eval", os.path.join(REF, "bridge_verifier", "ensemble_eval"))
+    import importlib
+    model = importlib.import_module("bridge_verifier.ensemble_eval.model")
+    eem = importlib.import_module("bridge_verifier.ensemble_eval.efficient_ensemble_merged")
+    return model, eem
+
+
+def build_reference_ensemble(model, eem, ckpt, pf, tf):
+    """EfficientEnsembleMerged via __new__, trainable_models filled with the reference's module classes loaded from the
+    synthetic merged checkpoint exactly as efficient_ensemble_merged.py:94-184 does; encoders stubbed at the feature
+    boundary (extract_features returns the supplied pf/tf)."""
+    ens = eem.EfficientEnsembleMerged.__new__(eem.EfficientEnsembleMerged)
+    ens.device = "cpu"
+    ens.use_transformer = True
+    ens.history_length = 10
+    ens.action_dim = 7
+    ens.num_models = len(ckpt["ensemble_components"])
+    ens.trainable_models = []
+    P, D = pf.shape[1], pf.shape[2]
+    for cs in ckpt["ensemble_components"]:
+        ta = model.TextAwareVisualExtraction(num_img_patches=P, vision_dim=D)
+        ta.load_state_dict(cs["text_aware_visual_extraction"])
+        vp = model.AttentionPooling(input_dim=D, output_dim=512, num_heads=8, num_layers=4, num_readouts=1)
+        vp.load_state_dict(cs["vision_poolings"])
+        tp = model.AttentionPooling(input_dim=tf.shape[2], output_dim=512, num_heads=8, num_layers=4, num_readouts=1)
+        tp.load_state_dict(cs["text_pooling"])
+        ip = torch.nn.Linear(1024, 512)
+        ip.load_state_dict(cs["input_projection"])
+        se = torch.nn.Linear(7, 512)
+        se.load_state_dict(cs["single_step_action_encoder"])
+        layer = torch.nn.TransformerEncoderLayer(d_model=512, nhead=8, dim_feedforward=1024, batch_first=False, dropout=0.1)
+        te = torch.nn.TransformerEncoder(layer, num_layers=4)
+        te.load_state_dict(cs["trajectory_encoder"])
+        for m in (ta, vp, tp, ip, se, te):
+            m.eval()
+        ens.trainable_models.append({
+            "text_aware_visual_extraction": ta, "vision_poolings": vp, "text_pooling": tp, "input_projection": ip,
+            "single_step_action_encoder": se, "trajectory_encoder": te, "complex_action_encoder": None,
+            "action_padding_value": cs["action_padding_value"]})
+
+    class _Feat:
+        def extract_features(self, img, tok):
+            return pf, tf
+    ens.full_model_for_features = _Feat()
+    ens.preprocess = lambda img: torch.zeros(3, 8, 8)
+    ens.tokenizer = lambda texts, context_length=64: torch.zeros(len(texts), context_length, dtype=torch.long)
+    ens.siglip_model = types.SimpleNamespace(context_length=64)
+    return ens
+
+
+def gen_verifier():
+    import warnings
+    warnings.filterwarnings("ignore")
+    model, eem = import_reference_verifier()
+    img = np.zeros((8, 8, 3), dtype=np.uint8)
+    for members, N, group, seed in [(2, 16, 2, 11), (3, 40, 5, 7), (3, 32, 4, 3), (1, 1, 1, 5)]:
+        ckpt = synth.verifier_checkpoint(members, seed=1234 + seed)
+        pf, tf, hists = synth.verifier_inputs(N, seed=seed)
+        ens = build_reference_ensemble(model, eem, ckpt, pf, tf)
+        with torch.no_grad():
+            score, instr, hist, gidx = ens.compute_max_similarity_scores_batch(
+                [img] * N, ["put the spoon on the towel"] * N, hists, cfg_repeat_language_instructions=group)
+            # per-member and fused embeddings through the reference's own methods
+            hb = torch.tensor(np.array([np.vstack([np.ones((10 - len(h), 7)) * -5, h]) if len(h) < 10 else h for h in hists]),
+                              dtype=torch.float32)
+            its, acts = [], []
+            for mi in range(members):
+                it, act = ens.get_embeddings_from_model_batch(mi, pf, tf, hb)
+                its.append(it[0:1])
+                acts.append(act)
+            its, acts = torch.stack(its), torch.stack(acts)
+            f_it = its.mean(0)
+            f_it = f_it / f_it.norm(dim=-1, keepdim=True)
+            f_act = acts.mean(0)
+            f_act = f_act / f_act.norm(dim=-1, keepdim=True)
+            scores = (f_it @ f_act.T)[0]
+        assert isinstance(gidx, torch.Tensor) and gidx.dtype == torch.int64 and gidx.dim() == 0
+        save(f"verifier_m{members}_n{N}_g{group}", members=members, N=N, group=group, ckpt_seed=1234 + seed, input_seed=seed,
+             its=its, acts=acts, scores=scores, max_score=np.float32(score), global_idx=np.int64(int(gidx)),
+             hist_lens=np.array([len(h) for h in hists]))
+    # selection edge cases (G4): exact ties and the grouped rule, through the reference's own selection code path
+    # by feeding features that make every candidate identical (all scores tie -> index 0 must win)
+    ckpt = synth.verifier_checkpoint(2, seed=99)
+    pf, tf, hists = synth.verifier_inputs(12, seed=99)
+    same = [hists[0]] * 12
+    ens = build_reference_ensemble(model, eem, ckpt, pf, tf)
+    with torch.no_grad():
+        score, _, _, gidx = ens.compute_max_similarity_scores_batch([img] * 12, ["x"] * 12, same, cfg_repeat_language_instructions=3)
+    save("verifier_ties", global_idx=np.int64(int(gidx)), max_score=np.float32(score), hist=same[0])
+
+
+# ======================================================================================== adapter math (P1 host glue)
+def gen_adapter():
+    """BridgeSimplerAdapter.postprocess / postprocess_verifier + geometry helpers on 64 random normalised action rows."""
+    _shell("cv2")
+    _shell("src", os.path.join(REF, "INT-ACT", "src"))
+    _shell("src.experiments", os.path.join(REF, "INT-ACT", "src", "experiments"))
+    _shell("src.experiments.env_adapters", os.path.join(REF, "INT-ACT", "src", "experiments", "env_adapters"))
+    _shell("src.utils", os.path.join(REF, "INT-ACT", "src", "utils"))
+    import importlib
+    geometry = importlib.import_module("src.utils.geometry")
+    simpler = importlib.import_module("src.experiments.env_adapters.simpler")
+    stats_path = os.path.join(REF, "INT-ACT", "config", "dataset", "bridge_statistics.json")
+    ad = simpler.BridgeSimplerAdapter.__new__(simpler.BridgeSimplerAdapter)
+    import json
+    with open(stats_path) as f:
+        ad.dataset_statistics = json.load(f)
+    ad.action_normalization_type = "bound"
+    ad.state_normalization_type = "bound"
+    rng = np.random.default_rng(5)
+    acts = rng.uniform(-1.2, 1.2, size=(64, 7)).astype(np.float32)
+    acts[:8, 6] = [0.5, 0.4999, 0.5001, 0.0, 1.0, -0.3, 0.75, 0.25]
+    exec_rows = ad.postprocess(acts.copy())
+    ver_rows = ad.postprocess_verifier(acts.copy())
+    exec_arr = np.stack([np.concatenate([d["world_vector"], d["rot_axangle"], d["gripper"]]) for d in exec_rows])
+    ver_arr = np.stack([np.asarray(r, dtype=np.float64) for r in ver_rows])
+    eul = rng.uniform(-3, 3, size=(32, 3))
+    ax = np.stack([geometry.euler2axangle(*e)[0] * geometry.euler2axangle(*e)[1] for e in eul])
+    quats = rng.normal(size=(16, 4))
+    quats /= np.linalg.norm(quats, axis=1, keepdims=True)
+    mats = np.stack([geometry.quat2mat(q) for q in quats])
+    eulers = np.stack([np.array(geometry.mat2euler(m)) for m in mats])
+    save("adapter_bridge", actions=acts, exec_rows=exec_arr, verifier_rows=ver_arr, euler_in=eul, axangle=ax, quats=quats,
+         quat_mats=mats, mat_eulers=eulers)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["verifier", "adapter", "pi0", "hf"]
+    torch.manual_seed(0)
+    if "verifier" in which:
+        gen_verifier()
+    if "adapter" in which:
+        gen_adapter()
+    if "pi0" in which:
+        from gen_golden_pi0 import gen_pi0
+        gen_pi0(save)
+    if "hf" in which:
+        from gen_golden_hf import gen_hf
+        gen_hf(save)
