@@ -176,3 +176,33 @@ def decoder_state(g: _G, *, dim: int, layers: int, Hq: int, Hkv: int, D: int, ml
     if vocab:
         sd["embed_tokens.weight"] = g.w(vocab, dim)
     return sd
+
+
+# ------------------------------------------------------------------------------------------------ pi0 (P1)
+def pi0_state(c: dict, seed: int = 1234, nontrivial: bool = True, std: float = 0.1) -> Dict[str, Tensor]:
+    """Neutral pi0 state dict (fp32 master copy) for a config dict with keys lm_dim, lm_mlp, ex_dim, ex_mlp, layers,
+    Hq, Hkv, D, vocab, vit_dim, vit_mlp, vit_layers, vit_heads, patch, image. Key layout: see oracle/cover_ref/pi0.py."""
+    g = _G(seed, nontrivial, std)
+    n_patches = (c["image"] // c["patch"]) ** 2
+    sd = {}
+    for k, v in vit_state(g, dim=c["vit_dim"], layers=c["vit_layers"], heads=c["vit_heads"], mlp=c["vit_mlp"],
+                          patch=c["patch"], n_pos=n_patches).items():
+        sd["vision." + k] = v
+    sd["projector.weight"] = g.w(c["lm_dim"], c["vit_dim"])
+    sd["projector.bias"] = g.b(c["lm_dim"])
+    for k, v in decoder_state(g, dim=c["lm_dim"], layers=c["layers"], Hq=c["Hq"], Hkv=c["Hkv"], D=c["D"], mlp=c["lm_mlp"],
+                              rms_base=0.0, vocab=c["vocab"]).items():
+        sd["lm." + k] = v
+    for k, v in decoder_state(g, dim=c["ex_dim"], layers=c["layers"], Hq=c["Hq"], Hkv=c["Hkv"], D=c["D"], mlp=c["ex_mlp"],
+                              rms_base=0.0).items():
+        sd["expert." + k] = v
+    pw = c["ex_dim"]
+    for n, (o, i) in {"state_proj": (pw, 32), "action_in_proj": (pw, 32), "action_out_proj": (32, pw),
+                      "action_time_mlp_in": (pw, 2 * pw), "action_time_mlp_out": (pw, pw)}.items():
+        sd[n + ".weight"] = g.w(o, i)
+        sd[n + ".bias"] = g.b(o)
+    return sd
+
+
+PI0_FULL = dict(lm_dim=2048, lm_mlp=16384, ex_dim=1024, ex_mlp=4096, layers=18, Hq=8, Hkv=1, D=256, vocab=257152,
+                vit_dim=1152, vit_mlp=4304, vit_layers=27, vit_heads=16, patch=14, image=224, chunk=4)

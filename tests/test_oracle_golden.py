@@ -41,3 +41,48 @@ def test_verifier_ties_first_index_wins():
         r = V.compute_max_similarity_scores(ckpt["ensemble_components"], pf, tf, [z["hist"]] * 12, 3)
     assert r["global_idx"] == int(z["global_idx"]) == 0
     assert abs(r["max_score"] - float(z["max_score"])) < 1e-5
+
+
+# ------------------------------------------------------------------------------------------------ pi0 sampler
+def _pi0_cfg(tiny):
+    from cover_ref import blocks as Bk, pi0 as P
+    vit = Bk.VitCfg(tiny["vit_dim"], tiny["vit_layers"], tiny["vit_heads"], tiny["vit_mlp"], tiny["patch"], "gelu_tanh", 1e-6)
+    lm = Bk.DecoderCfg(tiny["lm_dim"], tiny["layers"], tiny["Hq"], tiny["Hkv"], tiny["D"], tiny["lm_mlp"], "gelu_tanh", "gemma", 1e-6, "pi0")
+    ex = Bk.DecoderCfg(tiny["ex_dim"], tiny["layers"], tiny["Hq"], tiny["Hkv"], tiny["D"], tiny["ex_mlp"], "gelu_tanh", "gemma", 1e-6, "pi0")
+    return P.Pi0Cfg(vit, lm, ex, proj_width=tiny["ex_dim"], chunk_size=tiny["chunk"], n_img_tokens=(tiny["image"] // tiny["patch"]) ** 2)
+
+
+def pi0_case(path):
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    from gen_golden_pi0 import pi0_inputs
+    z = np.load(path)
+    tiny = {k[5:]: int(z[k]) for k in z.files if k.startswith("tiny_")}
+    B, L, seed = int(z["B"]), int(z["L"]), int(z["seed"])
+    sd = synth.pi0_state(tiny, seed=seed)
+    return z, tiny, sd, pi0_inputs(tiny, B, L, seed)
+
+
+@pytest.mark.parametrize("name", ["pi0_tiny_b6", "pi0_tiny_b1"])
+def test_pi0_oracle_matches_reference(name):
+    from cover_ref import pi0 as P
+    z, tiny, sd, (images, img_masks, toks, masks, state, noise) = pi0_case(os.path.join(GOLD, name + ".npz"))
+    cfg = _pi0_cfg(tiny)
+    sdr = P.cast_like_reference(sd)
+    with torch.no_grad():
+        pe, _, _ = P.embed_prefix(cfg, sdr, images, img_masks, toks, masks)
+        se, _, _ = P.embed_suffix(cfg, sdr, state, noise, torch.ones(state.shape[0]))
+        x = P.sample_actions(cfg, sdr, images, img_masks, toks, masks, state, noise)
+        x_iso = P.sample_actions(cfg, sdr, images, img_masks, toks, masks, state, noise,
+                                 prefix_embs=torch.from_numpy(z["prefix_embs"]).to(torch.bfloat16))
+    nimg = cfg.n_img_tokens
+    a, b = pe.float().numpy(), z["prefix_embs"]
+    # language tokens, suffix embedding: same eager op sequence -> bit-identical
+    assert np.array_equal(a[:, nimg:], b[:, nimg:])
+    assert np.array_equal(se.float().numpy(), z["suffix_embs_t1"])
+    # image tokens go through the un-vendored HF SigLIP tower whose attention rounds differently (sdpa, bf16 scores):
+    # bf16-ulp level agreement only
+    assert np.linalg.norm(a[:, :nimg] - b[:, :nimg]) / np.linalg.norm(b[:, :nimg]) < 1e-2
+    # decoder + flow matching, isolated from the tower by feeding the reference's own prefix embeddings
+    assert np.allclose(x_iso.numpy(), z["actions"], atol=2e-5), np.abs(x_iso.numpy() - z["actions"]).max()
+    # end to end: the tolerance the reference itself accepted against JAX (compare_with_jax.py:131-133)
+    assert np.allclose(x.numpy(), z["actions"], atol=3e-2), np.abs(x.numpy() - z["actions"]).max()
