@@ -280,6 +280,19 @@ def gemm_f32(a, b, *, bias=None, act="none", alpha=1.0, residual=None, out=None,
     return out
 
 
+def gemm_f32_raw(a_ptr, a_rs, a_ks, b_ptr, b_rs, b_ks, c_ptr, c_rs, M, N, K, *, bias=None, residual_ptr=None, ld_res=0,
+                 act="none", alpha=1.0, batch=1, a_bs=0, b_bs=0, c_bs=0):
+    """Pointer-level form of gemm_f32 (element strides) for strided / batched views that torch cannot express."""
+    g = L.GemmF32Args()
+    g.A, g.a_row_stride, g.a_k_stride = a_ptr, a_rs, a_ks
+    g.B, g.b_row_stride, g.b_k_stride = b_ptr, b_rs, b_ks
+    g.C, g.c_row_stride = c_ptr, c_rs
+    g.bias, g.residual, g.ld_residual = _ptr(bias), residual_ptr, ld_res
+    g.M, g.N, g.K, g.act, g.alpha = M, N, K, ACT[act], alpha
+    g.batch, g.a_batch_stride, g.b_batch_stride, g.c_batch_stride = batch, a_bs, b_bs, c_bs
+    L.check(L.lib().cover_gemm_f32(C.byref(g), _stream()), "gemm_f32")
+
+
 def layernorm_f32(x, w, b, eps=1e-5, out=None):
     _chk_dev(x)
     out = torch.empty_like(x) if out is None else out

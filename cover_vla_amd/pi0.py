@@ -1,0 +1,252 @@
+"""pi0 sampler on MI355X behind the reference's API.
+
+  PI0FlowMatching.sample_actions(images, img_masks, lang_tokens, lang_masks, state, noise=None, noise_std=1.0)
+      mirrors lerobot_custom/lerobot/common/policies/pi0/modeling_pi0.py:672-715 (tensor-level boundary)
+  PI0Policy.select_action(batch, noise=None, noise_std=1.0) -> collections.deque
+      mirrors modeling_pi0.py:263-307 (the drop-in the evaluation driver calls,
+      CoVer_VLA/inference/experiments/robot/simpler/run_simpler_eval_with_openpi.py:322-326)
+
+What changes underneath (results are unchanged): the reference runs vision + prefix B times on identical inputs
+(run_simpler_eval_with_openpi.py:305-313); here the SigLIP tower runs once per distinct camera frame and the
+PaliGemma prefix once per DISTINCT prompt, the KV cache is a static allocation the 10 denoise steps append to
+instead of torch.cat (paligemma_with_expert.py:305-308), masks are lengths, and every layer loop is one C call.
+All arithmetic is libcover_hip; torch here allocates buffers and does index bookkeeping only.
+"""
+from __future__ import annotations
+
+import collections
+import math
+from typing import Callable, Dict, List, Optional
+
+import torch
+
+from . import _lib as L
+from . import ops
+from .models import BF, Decoder, KvGeometry, VitTower, _f32
+
+
+class PI0FlowMatching:
+    def __init__(self, sd: Dict[str, torch.Tensor], c: dict, *, device="cuda:0", max_batch=64, max_prompts=16,
+                 max_lang=72, n_cams=1, num_steps=10, max_state_dim=32, max_action_dim=32):
+        """sd: neutral pi0 state dict (cover_vla_amd.synth.pi0_state layout / loader output), c: size dict."""
+        self.c, self.dev = dict(c), torch.device(device)
+        self.chunk, self.num_steps = c["chunk"], num_steps
+        self.max_state_dim, self.max_action_dim = max_state_dim, max_action_dim
+        self.W = c["ex_dim"]
+        self.n_img = (c["image"] // c["patch"]) ** 2
+        self.n_cams = n_cams
+        dev = self.dev
+        sub = lambda p: {k[len(p):]: v for k, v in sd.items() if k.startswith(p)}
+        self.vit = VitTower(sub("vision."), dim=c["vit_dim"], layers=c["vit_layers"], heads=c["vit_heads"], mlp=c["vit_mlp"],
+                            patch=c["patch"], act="gelu_tanh", eps=1e-6, device=device)
+        self.projector = ops.pack_linear(sd["projector.weight"].to(dev), sd["projector.bias"])
+        self.embed = sd["lm.embed_tokens.weight"].to(BF).contiguous().to(dev)
+        self.Tp_cap = self.n_img * n_cams + max_lang
+        S = 1 + self.chunk
+        geom = KvGeometry(c["Hkv"], c["D"], [max_prompts, max_batch], [self.Tp_cap, S])
+        n_pos = self.Tp_cap + S + 8
+        self.lm = Decoder(sub("lm."), dim=c["lm_dim"], layers=c["layers"], Hq=c["Hq"], Hkv=c["Hkv"], D=c["D"], mlp=c["lm_mlp"],
+                          act="gelu_tanh", norm="gemma", eps=1e-6, rope="pi0", n_pos=n_pos, device=device, cache=geom)
+        self.expert = Decoder(sub("expert."), dim=c["ex_dim"], layers=c["layers"], Hq=c["Hq"], Hkv=c["Hkv"], D=c["D"],
+                              mlp=c["ex_mlp"], act="gelu_tanh", norm="gemma", eps=1e-6, rope="pi0", n_pos=n_pos, device=device,
+                              share_cache_with=self.lm)
+        # pi0's own projections stay fp32 (modeling_pi0.py:488-494)
+        self.p = {n: (_f32(sd[n + ".weight"], dev), _f32(sd[n + ".bias"], dev))
+                  for n in ("state_proj", "action_in_proj", "action_out_proj", "action_time_mlp_in", "action_time_mlp_out")}
+        self.vis_len = torch.tensor([1] + [S] * self.chunk, dtype=torch.int32, device=dev)
+        self.max_batch, self.max_prompts, self.max_lang = max_batch, max_prompts, max_lang
+
+    # ---------------------------------------------------------------------------------------------- prefix
+    def _image_tokens(self, img: torch.Tensor) -> torch.Tensor:
+        """img fp32 [n,3,H,W] in [-1,1] -> bf16 [n, n_img, lm_dim]: tower -> projector -> (/sqrt(D))*bf16(sqrt(D))
+        (modeling_pi0.py:529-538 with HF-4.48.3 get_image_features; Appendix A.3 double rounding)."""
+        x = self.vit.embed(img.float().contiguous())
+        x = self.vit.forward(x, post_ln=True)
+        n, T, _ = x.shape
+        D = self.c["lm_dim"]
+        y = ops.gemm(x.view(n * T, -1), self.projector)
+        ops.scale_bf16(y, D ** 0.5, float(torch.tensor(D ** 0.5, dtype=BF)))
+        return y.view(n, T, D)
+
+    def sample_actions(self, images: List[torch.Tensor], img_masks: List[torch.Tensor], lang_tokens: torch.Tensor,
+                       lang_masks: torch.Tensor, state: torch.Tensor, noise: Optional[torch.Tensor] = None,
+                       noise_std: float = 1.0, trace: Optional[dict] = None) -> torch.Tensor:
+        dev, c = self.dev, self.c
+        B = state.shape[0]
+        Lg = lang_tokens.shape[1]
+        if B > self.max_batch or Lg > self.max_lang or len(images) != self.n_cams:
+            raise ValueError(f"batch {B}/lang {Lg}/cams {len(images)} exceed the sizes this model was built for")
+        if noise is None:
+            noise = torch.normal(mean=0.0, std=noise_std, size=(B, self.chunk, self.max_action_dim), dtype=torch.float32,
+                                 device=dev)
+        # ---- dedup (index bookkeeping): distinct prompts and distinct camera frames
+        key = torch.cat([lang_tokens, lang_masks.to(lang_tokens.dtype)], dim=1)
+        uniq, prompt_of_row = torch.unique(key, dim=0, return_inverse=True)
+        U = uniq.shape[0]
+        if U > self.max_prompts:
+            raise ValueError(f"{U} distinct prompts > max_prompts={self.max_prompts}")
+        first_row = torch.full((U,), B, device=dev, dtype=torch.long).scatter_reduce(
+            0, prompt_of_row, torch.arange(B, device=dev), "amin")
+        shared_img = all(bool(torch.equal(im[:1].expand_as(im), im)) for im in images) if B > 1 else True
+        n_img_all = self.n_img * self.n_cams
+        Tp = n_img_all + Lg
+        D = c["lm_dim"]
+        prefix = torch.empty(U, Tp, D, dtype=BF, device=dev)
+        for ci, im in enumerate(images):
+            src = im[:1] if shared_img else im[first_row]
+            tok = self._image_tokens(src)  # [1 or U, n_img, D]
+            rows = torch.arange(self.n_img, device=dev)
+            sidx = (rows[None] + (0 if shared_img else 1) * torch.arange(U, device=dev)[:, None] * self.n_img).reshape(-1)
+            didx = (torch.arange(U, device=dev)[:, None] * Tp + ci * self.n_img + rows[None]).reshape(-1)
+            ops.copy_rows(tok.view(-1, D), prefix.view(-1, D), U * self.n_img, D, sidx.to(torch.int32), didx.to(torch.int32))
+        utok = lang_tokens[first_row].contiguous()
+        umask = lang_masks[first_row]
+        lang = ops.embed_gather(self.embed, utok.view(-1), math.sqrt(D))
+        didx = (torch.arange(U, device=dev)[:, None] * Tp + n_img_all + torch.arange(Lg, device=dev)[None]).reshape(-1)
+        ops.copy_rows(lang, prefix.view(-1, D), U * Lg, D, None, didx.to(torch.int32))
+        if trace is not None:
+            trace["prefix_embs"] = prefix[prompt_of_row].clone()
+        # lengths / positions (prompts are right padded: valid keys are a contiguous prefix)
+        plen = (n_img_all + umask.sum(dim=1)).to(torch.int32)
+        pad = torch.cat([torch.ones(U, n_img_all, dtype=torch.bool, device=dev), umask.bool()], dim=1)
+        ppos = (torch.cumsum(pad, dim=1) - 1).clamp(min=0).to(torch.int32).contiguous()
+        g0 = self.lm.group(U, Tp, ppos.view(-1), [dict(region=0, length=Tp, len_of_batch=plen)], 0)
+        self.lm.forward(prefix.view(U * Tp, D), [g0], final_norm=False)
+
+        # ---- suffix constants
+        S, W, A = 1 + self.chunk, self.W, self.max_action_dim
+        row_prompt = prompt_of_row.to(torch.int32).contiguous()
+        row_plen = plen[prompt_of_row].contiguous()
+        spos = (row_plen[:, None] + torch.arange(S, device=dev, dtype=torch.int32)[None]).contiguous()
+        g1 = self.expert.group(B, S, spos.view(-1),
+                               [dict(region=0, length=Tp, len_of_batch=row_plen, slot_of_batch=row_prompt),
+                                dict(region=1, length=S, mask=ops.MASK_VISLEN, vis_len=self.vis_len)], 1)
+        suffix = torch.empty(B, S, W, dtype=torch.float32, device=dev)
+        st = ops.gemm_f32(state.float().contiguous(), self.p["state_proj"][0], bias=self.p["state_proj"][1])
+        ops.cast_bf16_to_f32(ops.cast_f32_to_bf16(st), out=suffix.view(B, S * W)[:, :W])  # bf16-rounded state token
+        x_t = noise.to(torch.float32).clone().contiguous()
+        cat = torch.empty(B * self.chunk, 2 * W, dtype=torch.float32, device=dev)
+        hid = torch.empty(B * self.chunk, W, dtype=torch.float32, device=dev)
+        xb = torch.empty(B * S, W, dtype=BF, device=dev)
+        out32 = torch.empty(B, S, W, dtype=torch.float32, device=dev)
+        tvec = torch.empty(B * self.chunk, dtype=torch.float32, device=dev)
+        dt = -1.0 / self.num_steps
+        # the reference loops `while time >= -dt/2` on an fp32 tensor: exactly num_steps iterations (modeling_pi0.py:697-715)
+        time = torch.tensor(1.0, dtype=torch.float32)
+        dt32 = torch.tensor(dt, dtype=torch.float32)
+        vs = []
+        while time >= -dt32 / 2:
+            tvec.fill_(float(time))
+            temb = ops.sincos_time_embed(tvec, W, 4e-3, 4.0)
+            ops.cast_bf16_to_f32(temb, out=cat[:, W:])
+            ops.gemm_f32(x_t.view(B * self.chunk, A), self.p["action_in_proj"][0], bias=self.p["action_in_proj"][1], out=cat[:, :W])
+            ops.gemm_f32(cat, self.p["action_time_mlp_in"][0], bias=self.p["action_time_mlp_in"][1], act="silu", out=hid)
+            wo, bo = self.p["action_time_mlp_out"]
+            ops.gemm_f32_raw(hid.data_ptr(), W, 1, wo.data_ptr(), W, 1, suffix.data_ptr() + 4 * W, W, self.chunk, W, W,
+                             bias=bo, batch=B, a_bs=self.chunk * W, c_bs=S * W)  # rows 1..chunk of every suffix
+            if trace is not None and not vs:
+                trace["suffix_embs_t1"] = suffix.clone()
+            self.expert.forward(xb, [g1], final_norm=True, x_f32=suffix.view(B * S, W))
+            ops.cast_bf16_to_f32(xb, out=out32.view(B * S, W))
+            # v_t = action_out_proj(suffix_out[:, -chunk:]) ; x_t += dt * v_t   (modeling_pi0.py:748-751, 713)
+            wp, bp = self.p["action_out_proj"]
+            ops.gemm_f32_raw(out32.data_ptr() + 4 * W, W, 1, wp.data_ptr(), W, 1, x_t.data_ptr(), A, self.chunk, A, W,
+                             bias=bp, residual_ptr=x_t.data_ptr(), ld_res=A, alpha=float(dt32), batch=B, a_bs=S * W,
+                             c_bs=self.chunk * A)
+            if trace is not None:
+                vs.append(x_t.clone())
+            time = time + dt32
+        if trace is not None:
+            trace["x_steps"] = vs
+        return x_t
+
+
+# --------------------------------------------------------------------------------------------------- policy wrapper
+def pad_vector(vector: torch.Tensor, new_dim: int) -> torch.Tensor:
+    """modeling_pi0.py:153-164."""
+    if vector.shape[-1] == new_dim:
+        return vector
+    shape = list(vector.shape)
+    shape[-1] = new_dim
+    out = torch.zeros(*shape, dtype=vector.dtype, device=vector.device)
+    out[..., : vector.shape[-1]] = vector
+    return out
+
+
+class PI0Config:
+    """The fields of lerobot's PI0Config the evaluation path touches (configuration_pi0.py:29-71, configs/policies.py)."""
+
+    def __init__(self, *, image_keys=("observation.images.top",), n_action_steps=4, chunk_size=4, max_state_dim=32,
+                 max_action_dim=32, tokenizer_max_length=72, num_steps=10, action_dim=7, device="cuda:0",
+                 resize_imgs_with_padding=(224, 224)):
+        self.image_features = list(image_keys)
+        self.n_action_steps, self.chunk_size = n_action_steps, chunk_size
+        self.max_state_dim, self.max_action_dim = max_state_dim, max_action_dim
+        self.tokenizer_max_length, self.num_steps = tokenizer_max_length, num_steps
+        self.action_dim, self.device = action_dim, device
+        self.resize_imgs_with_padding = resize_imgs_with_padding
+
+
+class PI0Policy:
+    """Drop-in for lerobot's PI0Policy on the CoVer evaluation path (modeling_pi0.py:226-307)."""
+
+    def __init__(self, config: PI0Config, model: PI0FlowMatching, tokenizer: Callable,
+                 action_mean: Optional[torch.Tensor] = None, action_std: Optional[torch.Tensor] = None,
+                 state_mean: Optional[torch.Tensor] = None, state_std: Optional[torch.Tensor] = None):
+        self.config, self.model, self.tokenizer = config, model, tokenizer
+        # INT-ACT checkpoints use IDENTITY normalisation (pi0_finetune_bridge.json:6-10); mean/std optional
+        self.action_mean, self.action_std, self.state_mean, self.state_std = action_mean, action_std, state_mean, state_std
+        self._preprocess_adapter = None
+        self.reset()
+
+    def to(self, device):
+        return self
+
+    def eval(self):
+        return self
+
+    def reset(self):
+        """modeling_pi0.py:256-258."""
+        self._action_queue = collections.deque([], maxlen=self.config.n_action_steps)
+
+    def prepare_images(self, batch):
+        """modeling_pi0.py:344-387 at the evaluated size: resize_with_pad is the identity at 224x224 and the adapter
+        already scaled to [-1,1] (INT-ACT .../simpler.py:48-65)."""
+        present = [k for k in self.config.image_features if k in batch]
+        if not present:
+            raise ValueError(f"All image features are missing from the batch. At least one expected. "
+                             f"(batch: {batch.keys()}) (image_features:{self.config.image_features})")
+        images, masks = [], []
+        for k in present:
+            img = batch[k]
+            if tuple(img.shape[2:]) != tuple(self.config.resize_imgs_with_padding):
+                raise ValueError(f"(b,c,{self.config.resize_imgs_with_padding}) expected, but {tuple(img.shape)}")
+            images.append(img)
+            masks.append(torch.ones(img.shape[0], dtype=torch.bool, device=img.device))
+        return images, masks
+
+    def prepare_language(self, batch):
+        """modeling_pi0.py:389-409: "<task>\\n", right padded to tokenizer_max_length, truncated."""
+        tasks = batch["task"]
+        tasks = [t if t.endswith("\n") else f"{t}\n" for t in tasks]
+        ids, mask = self.tokenizer(tasks, self.config.tokenizer_max_length)
+        dev = self.model.dev
+        return ids.to(dev), mask.to(dev).bool()
+
+    @torch.no_grad()
+    def select_action(self, batch: dict, noise: Optional[torch.Tensor] = None, noise_std: float = 1.0) -> collections.deque:
+        """Returns the deque itself (the local modification of modeling_pi0.py:303-307); the caller copies and clears it."""
+        if len(self._action_queue) == 0:
+            state = batch["observation.state"]
+            if self.state_mean is not None:
+                state = (state - self.state_mean) / (self.state_std + 1e-8)
+            images, img_masks = self.prepare_images(batch)
+            state = pad_vector(state, self.config.max_state_dim)
+            lang_tokens, lang_masks = self.prepare_language(batch)
+            actions = self.model.sample_actions(images, img_masks, lang_tokens, lang_masks, state, noise=noise,
+                                                noise_std=noise_std)
+            actions = actions[:, : self.config.n_action_steps, : self.config.action_dim]
+            if self.action_mean is not None:
+                actions = actions * self.action_std + self.action_mean
+            self._action_queue.extend(actions.transpose(0, 1))
+        return self._action_queue

@@ -1,0 +1,259 @@
+"""CoVer verifier on MI355X behind the reference's API (bridge_verifier/ensemble_eval/efficient_ensemble_merged.py).
+
+  EfficientEnsembleMerged(merged_checkpoint, device=...)                      :25-186
+      .extract_shared_features(img_tensor, text_tokens) -> (patch_features, text_features)      :188-192
+      .get_embeddings_from_model_batch(model_idx, pf, tf, histories)                            :194-247
+      .fuse_embeddings / .predict                                                               :249-307
+      .compute_max_similarity_scores_batch(images, instructions, histories, group) ->
+            (max_score: float, max_instruction: str, max_action_history: ndarray, global_action_idx: 0-dim int64) :309-454
+
+Same results, different schedule: the reference repeats the (image, text) heads N times on identical inputs
+(:213-214) and loops members sequentially; here the image-text embedding of a member is computed once per distinct
+(image, text) pair and only the trajectory encoder runs per candidate. Heads, fusion and scoring stay fp32 as in
+the reference; the frozen SigLIP2 towers run in bf16 through the shared ViT kernels.
+"""
+from __future__ import annotations
+
+from typing import Callable, Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from . import ops
+from .models import BF, VitTower, _f32
+
+
+def _dev_sd(sd, dev):
+    return {k: (_f32(v, dev) if torch.is_tensor(v) else v) for k, v in sd.items()}
+
+
+class _Pooling:
+    """AttentionPooling (model.py:76-112) with num_readouts = 1: one learned query cross-attends the kv tokens."""
+
+    def __init__(self, sd, dev, heads=8):
+        self.sd = _dev_sd(sd, dev)
+        self.heads = heads
+        self.n_layers = 1 + max(int(k.split(".")[1]) for k in sd if k.startswith("blocks."))
+        self.dim = sd["query"].shape[-1]
+        # K and V projections of all blocks read the same kv tokens: one stacked weight -> one GEMM per pooling
+        ws, bs = [], []
+        for i in range(self.n_layers):
+            p = f"blocks.{i}.attention."
+            b_in = self.sd[p + "in_proj_bias"]
+            ws += [self.sd[p + "k_proj_weight"], self.sd[p + "v_proj_weight"]]
+            bs += [b_in[self.dim:2 * self.dim], b_in[2 * self.dim:]]
+        self.w_kv = torch.cat(ws, 0).contiguous()
+        self.b_kv = torch.cat(bs, 0).contiguous()
+
+    def __call__(self, x: torch.Tensor) -> torch.Tensor:
+        """x fp32 [T, input_dim] -> [1, dim]."""
+        sd, E, H = self.sd, self.dim, self.heads
+        T = x.shape[0]
+        kv = ops.gemm_f32(x, self.w_kv, bias=self.b_kv)  # [T, n_layers*2*E]
+        q = sd["query"].view(1, E)
+        ld = kv.shape[1]
+        for i in range(self.n_layers):
+            p = f"blocks.{i}."
+            q = ops.layernorm_f32(q, sd[p + "q_layer_norm.weight"], sd[p + "q_layer_norm.bias"])
+            qp = ops.gemm_f32(q, sd[p + "attention.q_proj_weight"], bias=sd[p + "attention.in_proj_bias"][:E])
+            k = kv[:, (2 * i) * E:(2 * i + 1) * E]
+            v = kv[:, (2 * i + 1) * E:(2 * i + 2) * E]
+            a = ops.mha_f32(qp, k, v, 1, 1, T, H, E // H, (E, E), (T * ld, ld), (T * ld, ld))
+            q = ops.gemm_f32(a.view(1, E), sd[p + "attention.out_proj.weight"], bias=sd[p + "attention.out_proj.bias"], residual=q)
+            q = ops.layernorm_f32(q, sd[p + "layer_norm.weight"], sd[p + "layer_norm.bias"])
+            h = ops.gemm_f32(q, sd[p + "mlp.fc1.weight"], bias=sd[p + "mlp.fc1.bias"], act="gelu_erf")
+            q = ops.gemm_f32(h, sd[p + "mlp.fc2.weight"], bias=sd[p + "mlp.fc2.bias"], residual=q)
+        return ops.layernorm_f32(q, sd["layer_norm.weight"], sd["layer_norm.bias"])
+
+
+class _Member:
+    def __init__(self, comp: dict, dev):
+        self.dev = dev
+        ta = comp["text_aware_visual_extraction"]
+        self.inv_temp = 1.0 / float(torch.as_tensor(ta["temperature"]).clamp(0, 100))
+        self.pos_emb = _f32(ta["pos_emb"], dev)
+        self.vision = _Pooling(comp["vision_poolings"], dev)
+        self.text = _Pooling(comp["text_pooling"], dev)
+        self.ip = _dev_sd(comp["input_projection"], dev)
+        self.se = _dev_sd(comp["single_step_action_encoder"], dev)
+        self.traj = _dev_sd(comp["trajectory_encoder"], dev)
+        self.traj_layers = 1 + max(int(k.split(".")[1]) for k in comp["trajectory_encoder"])
+        self.pad_value = float(comp["action_padding_value"])
+
+    def image_text(self, pf: torch.Tensor, tf: torch.Tensor) -> torch.Tensor:
+        """pf fp32 [P, D], tf fp32 [T, D] unit rows -> unit [1, 512] (efficient_ensemble_merged.py:216-223)."""
+        sim = ops.gemm_f32(tf, pf)                               # [T, P]
+        ops.softmax_rows_f32(sim, self.inv_temp)
+        pfpe = ops.add_f32(pf, self.pos_emb)
+        taf = ops.gemm_f32(sim, pfpe, b_is_kn=True)              # [T, D]
+        vt = self.vision(taf)
+        tt = self.text(tf)
+        comb = torch.empty(1, vt.shape[1] + tt.shape[1], dtype=torch.float32, device=self.dev)
+        comb[:, :tt.shape[1]].copy_(tt)   # cat([text_token, vision_token]) (device copy, no arithmetic)
+        comb[:, tt.shape[1]:].copy_(vt)
+        y = ops.gemm_f32(comb, self.ip["weight"], bias=self.ip["bias"])
+        return ops.l2norm_rows_f32(y)
+
+    def trajectory(self, hist: torch.Tensor, pad: torch.Tensor) -> torch.Tensor:
+        """hist fp32 [N, 10, 7], pad uint8 [N, 10] -> unit [N, 512] (efficient_ensemble_merged.py:226-245)."""
+        N, T, A = hist.shape
+        sd, E, H = self.traj, self.se["weight"].shape[0], 8
+        x = ops.gemm_f32(hist.view(N * T, A), self.se["weight"], bias=self.se["bias"])
+        for i in range(self.traj_layers):
+            p = f"layers.{i}."
+            qkv = ops.gemm_f32(x, sd[p + "self_attn.in_proj_weight"], bias=sd[p + "self_attn.in_proj_bias"])  # [N*T, 3E]
+            a = ops.mha_f32(qkv, qkv[:, E:], qkv[:, 2 * E:], N, T, T, H, E // H, (T * 3 * E, 3 * E), (T * 3 * E, 3 * E),
+                            (T * 3 * E, 3 * E), key_pad=pad)
+            y = ops.gemm_f32(a.view(N * T, E), sd[p + "self_attn.out_proj.weight"], bias=sd[p + "self_attn.out_proj.bias"], residual=x)
+            x = ops.layernorm_f32(y, sd[p + "norm1.weight"], sd[p + "norm1.bias"])
+            h = ops.gemm_f32(x, sd[p + "linear1.weight"], bias=sd[p + "linear1.bias"], act="relu")
+            y = ops.gemm_f32(h, sd[p + "linear2.weight"], bias=sd[p + "linear2.bias"], residual=x)
+            x = ops.layernorm_f32(y, sd[p + "norm2.weight"], sd[p + "norm2.bias"])
+        m = ops.masked_mean_f32(x, pad, N, T, E)
+        return ops.l2norm_rows_f32(m)
+
+
+class SigLIP2Encoder:
+    """The frozen shared encoder: SigLIP2 ViT-L/16-384 image tower (patch features = the LAST block's attention-module
+    output, forward hook at finetune_trajectory_bridge_ddp.py:272-274) and text tower (transformer output -> ln_final
+    -> text_projection on all 64 positions, :318-330), both bf16, features cast to fp32 and L2-normalised per token.
+    State dict: image.* / text.* in synth.vit_state layout; text.tok_emb [vocab, dim]; text.proj.{weight,bias}."""
+
+    def __init__(self, sd: Dict[str, torch.Tensor], *, dim=1024, layers=24, heads=16, mlp=4096, patch=16, image=384,
+                 context_length=64, device="cuda:0"):
+        dev = torch.device(device)
+        self.dev, self.dim, self.context_length, self.image_size = dev, dim, context_length, image
+        self.num_patches = (image // patch) ** 2
+        sub = lambda p: {k[len(p):]: v for k, v in sd.items() if k.startswith(p)}
+        self.layers = layers
+        self.image = VitTower(sub("image."), dim=dim, layers=layers, heads=heads, mlp=mlp, patch=patch, act="gelu_tanh",
+                              eps=1e-6, device=device)
+        tsd = sub("text.")
+        tsd.setdefault("patch.weight", torch.zeros(dim, 3 * patch * patch))  # text tower has no patch embedding
+        tsd.setdefault("patch.bias", torch.zeros(dim))
+        self.text = VitTower(tsd, dim=dim, layers=layers, heads=heads, mlp=mlp, patch=patch, act="gelu_tanh", eps=1e-6,
+                             device=device)
+        self.tok_emb = sd["text.tok_emb"].to(BF).contiguous().to(dev)
+        self.text_pos = sd["text.pos"].to(BF).contiguous().to(dev)
+        self.text_proj = ops.pack_linear(sd["text.proj.weight"].to(dev), sd["text.proj.bias"])
+
+    def extract_features(self, images: torch.Tensor, text: torch.Tensor):
+        """images fp32 [B,3,384,384] (open_clip-preprocessed), text int64 [B,64] -> (pf fp32 [B,P,D], tf fp32 [B,64,D])."""
+        B = images.shape[0]
+        x = self.image.embed(images.float().contiguous())
+        a = self.image.forward(x, n_layers=self.layers, last_attn_only=True)
+        pf = ops.cast_bf16_to_f32(a.view(B * self.num_patches, self.dim))
+        pf = ops.l2norm_rows_f32(pf).view(B, self.num_patches, self.dim)
+        T = text.shape[1]
+        t = ops.embed_gather(self.tok_emb, text.reshape(-1).contiguous())
+        ops.add_rows(t, self.text_pos[:T])
+        t = self.text.forward(t.view(B, T, self.dim), post_ln=True)      # transformer -> ln_final
+        tp = ops.gemm(t.view(B * T, self.dim), self.text_proj)           # text_projection (Linear)
+        tf = ops.l2norm_rows_f32(ops.cast_bf16_to_f32(tp)).view(B, T, self.dim)
+        return pf, tf
+
+
+class EfficientEnsembleMerged:
+    def __init__(self, merged_checkpoint, device="cuda:0", encoder: Optional[SigLIP2Encoder] = None,
+                 preprocess: Optional[Callable] = None, tokenizer: Optional[Callable] = None):
+        """merged_checkpoint: path to the merged .pt (torch.load) or the already-loaded dict
+        (efficient_ensemble_merged.py:37-53). encoder/preprocess/tokenizer: the SigLIP2 towers and the open_clip
+        CPU transforms are injected (they are un-vendored pip dependencies of the reference, :57,69)."""
+        self.device = device
+        dev = torch.device(device)
+        ck = torch.load(merged_checkpoint, map_location="cpu", weights_only=False) if isinstance(merged_checkpoint, str) \
+            else merged_checkpoint
+        if "ensemble_components" in ck and "backbone" not in ck:
+            self.backbone, self.use_transformer, self.history_length, self.action_dim = \
+                "hf-hub:timm/ViT-L-16-SigLIP2-384", True, 10, 7
+            self.num_models = len(ck["ensemble_components"])
+        else:
+            self.backbone, self.use_transformer = ck["backbone"], ck["use_transformer"]
+            self.history_length, self.action_dim, self.num_models = ck["history_length"], ck["action_dim"], ck["num_models"]
+        if not self.use_transformer:
+            raise NotImplementedError("MLP action encoder variant (complex_action_encoder) is not on the evaluated path")
+        self.trainable_models = [_Member(c, dev) for c in ck["ensemble_components"]]
+        self.encoder, self.preprocess, self.tokenizer = encoder, preprocess, tokenizer
+        self._dev = dev
+
+    # ---- feature-level API (what the parity tests drive: tokenisation / resampling are inputs)
+    def extract_shared_features(self, img_tensor, text_tokens):
+        return self.encoder.extract_features(img_tensor.to(self._dev), text_tokens.to(self._dev))
+
+    def _pad_histories(self, all_action_histories):
+        """efficient_ensemble_merged.py:378-390 (front pad with -5 to length 10) + the padding mask of :229."""
+        max_len = 10
+        out = []
+        for ah in all_action_histories:
+            ah = np.array(ah)
+            if len(ah) < max_len:
+                ah = np.vstack([np.ones((max_len - len(ah), ah.shape[1])) * -5, ah])
+            out.append(ah)
+        hb = torch.tensor(np.array(out), dtype=torch.float32)
+        return hb
+
+    def get_embeddings_from_model_batch(self, model_idx, patch_features, text_features, action_histories_batch):
+        m = self.trainable_models[model_idx]
+        hb = action_histories_batch.float().to(self._dev).contiguous()
+        pad = (action_histories_batch[:, :, 0].cpu() == m.pad_value).to(torch.uint8).to(self._dev).contiguous()
+        it = m.image_text(patch_features[0].contiguous(), text_features[0].contiguous())
+        act = m.trajectory(hb, pad)
+        return it.expand(hb.shape[0], -1), act
+
+    def score_features(self, patch_features, text_features, all_action_histories, group_size=1):
+        """Scores every candidate history against ONE (image, text) pair given its features. Returns a dict with the
+        device tensors (scores [N], result int32[4], best f32[2]) plus per-member embeddings."""
+        hb = self._pad_histories(all_action_histories)
+        N = hb.shape[0]
+        pad = (hb[:, :, 0] == self.trainable_models[0].pad_value).to(torch.uint8).to(self._dev).contiguous()
+        hb = hb.to(self._dev).contiguous()
+        pf = patch_features[0].to(self._dev).contiguous()
+        tf = text_features[0].to(self._dev).contiguous()
+        M = self.num_models
+        its = torch.empty(M, 512, dtype=torch.float32, device=self._dev)
+        acts = torch.empty(M, N, 512, dtype=torch.float32, device=self._dev)
+        for i, m in enumerate(self.trainable_models):
+            its[i] = m.image_text(pf, tf)[0]
+            acts[i] = m.trajectory(hb, pad)
+        scores, result, best, fit, fact = ops.score_select(its, acts, group_size)
+        return {"scores": scores, "result": result, "best": best, "its": its, "acts": acts, "fused_it": fit, "fused_act": fact}
+
+    def fuse_embeddings(self, image, instruction, action_histories):
+        pf, tf = self._encode_pair(image, instruction)
+        r = self.score_features(pf, tf, action_histories, 1)
+        return r["fused_it"].view(1, -1), r["fused_act"]
+
+    def predict(self, image, instruction, possible_action_histories):
+        """efficient_ensemble_merged.py:295-307."""
+        pf, tf = self._encode_pair(image, instruction)
+        scores = self.score_features(pf, tf, possible_action_histories, 1)["scores"].cpu().numpy()
+        idx = scores.argmax()
+        return possible_action_histories[idx], {str(i): float(scores[i]) for i in range(len(scores))}
+
+    def _encode_pair(self, image, instruction):
+        if self.encoder is None or self.preprocess is None or self.tokenizer is None:
+            raise L.CoverError("EfficientEnsembleMerged needs encoder/preprocess/tokenizer for image/text inputs")
+        img_tensor = self.preprocess(image).unsqueeze(0)
+        if isinstance(instruction, str):
+            toks = self.tokenizer([instruction], context_length=self.encoder.context_length)
+        else:
+            toks = instruction if instruction.ndim > 1 else instruction.unsqueeze(0)
+        return self.extract_shared_features(img_tensor, toks)
+
+    def compute_max_similarity_scores_batch(self, images, instructions, all_action_histories,
+                                            cfg_repeat_language_instructions=1):
+        """efficient_ensemble_merged.py:309-454. The reference scores candidates against the FIRST (image, text) pair only
+        (reference_scores = similarity_matrix[0], :421-425), on both of its encode paths, so one pair is encoded here."""
+        group_size = cfg_repeat_language_instructions
+        pf, tf = self._encode_pair(images[0], instructions[0])
+        r = self.score_features(pf, tf, all_action_histories, group_size)
+        result = r["result"].cpu()
+        best = r["best"].cpu()
+        gidx, gbest = int(result[0]), int(result[1])
+        all_same = len(set(instructions)) == 1 if isinstance(instructions[0], str) else False
+        if all_same and len(images) > 1:
+            max_instruction = instructions[0]
+        else:
+            max_instruction = instructions[min(gbest * group_size, len(instructions) - 1)]
+        return float(best[0]), max_instruction, all_action_histories[gidx], torch.tensor(gidx, dtype=torch.int64)

@@ -175,8 +175,10 @@ def neutral_to_reference(model, sd):
             put(getattr(model, n).weight, sd[n + ".weight"]); put(getattr(model, n).bias, sd[n + ".bias"])
 
 
-TINY = dict(lm_dim=64, lm_mlp=128, ex_dim=32, ex_mlp=64, layers=2, Hq=4, Hkv=1, D=16, vocab=96,
-            vit_dim=48, vit_mlp=80, vit_layers=2, vit_heads=4, patch=14, image=56, chunk=4)
+# small but HIP-friendly: every GEMM K is a multiple of 128, head_dim 64 for the decoders; the tower exercises the
+# zero-padding paths (head_dim 32 -> 64, MLP 200 -> 256, patch K 588 -> 640)
+TINY = dict(lm_dim=256, lm_mlp=512, ex_dim=128, ex_mlp=256, layers=2, Hq=4, Hkv=1, D=64, vocab=96,
+            vit_dim=128, vit_mlp=200, vit_layers=2, vit_heads=4, patch=14, image=56, chunk=4)
 
 
 def pi0_inputs(tiny, B, L, seed):
@@ -205,7 +207,7 @@ def gen_pi0(save):
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from cover_vla_amd import synth
     pwe, mp = import_reference_pi0()
-    for name, B, L, seed in [("pi0_tiny_b6", 6, 12, 21), ("pi0_tiny_b1", 1, 8, 22)]:
+    for name, B, L, seed in [("pi0_tiny_b6", 6, 12, 21), ("pi0_tiny_b1", 1, 8, 22), ("pi0_tiny_b40", 40, 16, 23)]:
         tiny = dict(TINY)
         model = build_reference_model(pwe, mp, tiny)
         sd = synth.pi0_state(tiny, seed=seed)
