@@ -1,0 +1,155 @@
+"""OpenVLA-7B / Prismatic candidate sampler (profile P2: the shapes BASELINE.json's metric is quoted on).
+
+No OpenVLA code exists in the reference; this profile assembles the same kernel library
+into DINOv2-L/14 + SigLIP-So400m/14 (features of the second-to-last block) -> 3-layer GELU projector -> Llama-2-7B ->
+7 action tokens per step (256 bins, the de-tokeniser arithmetic the reference carries at
+INT-ACT/src/experiments/policies/policy_wrapper.py:259-266). Its parity pin is the CPU oracle
+(oracle/cover_ref/openvla.py), itself pinned to HF transformers modules.
+
+Work that is provably identical across candidates is done once:
+  * both vision towers and the projector: once per camera frame
+  * Llama prefill: the [BOS + 256 patch] prefix is causal, so its K/V do not depend on the prompt -> ONE shared
+    prefix segment; each distinct prompt only adds its ~20 text tokens. Prefix rows and all prompts' text rows go
+    through the 32 layers in a single pass (one read of the 13.5 GB of weights).
+  * decode: all N candidates advance together (M = N rows per weight pass); every candidate attends
+    [shared image prefix | its prompt's text | its own generated tokens] as three KV segments, no copies.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from . import ops
+from .models import BF, Decoder, KvGeometry, VitTower, _f32
+
+IMAGENET_MEAN, IMAGENET_STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
+
+
+class OpenVLA:
+    def __init__(self, sd: Dict[str, torch.Tensor], c: dict, *, device="cuda:0", max_prompts=8, max_candidates=32,
+                 max_text=32, horizon=1, n_cams=1):
+        self.c, self.dev = dict(c), torch.device(device)
+        dev = self.dev
+        sub = lambda p: {k[len(p):]: v for k, v in sd.items() if k.startswith(p)}
+        self.n_patches = (c["image"] // c["patch"]) ** 2
+        self.n_cams = n_cams
+        # second-to-last block features: only layers-1 blocks are ever executed, so only those are packed
+        self.dino = VitTower(sub("dino."), dim=c["dino_dim"], layers=c["dino_layers"], heads=c["dino_heads"], mlp=c["dino_mlp"],
+                             patch=c["patch"], act="gelu_erf", eps=1e-6, layerscale=True, prefix_tokens=c["dino_prefix"],
+                             device=device, n_layers_used=c["dino_layers"] - 1)
+        self.siglip = VitTower(sub("siglip."), dim=c["sig_dim"], layers=c["sig_layers"], heads=c["sig_heads"], mlp=c["sig_mlp"],
+                               patch=c["patch"], act="gelu_tanh", eps=1e-6, device=device, n_layers_used=c["sig_layers"] - 1)
+        self.fused = c["dino_dim"] + c["sig_dim"]
+        self.proj = [ops.pack_linear(sd[f"projector.fc{i}.weight"].to(dev), sd[f"projector.fc{i}.bias"]) for i in (1, 2, 3)]
+        self.embed = sd["llm.embed_tokens.weight"].to(BF).contiguous().to(dev)
+        self.lm_head = ops.pack_linear(sd["lm_head.weight"].to(dev))
+        self.n_gen = 7 * horizon
+        self.T0 = 1 + self.n_patches * n_cams          # [BOS] + patches
+        geom = KvGeometry(c["Hkv"], c["D"], [1, max_prompts, max_candidates], [self.T0, max_text, self.n_gen])
+        self.llm = Decoder(sub("llm."), dim=c["llm_dim"], layers=c["llm_layers"], Hq=c["Hq"], Hkv=c["Hkv"], D=c["D"],
+                           mlp=c["llm_mlp"], act="silu", norm="llama", eps=1e-5, rope="hf", n_pos=self.T0 + max_text + self.n_gen + 8,
+                           device=device, cache=geom)
+        self.max_prompts, self.max_candidates, self.max_text = max_prompts, max_candidates, max_text
+        D = c["llm_dim"]
+        self.action_lo = c["tok_vocab"] - c["n_bins"]
+        self.action_hi = c["tok_vocab"]
+        # static buffers (fixed addresses -> the whole decision can be captured in a hipGraph)
+        self.x_pre = torch.empty(self.T0 + max_prompts * max_text, D, dtype=BF, device=dev)
+        self.x_dec = torch.empty(max_candidates, D, dtype=BF, device=dev)
+        self.h_sel = torch.empty(max_candidates, D, dtype=BF, device=dev)
+        self.logits = torch.empty(max_candidates, c["vocab"], dtype=torch.float32, device=dev)
+        self.head_ws = ops.gemm_workspace(max_candidates, c["vocab"], D, dev)
+        self.zero_slots = torch.zeros(max(max_prompts, max_candidates), dtype=torch.int32, device=dev)
+        self.bos = torch.tensor([1], dtype=torch.int64, device=dev)
+
+    # ---------------------------------------------------------------------------------------------- vision
+    def encode_image(self, frame_u8: torch.Tensor) -> torch.Tensor:
+        """frame uint8 [n_cams, H, W, 3] -> projected patch embeddings bf16 [n_cams*256, llm_dim]."""
+        c, n = self.c, frame_u8.shape[0]
+        mul_d = [1.0 / (255.0 * s) for s in IMAGENET_STD]
+        add_d = [-m / s for m, s in zip(IMAGENET_MEAN, IMAGENET_STD)]
+        xd = self.dino.embed(frame_u8, mul_d, add_d)
+        xd = self.dino.forward(xd)
+        xs = self.siglip.embed(frame_u8, [1.0 / (255.0 * 0.5)] * 3, [-1.0] * 3)
+        xs = self.siglip.forward(xs)
+        P = self.n_patches
+        fused = torch.empty(n * P, self.fused, dtype=BF, device=self.dev)
+        fused[:, :c["dino_dim"]].copy_(xd[:, c["dino_prefix"]:, :].reshape(n * P, -1))   # channel concat (device copies)
+        fused[:, c["dino_dim"]:].copy_(xs.reshape(n * P, -1))
+        h = ops.gemm(fused, self.proj[0], act="gelu_erf")
+        h = ops.gemm(h, self.proj[1], act="gelu_erf")
+        return ops.gemm(h, self.proj[2])
+
+    # ---------------------------------------------------------------------------------------------- sampler
+    def sample(self, frame_u8: torch.Tensor, prompt_tokens: torch.Tensor, prompt_lens: torch.Tensor, n_samples: int,
+               uniforms: Optional[torch.Tensor] = None, temperature: float = 1.0, trace: Optional[dict] = None):
+        """frame_u8 [n_cams,H,W,3] uint8; prompt_tokens int64 [P, Lt] right padded, prompt_lens int32 [P] (device);
+        n_samples candidates per prompt (N = P*n_samples, candidate i belongs to prompt i // n_samples);
+        uniforms fp32 [N, n_gen] in [0,1) for inverse-CDF sampling over the 256 action tokens, None = greedy over the
+        tokenizer vocabulary. Returns (tokens int64 [N, n_gen], selected-logit fp32 [N, n_gen])."""
+        c, dev = self.c, self.dev
+        P, Lt = prompt_tokens.shape
+        N = P * n_samples
+        if P > self.max_prompts or N > self.max_candidates or Lt > self.max_text:
+            raise ValueError("prompts/candidates/text length exceed the sizes this model was built for")
+        D, T0 = c["llm_dim"], self.T0
+        # ---- prefill input rows: [BOS | patches] then P x Lt text rows
+        x = self.x_pre[: T0 + P * Lt]
+        ops.embed_gather(self.embed, self.bos, out=x[:1])
+        x[1:T0].copy_(self.encode_image(frame_u8))
+        ops.embed_gather(self.embed, prompt_tokens.reshape(-1).contiguous(), out=x[T0:])
+        pos0 = torch.arange(T0, dtype=torch.int32, device=dev)
+        pos1 = (T0 + torch.arange(Lt, dtype=torch.int32, device=dev))[None].expand(P, Lt).contiguous()
+        g0 = self.llm.group(1, T0, pos0, [dict(region=0, length=T0, mask=ops.MASK_CAUSAL)], 0)
+        g1 = self.llm.group(P, Lt, pos1.view(-1),
+                            [dict(region=0, length=T0, slot_of_batch=self.zero_slots),
+                             dict(region=1, length=Lt, mask=ops.MASK_CAUSAL)], 1)
+        self.llm.forward(x, [g0, g1], final_norm=False)
+        # ---- first action token: last valid text position of each candidate's prompt
+        prompt_of_cand = (torch.arange(N, device=dev) // n_samples).to(torch.int32)
+        cand_len = prompt_lens.to(torch.int32)[prompt_of_cand.long()].contiguous()
+        last_row = (T0 + prompt_of_cand * Lt + cand_len - 1).to(torch.int32)
+        ops.copy_rows(x, self.h_sel, N, D, last_row, None)
+        tokens = torch.empty(N, self.n_gen, dtype=torch.int64, device=dev)
+        sel = torch.empty(N, self.n_gen, dtype=torch.float32, device=dev)
+        self._head_select(self.h_sel[:N], uniforms, 0, temperature, tokens, sel, trace)
+        # ---- decode
+        pos_base = (T0 + cand_len).contiguous()
+        xd = self.x_dec[:N]
+        for i in range(1, self.n_gen):
+            ops.embed_gather(self.embed, tokens[:, i - 1].contiguous(), out=xd)
+            pos = (pos_base + (i - 1)).contiguous()
+            g = self.llm.group(N, 1, pos,
+                               [dict(region=0, length=T0, slot_of_batch=self.zero_slots),
+                                dict(region=1, length=Lt, len_of_batch=cand_len, slot_of_batch=prompt_of_cand),
+                                dict(region=2, length=i)], 2, write_t_off=i - 1)
+            self.llm.forward(xd, [g], final_norm=False)
+            self._head_select(xd, uniforms, i, temperature, tokens, sel, trace)
+        return tokens, sel
+
+    def _head_select(self, h, uniforms, i, temperature, tokens, sel, trace):
+        N = h.shape[0]
+        hn = ops.rmsnorm(h, self.llm.final_norm, 1e-5, w_offset=0.0, style=1)
+        lg = ops.gemm(hn, self.lm_head, out=self.logits[:N], ws=self.head_ws)
+        if trace is not None:
+            trace.setdefault("logits", []).append(lg.clone())
+        if uniforms is None:
+            t, s = ops.token_select(lg, 0, self.c["tok_vocab"])
+        else:
+            t, s = ops.token_select(lg, self.action_lo, self.action_hi, uniform=uniforms[:, i].contiguous(),
+                                    temperature=temperature)
+        tokens[:, i].copy_(t)
+        sel[:, i].copy_(s)
+
+    # ---------------------------------------------------------------------------------------------- de-tokeniser
+    def tokens_to_actions(self, tokens: np.ndarray) -> np.ndarray:
+        """256-bin de-tokeniser (policy_wrapper.py:259-266 arithmetic): discretized = vocab - token, clip(d-1, 0, 254),
+        bin centres of linspace(-1, 1, 256). Host numpy on N x 7 integers."""
+        bins = np.linspace(-1, 1, self.c["n_bins"])
+        centers = (bins[:-1] + bins[1:]) / 2.0
+        d = self.c["tok_vocab"] - np.asarray(tokens)
+        d = np.clip(d - 1, a_min=0, a_max=centers.shape[0] - 1)
+        return centers[d]

@@ -21,22 +21,30 @@ Tensor = torch.Tensor
 
 
 class _G:
-    def __init__(self, seed: int, nontrivial: bool = True, std: float = 0.02):
-        self.g = torch.Generator().manual_seed(seed)
+    """Seeded tensor source. device="cpu" (tests, goldens: bit-reproducible everywhere) or a cuda device with
+    wdtype=bf16 (bench: a 7B-parameter synthetic checkpoint is drawn directly in HBM in about a second)."""
+
+    def __init__(self, seed: int, nontrivial: bool = True, std: float = 0.02, device="cpu", wdtype=torch.float32):
+        self.device = torch.device(device)
+        self.g = torch.Generator(device=self.device).manual_seed(seed)
         self.nontrivial = nontrivial
         self.std = std
+        self.wdtype = wdtype
 
     def w(self, *shape, std=None) -> Tensor:
-        return torch.randn(*shape, generator=self.g) * (self.std if std is None else std)
+        t = torch.randn(*shape, generator=self.g, device=self.device, dtype=self.wdtype)
+        return t * (self.std if std is None else std)
 
     def b(self, n) -> Tensor:
-        return torch.randn(n, generator=self.g) * 0.02 if self.nontrivial else torch.zeros(n)
+        return torch.randn(n, generator=self.g, device=self.device) * 0.02 if self.nontrivial else torch.zeros(n, device=self.device)
 
     def ln_w(self, n) -> Tensor:
-        return 1.0 + torch.randn(n, generator=self.g) * 0.1 if self.nontrivial else torch.ones(n)
+        return 1.0 + torch.randn(n, generator=self.g, device=self.device) * 0.1 if self.nontrivial else torch.ones(n, device=self.device)
 
     def rms_w(self, n, base=0.0) -> Tensor:
-        return base + torch.randn(n, generator=self.g) * 0.1 if self.nontrivial else torch.full((n,), base)
+        if self.nontrivial:
+            return base + torch.randn(n, generator=self.g, device=self.device) * 0.1
+        return torch.full((n,), base, device=self.device)
 
 
 def sincos_position_embedding(seq_len: int, dim: int) -> Tensor:
@@ -147,8 +155,8 @@ def vit_state(g: _G, *, dim: int, layers: int, heads: int, mlp: int, patch: int,
         sd[p + "fc2.weight"] = g.w(dim, mlp)
         sd[p + "fc2.bias"] = g.b(dim)
         if layerscale:
-            sd[p + "ls1"] = torch.full((dim,), 1.0) + (torch.randn(dim, generator=g.g) * 0.1 if g.nontrivial else 0)
-            sd[p + "ls2"] = torch.full((dim,), 1.0) + (torch.randn(dim, generator=g.g) * 0.1 if g.nontrivial else 0)
+            sd[p + "ls1"] = g.ln_w(dim)
+            sd[p + "ls2"] = g.ln_w(dim)
     if post_ln:
         sd["post_ln.weight"] = g.ln_w(dim)
         sd["post_ln.bias"] = g.b(dim)
@@ -206,3 +214,61 @@ def pi0_state(c: dict, seed: int = 1234, nontrivial: bool = True, std: float = 0
 
 PI0_FULL = dict(lm_dim=2048, lm_mlp=16384, ex_dim=1024, ex_mlp=4096, layers=18, Hq=8, Hkv=1, D=256, vocab=257152,
                 vit_dim=1152, vit_mlp=4304, vit_layers=27, vit_heads=16, patch=14, image=224, chunk=4)
+
+
+# ------------------------------------------------------------------------------------------------ OpenVLA-7B (P2)
+OPENVLA_7B = dict(dino_dim=1024, dino_layers=24, dino_heads=16, dino_mlp=4096, dino_prefix=5,
+                  sig_dim=1152, sig_layers=27, sig_heads=16, sig_mlp=4304, patch=14, image=224,
+                  llm_dim=4096, llm_layers=32, Hq=32, Hkv=32, D=128, llm_mlp=11008, vocab=32064, tok_vocab=32000, n_bins=256)
+OPENVLA_SMALL = dict(dino_dim=128, dino_layers=3, dino_heads=4, dino_mlp=256, dino_prefix=5,
+                     sig_dim=128, sig_layers=3, sig_heads=2, sig_mlp=200, patch=14, image=56,
+                     llm_dim=256, llm_layers=2, Hq=4, Hkv=4, D=64, llm_mlp=512, vocab=1088, tok_vocab=1024, n_bins=256)
+
+
+def openvla_state(c: dict, seed: int = 1234, nontrivial: bool = True, std: float = 0.02, device="cpu",
+                  wdtype=torch.float32) -> Dict[str, Tensor]:
+    """Prismatic / OpenVLA-7B shaped checkpoint (no such model exists in the reference):
+    dino.* and siglip.* (vit_state layout), projector.fc{1,2,3}.{weight,bias}, llm.* (decoder_state layout, Llama),
+    lm_head.weight."""
+    g = _G(seed, nontrivial, std, device, wdtype)
+    n_patches = (c["image"] // c["patch"]) ** 2
+    sd = {}
+    for k, v in vit_state(g, dim=c["dino_dim"], layers=c["dino_layers"], heads=c["dino_heads"], mlp=c["dino_mlp"],
+                          patch=c["patch"], n_pos=n_patches + c["dino_prefix"], layerscale=True,
+                          prefix_tokens=c["dino_prefix"], post_ln=False).items():
+        sd["dino." + k] = v
+    for k, v in vit_state(g, dim=c["sig_dim"], layers=c["sig_layers"], heads=c["sig_heads"], mlp=c["sig_mlp"],
+                          patch=c["patch"], n_pos=n_patches, post_ln=False).items():
+        sd["siglip." + k] = v
+    fused = c["dino_dim"] + c["sig_dim"]
+    for n, (o, i) in {"fc1": (4 * fused, fused), "fc2": (c["llm_dim"], 4 * fused), "fc3": (c["llm_dim"], c["llm_dim"])}.items():
+        sd[f"projector.{n}.weight"] = g.w(o, i)
+        sd[f"projector.{n}.bias"] = g.b(o)
+    for k, v in decoder_state(g, dim=c["llm_dim"], layers=c["llm_layers"], Hq=c["Hq"], Hkv=c["Hkv"], D=c["D"],
+                              mlp=c["llm_mlp"], rms_base=1.0, vocab=c["vocab"]).items():
+        sd["llm." + k] = v
+    sd["lm_head.weight"] = g.w(c["vocab"], c["llm_dim"])
+    return sd
+
+
+SIGLIP2_L = dict(dim=1024, layers=24, heads=16, mlp=4096, patch=16, image=384, context_length=64, vocab=256000)
+SIGLIP2_SMALL = dict(dim=128, layers=2, heads=2, mlp=256, patch=16, image=64, context_length=16, vocab=128)
+
+
+def siglip2_state(c: dict, seed: int = 4321, nontrivial: bool = True, std: float = 0.02, device="cpu",
+                  wdtype=torch.float32) -> Dict[str, Tensor]:
+    """Verifier backbone (SigLIP2 ViT-L/16-384 shapes): image.* / text.* towers, text.tok_emb, text.proj.{weight,bias}."""
+    g = _G(seed, nontrivial, std, device, wdtype)
+    n_patches = (c["image"] // c["patch"]) ** 2
+    sd = {}
+    for k, v in vit_state(g, dim=c["dim"], layers=c["layers"], heads=c["heads"], mlp=c["mlp"], patch=c["patch"],
+                          n_pos=n_patches, post_ln=False).items():
+        sd["image." + k] = v
+    for k, v in vit_state(g, dim=c["dim"], layers=c["layers"], heads=c["heads"], mlp=c["mlp"], patch=c["patch"],
+                          n_pos=c["context_length"], post_ln=True).items():
+        if not k.startswith("patch."):
+            sd["text." + k] = v
+    sd["text.tok_emb"] = g.w(c["vocab"], c["dim"])
+    sd["text.proj.weight"] = g.w(c["dim"], c["dim"])
+    sd["text.proj.bias"] = g.b(c["dim"])
+    return sd
