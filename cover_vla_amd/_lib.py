@@ -181,6 +181,8 @@ SYMBOLS = {
     "cover_timer_stop": (c_i, [c_p, c_p, _P(c_f)]),
     "cover_timer_destroy": (c_i, [c_p]),
     "cover_stream_sync": (c_i, [c_p]),
+    "cover_profile_begin": (c_i, [c_i]),
+    "cover_profile_end": (c_i, [_P(C.c_double), _P(C.c_longlong), _P(C.c_double)]),
     "cover_sizeof": (C.c_size_t, [C.c_char_p]),
 }
 

@@ -242,11 +242,15 @@ hipError_t launch_attention_bf16(const cover_attn_args* x, hipStream_t st) {
         if (d.mode == COVER_MASK_VISLEN && d.vis_len == nullptr) return hipErrorInvalidValue;
     }
     if (a.B <= 0 || a.R <= 0) return hipSuccess;
+    const int pid = prof_enabled() ? prof_open(st, 2, 0.0) : -1;
+    hipError_t e;
     switch (x->D) {
-        case 64: return launch_d<64>(a, st);
-        case 96: return launch_d<96>(a, st);
-        case 128: return launch_d<128>(a, st);
-        case 256: return launch_d<256>(a, st);
-        default: return hipErrorInvalidValue;
+        case 64: e = launch_d<64>(a, st); break;
+        case 96: e = launch_d<96>(a, st); break;
+        case 128: e = launch_d<128>(a, st); break;
+        case 256: e = launch_d<256>(a, st); break;
+        default: e = hipErrorInvalidValue;
     }
+    prof_close(st, pid);
+    return e;
 }

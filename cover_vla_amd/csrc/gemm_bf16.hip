@@ -468,12 +468,14 @@ hipError_t launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* Wp, void* C,
         SkinnyPlan p = plan_skinny(M, N, Kp);
         if (ws == nullptr || ws_bytes < p.ws_bytes) return hipErrorInvalidValue;
         dim3 grid(p.gx, p.S), block(512);
+        const int pid = prof_enabled() ? prof_open(st, 0, 2.0 * (double)N * (double)K) : -1;
         switch (p.MF) {
             case 1: hipLaunchKernelGGL(gemm_skinny<1>, grid, block, p.lds, st, A, lda, Wp, ws, M, N, Kp, p.KC, p.nbpb); break;
             case 2: hipLaunchKernelGGL(gemm_skinny<2>, grid, block, p.lds, st, A, lda, Wp, ws, M, N, Kp, p.KC, p.nbpb); break;
             case 3: hipLaunchKernelGGL(gemm_skinny<3>, grid, block, p.lds, st, A, lda, Wp, ws, M, N, Kp, p.KC, p.nbpb); break;
             default: hipLaunchKernelGGL(gemm_skinny<4>, grid, block, p.lds, st, A, lda, Wp, ws, M, N, Kp, p.KC, p.nbpb); break;
         }
+        prof_close(st, pid);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
         const int Nout = epi.glu ? N / 2 : N;
@@ -486,10 +488,12 @@ hipError_t launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* Wp, void* C,
     const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
     const size_t lds = 4 * TILE_BYTES;
     dim3 grid(tiles_m * tiles_n), block(256);
+    const int pid = prof_enabled() ? prof_open(st, 1, 2.0 * (double)M * (double)N * (double)K) : -1;
     if (variant == 2)
         hipLaunchKernelGGL(gemm_tiled<false>, grid, block, lds, st, A, lda, Wp, C, ldc, M, N, K, Kp, epi, tiles_m, tiles_n);
     else
         hipLaunchKernelGGL(gemm_tiled<true>, grid, block, lds, st, A, lda, Wp, C, ldc, M, N, K, Kp, epi, tiles_m, tiles_n);
+    prof_close(st, pid);
     return hipGetLastError();
 }
 

@@ -53,3 +53,8 @@ hipError_t launch_token_select(const cover_token_select_args* a, hipStream_t st)
 hipError_t launch_score_select(const cover_score_select_args* a, hipStream_t st);
 hipError_t launch_group_argmax(const float* scores, int N, int gs, int* result, float* best, hipStream_t st);
 size_t gemm_workspace_bytes(int M, int N, int K);
+
+// ---- prof.hip: optional per-launch hipEvent timing (classes: 0 skinny GEMM, 1 tiled GEMM, 2 attention) ----------
+bool prof_enabled();
+int prof_open(hipStream_t st, int cls, double work);
+void prof_close(hipStream_t st, int id);

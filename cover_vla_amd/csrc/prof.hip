@@ -1,0 +1,57 @@
+// Optional in-library kernel timing with hipEvents on the launch stream (bench.py's `roofline` object):
+// when enabled, the GEMM / attention launchers bracket each launch with an event pair taken from a pre-created pool.
+// Classes: 0 = weight-streaming GEMM (work = weight bytes), 1 = LDS-tiled GEMM (work = FLOPs), 2 = attention (work = 0).
+#include <hip/hip_runtime.h>
+#include <vector>
+#include "kernels.h"
+
+namespace {
+struct Rec { hipEvent_t a, b; int cls; double work; };
+std::vector<Rec> g_pool;
+size_t g_used = 0;
+bool g_on = false;
+}  // namespace
+
+bool prof_enabled() { return g_on; }
+
+int prof_open(hipStream_t st, int cls, double work) {
+    if (!g_on || g_used >= g_pool.size()) return -1;
+    Rec& r = g_pool[g_used];
+    r.cls = cls;
+    r.work = work;
+    if (hipEventRecord(r.a, st) != hipSuccess) return -1;
+    return (int)g_used++;
+}
+void prof_close(hipStream_t st, int id) {
+    if (id >= 0) (void)hipEventRecord(g_pool[id].b, st);
+}
+
+extern "C" int cover_profile_begin(int max_events) {
+    if (max_events <= 0) return COVER_EINVAL;
+    while ((int)g_pool.size() < max_events) {
+        Rec r;
+        if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return COVER_EHIP;
+        g_pool.push_back(r);
+    }
+    g_used = 0;
+    g_on = true;
+    return COVER_OK;
+}
+
+// ms[3], count[3], work[3]; synchronises the device
+extern "C" int cover_profile_end(double* ms, long long* count, double* work) {
+    g_on = false;
+    if (hipDeviceSynchronize() != hipSuccess) return COVER_EHIP;
+    for (int c = 0; c < 3; ++c) { ms[c] = 0; count[c] = 0; work[c] = 0; }
+    for (size_t i = 0; i < g_used; ++i) {
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, g_pool[i].a, g_pool[i].b) != hipSuccess) continue;
+        const int c = g_pool[i].cls;
+        if (c < 0 || c > 2) continue;
+        ms[c] += t;
+        count[c] += 1;
+        work[c] += g_pool[i].work;
+    }
+    g_used = 0;
+    return COVER_OK;
+}

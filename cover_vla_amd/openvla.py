@@ -85,11 +85,13 @@ class OpenVLA:
 
     # ---------------------------------------------------------------------------------------------- sampler
     def sample(self, frame_u8: torch.Tensor, prompt_tokens: torch.Tensor, prompt_lens: torch.Tensor, n_samples: int,
-               uniforms: Optional[torch.Tensor] = None, temperature: float = 1.0, trace: Optional[dict] = None):
+               uniforms: Optional[torch.Tensor] = None, temperature: float = 1.0, trace: Optional[dict] = None,
+               force_tokens: Optional[torch.Tensor] = None):
         """frame_u8 [n_cams,H,W,3] uint8; prompt_tokens int64 [P, Lt] right padded, prompt_lens int32 [P] (device);
         n_samples candidates per prompt (N = P*n_samples, candidate i belongs to prompt i // n_samples);
         uniforms fp32 [N, n_gen] in [0,1) for inverse-CDF sampling over the 256 action tokens, None = greedy over the
-        tokenizer vocabulary. Returns (tokens int64 [N, n_gen], selected-logit fp32 [N, n_gen])."""
+        tokenizer vocabulary. force_tokens int64 [N, n_gen] (tests): teacher-force the fed-back tokens while still
+        returning this path's own picks. Returns (tokens int64 [N, n_gen], selected-logit fp32 [N, n_gen])."""
         c, dev = self.c, self.dev
         P, Lt = prompt_tokens.shape
         N = P * n_samples
@@ -120,7 +122,8 @@ class OpenVLA:
         pos_base = (T0 + cand_len).contiguous()
         xd = self.x_dec[:N]
         for i in range(1, self.n_gen):
-            ops.embed_gather(self.embed, tokens[:, i - 1].contiguous(), out=xd)
+            fed = tokens if force_tokens is None else force_tokens
+            ops.embed_gather(self.embed, fed[:, i - 1].contiguous(), out=xd)
             pos = (pos_base + (i - 1)).contiguous()
             g = self.llm.group(N, 1, pos,
                                [dict(region=0, length=T0, slot_of_batch=self.zero_slots),

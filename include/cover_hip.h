@@ -336,6 +336,12 @@ int cover_timer_stop(void* timer, void* stream, float* ms_out);
 int cover_timer_destroy(void* timer);
 int cover_stream_sync(void* stream);
 
+/* Per-launch kernel timing for bench.py's roofline object: between begin/end every GEMM / attention launch issued by
+ * this library is bracketed by a hipEvent pair on its own stream. Classes: 0 = weight-streaming GEMM (work = weight bytes),
+ * 1 = LDS-tiled GEMM (work = FLOPs), 2 = attention. end() synchronises the device and fills ms[3], count[3], work[3]. */
+int cover_profile_begin(int max_events);
+int cover_profile_end(double* ms, long long* count, double* work);
+
 /* sizeof() of every struct above by name ("cover_attn_args", ...): lets a foreign-language binding check its
  * mirrored layouts at load time. Returns 0 for unknown names. */
 size_t cover_sizeof(const char* struct_name);
