@@ -9,6 +9,11 @@ from __future__ import annotations
 import ctypes as C
 import os
 
+# PyTorch-ROCm bundles its own libamdhip64; it MUST be the HIP runtime this process uses (device pointers and streams
+# are shared with torch), so torch is imported before libcover_hip.so is dlopen'ed: the loader then resolves the
+# library's libamdhip64.so.7 dependency to the copy torch already mapped instead of loading a second runtime.
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcover_hip.so")
 
