@@ -190,8 +190,8 @@ def gen_adapter():
     acts[:8, 6] = [0.5, 0.4999, 0.5001, 0.0, 1.0, -0.3, 0.75, 0.25]
     exec_rows = ad.postprocess(acts.copy())
     ver_rows = ad.postprocess_verifier(acts.copy())
-    exec_arr = np.stack([np.concatenate([d["world_vector"], d["rot_axangle"], d["gripper"]]) for d in exec_rows])
-    ver_arr = np.stack([np.asarray(r, dtype=np.float64) for r in ver_rows])
+    exec_arr = np.asarray(exec_rows, dtype=np.float64)
+    ver_arr = np.asarray(ver_rows, dtype=np.float64)
     eul = rng.uniform(-3, 3, size=(32, 3))
     ax = np.stack([geometry.euler2axangle(*e)[0] * geometry.euler2axangle(*e)[1] for e in eul])
     quats = rng.normal(size=(16, 4))

@@ -90,3 +90,59 @@ def test_pi0_oracle_matches_reference(name):
     upd = z["actions"] - noise.numpy()
     assert np.linalg.norm(x.numpy() - z["actions"]) / np.linalg.norm(upd) < 2e-2
     assert np.abs(x.numpy() - z["actions"]).max() < 6e-2
+
+
+# ------------------------------------------------------------------------------------------------ P2 blocks vs HF modules
+class _fp32_blocks:
+    """Evaluate the oracle's blocks in fp32 (module-level BF switched) to pin STRUCTURE against HF's fp32 modules."""
+
+    def __enter__(self):
+        from cover_ref import blocks as Bk
+        self.Bk, self.old = Bk, Bk.BF
+        Bk.BF = torch.float32
+        return Bk
+
+    def __exit__(self, *a):
+        self.Bk.BF = self.old
+
+
+def _load(name):
+    z = np.load(os.path.join(GOLD, name + ".npz"))
+    sd = {k: torch.from_numpy(z[k]) for k in z.files if z[k].dtype.kind == "f" and k not in ("logits", "pixels", "last_hidden", "hidden_1", "hidden_2")}
+    return z, sd
+
+
+def test_blocks_match_hf_llama():
+    z, sd = _load("hf_llama_tiny")
+    with _fp32_blocks() as Bk, torch.no_grad():
+        cfg = Bk.DecoderCfg(64, 2, 4, 4, 16, 128, "silu", "llama", 1e-5, "hf")
+        ids = torch.from_numpy(z["ids"])
+        x = torch.nn.functional.embedding(ids, sd["llm.embed_tokens.weight"])
+        T = ids.shape[1]
+        mask = torch.tril(torch.ones(T, T, dtype=torch.bool))[None].expand(2, -1, -1)
+        lsd = {k[4:]: v for k, v in sd.items() if k.startswith("llm.")}
+        h, _ = Bk.decoder_forward(cfg, lsd, x, torch.arange(T)[None].expand(2, -1), mask, final_norm=True, n_pos=64)
+        logits = torch.nn.functional.linear(h, sd["lm_head.weight"])
+    assert np.allclose(logits.numpy(), z["logits"], atol=2e-4, rtol=1e-4), np.abs(logits.numpy() - z["logits"]).max()
+
+
+def test_blocks_match_hf_siglip():
+    z, sd = _load("hf_siglip_tiny")
+    with _fp32_blocks() as Bk, torch.no_grad():
+        cfg = Bk.VitCfg(48, 2, 4, 80, 14, "gelu_tanh", 1e-6)
+        x = Bk.vit_embed(cfg, sd, torch.from_numpy(z["pixels"]))
+        h1 = Bk.vit_encode(cfg, sd, x.clone(), n_blocks=1)
+        out = Bk.vit_encode(cfg, sd, x, post_ln=True)
+    assert np.allclose(h1.numpy(), z["hidden_1"], atol=2e-4, rtol=1e-4)
+    assert np.allclose(out.numpy(), z["last_hidden"], atol=2e-4, rtol=1e-4)
+
+
+def test_blocks_match_hf_dinov2_with_registers():
+    z, sd = _load("hf_dinov2_tiny")
+    with _fp32_blocks() as Bk, torch.no_grad():
+        cfg = Bk.VitCfg(48, 2, 4, 96, 14, "gelu_erf", 1e-6, layerscale=True, prefix_tokens=5)
+        x = Bk.vit_embed(cfg, sd, torch.from_numpy(z["pixels"]))
+        h1 = Bk.vit_encode(cfg, sd, x.clone(), n_blocks=1)
+        h2 = Bk.vit_encode(cfg, sd, x, n_blocks=2)
+    assert np.allclose(h1.numpy(), z["hidden_1"], atol=2e-4, rtol=1e-4)
+    assert np.allclose(h2.numpy(), z["hidden_2"], atol=2e-4, rtol=1e-4)
