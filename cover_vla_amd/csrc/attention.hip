@@ -206,8 +206,8 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnDev a) {
 template <int D>
 static hipError_t launch_d(const AttnDev& a, hipStream_t st) {
     const int tiles = (a.R + 15) / 16;
-    if (tiles <= 2) {
-        // few query rows: split keys over 4 waves
+    if ((long long)tiles * a.Hkv * a.B < 1024) {
+        // too few query tiles to fill the chip (single-token decode, ViT-sized sequences): split keys over 4 waves
         const size_t lds = (size_t)(4 * (D / 16) * 4 * 64 + 2 * 4 * 16) * sizeof(float);
         dim3 grid(tiles, a.Hkv, a.B), block(256);
         hipLaunchKernelGGL((attn_kernel<D, true>), grid, block, lds, st, a);

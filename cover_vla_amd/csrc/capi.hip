@@ -202,7 +202,7 @@ static size_t vit_ws(const cover_vit_desc* d, int n_seq, int T, Carver* c, void*
     p = cc.take(R * d->mlp_p * 2); if (mlp) *mlp = p;
     p = cc.take((size_t)n_seq * HD * (*tcap) * 2); if (vt) *vt = p;
     size_t skb = 0;
-    if (R <= 64) {
+    {
         const int ns[4] = {3 * HD, d->dim, d->mlp_p, d->dim};
         const int ks[4] = {d->dim, HD, d->dim, d->mlp_p};
         for (int i = 0; i < 4; ++i) {
@@ -290,7 +290,7 @@ static size_t dec_ws(const cover_dec_desc* d, int rows, Carver* c, void** h, voi
     p = cc.take((size_t)rows * d->Hq * d->D * 2); if (attn) *attn = p;
     p = cc.take((size_t)rows * d->mlp * 2); if (mlp) *mlp = p;
     size_t skb = 0;
-    if (rows <= 64) {
+    {
         const int ns[4] = {nqkv, d->dim, 2 * d->mlp, d->dim};
         const int ks[4] = {d->dim, d->Hq * d->D, d->dim, d->mlp};
         for (int i = 0; i < 4; ++i) {

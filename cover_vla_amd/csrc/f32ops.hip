@@ -7,76 +7,82 @@
 
 // ---------------------------------------------------------------------------------------------------
 // C[m,n] = residual + alpha * act(sum_k A[m,k] B[n,k] + bias[n])     (generic strides, optional batch)
-// 64x64 tile, BK = 32, 4 waves each a 32x32 sub-tile of 2x2 MFMA fragments.
 // ---------------------------------------------------------------------------------------------------
-#define FT 64
+// Tile = TM x TN (64x64 or 32x32), BK = 32, 4 waves (2x2), each wave (TM/32)x(TN/32) MFMA fragments. The next k-tile is
+// fetched into registers while the current one is multiplied (these GEMMs have tiny grids, so nothing else hides the
+// global-load latency).
 #define FK 32
+template <int TM, int TN>
 __global__ __launch_bounds__(256) void gemm_f32_k(cover_gemm_f32_args a) {
-    __shared__ float As[FT][FK + 1];
-    __shared__ float Bs[FT][FK + 1];
+    constexpr int FM = TM / 32, FN = TN / 32;
+    constexpr int EA = TM * FK / 256, EB = TN * FK / 256;  // elements per thread per tile
+    __shared__ float As[TM][FK + 1];
+    __shared__ float Bs[TN][FK + 1];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int wm = w >> 1, wn = w & 1;
-    const int m0 = blockIdx.y * FT, n0 = blockIdx.x * FT;
+    const int m0 = blockIdx.y * TM, n0 = blockIdx.x * TN;
     const int bz = blockIdx.z;
     const float* A = a.A + (size_t)bz * a.a_batch_stride;
     const float* B = a.B + (size_t)bz * a.b_batch_stride;
     float* C = a.C + (size_t)bz * a.c_batch_stride;
 
-    f32x4 acc[2][2];
+    f32x4 acc[FM][FN];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < FM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    // tile loader: pick the thread->element map that makes the unit-stride axis contiguous across threads
-    auto load_tile = [&](float(&S)[FT][FK + 1], const float* P, long long rs, long long ks, int r0, int R, int k0) {
-        if (rs == 1 && ks != 1) {
-            const int row = tid & 63, kb = (tid >> 6) * 8;
+    // thread -> (row, k-run) maps: unit-stride axis contiguous across threads
+    const bool a_rowmajor = !(a.a_row_stride == 1 && a.a_k_stride != 1);
+    const bool b_rowmajor = !(a.b_row_stride == 1 && a.b_k_stride != 1);
+    const int ar = a_rowmajor ? tid / (FK / EA) : tid % TM, ak = a_rowmajor ? (tid % (FK / EA)) * EA : (tid / TM) * EA;
+    const int br = b_rowmajor ? tid / (FK / EB) : tid % TN, bk = b_rowmajor ? (tid % (FK / EB)) * EB : (tid / TN) * EB;
+    float ra[EA], rb[EB];
+    auto fetch = [&](int k0) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int k = k0 + kb + e, rr = r0 + row;
-                S[row][kb + e] = (rr < R && k < a.K) ? P[(size_t)rr * rs + (size_t)k * ks] : 0.f;
-            }
-        } else {
-            const int row = tid >> 2, kb = (tid & 3) * 8;
+        for (int e = 0; e < EA; ++e) {
+            const int k = k0 + ak + e, rr = m0 + ar;
+            ra[e] = (rr < a.M && k < a.K) ? A[(size_t)rr * a.a_row_stride + (size_t)k * a.a_k_stride] : 0.f;
+        }
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int k = k0 + kb + e, rr = r0 + row;
-                S[row][kb + e] = (rr < R && k < a.K) ? P[(size_t)rr * rs + (size_t)k * ks] : 0.f;
-            }
+        for (int e = 0; e < EB; ++e) {
+            const int k = k0 + bk + e, rr = n0 + br;
+            rb[e] = (rr < a.N && k < a.K) ? B[(size_t)rr * a.b_row_stride + (size_t)k * a.b_k_stride] : 0.f;
         }
     };
-
     const int r = lane & 15, g = lane >> 4;
+    fetch(0);
     for (int k0 = 0; k0 < a.K; k0 += FK) {
         __syncthreads();
-        load_tile(As, A, a.a_row_stride, a.a_k_stride, m0, a.M, k0);
-        load_tile(Bs, B, a.b_row_stride, a.b_k_stride, n0, a.N, k0);
+#pragma unroll
+        for (int e = 0; e < EA; ++e) As[ar][ak + e] = ra[e];
+#pragma unroll
+        for (int e = 0; e < EB; ++e) Bs[br][bk + e] = rb[e];
         __syncthreads();
+        if (k0 + FK < a.K) fetch(k0 + FK);
 #pragma unroll
         for (int k4 = 0; k4 < FK / 4; ++k4) {
-            float af[2], bf[2];
+            float af[FM], bf[FN];
 #pragma unroll
-            for (int f = 0; f < 2; ++f) {
-                af[f] = As[wm * 32 + f * 16 + r][k4 * 4 + g];
-                bf[f] = Bs[wn * 32 + f * 16 + r][k4 * 4 + g];
-            }
+            for (int f = 0; f < FM; ++f) af[f] = As[wm * (TM / 2) + f * 16 + r][k4 * 4 + g];
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int f = 0; f < FN; ++f) bf[f] = Bs[wn * (TN / 2) + f * 16 + r][k4 * 4 + g];
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[j], acc[i][j], 0, 0, 0);
         }
     }
     // D[row = 4g + e][col = r]
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < FM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < FN; ++j)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const int m = m0 + wm * 32 + i * 16 + 4 * g + e;
-                const int n = n0 + wn * 32 + j * 16 + r;
+                const int m = m0 + wm * (TM / 2) + i * 16 + 4 * g + e;
+                const int n = n0 + wn * (TN / 2) + j * 16 + r;
                 if (m < a.M && n < a.N) {
                     float v = acc[i][j][e];
                     if (a.bias) v += a.bias[n];
@@ -90,8 +96,14 @@ __global__ __launch_bounds__(256) void gemm_f32_k(cover_gemm_f32_args a) {
 hipError_t launch_gemm_f32(const cover_gemm_f32_args* a, hipStream_t st) {
     if (a->M <= 0 || a->N <= 0) return hipSuccess;
     const int nb = a->batch > 0 ? a->batch : 1;
-    dim3 grid((a->N + FT - 1) / FT, (a->M + FT - 1) / FT, nb);
-    hipLaunchKernelGGL(gemm_f32_k, grid, dim3(256), 0, st, *a);
+    const long long blocks64 = (long long)((a->N + 63) / 64) * ((a->M + 63) / 64) * nb;
+    if (blocks64 >= 256) {
+        dim3 grid((a->N + 63) / 64, (a->M + 63) / 64, nb);
+        hipLaunchKernelGGL((gemm_f32_k<64, 64>), grid, dim3(256), 0, st, *a);
+    } else {
+        dim3 grid((a->N + 31) / 32, (a->M + 31) / 32, nb);
+        hipLaunchKernelGGL((gemm_f32_k<32, 32>), grid, dim3(256), 0, st, *a);
+    }
     return hipGetLastError();
 }
 

@@ -111,21 +111,24 @@ __device__ __forceinline__ void epi_store4_glu(const EpiDev& e, void* C, int ldc
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Tiled kernel
+// Tiled kernel: tile = (2*WM*16) x (2*WN*16) x 64, 4 waves in 2x2, each wave WM x WN MFMA fragments.
+//   <4,4> 128x128 (large GEMMs), <2,4> 64x128, <2,2> 64x64 (ViT-sized GEMMs whose 128x128 grid cannot fill 256 CUs).
+// Optional split-K over gridDim.y: slice s accumulates k-tiles [s*kt_per, ...) and stores raw fp32 partials
+// [S][M][N] that splitk_reduce folds with the epilogue.
 // ---------------------------------------------------------------------------------------------------
-#define BM 128
-#define BN 128
 #define BK 64
-#define TILE_BYTES (BM * BK * 2)  // 16 KiB per operand per buffer
 
-template <bool GLDS>
+template <int WM, int WN, bool GLDS>
 __global__ __launch_bounds__(256) void gemm_tiled(const bf16_t* __restrict__ A, int lda,
-                                                     const bf16_t* __restrict__ Wp, void* C, int ldc, int M, int N,
-                                                     int K, int Kp, EpiDev epi, int tiles_m, int tiles_n) {
+                                                  const bf16_t* __restrict__ Wp, void* C, int ldc, int M, int N,
+                                                  int Kp, EpiDev epi, int tiles_m, int tiles_n, int kt_per,
+                                                  float* __restrict__ partial) {
+    constexpr int BM_ = 2 * WM * 16, BN_ = 2 * WN * 16;
+    constexpr int A_BYTES = BM_ * BK * 2, B_BYTES = BN_ * BK * 2;
+    constexpr int AI = BM_ / 32, BI = BN_ / 32;  // 1-KiB staging instructions per wave per tile
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    // layout: [A buf0][A buf1][B buf0][B buf1]
-    char* As = smem;
-    char* Bs = smem + 2 * TILE_BYTES;
+    char* As = smem;                 // [2][A_BYTES]
+    char* Bs = smem + 2 * A_BYTES;   // [2][B_BYTES]
 
     // XCD-aware bijective remap of the linear block id: blocks dispatched round-robin over the 8 XCDs get a
     // contiguous range of tiles each, so the m-tiles that share one weight tile hit the same L2.
@@ -137,81 +140,83 @@ __global__ __launch_bounds__(256) void gemm_tiled(const bf16_t* __restrict__ A, 
         bid = base + (bid >> 3);
     }
     const int tn = bid / tiles_m, tm = bid % tiles_m;
-    const int m0 = tm * BM, n0 = tn * BN;
+    const int m0 = tm * BM_, n0 = tn * BN_;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = w >> 1, wn = w & 1;
     const int K32 = Kp >> 5;
     const int N16 = (N + 15) >> 4;
-    const int nk = Kp / BK;
+    const int nk_total = Kp / BK;
+    const int kt0 = blockIdx.y * kt_per;
+    const int nk = min(kt_per, nk_total - kt0);
 
-    // ---- staging addresses (4 x 16 B per thread per operand per tile) ----
-    // A: LDS chunk position p = j*64 + lane (j = w*4+i): row = p>>3, c = p&7 holds global chunk c ^ (row&7)
-    const bf16_t* a_src[4];
-    const bf16_t* b_src[4];
+    // ---- staging addresses ----
+    // A: LDS chunk position p = j*64 + lane: row = p>>3, c = p&7 holds global chunk c ^ (row&7)
+    const bf16_t* a_src[AI];
+    const bf16_t* b_src[BI];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int j = w * 4 + i;
+    for (int i = 0; i < AI; ++i) {
+        const int j = w * AI + i;
         const int row = j * 8 + (lane >> 3), c = lane & 7;
         int gr = m0 + row;
         gr = gr < M ? gr : M - 1;
-        a_src[i] = A + (size_t)gr * lda + ((c ^ (row & 7)) << 3);
+        a_src[i] = A + (size_t)gr * lda + (size_t)kt0 * BK + ((c ^ (row & 7)) << 3);
+    }
+#pragma unroll
+    for (int i = 0; i < BI; ++i) {
+        const int j = w * BI + i;
         const int nbi = j >> 1, kbi = j & 1;
         int nb = (n0 >> 4) + nbi;
         nb = nb < N16 ? nb : N16 - 1;
-        b_src[i] = Wp + ((size_t)nb * K32 + kbi) * 512 + lane * 8;
+        b_src[i] = Wp + ((size_t)nb * K32 + (size_t)kt0 * 2 + kbi) * 512 + lane * 8;
     }
 
-    f32x4 acc[4][4];  // [n-block b][m-frag f]
+    f32x4 acc[WN][WM];  // [n-block b][m-frag f]
 #pragma unroll
-    for (int b = 0; b < 4; ++b)
+    for (int b = 0; b < WN; ++b)
 #pragma unroll
-        for (int f = 0; f < 4; ++f) acc[b][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int f = 0; f < WM; ++f) acc[b][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    uint4 ra[4], rb[4];
+    uint4 ra[AI], rb[BI];
     auto stage_glds = [&](int buf, int kt) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int j = w * 4 + i;
-            glds16(a_src[i] + kt * BK, As + buf * TILE_BYTES + j * 1024);
-            glds16(b_src[i] + (size_t)kt * 2 * 512, Bs + buf * TILE_BYTES + j * 1024);
-        }
+        for (int i = 0; i < AI; ++i) glds16(a_src[i] + kt * BK, As + buf * A_BYTES + (w * AI + i) * 1024);
+#pragma unroll
+        for (int i = 0; i < BI; ++i) glds16(b_src[i] + (size_t)kt * 2 * 512, Bs + buf * B_BYTES + (w * BI + i) * 1024);
     };
     auto stage_load = [&](int kt) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            ra[i] = *(const uint4*)(a_src[i] + kt * BK);
-            rb[i] = *(const uint4*)(b_src[i] + (size_t)kt * 2 * 512);
-        }
+        for (int i = 0; i < AI; ++i) ra[i] = *(const uint4*)(a_src[i] + kt * BK);
+#pragma unroll
+        for (int i = 0; i < BI; ++i) rb[i] = *(const uint4*)(b_src[i] + (size_t)kt * 2 * 512);
     };
     auto stage_write = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int j = w * 4 + i;
-            *(uint4*)(As + buf * TILE_BYTES + j * 1024 + lane * 16) = ra[i];
-            *(uint4*)(Bs + buf * TILE_BYTES + j * 1024 + lane * 16) = rb[i];
-        }
+        for (int i = 0; i < AI; ++i) *(uint4*)(As + buf * A_BYTES + (w * AI + i) * 1024 + lane * 16) = ra[i];
+#pragma unroll
+        for (int i = 0; i < BI; ++i) *(uint4*)(Bs + buf * B_BYTES + (w * BI + i) * 1024 + lane * 16) = rb[i];
     };
     const int r = lane & 15, g = lane >> 4;
     auto compute = [&](int buf) {
-        const char* Ab = As + buf * TILE_BYTES;
-        const char* Bb = Bs + buf * TILE_BYTES;
+        const char* Ab = As + buf * A_BYTES;
+        const char* Bb = Bs + buf * B_BYTES;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 xf[4], wf[4];
+            bf16x8 xf[WM], wf[WN];
 #pragma unroll
-            for (int f = 0; f < 4; ++f) {
-                const int row = wm * 64 + f * 16 + r;
+            for (int f = 0; f < WM; ++f) {
+                const int row = wm * (WM * 16) + f * 16 + r;
                 const int c = (ks * 4 + g) ^ (row & 7);
                 xf[f] = as_bf16x8(*(const uint4*)(Ab + (row * 8 + c) * 16));
             }
 #pragma unroll
-            for (int b = 0; b < 4; ++b) wf[b] = as_bf16x8(*(const uint4*)(Bb + (((wn * 4 + b) * 2 + ks) * 64 + lane) * 16));
+            for (int b = 0; b < WN; ++b)
+                wf[b] = as_bf16x8(*(const uint4*)(Bb + (((wn * WN + b) * 2 + ks) * 64 + lane) * 16));
 #pragma unroll
-            for (int b = 0; b < 4; ++b)
+            for (int b = 0; b < WN; ++b)
 #pragma unroll
-                for (int f = 0; f < 4; ++f)
+                for (int f = 0; f < WM; ++f)
                     acc[b][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[b], xf[f], acc[b][f], 0, 0, 0);
         }
     };
@@ -237,22 +242,36 @@ __global__ __launch_bounds__(256) void gemm_tiled(const bf16_t* __restrict__ A, 
 
     // ---- epilogue ----
 #pragma unroll
-    for (int f = 0; f < 4; ++f) {
-        const int m = m0 + wm * 64 + f * 16 + r;
+    for (int f = 0; f < WM; ++f) {
+        const int m = m0 + wm * (WM * 16) + f * 16 + r;
         if (m >= M) continue;
-        if (epi.glu) {
+        if (partial) {  // split-K: raw fp32 partial sums, epilogue applied by splitk_reduce
 #pragma unroll
-            for (int b = 0; b < 4; b += 2) {
-                const int nblk = (n0 >> 4) + wn * 4 + b;  // even block = gate, odd = up
+            for (int b = 0; b < WN; ++b) {
+                const int n = n0 + wn * (WN * 16) + b * 16 + 4 * g;
+                if (n < N) {
+                    float* o = partial + ((size_t)blockIdx.y * M + m) * N + n;
+                    if (n + 3 < N && ((((uintptr_t)o) & 15) == 0)) {
+                        *(float4*)o = make_float4(acc[b][f][0], acc[b][f][1], acc[b][f][2], acc[b][f][3]);
+                    } else {
+                        for (int i = 0; i < 4; ++i)
+                            if (n + i < N) o[i] = acc[b][f][i];
+                    }
+                }
+            }
+        } else if (epi.glu) {
+#pragma unroll
+            for (int b = 0; b < WN; b += 2) {
+                const int nblk = (n0 >> 4) + wn * WN + b;  // even block = gate, odd = up
                 float gv[4] = {acc[b][f][0], acc[b][f][1], acc[b][f][2], acc[b][f][3]};
                 float uv[4] = {acc[b + 1][f][0], acc[b + 1][f][1], acc[b + 1][f][2], acc[b + 1][f][3]};
                 epi_store4_glu(epi, C, ldc, m, (nblk >> 1) * 16 + 4 * g, N >> 1, gv, uv);
             }
         } else {
 #pragma unroll
-            for (int b = 0; b < 4; ++b) {
+            for (int b = 0; b < WN; ++b) {
                 float v[4] = {acc[b][f][0], acc[b][f][1], acc[b][f][2], acc[b][f][3]};
-                epi_store4(epi, C, ldc, m, n0 + wn * 64 + b * 16 + 4 * g, N, v);
+                epi_store4(epi, C, ldc, m, n0 + wn * (WN * 16) + b * 16 + 4 * g, N, v);
             }
         }
     }
@@ -295,51 +314,65 @@ __global__ __launch_bounds__(512) void gemm_skinny(const bf16_t* __restrict__ A,
     const int nbatch = kc >> 7;  // batches of 4 k-steps (128 k)
     const int r = lane & 15, g = lane >> 4;
 
-    for (int nb = nb_begin + w; nb < nb_end; nb += 8) {
-        const u32x4* wsrc = (const u32x4*)(Wp + ((size_t)nb * K32 + (k0 >> 5)) * 512) + lane;  // +64 x 16 B per k-step
-        f32x4 acc[MF];
+    // One continuous stream over (n-block, k-batch): loads run two batches (8 KiB per wave) ahead and keep flowing
+    // across n-block boundaries, so the HBM pipe never drains while a wave finishes one block of output columns.
+    const int n_nb = (nb_end - nb_begin - w + 7) / 8;  // n-blocks of this wave: nb_begin + w + 8*i
+    const int total = n_nb > 0 ? n_nb * nbatch : 0;
+    const u32x4* wbase = (const u32x4*)(Wp + ((size_t)(nb_begin + w) * K32 + (k0 >> 5)) * 512) + lane;
+    const size_t nb_stride = (size_t)8 * K32 * 64;  // u32x4 units between consecutive n-blocks of this wave
+    f32x4 acc[MF];
 #pragma unroll
-        for (int f = 0; f < MF; ++f) acc[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        u32x4 w0[4], w1[4];
-        auto load4 = [&](u32x4(&dst)[4], int b) {
+    for (int f = 0; f < MF; ++f) acc[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    u32x4 b0[4], b1[4], b2[4];
+    auto load4 = [&](u32x4(&dst)[4], int fidx) {
+        const int i = fidx / nbatch, b = fidx - i * nbatch;
+        const u32x4* src = wbase + (size_t)i * nb_stride + (size_t)b * 4 * 64;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) dst[u] = __builtin_nontemporal_load(wsrc + (size_t)(b * 4 + u) * 64);
-        };
-        auto comp4 = [&](u32x4(&src)[4], int b) {
+        for (int u = 0; u < 4; ++u) dst[u] = __builtin_nontemporal_load(src + u * 64);
+    };
+    auto comp4 = [&](u32x4(&src)[4], int fidx) {
+        const int i = fidx / nbatch, b = fidx - i * nbatch;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int ks = b * 4 + u;
-                const bf16x8 wf = __builtin_bit_cast(bf16x8, src[u]);
+        for (int u = 0; u < 4; ++u) {
+            const int ks = b * 4 + u;
+            const bf16x8 wf = __builtin_bit_cast(bf16x8, src[u]);
 #pragma unroll
-                for (int f = 0; f < MF; ++f) {
-                    const bf16x8 xf = as_bf16x8(*(const uint4*)(smem + ((ks * MF + f) * 64 + lane) * 16));
-                    acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf, acc[f], 0, 0, 0);
-                }
-            }
-        };
-        load4(w0, 0);
-        for (int b = 0; b < nbatch; b += 2) {
-            if (b + 1 < nbatch) load4(w1, b + 1);
-            comp4(w0, b);
-            if (b + 1 < nbatch) {
-                if (b + 2 < nbatch) load4(w0, b + 2);
-                comp4(w1, b + 1);
+            for (int f = 0; f < MF; ++f) {
+                const bf16x8 xf = as_bf16x8(*(const uint4*)(smem + ((ks * MF + f) * 64 + lane) * 16));
+                acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf, acc[f], 0, 0, 0);
             }
         }
-        // partial[s][m][n]: lane holds m = f*16 + r, n = nb*16 + 4g .. +3
+        if (b == nbatch - 1) {  // finished this n-block's K-slice: partial[s][m][n], lane holds m = f*16 + r, n = nb*16 + 4g..
+            const int nb = nb_begin + w + 8 * i;
 #pragma unroll
-        for (int f = 0; f < MF; ++f) {
-            const int m = f * 16 + r;
-            const int n = nb * 16 + 4 * g;
-            if (m < M && n < N) {
-                float* o = partial + ((size_t)s * M + m) * N + n;
-                if (n + 3 < N && ((((uintptr_t)o) & 15) == 0)) {
-                    *(float4*)o = make_float4(acc[f][0], acc[f][1], acc[f][2], acc[f][3]);
-                } else {
-                    for (int i = 0; i < 4; ++i)
-                        if (n + i < N) o[i] = acc[f][i];
+            for (int f = 0; f < MF; ++f) {
+                const int m = f * 16 + r;
+                const int n = nb * 16 + 4 * g;
+                if (m < M && n < N) {
+                    float* o = partial + ((size_t)s * M + m) * N + n;
+                    if (n + 3 < N && ((((uintptr_t)o) & 15) == 0)) {
+                        *(float4*)o = make_float4(acc[f][0], acc[f][1], acc[f][2], acc[f][3]);
+                    } else {
+                        for (int e = 0; e < 4; ++e)
+                            if (n + e < N) o[e] = acc[f][e];
+                    }
                 }
+                acc[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
             }
+        }
+    };
+    if (total > 0) load4(b0, 0);
+    if (total > 1) load4(b1, 1);
+    for (int fi = 0; fi < total; fi += 3) {
+        if (fi + 2 < total) load4(b2, fi + 2);
+        comp4(b0, fi);
+        if (fi + 1 < total) {
+            if (fi + 3 < total) load4(b0, fi + 3);
+            comp4(b1, fi + 1);
+        }
+        if (fi + 2 < total) {
+            if (fi + 4 < total) load4(b1, fi + 4);
+            comp4(b2, fi + 2);
         }
     }
 }
@@ -452,8 +485,12 @@ static SkinnyPlan plan_skinny(int M, int N, int Kp) {
 }
 
 size_t gemm_workspace_bytes(int M, int N, int K) {
-    if (M > 64) return 0;
     const int Kp = (K + 127) / 128 * 128;
+    if (M > 64) {
+        // tiled kernel: split-K (up to 8 slices of fp32 partials) is only used when the output tile grid is small
+        const long long blocks64 = (long long)((M + 63) / 64) * ((N + 63) / 64);
+        return blocks64 < 192 ? (size_t)8 * M * N * sizeof(float) : 0;
+    }
     return plan_skinny(M, N, Kp).ws_bytes;
 }
 
@@ -485,16 +522,55 @@ hipError_t launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* Wp, void* C,
         hipLaunchKernelGGL(splitk_reduce, dim3(rb), dim3(256), 0, st, (const float*)ws, p.S, C, ldc, M, N, epi);
         return hipGetLastError();
     }
-    const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
-    const size_t lds = 4 * TILE_BYTES;
-    dim3 grid(tiles_m * tiles_n), block(256);
+    // ---- tile / split-K selection: fill >= ~1 block per CU when the problem allows it
+    struct Cand { int wm, wn; };
+    const Cand cands[3] = {{4, 4}, {2, 4}, {2, 2}};
+    int pick = 0;
+    for (int c = 0; c < 3; ++c) {
+        const int bm = cands[c].wm * 32, bn = cands[c].wn * 32;
+        const long long blocks = (long long)((M + bm - 1) / bm) * ((N + bn - 1) / bn);
+        pick = c;
+        if (blocks >= 224) break;
+    }
+    const int bm = cands[pick].wm * 32, bn = cands[pick].wn * 32;
+    const int tiles_m = (M + bm - 1) / bm, tiles_n = (N + bn - 1) / bn;
+    const int nk_total = Kp / BK;
+    int S = 1;
+    if (ws != nullptr) {
+        while ((long long)tiles_m * tiles_n * S < 192 && S < 8 && nk_total / (S * 2) >= 8 &&
+               (size_t)(S * 2) * M * N * sizeof(float) <= ws_bytes)
+            S *= 2;
+    }
+    const int kt_per = (nk_total + S - 1) / S;
+    S = (nk_total + kt_per - 1) / kt_per;
+    float* partial = S > 1 ? ws : nullptr;
+    const size_t lds = (size_t)2 * (bm + bn) * BK * 2;
+    dim3 grid(tiles_m * tiles_n, S), block(256);
     const int pid = prof_enabled() ? prof_open(st, 1, 2.0 * (double)M * (double)N * (double)K) : -1;
-    if (variant == 2)
-        hipLaunchKernelGGL(gemm_tiled<false>, grid, block, lds, st, A, lda, Wp, C, ldc, M, N, K, Kp, epi, tiles_m, tiles_n);
-    else
-        hipLaunchKernelGGL(gemm_tiled<true>, grid, block, lds, st, A, lda, Wp, C, ldc, M, N, K, Kp, epi, tiles_m, tiles_n);
+#define LAUNCH_TILED(WM_, WN_)                                                                                              \
+    do {                                                                                                                    \
+        if (variant == 2)                                                                                                   \
+            hipLaunchKernelGGL((gemm_tiled<WM_, WN_, false>), grid, block, lds, st, A, lda, Wp, C, ldc, M, N, Kp, epi, tiles_m, \
+                               tiles_n, kt_per, partial);                                                                   \
+        else                                                                                                                \
+            hipLaunchKernelGGL((gemm_tiled<WM_, WN_, true>), grid, block, lds, st, A, lda, Wp, C, ldc, M, N, Kp, epi, tiles_m,  \
+                               tiles_n, kt_per, partial);                                                                   \
+    } while (0)
+    if (pick == 0) LAUNCH_TILED(4, 4);
+    else if (pick == 1) LAUNCH_TILED(2, 4);
+    else LAUNCH_TILED(2, 2);
+#undef LAUNCH_TILED
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess && S > 1) {
+        const int Nout = epi.glu ? N / 2 : N;
+        const long long total = (long long)M * ((Nout + 3) / 4);
+        int rb = (int)((total + 255) / 256);
+        if (rb > 2048) rb = 2048;
+        hipLaunchKernelGGL(splitk_reduce, dim3(rb), dim3(256), 0, st, (const float*)ws, S, C, ldc, M, N, epi);
+        e = hipGetLastError();
+    }
     prof_close(st, pid);
-    return hipGetLastError();
+    return e;
 }
 
 hipError_t launch_pack_weight_bf16(const bf16_t* W, int ldw, int N, int K, bf16_t* Wp, int Kpad, int glu,

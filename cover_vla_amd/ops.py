@@ -88,8 +88,8 @@ def gemm(a: torch.Tensor, lin: PackedLinear, *, act: str = "none", residual: Opt
     e.glu = 1 if lin.glu else 0
     e.out_f32 = 1 if out.dtype == torch.float32 else 0
     e.out_scale = out_scale
-    if ws is None and (variant == 3 or (variant == 0 and M <= 64)):
-        ws = gemm_workspace(M, lin.N, lin.K, a.device)
+    if ws is None:
+        ws = gemm_workspace(M, lin.N, lin.K, a.device)   # None when this shape needs no split-K scratch
     L.check(h.cover_gemm_bf16(a.data_ptr(), a.stride(0), lin.wp.data_ptr(), out.data_ptr(), out.stride(0), M, lin.N,
                               lin.K, C.byref(e), _ptr(ws), ws.numel() * 4 if ws is not None else 0, variant,
                               _stream()), "gemm_bf16")
