@@ -45,7 +45,8 @@ class AttnArgs(C.Structure):
                 ("q_b_stride", c_ll), ("q_t_stride", c_ll), ("q_h_stride", c_ll),
                 ("o_b_stride", c_ll), ("o_t_stride", c_ll), ("o_h_stride", c_ll),
                 ("B", c_i), ("Tq", c_i), ("Hq", c_i), ("Hkv", c_i), ("D", c_i), ("scale", c_f),
-                ("n_seg", c_i), ("_pad", c_i), ("seg", KvSegment * 3)]
+                ("n_seg", c_i), ("_pad", c_i), ("seg", KvSegment * 3),
+                ("state_in_o", c_p), ("state_in_ml", c_p), ("state_out_o", c_p), ("state_out_ml", c_p)]
 
 
 class RopeArgs(C.Structure):
@@ -124,7 +125,7 @@ class DecGroup(C.Structure):
     _fields_ = [("B", c_i), ("T", c_i), ("positions", c_p), ("n_seg", c_i), ("write_seg", c_i),
                 ("segs", KvSegment * 3), ("seg_k_offset", c_ll * 3), ("seg_vt_offset", c_ll * 3),
                 ("write_slot_of_batch", c_p), ("write_t_offset_of_batch", c_p),
-                ("write_t_offset", c_i), ("_pad", c_i)]
+                ("write_t_offset", c_i), ("seg0_shared", c_i)]
 
 
 class DecPass(C.Structure):

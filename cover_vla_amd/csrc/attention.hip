@@ -37,6 +37,8 @@ struct AttnDev {
     float scale_log2e;
     int n_seg;
     SegDev seg[3];
+    const float* si_o; const float* si_ml;
+    float* so_o; float* so_ml;
 };
 
 template <int D, bool KSPLIT>
@@ -70,6 +72,17 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnDev a) {
     f32x4 oacc[DB];
 #pragma unroll
     for (int db = 0; db < DB; ++db) oacc[db] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const long long srow = ((long long)b * a.Tq + t) * a.Hq + h;  // state row of this lane's query
+    if (a.si_o && q_ok && (!KSPLIT || w == 0)) {  // resume from a previous call's state (one wave owns it)
+        m_run = a.si_ml[srow * 2];
+        l_run = a.si_ml[srow * 2 + 1];
+        const float* so = a.si_o + srow * D + 4 * g;
+#pragma unroll
+        for (int db = 0; db < DB; ++db) {
+            const float4 v = *(const float4*)(so + db * 16);
+            oacc[db] = (f32x4){v.x * l_run, v.y * l_run, v.z * l_run, v.w * l_run};
+        }
+    }
 
     // largest token index in this tile (wave-uniform) for causal early exit
     int t_hi = (tile * 16 + 15) / a.G;
@@ -193,6 +206,17 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnDev a) {
 
     if (!q_ok) return;
     const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
+    if (a.so_o) {  // hand the state to the next call instead of writing the final output
+        if (g == 0) {
+            a.so_ml[srow * 2] = m_run;
+            a.so_ml[srow * 2 + 1] = l_run;
+        }
+        float* so = a.so_o + srow * D + 4 * g;
+#pragma unroll
+        for (int db = 0; db < DB; ++db)
+            *(float4*)(so + db * 16) = make_float4(oacc[db][0] * inv, oacc[db][1] * inv, oacc[db][2] * inv, oacc[db][3] * inv);
+        return;
+    }
     bf16_t* op = a.out + (long long)b * a.o_b + (long long)t * a.o_t + (long long)h * a.o_h + 4 * g;
 #pragma unroll
     for (int db = 0; db < DB; ++db) {
@@ -231,6 +255,8 @@ hipError_t launch_attention_bf16(const cover_attn_args* x, hipStream_t st) {
     a.R = x->Tq * a.G;
     a.scale_log2e = x->scale * 1.4426950408889634f;
     a.n_seg = x->n_seg;
+    a.si_o = x->state_in_o; a.si_ml = x->state_in_ml; a.so_o = x->state_out_o; a.so_ml = x->state_out_ml;
+    if ((a.si_o == nullptr) != (a.si_ml == nullptr) || (a.so_o == nullptr) != (a.so_ml == nullptr)) return hipErrorInvalidValue;
     for (int i = 0; i < x->n_seg; ++i) {
         const cover_kv_segment& s = x->seg[i];
         SegDev& d = a.seg[i];

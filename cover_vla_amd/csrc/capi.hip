@@ -280,7 +280,7 @@ int cover_vit_forward(const cover_vit_desc* d, void* x, int n_seq, int T, void* 
 }
 
 static size_t dec_ws(const cover_dec_desc* d, int rows, Carver* c, void** h, void** qkv, void** attn, void** mlp, void** sk,
-                     size_t* sk_bytes) {
+                     size_t* sk_bytes, void** st_o = nullptr, void** st_ml = nullptr) {
     Carver tmp{nullptr, 0, 0};
     Carver& cc = c ? *c : tmp;
     const int nqkv = (d->Hq + 2 * d->Hkv) * d->D;
@@ -289,6 +289,8 @@ static size_t dec_ws(const cover_dec_desc* d, int rows, Carver* c, void** h, voi
     p = cc.take((size_t)rows * nqkv * 2); if (qkv) *qkv = p;
     p = cc.take((size_t)rows * d->Hq * d->D * 2); if (attn) *attn = p;
     p = cc.take((size_t)rows * d->mlp * 2); if (mlp) *mlp = p;
+    p = cc.take((size_t)rows * d->Hq * d->D * 4); if (st_o) *st_o = p;   // attention state (seg0_shared decode)
+    p = cc.take((size_t)rows * d->Hq * 2 * 4); if (st_ml) *st_ml = p;
     size_t skb = 0;
     {
         const int ns[4] = {nqkv, d->dim, 2 * d->mlp, d->dim};
@@ -320,9 +322,9 @@ int cover_decoder_forward(const cover_dec_desc* d, const cover_dec_pass* p, void
         rows += G.B * G.T;
     }
     Carver c{(char*)ws.ptr, ws.bytes, 0};
-    void *h, *qkv, *attn, *mlp, *sk;
+    void *h, *qkv, *attn, *mlp, *sk, *st_o, *st_ml;
     size_t skb;
-    const size_t need = dec_ws(d, rows, &c, &h, &qkv, &attn, &mlp, &sk, &skb);
+    const size_t need = dec_ws(d, rows, &c, &h, &qkv, &attn, &mlp, &sk, &skb, &st_o, &st_ml);
     if (!ws.ptr || ws.bytes < need) return fail(COVER_EWORKSPACE, "cover_decoder_forward: workspace too small");
     const int dim = d->dim, Hq = d->Hq, Hkv = d->Hkv, D = d->D, nqkv = (Hq + 2 * Hkv) * D, HD = Hq * D;
 
@@ -361,6 +363,21 @@ int cover_decoder_forward(const cover_dec_desc* d, const cover_dec_pass* p, void
                 aa.seg[s] = G.segs[s];
                 aa.seg[s].k = (const bf16_t*)L.k_cache + G.seg_k_offset[s];
                 aa.seg[s].vt = (const bf16_t*)L.vt_cache + G.seg_vt_offset[s];
+            }
+            if (G.seg0_shared && G.T == 1 && G.n_seg >= 2 && G.segs[0].mask_mode == COVER_MASK_LEN) {
+                // phase A: the shared segment, candidates as the query rows of one "sequence"
+                cover_attn_args pa = aa;
+                pa.B = 1; pa.Tq = G.B; pa.q_b_stride = 0; pa.q_t_stride = nqkv;
+                pa.n_seg = 1;
+                pa.out = nullptr;
+                pa.state_out_o = (float*)st_o + (size_t)row0[g] * Hq * D;
+                pa.state_out_ml = (float*)st_ml + (size_t)row0[g] * Hq * 2;
+                HIPCHK(launch_attention_bf16(&pa, st), "dec attention (shared segment)");
+                // phase B: each candidate's own segments, seeded with the phase-A state
+                for (int s = 1; s < G.n_seg; ++s) aa.seg[s - 1] = aa.seg[s];
+                aa.n_seg = G.n_seg - 1;
+                aa.state_in_o = pa.state_out_o;
+                aa.state_in_ml = pa.state_out_ml;
             }
             HIPCHK(launch_attention_bf16(&aa, st), "dec attention");
         }

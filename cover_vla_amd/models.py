@@ -224,7 +224,8 @@ class Decoder:
         self.desc = d
         self._ws = None
 
-    def group(self, B, T, positions, segs, write_seg, write_slot=None, write_t_off_of_batch=None, write_t_off=0):
+    def group(self, B, T, positions, segs, write_seg, write_slot=None, write_t_off_of_batch=None, write_t_off=0,
+              seg0_shared=False):
         """segs: list of dicts {region, length, len_of_batch, slot_of_batch, mask, causal_offset, vis_len}."""
         g = L.DecGroup()
         g.B, g.T = B, T
@@ -248,6 +249,7 @@ class Decoder:
         g.write_slot_of_batch = write_slot.data_ptr() if write_slot is not None else None
         g.write_t_offset_of_batch = write_t_off_of_batch.data_ptr() if write_t_off_of_batch is not None else None
         g.write_t_offset = write_t_off
+        g.seg0_shared = 1 if seg0_shared else 0
         g._keep = keep
         return g
 

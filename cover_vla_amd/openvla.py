@@ -128,7 +128,7 @@ class OpenVLA:
             g = self.llm.group(N, 1, pos,
                                [dict(region=0, length=T0, slot_of_batch=self.zero_slots),
                                 dict(region=1, length=Lt, len_of_batch=cand_len, slot_of_batch=prompt_of_cand),
-                                dict(region=2, length=i)], 2, write_t_off=i - 1)
+                                dict(region=2, length=i)], 2, write_t_off=i - 1, seg0_shared=True)
             self.llm.forward(xd, [g], final_norm=False)
             self._head_select(xd, uniforms, i, temperature, tokens, sel, trace)
         return tokens, sel

@@ -126,11 +126,16 @@ def fill_segment(s: L.KvSegment, seg: Segment) -> None:
     s.causal_offset = seg.causal_offset
 
 
-def attention(q: torch.Tensor, q_strides: Sequence[int], out: torch.Tensor, o_strides: Sequence[int], B: int, Tq: int,
-              Hq: int, Hkv: int, D: int, scale: float, segments: Sequence[Segment]) -> torch.Tensor:
+def attention(q: torch.Tensor, q_strides: Sequence[int], out: Optional[torch.Tensor], o_strides: Sequence[int], B: int, Tq: int,
+              Hq: int, Hkv: int, D: int, scale: float, segments: Sequence[Segment], state_in=None, state_out=None):
+    """state_in / state_out: optional (o fp32 [B,Tq,Hq,D], ml fp32 [B,Tq,Hq,2]) pairs chaining calls over KV segments."""
     _chk_dev(q, out)
     a = L.AttnArgs()
-    a.q, a.out = q.data_ptr(), out.data_ptr()
+    a.q, a.out = q.data_ptr(), _ptr(out)
+    if state_in is not None:
+        a.state_in_o, a.state_in_ml = state_in[0].data_ptr(), state_in[1].data_ptr()
+    if state_out is not None:
+        a.state_out_o, a.state_out_ml = state_out[0].data_ptr(), state_out[1].data_ptr()
     a.q_b_stride, a.q_t_stride, a.q_h_stride = q_strides
     a.o_b_stride, a.o_t_stride, a.o_h_stride = o_strides
     a.B, a.Tq, a.Hq, a.Hkv, a.D, a.scale = B, Tq, Hq, Hkv, D, scale

@@ -111,6 +111,13 @@ typedef struct cover_attn_args {
     int n_seg;
     int _pad;
     cover_kv_segment seg[3];
+    /* Optional chaining of calls over different KV segments (flash-decoding style): state = per (b, t, h) the
+     * normalised output so far (fp32 [B][Tq][Hq][D]) and its softmax statistics (fp32 [B][Tq][Hq][2] = running max in
+     * scaled-log2 units, running sum). state_in seeds the online softmax; state_out receives the result INSTEAD of `out`
+     * (which may then be NULL). Used by the decoder to attend a KV segment shared by every candidate once per 16
+     * candidates instead of once per candidate. */
+    const float* state_in_o; const float* state_in_ml;
+    float* state_out_o; float* state_out_ml;
 } cover_attn_args;
 int cover_attention_bf16(const cover_attn_args* args, void* stream);
 
@@ -310,7 +317,10 @@ typedef struct cover_dec_group {
     cover_kv_segment segs[3];
     long long seg_k_offset[3], seg_vt_offset[3];
     const int* write_slot_of_batch; const int* write_t_offset_of_batch;
-    int write_t_offset; int _pad;
+    int write_t_offset;
+    int seg0_shared;   /* 1: segs[0] is the SAME slot and length for every batch row and T == 1 (decode): it is attended
+                          with the batch rows as query rows of one tile (K/V read once per 16 candidates) and chained into
+                          the per-row segments through the attention state */
 } cover_dec_group;
 typedef struct cover_dec_pass {
     int n_groups; int final_norm;      /* final_norm: apply final_norm_w to x at the end */

@@ -408,3 +408,38 @@ def test_score_select(dev):
     s[7] = s[10] = 1.0
     r, _ = ops.group_argmax(s.to(dev), 3)
     assert r.cpu().tolist()[:3] == [7, 2, 1]
+
+
+def test_attention_state_chaining_decode(dev):
+    # decode shape: shared segment attended with the candidates as query rows (phase A), then per-candidate segments
+    # seeded with that state (phase B) == one call over all three segments
+    N, Hq, Hkv, D = 32, 8, 8, 128
+    T0, T1, T2 = 257, 24, 5
+    g = torch.Generator().manual_seed(77)
+    q = bf(torch.randn(N, 1, Hq, D, generator=g))
+    k0, v0 = bf(torch.randn(1, T0, Hkv, D, generator=g)), bf(torch.randn(1, T0, Hkv, D, generator=g))
+    k1, v1 = bf(torch.randn(8, T1, Hkv, D, generator=g)), bf(torch.randn(8, T1, Hkv, D, generator=g))
+    k2, v2 = bf(torch.randn(N, T2, Hkv, D, generator=g)), bf(torch.randn(N, T2, Hkv, D, generator=g))
+    slot1 = (torch.arange(N) // 4).to(torch.int32)
+    len1 = (16 + slot1 % 8).to(torch.int32)
+    zero = torch.zeros(N, dtype=torch.int32)
+    c0, c1, c2 = make_cache(k0, v0, dev), make_cache(k1, v1, dev), make_cache(k2, v2, dev)
+    s0 = ops.Segment(c0[0], c0[1], c0[2], c0[3], length=T0, slot_of_batch=zero.to(dev))
+    s1 = ops.Segment(c1[0], c1[1], c1[2], c1[3], length=T1, slot_of_batch=slot1.to(dev), len_of_batch=len1.to(dev))
+    s2 = ops.Segment(c2[0], c2[1], c2[2], c2[3], length=3)
+    qd = q.to(dev)
+    st = (Hq * D, Hq * D, D)
+    one = torch.empty(N, 1, Hq, D, dtype=torch.bfloat16, device=dev)
+    ops.attention(qd, st, one, st, N, 1, Hq, Hkv, D, D ** -0.5, [s0, s1, s2])
+    so = torch.empty(N, Hq, D, dtype=torch.float32, device=dev)
+    sml = torch.empty(N, Hq, 2, dtype=torch.float32, device=dev)
+    ops.attention(qd, (0, Hq * D, D), None, st, 1, N, Hq, Hkv, D, D ** -0.5, [s0], state_out=(so, sml))
+    two = torch.empty_like(one)
+    ops.attention(qd, st, two, st, N, 1, Hq, Hkv, D, D ** -0.5, [s1, s2], state_in=(so, sml))
+    vis0 = torch.ones(N, 1, T0, dtype=torch.bool)
+    vis1 = (torch.arange(T1)[None, None, :] < len1[:, None, None])
+    vis2 = (torch.arange(T2)[None, None, :] < 3).expand(N, 1, T2)
+    ref = attn_ref(q, [(k0.expand(N, -1, -1, -1), v0.expand(N, -1, -1, -1), vis0), (k1[slot1.long()], v1[slot1.long()], vis1),
+                       (k2, v2, vis2)], D ** -0.5)
+    assert rel_l2(one, ref) < 1.2e-2 and rel_l2(two, ref) < 1.2e-2
+    assert torch.allclose(one.float().cpu(), two.float().cpu(), atol=2e-2, rtol=2e-2)

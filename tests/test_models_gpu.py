@@ -50,7 +50,7 @@ def test_verifier_ties_and_short_histories(dev):
 @pytest.mark.parametrize("name", ["pi0_tiny_b6", "pi0_tiny_b1", "pi0_tiny_b40"])
 def test_pi0_sampler_matches_reference_golden(dev, name):
     from cover_vla_amd.pi0 import PI0FlowMatching
-    from test_oracle_golden import pi0_case
+    from tests.helpers import pi0_case
     z, tiny, sd, (images, img_masks, toks, masks, state, noise) = pi0_case(os.path.join(GOLD, name + ".npz"))
     B = state.shape[0]
     model = PI0FlowMatching(sd, tiny, device="cuda:0", max_batch=max(B, 8), max_prompts=max(B, 8), max_lang=toks.shape[1])

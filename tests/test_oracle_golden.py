@@ -44,22 +44,7 @@ def test_verifier_ties_first_index_wins():
 
 
 # ------------------------------------------------------------------------------------------------ pi0 sampler
-def _pi0_cfg(tiny):
-    from cover_ref import blocks as Bk, pi0 as P
-    vit = Bk.VitCfg(tiny["vit_dim"], tiny["vit_layers"], tiny["vit_heads"], tiny["vit_mlp"], tiny["patch"], "gelu_tanh", 1e-6)
-    lm = Bk.DecoderCfg(tiny["lm_dim"], tiny["layers"], tiny["Hq"], tiny["Hkv"], tiny["D"], tiny["lm_mlp"], "gelu_tanh", "gemma", 1e-6, "pi0")
-    ex = Bk.DecoderCfg(tiny["ex_dim"], tiny["layers"], tiny["Hq"], tiny["Hkv"], tiny["D"], tiny["ex_mlp"], "gelu_tanh", "gemma", 1e-6, "pi0")
-    return P.Pi0Cfg(vit, lm, ex, proj_width=tiny["ex_dim"], chunk_size=tiny["chunk"], n_img_tokens=(tiny["image"] // tiny["patch"]) ** 2)
-
-
-def pi0_case(path):
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    from gen_golden_pi0 import pi0_inputs
-    z = np.load(path)
-    tiny = {k[5:]: int(z[k]) for k in z.files if k.startswith("tiny_")}
-    B, L, seed = int(z["B"]), int(z["L"]), int(z["seed"])
-    sd = synth.pi0_state(tiny, seed=seed)
-    return z, tiny, sd, pi0_inputs(tiny, B, L, seed)
+from tests.helpers import _pi0_cfg, pi0_case  # noqa: E402
 
 
 @pytest.mark.parametrize("name", ["pi0_tiny_b6", "pi0_tiny_b1", "pi0_tiny_b40"])
