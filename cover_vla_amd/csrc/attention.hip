@@ -103,22 +103,33 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnDev a) {
 
         for (int t0 = 0; t0 < kend; t0 += 32, ++tile_counter) {
             if (KSPLIT && (tile_counter & (nw - 1)) != w) continue;
+            // ---- issue every load of this tile up front (K fragments, and V^T fragments when they fit in registers):
+            // single-token decode is a chain of dependent global round trips, so K and V must travel together ----
+            int key0 = t0 + 8 * (r >> 2) + (r & 3);
+            int key1 = key0 + 4;
+            key0 = key0 < len ? key0 : len - 1;
+            key1 = key1 < len ? key1 : len - 1;
+            const bf16_t* k0p = kb + (long long)key0 * sg.k_t;
+            const bf16_t* k1p = kb + (long long)key1 * sg.k_t;
+            const bf16_t* vp = vb + t0;
+            uint4 kr0[KS], kr1[KS];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                kr0[ks] = *(const uint4*)(k0p + ks * 32);
+                kr1[ks] = *(const uint4*)(k1p + ks * 32);
+            }
+            constexpr bool V_EARLY = (D <= 128);
+            uint4 vr[V_EARLY ? DB : 1];
+            if (V_EARLY) {
+#pragma unroll
+                for (int db = 0; db < DB; ++db) vr[db] = *(const uint4*)(vp + (long long)(db * 16) * sg.vt_d);
+            }
             // ---- S^T = K . Q^T for two 16-key blocks ----
             f32x4 s0 = (f32x4){0.f, 0.f, 0.f, 0.f}, s1 = s0;
-            {
-                int key0 = t0 + 8 * (r >> 2) + (r & 3);
-                int key1 = key0 + 4;
-                key0 = key0 < len ? key0 : len - 1;
-                key1 = key1 < len ? key1 : len - 1;
-                const bf16_t* k0p = kb + (long long)key0 * sg.k_t;
-                const bf16_t* k1p = kb + (long long)key1 * sg.k_t;
 #pragma unroll
-                for (int ks = 0; ks < KS; ++ks) {
-                    const bf16x8 kf0 = as_bf16x8(*(const uint4*)(k0p + ks * 32));
-                    const bf16x8 kf1 = as_bf16x8(*(const uint4*)(k1p + ks * 32));
-                    s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf0, qf[ks], s0, 0, 0, 0);
-                    s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf1, qf[ks], s1, 0, 0, 0);
-                }
+            for (int ks = 0; ks < KS; ++ks) {
+                s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(kr0[ks]), qf[ks], s0, 0, 0, 0);
+                s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(kr1[ks]), qf[ks], s1, 0, 0, 0);
             }
             // lane (q = r, g) holds keys t0 + 8g + e, e = 0..7 (s0 -> e 0..3, s1 -> e 4..7)
             float sc[8];
@@ -157,10 +168,9 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnDev a) {
             pp.w = pack_bf2(p[6], p[7]);
             const bf16x8 pf = as_bf16x8(pp);
             // ---- O^T += V^T . P ----
-            const bf16_t* vp = vb + t0;
 #pragma unroll
             for (int db = 0; db < DB; ++db) {
-                const bf16x8 vf = as_bf16x8(*(const uint4*)(vp + (long long)(db * 16) * sg.vt_d));
+                const bf16x8 vf = as_bf16x8(V_EARLY ? vr[V_EARLY ? db : 0] : *(const uint4*)(vp + (long long)(db * 16) * sg.vt_d));
                 f32x4 o = oacc[db];
                 o[0] *= alpha; o[1] *= alpha; o[2] *= alpha; o[3] *= alpha;
                 oacc[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, o, 0, 0, 0);
@@ -202,6 +212,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnDev a) {
                 oacc[db][e] = acc;
             }
         l_run = lt;
+        m_run = mx;
     }
 
     if (!q_ok) return;

@@ -328,11 +328,15 @@ int cover_decoder_forward(const cover_dec_desc* d, const cover_dec_pass* p, void
     if (!ws.ptr || ws.bytes < need) return fail(COVER_EWORKSPACE, "cover_decoder_forward: workspace too small");
     const int dim = d->dim, Hq = d->Hq, Hkv = d->Hkv, D = d->D, nqkv = (Hq + 2 * Hkv) * D, HD = Hq * D;
 
+    // h = in_norm_0(x); afterwards every norm is folded into the epilogue of the GEMM that produces its input
+    {
+        const bool f32in = p->x_f32 != nullptr;
+        HIPCHK(launch_rmsnorm(f32in ? (const void*)p->x_f32 : (const void*)x, f32in ? 1 : 0, dim, d->layers_host[0].in_norm_w,
+                              d->norm_w_offset, d->norm_style, (bf16_t*)h, dim, rows, dim, d->norm_eps, st), "dec in_norm");
+    }
     for (int l = 0; l < d->n_layers; ++l) {
         const cover_dec_layer& L = d->layers_host[l];
         const bool first_f32 = (l == 0 && p->x_f32 != nullptr);
-        HIPCHK(launch_rmsnorm(first_f32 ? (const void*)p->x_f32 : (const void*)x, first_f32 ? 1 : 0, dim, L.in_norm_w,
-                              d->norm_w_offset, d->norm_style, (bf16_t*)h, dim, rows, dim, d->norm_eps, st), "dec in_norm");
         cover_gemm_epi e;
         memset(&e, 0, sizeof e);
         e.out_scale = 1.0f;
@@ -384,8 +388,9 @@ int cover_decoder_forward(const cover_dec_desc* d, const cover_dec_pass* p, void
         memset(&e, 0, sizeof e);
         e.out_scale = 1.0f;
         e.residual = first_f32 ? (const void*)p->x_f32 : (const void*)x; e.residual_f32 = first_f32 ? 1 : 0; e.ld_residual = dim;
-        HIPCHK(launch_gemm_bf16((const bf16_t*)attn, HD, (const bf16_t*)L.o_w, x, dim, rows, dim, HD, &e, (float*)sk, skb, variant, st), "dec o_proj");
-        HIPCHK(launch_rmsnorm(x, 0, dim, L.post_norm_w, d->norm_w_offset, d->norm_style, (bf16_t*)h, dim, rows, dim, d->norm_eps, st), "dec post_norm");
+        e.norm_w = L.post_norm_w; e.norm_out = h; e.ld_norm_out = dim; e.norm_style = d->norm_style;
+        e.norm_w_offset = d->norm_w_offset; e.norm_eps = d->norm_eps;
+        HIPCHK(launch_gemm_bf16((const bf16_t*)attn, HD, (const bf16_t*)L.o_w, x, dim, rows, dim, HD, &e, (float*)sk, skb, variant, st), "dec o_proj (+post_norm)");
         memset(&e, 0, sizeof e);
         e.out_scale = 1.0f;
         e.act = d->act; e.glu = 1;
@@ -393,7 +398,11 @@ int cover_decoder_forward(const cover_dec_desc* d, const cover_dec_pass* p, void
         memset(&e, 0, sizeof e);
         e.out_scale = 1.0f;
         e.residual = x; e.ld_residual = dim;
-        HIPCHK(launch_gemm_bf16((const bf16_t*)mlp, d->mlp, (const bf16_t*)L.down_w, x, dim, rows, dim, d->mlp, &e, (float*)sk, skb, variant, st), "dec down");
+        if (l + 1 < d->n_layers) {  // next layer's input norm rides on this GEMM
+            e.norm_w = d->layers_host[l + 1].in_norm_w; e.norm_out = h; e.ld_norm_out = dim; e.norm_style = d->norm_style;
+            e.norm_w_offset = d->norm_w_offset; e.norm_eps = d->norm_eps;
+        }
+        HIPCHK(launch_gemm_bf16((const bf16_t*)mlp, d->mlp, (const bf16_t*)L.down_w, x, dim, rows, dim, d->mlp, &e, (float*)sk, skb, variant, st), "dec down (+next in_norm)");
     }
     if (p->final_norm)
         HIPCHK(launch_rmsnorm(x, 0, dim, d->final_norm_w, d->norm_w_offset, d->norm_style, (bf16_t*)x, dim, rows, dim, d->norm_eps, st), "dec final_norm");

@@ -23,11 +23,14 @@ struct EpiDev {
     const float* lscale;
     int ldr, res_f32, act, glu, out_f32;
     float out_scale;
+    const float* norm_w;
+    bf16_t* norm_out;
+    int ld_norm_out, norm_style;
+    float norm_w_offset, norm_eps;
 };
 
-// val[4] are 4 consecutive columns n0..n0+3 of row m. Handles bias/act/residual/scale + store.
-__device__ __forceinline__ void epi_store4(const EpiDev& e, void* C, int ldc, int m, int n0, int N, float v[4]) {
-    if (n0 >= N) return;
+// val[4] are 4 consecutive columns n0..n0+3 of row m: bias / activation / layer-scale / residual / scale, in place.
+__device__ __forceinline__ void epi_value4(const EpiDev& e, int m, int n0, int N, float v[4]) {
     const bool full = (n0 + 3 < N);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -59,6 +62,11 @@ __device__ __forceinline__ void epi_store4(const EpiDev& e, void* C, int ldc, in
 #pragma unroll
         for (int i = 0; i < 4; ++i) v[i] *= e.out_scale;
     }
+}
+__device__ __forceinline__ void epi_store4(const EpiDev& e, void* C, int ldc, int m, int n0, int N, float v[4]) {
+    if (n0 >= N) return;
+    const bool full = (n0 + 3 < N);
+    epi_value4(e, m, n0, N, v);
     if (e.out_f32) {
         float* o = (float*)C + (size_t)m * ldc + n0;
         if (full && ((((uintptr_t)o) & 15) == 0)) {
@@ -413,6 +421,55 @@ __global__ __launch_bounds__(256) void splitk_reduce(const float* __restrict__ p
     }
 }
 
+// out = epi(sum_s partial[s]) AND norm_out = rmsnorm(out): one 256-thread block per output row (N % 8 == 0, N <= 8192,
+// no GLU, bf16 output). The sum of squares is taken over the bf16-ROUNDED outputs, i.e. exactly what the separate
+// rmsnorm kernel would read back.
+__global__ __launch_bounds__(256) void splitk_reduce_norm(const float* __restrict__ partial, int S, bf16_t* C, int ldc, int M,
+                                                          int N, EpiDev epi) {
+    __shared__ float red[16];
+    const int m = blockIdx.x;
+    float vals[4][8];
+    float q = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int n0 = (threadIdx.x + c * 256) * 8;
+        if (n0 < N) {
+            float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int s = 0; s < S; ++s) {
+                const float* p = partial + ((size_t)s * M + m) * N + n0;
+                const float4 a = *(const float4*)p, b = *(const float4*)(p + 4);
+                v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w; v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
+            }
+            epi_value4(epi, m, n0, N, v);
+            epi_value4(epi, m, n0 + 4, N, v + 4);
+            uint4 u;
+            u.x = pack_bf2(v[0], v[1]); u.y = pack_bf2(v[2], v[3]); u.z = pack_bf2(v[4], v[5]); u.w = pack_bf2(v[6], v[7]);
+            *(uint4*)(C + (size_t)m * ldc + n0) = u;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                vals[c][i] = bfround(v[i]);
+                q += vals[c][i] * vals[c][i];
+            }
+        }
+    }
+    const float rstd = rsqrtf(block_sum(q, red) / N + epi.norm_eps);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int n0 = (threadIdx.x + c * 256) * 8;
+        if (n0 < N) {
+            float o[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float ww = epi.norm_w[n0 + i];
+                o[i] = epi.norm_style == 1 ? ww * bfround(vals[c][i] * rstd) : vals[c][i] * rstd * (epi.norm_w_offset + ww);
+            }
+            uint4 u;
+            u.x = pack_bf2(o[0], o[1]); u.y = pack_bf2(o[2], o[3]); u.z = pack_bf2(o[4], o[5]); u.w = pack_bf2(o[6], o[7]);
+            *(uint4*)(epi.norm_out + (size_t)m * epi.ld_norm_out + n0) = u;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // Weight packing: W[N, ldw] row-major -> fragment-major. One thread per 16-B chunk of the packed image.
 // ---------------------------------------------------------------------------------------------------
@@ -457,6 +514,12 @@ static EpiDev make_epi(const cover_gemm_epi* e) {
     d.out_f32 = e ? e->out_f32 : 0;
     d.out_scale = e ? e->out_scale : 1.0f;
     if (d.out_scale == 0.0f) d.out_scale = 1.0f;
+    d.norm_w = e ? e->norm_w : nullptr;
+    d.norm_out = e ? (bf16_t*)e->norm_out : nullptr;
+    d.ld_norm_out = e ? e->ld_norm_out : 0;
+    d.norm_style = e ? e->norm_style : 0;
+    d.norm_w_offset = e ? e->norm_w_offset : 0.f;
+    d.norm_eps = e ? e->norm_eps : 0.f;
     return d;
 }
 
@@ -515,12 +578,21 @@ hipError_t launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* Wp, void* C,
         prof_close(st, pid);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
+        const bool want_norm = epi.norm_w != nullptr && epi.norm_out != nullptr;
+        if (want_norm && !epi.glu && !epi.out_f32 && (N % 8) == 0 && N <= 8192 && (ldc % 8) == 0 && (epi.ld_norm_out % 8) == 0) {
+            hipLaunchKernelGGL(splitk_reduce_norm, dim3(M), dim3(256), 0, st, (const float*)ws, p.S, (bf16_t*)C, ldc, M, N, epi);
+            return hipGetLastError();
+        }
         const int Nout = epi.glu ? N / 2 : N;
         const long long total = (long long)M * ((Nout + 3) / 4);
         int rb = (int)((total + 255) / 256);
         if (rb > 2048) rb = 2048;
         hipLaunchKernelGGL(splitk_reduce, dim3(rb), dim3(256), 0, st, (const float*)ws, p.S, C, ldc, M, N, epi);
-        return hipGetLastError();
+        e = hipGetLastError();
+        if (e == hipSuccess && want_norm)
+            e = launch_rmsnorm(C, 0, ldc, epi.norm_w, epi.norm_w_offset, epi.norm_style, epi.norm_out, epi.ld_norm_out, M,
+                               epi.glu ? N / 2 : N, epi.norm_eps, st);
+        return e;
     }
     // ---- tile / split-K selection: fill >= ~1 block per CU when the problem allows it
     struct Cand { int wm, wn; };
@@ -570,6 +642,9 @@ hipError_t launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* Wp, void* C,
         e = hipGetLastError();
     }
     prof_close(st, pid);
+    if (e == hipSuccess && epi.norm_w != nullptr && epi.norm_out != nullptr)
+        e = launch_rmsnorm(C, 0, ldc, epi.norm_w, epi.norm_w_offset, epi.norm_style, epi.norm_out, epi.ld_norm_out, M,
+                           epi.glu ? N / 2 : N, epi.norm_eps, st);
     return e;
 }
 

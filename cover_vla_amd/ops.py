@@ -70,7 +70,9 @@ def gemm_workspace(M: int, N: int, K: int, device) -> Optional[torch.Tensor]:
 
 def gemm(a: torch.Tensor, lin: PackedLinear, *, act: str = "none", residual: Optional[torch.Tensor] = None,
          layer_scale: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, out_f32: bool = False,
-         out_scale: float = 1.0, variant: int = 0, ws: Optional[torch.Tensor] = None) -> torch.Tensor:
+         out_scale: float = 1.0, variant: int = 0, ws: Optional[torch.Tensor] = None, norm_w: Optional[torch.Tensor] = None,
+         norm_out: Optional[torch.Tensor] = None, norm_style: int = 0, norm_w_offset: float = 0.0, norm_eps: float = 1e-6
+         ) -> torch.Tensor:
     """out[M, n_out] = epi(a[M, K] @ W^T). `a` is bf16 with row stride >= padded K (zero padded)."""
     _chk_dev(a, residual, out)
     assert a.dtype == torch.bfloat16 and a.dim() == 2 and a.stride(1) == 1
@@ -88,6 +90,9 @@ def gemm(a: torch.Tensor, lin: PackedLinear, *, act: str = "none", residual: Opt
     e.glu = 1 if lin.glu else 0
     e.out_f32 = 1 if out.dtype == torch.float32 else 0
     e.out_scale = out_scale
+    if norm_w is not None:
+        e.norm_w, e.norm_out, e.ld_norm_out = norm_w.data_ptr(), norm_out.data_ptr(), norm_out.stride(0)
+        e.norm_style, e.norm_w_offset, e.norm_eps = norm_style, norm_w_offset, norm_eps
     if ws is None:
         ws = gemm_workspace(M, lin.N, lin.K, a.device)   # None when this shape needs no split-K scratch
     L.check(h.cover_gemm_bf16(a.data_ptr(), a.stride(0), lin.wp.data_ptr(), out.data_ptr(), out.stride(0), M, lin.N,

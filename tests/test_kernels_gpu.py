@@ -443,3 +443,26 @@ def test_attention_state_chaining_decode(dev):
                        (k2, v2, vis2)], D ** -0.5)
     assert rel_l2(one, ref) < 1.2e-2 and rel_l2(two, ref) < 1.2e-2
     assert torch.allclose(one.float().cpu(), two.float().cpu(), atol=2e-2, rtol=2e-2)
+
+
+@pytest.mark.parametrize("variant,M", [(3, 32), (3, 5), (1, 150)])
+@pytest.mark.parametrize("style", [0, 1])
+def test_gemm_fused_rmsnorm(dev, variant, M, style):
+    # out = residual + A W^T ; norm_out = rmsnorm(out): fused into the split-K reduction on the streaming path
+    N, K = 1024, 512
+    g = torch.Generator().manual_seed(M + style)
+    a = bf(torch.randn(M, K, generator=g))
+    w = bf(torch.randn(N, K, generator=g) * 0.05)
+    res = bf(torch.randn(M, N, generator=g))
+    nw = torch.randn(N, generator=g) * 0.2 + (1.0 if style == 1 else 0.0)
+    lin = ops.pack_linear(w.to(dev))
+    x = res.clone().to(dev)
+    h = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+    ops.gemm(a.to(dev), lin, residual=x, out=x, variant=variant, norm_w=nw.to(dev), norm_out=h, norm_style=style,
+             norm_w_offset=0.0 if style == 1 else 1.0, norm_eps=1e-6)
+    ref_x = bf(res.float() + a.float() @ w.float().T)
+    assert rel_l2(x, ref_x) < 6e-3
+    xf = x.float().cpu()  # the norm must be the norm of what was actually stored
+    rstd = torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-6)
+    ref_h = bf(nw * bf(xf * rstd).float()) if style == 1 else bf(xf * rstd * (1 + nw))
+    assert torch.allclose(h.float().cpu(), ref_h.float(), atol=2e-2, rtol=1e-2)
