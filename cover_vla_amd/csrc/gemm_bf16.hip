@@ -385,6 +385,109 @@ __global__ __launch_bounds__(512) void gemm_skinny(const bf16_t* __restrict__ A,
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Weight-streaming kernel, second generation: the 8 waves of a block are NG n-groups x KS k-slices. A wave streams
+// NBW n-blocks over ITS 256-wide k-slice of the block's K chunk (KC = 256*KS, staged once in LDS), keeps one
+// accumulator set per n-block, and the KS slices are summed through LDS at the end. Same parallelism as the first
+// generation with KS-times fewer grid-level K splits => KS-times less fp32 partial traffic for the reduce kernel.
+// ---------------------------------------------------------------------------------------------------
+template <int MF, int KS, int NBW>
+__global__ __launch_bounds__(512) void gemm_skinny2(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ Wp,
+                                                    float* __restrict__ partial, int M, int N, int Kp) {
+    constexpr int NG = 8 / KS, KC = 256 * KS, NBPB = NG * NBW;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ks = w % KS, ng = w / KS;
+    const int s = blockIdx.y;
+    const int k0 = s * KC;
+    const int kc = min(KC, Kp - k0);  // multiple of 128
+    const int K32 = Kp >> 5;
+    const int N16 = (N + 15) >> 4;
+    {   // stage the activation chunk (fragment-major), zero beyond kc
+        const int cpr = KC >> 3;
+        const int total = MF * 16 * cpr;
+        for (int c = tid; c < total; c += 512) {
+            const int row = c / cpr, kc8 = c - row * cpr;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (row < M && kc8 * 8 < kc) v = *(const uint4*)(A + (size_t)row * lda + k0 + kc8 * 8);
+            const int kst = kc8 >> 2, gg = kc8 & 3, f = row >> 4, rr = row & 15;
+            *(uint4*)(smem + (((kst * MF + f) * 64) + rr + 16 * gg) * 16) = v;
+        }
+    }
+    __syncthreads();
+    const int nb_begin = blockIdx.x * NBPB;
+    const int kw0 = ks * 256;               // this wave's k-slice inside the chunk
+    const int nsteps = max(0, min(8, (kc - kw0) >> 5));
+    f32x4 acc[NBW][MF];
+#pragma unroll
+    for (int i = 0; i < NBW; ++i)
+#pragma unroll
+        for (int f = 0; f < MF; ++f) acc[i][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    u32x4 buf[2][8];
+    auto load8 = [&](u32x4(&dst)[8], int i) {
+        int nb = nb_begin + ng + NG * i;
+        nb = nb < N16 ? nb : N16 - 1;
+        const u32x4* src = (const u32x4*)(Wp + ((size_t)nb * K32 + ((k0 + kw0) >> 5)) * 512) + lane;
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (u < nsteps) dst[u] = __builtin_nontemporal_load(src + u * 64);
+    };
+    auto comp8 = [&](u32x4(&src)[8], f32x4(&a)[MF]) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (u < nsteps) {
+                const bf16x8 wf = __builtin_bit_cast(bf16x8, src[u]);
+                const int kst = (kw0 >> 5) + u;
+#pragma unroll
+                for (int f = 0; f < MF; ++f) {
+                    const bf16x8 xf = as_bf16x8(*(const uint4*)(smem + ((kst * MF + f) * 64 + lane) * 16));
+                    a[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf, a[f], 0, 0, 0);
+                }
+            }
+        }
+    };
+    load8(buf[0], 0);
+#pragma unroll
+    for (int i = 0; i < NBW; ++i) {
+        if (i + 1 < NBW) load8(buf[(i + 1) & 1], i + 1);
+        comp8(buf[i & 1], acc[i]);
+    }
+    // ---- sum the KS k-slices through LDS (the X chunk is dead now) ----
+    __syncthreads();
+    float* red = (float*)smem;  // [w][i][f][4][64]
+#pragma unroll
+    for (int i = 0; i < NBW; ++i)
+#pragma unroll
+        for (int f = 0; f < MF; ++f)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) red[(((w * NBW + i) * MF + f) * 4 + e) * 64 + lane] = acc[i][f][e];
+    __syncthreads();
+    const int r = lane & 15, g = lane >> 4;
+    constexpr int NFRAG = NG * NBW * MF;
+    for (int j = w; j < NFRAG; j += 8) {
+        const int f = j % MF, i = (j / MF) % NBW, gsel = j / (MF * NBW);
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) {
+            const int ww = gsel * KS + kk;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += red[(((ww * NBW + i) * MF + f) * 4 + e) * 64 + lane];
+        }
+        const int nb = nb_begin + gsel + NG * i;
+        const int m = f * 16 + r, n = nb * 16 + 4 * g;
+        if (nb < N16 && m < M && n < N) {
+            float* o = partial + ((size_t)s * M + m) * N + n;
+            if (n + 3 < N && ((((uintptr_t)o) & 15) == 0)) {
+                *(float4*)o = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+                for (int e = 0; e < 4; ++e)
+                    if (n + e < N) o[e] = v[e];
+            }
+        }
+    }
+}
+
 // out = epi(sum_s partial[s]) ; one thread per 4 output columns
 __global__ __launch_bounds__(256) void splitk_reduce(const float* __restrict__ partial, int S, void* C, int ldc, int M,
                                                      int N, EpiDev epi) {
@@ -547,6 +650,27 @@ static SkinnyPlan plan_skinny(int M, int N, int Kp) {
     return p;
 }
 
+struct Skinny2Plan {
+    int MF, KS, NBW, gx, S;
+    size_t lds, ws_bytes;
+};
+static Skinny2Plan plan_skinny2(int M, int N, int Kp) {
+    Skinny2Plan p;
+    p.MF = (M + 15) / 16;
+    p.KS = p.MF <= 2 ? 4 : 2;
+    const int KC = 256 * p.KS, NG = 8 / p.KS;
+    p.S = (Kp + KC - 1) / KC;
+    const int N16 = (N + 15) / 16;
+    p.NBW = p.MF <= 2 ? 4 : 2;  // the LDS reduction buffer (8 * NBW * MF KiB) must stay within 64 KiB
+    while (p.NBW > 1 && (long long)((N16 + NG * p.NBW - 1) / (NG * p.NBW)) * p.S < 256) p.NBW >>= 1;
+    if (p.NBW == 1) p.NBW = 2;  // keep >= 2 n-blocks per wave so the activation chunk is amortised
+    p.gx = (N16 + NG * p.NBW - 1) / (NG * p.NBW);
+    const size_t x = (size_t)p.MF * 16 * KC * 2, red = (size_t)8 * p.NBW * p.MF * 4 * 64 * 4;
+    p.lds = x > red ? x : red;
+    p.ws_bytes = (size_t)p.S * M * N * sizeof(float);
+    return p;
+}
+
 size_t gemm_workspace_bytes(int M, int N, int K) {
     const int Kp = (K + 127) / 128 * 128;
     if (M > 64) {
@@ -554,7 +678,8 @@ size_t gemm_workspace_bytes(int M, int N, int K) {
         const long long blocks64 = (long long)((M + 63) / 64) * ((N + 63) / 64);
         return blocks64 < 192 ? (size_t)8 * M * N * sizeof(float) : 0;
     }
-    return plan_skinny(M, N, Kp).ws_bytes;
+    const size_t a = plan_skinny(M, N, Kp).ws_bytes, b = plan_skinny2(M, N, Kp).ws_bytes;
+    return a > b ? a : b;
 }
 
 hipError_t launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* Wp, void* C, int ldc, int M, int N, int K,
@@ -563,7 +688,38 @@ hipError_t launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* Wp, void* C,
     const int Kp = (K + 127) / 128 * 128;
     EpiDev epi = make_epi(epi_in);
     if (variant == 0) variant = (M <= 64 && ws != nullptr) ? 3 : 1;
-    if (variant == 3) {
+    if (variant == 3) {  // second-generation weight streaming (in-block k-slices)
+        if (M > 64) return hipErrorInvalidValue;
+        Skinny2Plan p = plan_skinny2(M, N, Kp);
+        if (ws == nullptr || ws_bytes < p.ws_bytes) return hipErrorInvalidValue;
+        dim3 grid(p.gx, p.S), block(512);
+        const int pid = prof_enabled() ? prof_open(st, 0, 2.0 * (double)N * (double)K) : -1;
+#define SK2(MF_, KS_, NBW_) hipLaunchKernelGGL((gemm_skinny2<MF_, KS_, NBW_>), grid, block, p.lds, st, A, lda, Wp, ws, M, N, Kp)
+        if (p.MF == 1) { if (p.NBW == 4) SK2(1, 4, 4); else SK2(1, 4, 2); }
+        else if (p.MF == 2) { if (p.NBW == 4) SK2(2, 4, 4); else SK2(2, 4, 2); }
+        else if (p.MF == 3) { if (p.NBW == 4) SK2(3, 2, 4); else SK2(3, 2, 2); }
+        else { if (p.NBW == 4) SK2(4, 2, 4); else SK2(4, 2, 2); }
+#undef SK2
+        prof_close(st, pid);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        const bool want_norm = epi.norm_w != nullptr && epi.norm_out != nullptr;
+        if (want_norm && !epi.glu && !epi.out_f32 && (N % 8) == 0 && N <= 8192 && (ldc % 8) == 0 && (epi.ld_norm_out % 8) == 0) {
+            hipLaunchKernelGGL(splitk_reduce_norm, dim3(M), dim3(256), 0, st, (const float*)ws, p.S, (bf16_t*)C, ldc, M, N, epi);
+            return hipGetLastError();
+        }
+        const int Nout = epi.glu ? N / 2 : N;
+        const long long total = (long long)M * ((Nout + 3) / 4);
+        int rb = (int)((total + 255) / 256);
+        if (rb > 2048) rb = 2048;
+        hipLaunchKernelGGL(splitk_reduce, dim3(rb), dim3(256), 0, st, (const float*)ws, p.S, C, ldc, M, N, epi);
+        e = hipGetLastError();
+        if (e == hipSuccess && want_norm)
+            e = launch_rmsnorm(C, 0, ldc, epi.norm_w, epi.norm_w_offset, epi.norm_style, epi.norm_out, epi.ld_norm_out, M,
+                               epi.glu ? N / 2 : N, epi.norm_eps, st);
+        return e;
+    }
+    if (variant == 5) {  // first-generation weight streaming (grid-level split-K only), kept for A/B measurements
         if (M > 64) return hipErrorInvalidValue;
         SkinnyPlan p = plan_skinny(M, N, Kp);
         if (ws == nullptr || ws_bytes < p.ws_bytes) return hipErrorInvalidValue;

@@ -56,18 +56,19 @@ def test_gemm_transpose_detecting(dev):
         assert torch.equal(out.float().cpu(), w.float().T)
 
 
+@pytest.mark.parametrize("variant", [3, 5])
 @pytest.mark.parametrize("M", [1, 5, 16, 32, 40, 64])
-@pytest.mark.parametrize("N,K", [(512, 1024), (4096, 512), (264, 128), (1376, 2176)])
-def test_gemm_skinny(dev, M, N, K):
+@pytest.mark.parametrize("N,K", [(512, 1024), (4096, 512), (264, 128), (1376, 2176), (1024, 4096)])
+def test_gemm_skinny(dev, variant, M, N, K):
     g = torch.Generator().manual_seed(M * 131 + N + K)
     a = bf(torch.randn(M, K, generator=g))
     w = bf(torch.randn(N, K, generator=g) * 0.05)
     bias = torch.randn(N, generator=g)
     lin = ops.pack_linear(w.to(dev), bias.to(dev))
-    out = ops.gemm(a.to(dev), lin, variant=3)
+    out = ops.gemm(a.to(dev), lin, variant=variant)
     ref = a.float() @ w.float().T + bias
     assert rel_l2(out, ref) < 6e-3
-    out32 = ops.gemm(a.to(dev), lin, variant=3, out_f32=True)
+    out32 = ops.gemm(a.to(dev), lin, variant=variant, out_f32=True)
     assert torch.allclose(out32.cpu(), bf(ref).float(), atol=0.05, rtol=2e-2)
 
 

@@ -24,14 +24,14 @@ def main():
     dev = torch.device("cuda:0")
     out = []
     shapes = [(4096, 12288), (4096, 4096), (4096, 22016), (11008, 4096), (4096, 32064)]
-    for M in (441, 2240):
+    for M in (441,):
         for K, N in shapes[:4]:
             glu = N == 22016
             w = (torch.randn(N, K, device=dev) * 0.02).bfloat16()
             lin = ops.pack_linear(w, glu=glu)
             a = torch.randn(M, K, device=dev).bfloat16()
             o = torch.empty(M, lin.n_out, dtype=torch.bfloat16, device=dev)
-            for variant in (1, 2):
+            for variant in (1,):
                 ms = timeit(lambda: ops.gemm(a, lin, act="silu" if glu else "none", out=o, variant=variant))
                 out.append({"kernel": "tiled", "variant": variant, "M": M, "N": N, "K": K, "ms": ms,
                             "TFLOPs": 2.0 * M * N * K / ms / 1e9})
@@ -45,9 +45,10 @@ def main():
             a = torch.randn(M, K, device=dev).bfloat16()
             o = torch.empty(M, lin.n_out, dtype=torch.bfloat16, device=dev)
             ws = ops.gemm_workspace(M, N, K, dev)
-            ms = timeit(lambda: ops.gemm(a, lin, act="silu" if glu else "none", out=o, variant=3, ws=ws))
-            out.append({"kernel": "skinny+reduce", "M": M, "N": N, "K": K, "ms": ms, "GBps": 2.0 * N * K / ms / 1e6})
-            print(out[-1], flush=True)
+            for variant in (3, 5):
+                ms = timeit(lambda: ops.gemm(a, lin, act="silu" if glu else "none", out=o, variant=variant, ws=ws))
+                out.append({"kernel": "skinny+reduce", "variant": variant, "M": M, "N": N, "K": K, "ms": ms, "GBps": 2.0 * N * K / ms / 1e6})
+                print(out[-1], flush=True)
             del w, lin
     os.makedirs("gpurun_out", exist_ok=True)
     json.dump(out, open("gpurun_out/bench_kernels.json", "w"), indent=1)
