@@ -14,6 +14,7 @@
 //                LDS in fragment-major form, every wave streams whole 1 KiB weight blocks straight into VGPRs
 //                (no LDS round trip for the streamed operand), split-K over grid.y with fp32 partials that a
 //                small reduce kernel folds together with the epilogue.
+#include <stdlib.h>
 #include "common.h"
 #include "kernels.h"
 
@@ -753,12 +754,18 @@ hipError_t launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* Wp, void* C,
     // ---- tile / split-K selection: fill >= ~1 block per CU when the problem allows it
     struct Cand { int wm, wn; };
     const Cand cands[3] = {{4, 4}, {2, 4}, {2, 2}};
+    // Measured on MI355X (tools/bench_kernels.py, M = 441): this single-barrier-per-k-tile structure is latency-bound per
+    // block, so residency beats tile size until the tile grid oversubscribes the chip several times over, while 64x64
+    // tiles on a wide N become L2-traffic-bound (the activation panel is re-read N/64 times).
+    auto nblocks = [&](int c) {
+        const int bm_ = cands[c].wm * 32, bn_ = cands[c].wn * 32;
+        return (long long)((M + bm_ - 1) / bm_) * ((N + bn_ - 1) / bn_);
+    };
     int pick = 0;
-    for (int c = 0; c < 3; ++c) {
-        const int bm = cands[c].wm * 32, bn = cands[c].wn * 32;
-        const long long blocks = (long long)((M + bm - 1) / bm) * ((N + bn - 1) / bn);
-        pick = c;
-        if (blocks >= 224) break;
+    if (nblocks(0) < 1024) pick = (nblocks(1) >= 384) ? 1 : 2;
+    {
+        static const char* force = getenv("COVER_TILE_PICK");  // experiment knob: 0 = 128x128, 1 = 64x128, 2 = 64x64
+        if (force && force[0] >= '0' && force[0] <= '2') pick = force[0] - '0';
     }
     const int bm = cands[pick].wm * 32, bn = cands[pick].wn * 32;
     const int tiles_m = (M + bm - 1) / bm, tiles_n = (N + bn - 1) / bn;
