@@ -83,3 +83,23 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
+
+// Same copy issued from inline asm: hipcc does not see a VMEM operation, so it neither counts it nor drains it with an
+// automatic `s_waitcnt vmcnt(0)` in front of the next ds_read (it cannot prove the LDS-DMA destination does not alias
+// the read). The caller owns the waits: counted `s_waitcnt vmcnt(N)` + s_barrier before the data is read.
+// lds_wave_base_u32 = wave-uniform LDS byte address (readfirstlane'd). M0 is saved/restored inside the statement.
+__device__ __forceinline__ void glds16_asm(const void* gsrc, uint32_t lds_wave_base_u32) {
+    uint32_t keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(gsrc), "s"(lds_wave_base_u32)
+        : "memory");
+}
+__device__ __forceinline__ uint32_t lds_addr_u32(const void* p) {
+    return (uint32_t)(uintptr_t)((const __attribute__((address_space(3))) char*)p);
+}

@@ -135,9 +135,10 @@ __global__ __launch_bounds__(256) void gemm_tiled(const bf16_t* __restrict__ A, 
     constexpr int BM_ = 2 * WM * 16, BN_ = 2 * WN * 16;
     constexpr int A_BYTES = BM_ * BK * 2, B_BYTES = BN_ * BK * 2;
     constexpr int AI = BM_ / 32, BI = BN_ / 32;  // 1-KiB staging instructions per wave per tile
+    constexpr int NST = GLDS ? 3 : 2;            // LDS stages: async staging keeps one extra k-tile in flight
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* As = smem;                 // [2][A_BYTES]
-    char* Bs = smem + 2 * A_BYTES;   // [2][B_BYTES]
+    char* As = smem;                   // [NST][A_BYTES]
+    char* Bs = smem + NST * A_BYTES;   // [NST][B_BYTES]
 
     // XCD-aware bijective remap of the linear block id: blocks dispatched round-robin over the 8 XCDs get a
     // contiguous range of tiles each, so the m-tiles that share one weight tile hit the same L2.
@@ -188,11 +189,13 @@ __global__ __launch_bounds__(256) void gemm_tiled(const bf16_t* __restrict__ A, 
         for (int f = 0; f < WM; ++f) acc[b][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     uint4 ra[AI], rb[BI];
+    const uint32_t as_u32 = __builtin_amdgcn_readfirstlane(lds_addr_u32(As) + w * AI * 1024);
+    const uint32_t bs_u32 = __builtin_amdgcn_readfirstlane(lds_addr_u32(Bs) + w * BI * 1024);
     auto stage_glds = [&](int buf, int kt) {
 #pragma unroll
-        for (int i = 0; i < AI; ++i) glds16(a_src[i] + kt * BK, As + buf * A_BYTES + (w * AI + i) * 1024);
+        for (int i = 0; i < AI; ++i) glds16_asm(a_src[i] + kt * BK, as_u32 + buf * A_BYTES + i * 1024);
 #pragma unroll
-        for (int i = 0; i < BI; ++i) glds16(b_src[i] + (size_t)kt * 2 * 512, Bs + buf * B_BYTES + (w * BI + i) * 1024);
+        for (int i = 0; i < BI; ++i) glds16_asm(b_src[i] + (size_t)kt * 2 * 512, bs_u32 + buf * B_BYTES + i * 1024);
     };
     auto stage_load = [&](int kt) {
 #pragma unroll
@@ -231,12 +234,19 @@ __global__ __launch_bounds__(256) void gemm_tiled(const bf16_t* __restrict__ A, 
     };
 
     if (GLDS) {
+        // 3-stage ring, two k-tiles in flight: tile kt is waited for with a COUNTED vmcnt (the AI+BI loads of tile kt+1
+        // stay outstanding across the barrier), a raw s_barrier publishes it, then tile kt+2 is issued into the stage
+        // that compute(kt-1) has just released. __syncthreads() would drain vmcnt to 0 here.
         stage_glds(0, 0);
+        if (nk > 1) stage_glds(1, 1);
+        int cur = 0;
         for (int kt = 0; kt < nk; ++kt) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (kt + 1 < nk) stage_glds((kt + 1) & 1, kt + 1);
-            compute(kt & 1);
+            if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AI + BI) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (kt + 2 < nk) stage_glds(cur >= 1 ? cur - 1 : 2, kt + 2);  // stage (kt+2) % 3 == (kt-1) % 3
+            compute(cur);
+            cur = cur == 2 ? 0 : cur + 1;
         }
     } else {
         stage_load(0);
@@ -779,7 +789,14 @@ hipError_t launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* Wp, void* C,
     const int kt_per = (nk_total + S - 1) / S;
     S = (nk_total + kt_per - 1) / kt_per;
     float* partial = S > 1 ? ws : nullptr;
-    const size_t lds = (size_t)2 * (bm + bn) * BK * 2;
+    const size_t lds = (size_t)(variant == 2 ? 2 : 3) * (bm + bn) * BK * 2;
+    if (lds > 65536) {  // 128x128 tile with 3 stages = 96 KiB of dynamic LDS: raise the per-kernel limit once
+        static bool raised = false;
+        if (!raised) {
+            (void)hipFuncSetAttribute((const void*)gemm_tiled<4, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 98304);
+            raised = true;
+        }
+    }
     dim3 grid(tiles_m * tiles_n, S), block(256);
     const int pid = prof_enabled() ? prof_open(st, 1, 2.0 * (double)M * (double)N * (double)K) : -1;
 #define LAUNCH_TILED(WM_, WN_)                                                                                              \
