@@ -127,7 +127,7 @@ __device__ __forceinline__ void epi_store4_glu(const EpiDev& e, void* C, int ldc
 // ---------------------------------------------------------------------------------------------------
 #define BK 64
 
-template <int WM, int WN, bool GLDS>
+template <int WM, int WN, bool GLDS, int NST_ = 2>
 __global__ __launch_bounds__(256) void gemm_tiled(const bf16_t* __restrict__ A, int lda,
                                                   const bf16_t* __restrict__ Wp, void* C, int ldc, int M, int N,
                                                   int Kp, EpiDev epi, int tiles_m, int tiles_n, int kt_per,
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256) void gemm_tiled(const bf16_t* __restrict__ A, 
     constexpr int BM_ = 2 * WM * 16, BN_ = 2 * WN * 16;
     constexpr int A_BYTES = BM_ * BK * 2, B_BYTES = BN_ * BK * 2;
     constexpr int AI = BM_ / 32, BI = BN_ / 32;  // 1-KiB staging instructions per wave per tile
-    constexpr int NST = GLDS ? 3 : 2;            // LDS stages: async staging keeps one extra k-tile in flight
+    constexpr int NST = GLDS ? NST_ : 2;         // LDS stages (3: one extra k-tile stays in flight across the barrier)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* As = smem;                   // [NST][A_BYTES]
     char* Bs = smem + NST * A_BYTES;   // [NST][B_BYTES]
@@ -237,16 +237,26 @@ __global__ __launch_bounds__(256) void gemm_tiled(const bf16_t* __restrict__ A, 
         // 3-stage ring, two k-tiles in flight: tile kt is waited for with a COUNTED vmcnt (the AI+BI loads of tile kt+1
         // stay outstanding across the barrier), a raw s_barrier publishes it, then tile kt+2 is issued into the stage
         // that compute(kt-1) has just released. __syncthreads() would drain vmcnt to 0 here.
-        stage_glds(0, 0);
-        if (nk > 1) stage_glds(1, 1);
-        int cur = 0;
-        for (int kt = 0; kt < nk; ++kt) {
-            if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AI + BI) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            if (kt + 2 < nk) stage_glds(cur >= 1 ? cur - 1 : 2, kt + 2);  // stage (kt+2) % 3 == (kt-1) % 3
-            compute(cur);
-            cur = cur == 2 ? 0 : cur + 1;
+        if (NST == 3) {
+            stage_glds(0, 0);
+            if (nk > 1) stage_glds(1, 1);
+            int cur = 0;
+            for (int kt = 0; kt < nk; ++kt) {
+                if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AI + BI) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                if (kt + 2 < nk) stage_glds(cur >= 1 ? cur - 1 : 2, kt + 2);  // stage (kt+2) % 3 == (kt-1) % 3
+                compute(cur);
+                cur = cur == 2 ? 0 : cur + 1;
+            }
+        } else {  // 2 stages: smaller LDS footprint -> one more resident block per CU (better when L2->LDS bandwidth-bound)
+            stage_glds(0, 0);
+            for (int kt = 0; kt < nk; ++kt) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                if (kt + 1 < nk) stage_glds((kt + 1) & 1, kt + 1);
+                compute(kt & 1);
+            }
         }
     } else {
         stage_load(0);
@@ -789,14 +799,11 @@ hipError_t launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* Wp, void* C,
     const int kt_per = (nk_total + S - 1) / S;
     S = (nk_total + kt_per - 1) / kt_per;
     float* partial = S > 1 ? ws : nullptr;
-    const size_t lds = (size_t)(variant == 2 ? 2 : 3) * (bm + bn) * BK * 2;
-    if (lds > 65536) {  // 128x128 tile with 3 stages = 96 KiB of dynamic LDS: raise the per-kernel limit once
-        static bool raised = false;
-        if (!raised) {
-            (void)hipFuncSetAttribute((const void*)gemm_tiled<4, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 98304);
-            raised = true;
-        }
-    }
+    // stages: measured at M = 441 (tools/bench_kernels.py): the 64x64 tile gains 40-55 % from a third stage (48 KiB, still
+    // 3 blocks/CU); 64x128 and 128x128 are L2->LDS bandwidth-bound (~12.8 TB/s => 42.7 / 64 FLOP per byte) and lose more
+    // from the residency a third stage costs than they gain from it.
+    const int nst = (variant != 2 && pick == 2) ? 3 : 2;
+    const size_t lds = (size_t)nst * (bm + bn) * BK * 2;
     dim3 grid(tiles_m * tiles_n, S), block(256);
     const int pid = prof_enabled() ? prof_open(st, 1, 2.0 * (double)M * (double)N * (double)K) : -1;
 #define LAUNCH_TILED(WM_, WN_)                                                                                              \
@@ -804,8 +811,11 @@ hipError_t launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* Wp, void* C,
         if (variant == 2)                                                                                                   \
             hipLaunchKernelGGL((gemm_tiled<WM_, WN_, false>), grid, block, lds, st, A, lda, Wp, C, ldc, M, N, Kp, epi, tiles_m, \
                                tiles_n, kt_per, partial);                                                                   \
+        else if (nst == 3)                                                                                                  \
+            hipLaunchKernelGGL((gemm_tiled<WM_, WN_, true, 3>), grid, block, lds, st, A, lda, Wp, C, ldc, M, N, Kp, epi, tiles_m, \
+                               tiles_n, kt_per, partial);                                                                   \
         else                                                                                                                \
-            hipLaunchKernelGGL((gemm_tiled<WM_, WN_, true>), grid, block, lds, st, A, lda, Wp, C, ldc, M, N, Kp, epi, tiles_m,  \
+            hipLaunchKernelGGL((gemm_tiled<WM_, WN_, true, 2>), grid, block, lds, st, A, lda, Wp, C, ldc, M, N, Kp, epi, tiles_m, \
                                tiles_n, kt_per, partial);                                                                   \
     } while (0)
     if (pick == 0) LAUNCH_TILED(4, 4);
