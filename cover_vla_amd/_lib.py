@@ -58,7 +58,8 @@ class RopeArgs(C.Structure):
                 ("rope_mode", c_i),
                 ("k_cache", c_p), ("k_slot_stride", c_ll), ("k_t_stride", c_ll), ("k_h_stride", c_ll),
                 ("vt_cache", c_p), ("vt_slot_stride", c_ll), ("vt_h_stride", c_ll), ("vt_d_stride", c_ll),
-                ("slot_of_batch", c_p), ("t_offset_of_batch", c_p), ("t_offset", c_i), ("_pad", c_i)]
+                ("slot_of_batch", c_p), ("t_offset_of_batch", c_p), ("t_offset", c_i), ("n_splits", c_i),
+                ("partial", c_p), ("bias", c_p)]
 
 
 class PatchifyArgs(C.Structure):

@@ -42,7 +42,7 @@ struct AttnDev {
 };
 
 template <int D, bool KSPLIT>
-__global__ __launch_bounds__(256) void attn_kernel(AttnDev a) {
+__global__ __launch_bounds__(512) void attn_kernel(AttnDev a) {
     constexpr int KS = D / 32;  // k-steps of QK^T
     constexpr int DB = D / 16;  // 16-row d blocks of O^T
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -182,8 +182,8 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnDev a) {
         // merge the nw partial states: LDS layout per wave: [DB*4 floats per lane][64 lanes] + m[16] + l[16]
         float* so = (float*)smem;
         constexpr int OW = DB * 4 * 64;
-        float* sm = so + 4 * OW;
-        float* sl = sm + 4 * 16;
+        float* sm = so + nw * OW;
+        float* sl = sm + nw * 16;
 #pragma unroll
         for (int db = 0; db < DB; ++db)
 #pragma unroll
@@ -197,8 +197,12 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnDev a) {
         float mx = -INFINITY;
         for (int i = 0; i < nw; ++i) mx = fmaxf(mx, sm[i * 16 + r]);
         float lt = 0.f;
-        float f[4];
-        for (int i = 0; i < nw; ++i) {
+        float f[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) f[i] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (i >= nw) break;
             const float mi = sm[i * 16 + r];
             f[i] = (mi == -INFINITY) ? 0.f : exp2f(mi - mx);
             lt += sl[i * 16 + r] * f[i];
@@ -208,7 +212,9 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnDev a) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 float acc = 0.f;
-                for (int i = 0; i < nw; ++i) acc += so[i * OW + (db * 4 + e) * 64 + lane] * f[i];
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    if (i < nw) acc += so[i * OW + (db * 4 + e) * 64 + lane] * f[i];
                 oacc[db][e] = acc;
             }
         l_run = lt;
@@ -241,10 +247,13 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnDev a) {
 template <int D>
 static hipError_t launch_d(const AttnDev& a, hipStream_t st) {
     const int tiles = (a.R + 15) / 16;
-    if ((long long)tiles * a.Hkv * a.B < 1024) {
-        // too few query tiles to fill the chip (single-token decode, ViT-sized sequences): split keys over 4 waves
-        const size_t lds = (size_t)(4 * (D / 16) * 4 * 64 + 2 * 4 * 16) * sizeof(float);
-        dim3 grid(tiles, a.Hkv, a.B), block(256);
+    const long long qtiles = (long long)tiles * a.Hkv * a.B;
+    if (qtiles <= 1024) {
+        // too few query tiles to fill the chip (single-token decode, ViT-sized sequences): split the key tiles over the
+        // 4 (or, when even 4 waves per tile leave most CUs idle and D allows the LDS merge buffer, 8) waves of a block
+        const int nw = (qtiles <= 128 && D <= 128) ? 8 : 4;
+        const size_t lds = (size_t)(nw * (D / 16) * 4 * 64 + 2 * nw * 16) * sizeof(float);
+        dim3 grid(tiles, a.Hkv, a.B), block(64 * nw);
         hipLaunchKernelGGL((attn_kernel<D, true>), grid, block, lds, st, a);
     } else {
         const int nw = tiles >= 4 ? 4 : tiles;

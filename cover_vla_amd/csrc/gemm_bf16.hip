@@ -548,20 +548,35 @@ __global__ __launch_bounds__(256) void splitk_reduce(const float* __restrict__ p
 // out = epi(sum_s partial[s]) AND norm_out = rmsnorm(out): one 256-thread block per output row (N % 8 == 0, N <= 8192,
 // no GLU, bf16 output). The sum of squares is taken over the bf16-ROUNDED outputs, i.e. exactly what the separate
 // rmsnorm kernel would read back.
-__global__ __launch_bounds__(256) void splitk_reduce_norm(const float* __restrict__ partial, int S, bf16_t* C, int ldc, int M,
+__global__ __launch_bounds__(512) void splitk_reduce_norm(const float* __restrict__ partial, int S, bf16_t* C, int ldc, int M,
                                                           int N, EpiDev epi) {
     __shared__ float red[16];
     const int m = blockIdx.x;
-    float vals[4][8];
+    float vals[2][8];
     float q = 0.f;
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        const int n0 = (threadIdx.x + c * 256) * 8;
+    for (int c = 0; c < 2; ++c) {
+        const int n0 = (threadIdx.x + c * 512) * 8;
         if (n0 < N) {
             float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            for (int s = 0; s < S; ++s) {
-                const float* p = partial + ((size_t)s * M + m) * N + n0;
-                const float4 a = *(const float4*)p, b = *(const float4*)(p + 4);
+            const float* p0 = partial + (size_t)m * N + n0;
+            const size_t sstride = (size_t)M * N;
+            int s = 0;
+            for (; s + 4 <= S; s += 4) {  // four slices in flight
+                float4 a[4], b[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    a[j] = *(const float4*)(p0 + (s + j) * sstride);
+                    b[j] = *(const float4*)(p0 + (s + j) * sstride + 4);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    v[0] += a[j].x; v[1] += a[j].y; v[2] += a[j].z; v[3] += a[j].w;
+                    v[4] += b[j].x; v[5] += b[j].y; v[6] += b[j].z; v[7] += b[j].w;
+                }
+            }
+            for (; s < S; ++s) {
+                const float4 a = *(const float4*)(p0 + s * sstride), b = *(const float4*)(p0 + s * sstride + 4);
                 v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w; v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
             }
             epi_value4(epi, m, n0, N, v);
@@ -578,8 +593,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_norm(const float* __restric
     }
     const float rstd = rsqrtf(block_sum(q, red) / N + epi.norm_eps);
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        const int n0 = (threadIdx.x + c * 256) * 8;
+    for (int c = 0; c < 2; ++c) {
+        const int n0 = (threadIdx.x + c * 512) * 8;
         if (n0 < N) {
             float o[8];
 #pragma unroll
@@ -726,7 +741,7 @@ hipError_t launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* Wp, void* C,
         if (e != hipSuccess) return e;
         const bool want_norm = epi.norm_w != nullptr && epi.norm_out != nullptr;
         if (want_norm && !epi.glu && !epi.out_f32 && (N % 8) == 0 && N <= 8192 && (ldc % 8) == 0 && (epi.ld_norm_out % 8) == 0) {
-            hipLaunchKernelGGL(splitk_reduce_norm, dim3(M), dim3(256), 0, st, (const float*)ws, p.S, (bf16_t*)C, ldc, M, N, epi);
+            hipLaunchKernelGGL(splitk_reduce_norm, dim3(M), dim3(512), 0, st, (const float*)ws, p.S, (bf16_t*)C, ldc, M, N, epi);
             return hipGetLastError();
         }
         const int Nout = epi.glu ? N / 2 : N;
@@ -757,7 +772,7 @@ hipError_t launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* Wp, void* C,
         if (e != hipSuccess) return e;
         const bool want_norm = epi.norm_w != nullptr && epi.norm_out != nullptr;
         if (want_norm && !epi.glu && !epi.out_f32 && (N % 8) == 0 && N <= 8192 && (ldc % 8) == 0 && (epi.ld_norm_out % 8) == 0) {
-            hipLaunchKernelGGL(splitk_reduce_norm, dim3(M), dim3(256), 0, st, (const float*)ws, p.S, (bf16_t*)C, ldc, M, N, epi);
+            hipLaunchKernelGGL(splitk_reduce_norm, dim3(M), dim3(512), 0, st, (const float*)ws, p.S, (bf16_t*)C, ldc, M, N, epi);
             return hipGetLastError();
         }
         const int Nout = epi.glu ? N / 2 : N;
@@ -836,6 +851,27 @@ hipError_t launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* Wp, void* C,
         e = launch_rmsnorm(C, 0, ldc, epi.norm_w, epi.norm_w_offset, epi.norm_style, epi.norm_out, epi.ld_norm_out, M,
                            epi.glu ? N / 2 : N, epi.norm_eps, st);
     return e;
+}
+
+// Weight-streaming GEMM WITHOUT its reduction: leaves fp32 partials [S][M][N] in ws for a consumer that folds them
+// (the decoder fuses the QKV reduction into rope_kv_write). Returns the number of K slices through *S_out.
+hipError_t launch_gemm_skinny_partial(const bf16_t* A, int lda, const bf16_t* Wp, float* ws, size_t ws_bytes, int M, int N,
+                                      int K, int* S_out, hipStream_t st) {
+    if (M <= 0 || M > 64 || N <= 0) return hipErrorInvalidValue;
+    const int Kp = (K + 127) / 128 * 128;
+    Skinny2Plan p = plan_skinny2(M, N, Kp);
+    if (ws == nullptr || ws_bytes < p.ws_bytes) return hipErrorInvalidValue;
+    dim3 grid(p.gx, p.S), block(512);
+    const int pid = prof_enabled() ? prof_open(st, 0, 2.0 * (double)N * (double)K) : -1;
+#define SK2(MF_, KS_, NBW_) hipLaunchKernelGGL((gemm_skinny2<MF_, KS_, NBW_>), grid, block, p.lds, st, A, lda, Wp, ws, M, N, Kp)
+    if (p.MF == 1) { if (p.NBW == 4) SK2(1, 4, 4); else SK2(1, 4, 2); }
+    else if (p.MF == 2) { if (p.NBW == 4) SK2(2, 4, 4); else SK2(2, 4, 2); }
+    else if (p.MF == 3) { if (p.NBW == 4) SK2(3, 2, 4); else SK2(3, 2, 2); }
+    else { if (p.NBW == 4) SK2(4, 2, 4); else SK2(4, 2, 2); }
+#undef SK2
+    prof_close(st, pid);
+    *S_out = p.S;
+    return hipGetLastError();
 }
 
 hipError_t launch_pack_weight_bf16(const bf16_t* W, int ldw, int N, int K, bf16_t* Wp, int Kpad, int glu,

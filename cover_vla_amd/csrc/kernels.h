@@ -12,6 +12,8 @@ typedef uint16_t bf16_t;
 hipError_t launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* Wp, void* C, int ldc, int M, int N, int K,
                             const cover_gemm_epi* epi, float* splitk_ws, size_t splitk_ws_bytes, int variant,
                             hipStream_t st);
+hipError_t launch_gemm_skinny_partial(const bf16_t* A, int lda, const bf16_t* Wp, float* ws, size_t ws_bytes, int M, int N,
+                                      int K, int* S_out, hipStream_t st);
 hipError_t launch_pack_weight_bf16(const bf16_t* W, int ldw, int N, int K, bf16_t* Wp, int Kpad, int glu_interleave,
                                    hipStream_t st);
 

@@ -146,11 +146,23 @@ __global__ __launch_bounds__(256) void rope_kv_write_k(cover_rope_args a) {
     const int half = a.D >> 1;
     const int slot = a.slot_of_batch ? a.slot_of_batch[b] : b;
     const int tt = a.t_offset + (a.t_offset_of_batch ? a.t_offset_of_batch[b] : 0) + t;
+    // element d of this (row, head): either the stored bf16 projection or, on the weight-streaming path, the split-K
+    // partial sums folded here (bf16-rounded like the projection output would have been)
+    const int ncols = nh * a.D;
+    const size_t pbase = (size_t)row * ncols + (size_t)hh * a.D;
+    const size_t pstride = (size_t)rows * ncols;
+    auto ld = [&](int d) -> float {
+        if (a.n_splits <= 0) return bf2f(src[d]);
+        float v = 0.f;
+        for (int s = 0; s < a.n_splits; ++s) v += a.partial[s * pstride + pbase + d];
+        if (a.bias) v += a.bias[hh * a.D + d];
+        return bfround(v);
+    };
 
     if (hh >= a.Hq + a.Hkv) {  // V head -> transposed cache
         const int h = hh - a.Hq - a.Hkv;
         bf16_t* dst = (bf16_t*)a.vt_cache + (size_t)slot * a.vt_slot_stride + (size_t)h * a.vt_h_stride + tt;
-        for (int d = lane; d < a.D; d += 64) dst[(size_t)d * a.vt_d_stride] = src[d];
+        for (int d = lane; d < a.D; d += 64) dst[(size_t)d * a.vt_d_stride] = f2bf(ld(d));
         return;
     }
     const bool is_k = hh >= a.Hq;
@@ -159,8 +171,8 @@ __global__ __launch_bounds__(256) void rope_kv_write_k(cover_rope_args a) {
         dst = (bf16_t*)a.k_cache + (size_t)slot * a.k_slot_stride + (size_t)tt * a.k_t_stride +
               (size_t)(hh - a.Hq) * a.k_h_stride;
     if (a.rope_mode == 0) {
-        if (dst != src)
-            for (int d = lane; d < a.D; d += 64) dst[d] = src[d];
+        if (dst != src || a.n_splits > 0)
+            for (int d = lane; d < a.D; d += 64) dst[d] = f2bf(ld(d));
         return;
     }
     int pos = a.positions ? a.positions[row] : t;
@@ -168,7 +180,7 @@ __global__ __launch_bounds__(256) void rope_kv_write_k(cover_rope_args a) {
     const float* ct = a.cos_table + (size_t)pos * half;
     const float* stb = a.sin_table + (size_t)pos * half;
     for (int i = lane; i < half; i += 64) {
-        const float x1 = bf2f(src[i]), x2 = bf2f(src[i + half]);
+        const float x1 = ld(i), x2 = ld(i + half);
         float c = ct[i], s = stb[i], o1, o2;
         if (a.rope_mode == 2) {  // HF rotate_half in bf16 arithmetic
             c = bfround(c); s = bfround(s);

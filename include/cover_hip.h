@@ -161,7 +161,12 @@ typedef struct cover_rope_args {
     const int* slot_of_batch;    /* [B] or NULL */
     const int* t_offset_of_batch;/* [B] or NULL */
     int t_offset;
-    int _pad;
+    int n_splits;                /* > 0: the q/k/v values are NOT read from qkv but formed on the fly as
+                                    bf16(sum_s partial[s][row][col] + bias[col]) from the split-K partials of the QKV
+                                    GEMM (fuses the reduction into this kernel on the weight-streaming path); q is still
+                                    written to qkv (rotated), k/v go to the caches */
+    const float* partial;        /* fp32 [n_splits][B*T][ld_qkv-compatible N = (Hq+2Hkv)*D] */
+    const float* bias;           /* [N] or NULL */
 } cover_rope_args;
 int cover_rope_kv_write(const cover_rope_args* args, void* stream);
 
