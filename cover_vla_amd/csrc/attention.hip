@@ -17,6 +17,7 @@
 // kv head share K/V loads (pi0: 8 q heads x 1 kv head; decode: 5 suffix tokens x 8 heads = 40 rows = 3 waves).
 // KSPLIT mode (few query rows, e.g. single-token decode): the 4 waves of a block split the key tiles and merge
 // their (m, l, O) partial states through LDS.
+#include <stdlib.h>
 #include "common.h"
 #include "kernels.h"
 
@@ -248,10 +249,13 @@ template <int D>
 static hipError_t launch_d(const AttnDev& a, hipStream_t st) {
     const int tiles = (a.R + 15) / 16;
     const long long qtiles = (long long)tiles * a.Hkv * a.B;
-    if (qtiles <= 1024) {
+    static const char* e_max = getenv("COVER_ATTN_KSPLIT_MAX");
+    static const char* e_nw8 = getenv("COVER_ATTN_NW8_MAX");
+    const long long ks_max = e_max ? atoll(e_max) : 1023, nw8_max = e_nw8 ? atoll(e_nw8) : 0;
+    if (qtiles <= ks_max) {
         // too few query tiles to fill the chip (single-token decode, ViT-sized sequences): split the key tiles over the
         // 4 (or, when even 4 waves per tile leave most CUs idle and D allows the LDS merge buffer, 8) waves of a block
-        const int nw = (qtiles <= 128 && D <= 128) ? 8 : 4;
+        const int nw = (qtiles <= nw8_max && D <= 128) ? 8 : 4;
         const size_t lds = (size_t)(nw * (D / 16) * 4 * 64 + 2 * nw * 16) * sizeof(float);
         dim3 grid(tiles, a.Hkv, a.B), block(64 * nw);
         hipLaunchKernelGGL((attn_kernel<D, true>), grid, block, lds, st, a);

@@ -343,7 +343,7 @@ int cover_decoder_forward(const cover_dec_desc* d, const cover_dec_pass* p, void
         e.bias = L.qkv_b;
         // weight-streaming path: leave the split-K partials for rope_kv_write to fold (one launch and one pass less)
         int qkv_splits = 0;
-        if (rows <= 64 && (variant == 0 || variant == 3))
+        if (rows <= 64 && p->n_groups == 1 && (variant == 0 || variant == 3))
             HIPCHK(launch_gemm_skinny_partial((const bf16_t*)h, dim, (const bf16_t*)L.qkv_w, (float*)sk, skb, rows, nqkv, dim, &qkv_splits, st), "dec qkv (partials)");
         else
             HIPCHK(launch_gemm_bf16((const bf16_t*)h, dim, (const bf16_t*)L.qkv_w, qkv, nqkv, rows, nqkv, dim, &e, (float*)sk, skb, variant, st), "dec qkv");
@@ -363,7 +363,6 @@ int cover_decoder_forward(const cover_dec_desc* d, const cover_dec_pass* p, void
             ra.vt_slot_stride = W.vt_slot_stride; ra.vt_h_stride = W.vt_h_stride; ra.vt_d_stride = W.vt_d_stride;
             ra.slot_of_batch = G.write_slot_of_batch; ra.t_offset_of_batch = G.write_t_offset_of_batch; ra.t_offset = G.write_t_offset;
             if (qkv_splits > 0) {
-                if (p->n_groups != 1) return fail(COVER_EUNSUPPORTED, "cover_decoder_forward: fused qkv reduction needs a single row group");
                 ra.n_splits = qkv_splits; ra.partial = (const float*)sk; ra.bias = L.qkv_b;
             }
             HIPCHK(launch_rope_kv_write(&ra, st), "dec rope/kv");
