@@ -425,18 +425,6 @@ __global__ __launch_bounds__(512) void gemm_skinny2(const bf16_t* __restrict__ A
     const int kc = min(KC, Kp - k0);  // multiple of 128
     const int K32 = Kp >> 5;
     const int N16 = (N + 15) >> 4;
-    {   // stage the activation chunk (fragment-major), zero beyond kc
-        const int cpr = KC >> 3;
-        const int total = MF * 16 * cpr;
-        for (int c = tid; c < total; c += 512) {
-            const int row = c / cpr, kc8 = c - row * cpr;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (row < M && kc8 * 8 < kc) v = *(const uint4*)(A + (size_t)row * lda + k0 + kc8 * 8);
-            const int kst = kc8 >> 2, gg = kc8 & 3, f = row >> 4, rr = row & 15;
-            *(uint4*)(smem + (((kst * MF + f) * 64) + rr + 16 * gg) * 16) = v;
-        }
-    }
-    __syncthreads();
     const int nb_begin = blockIdx.x * NBPB;
     const int kw0 = ks * 256;               // this wave's k-slice inside the chunk
     const int nsteps = max(0, min(8, (kc - kw0) >> 5));
@@ -454,6 +442,20 @@ __global__ __launch_bounds__(512) void gemm_skinny2(const bf16_t* __restrict__ A
         for (int u = 0; u < 8; ++u)
             if (u < nsteps) dst[u] = __builtin_nontemporal_load(src + u * 64);
     };
+    load8(buf[0], 0);  // the first two weight blocks are in flight while the activation chunk is staged
+    if (NBW > 1) load8(buf[1], 1);
+    {   // stage the activation chunk (fragment-major), zero beyond kc
+        const int cpr = KC >> 3;
+        const int total = MF * 16 * cpr;
+        for (int c = tid; c < total; c += 512) {
+            const int row = c / cpr, kc8 = c - row * cpr;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (row < M && kc8 * 8 < kc) v = *(const uint4*)(A + (size_t)row * lda + k0 + kc8 * 8);
+            const int kst = kc8 >> 2, gg = kc8 & 3, f = row >> 4, rr = row & 15;
+            *(uint4*)(smem + (((kst * MF + f) * 64) + rr + 16 * gg) * 16) = v;
+        }
+    }
+    __syncthreads();
     auto comp8 = [&](u32x4(&src)[8], f32x4(&a)[MF]) {
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
@@ -468,11 +470,10 @@ __global__ __launch_bounds__(512) void gemm_skinny2(const bf16_t* __restrict__ A
             }
         }
     };
-    load8(buf[0], 0);
 #pragma unroll
     for (int i = 0; i < NBW; ++i) {
-        if (i + 1 < NBW) load8(buf[(i + 1) & 1], i + 1);
         comp8(buf[i & 1], acc[i]);
+        if (i + 2 < NBW) load8(buf[i & 1], i + 2);  // refill the buffer just consumed: two blocks stay in flight
     }
     // ---- sum the KS k-slices through LDS (the X chunk is dead now) ----
     __syncthreads();

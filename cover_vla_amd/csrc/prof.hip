@@ -55,3 +55,25 @@ extern "C" int cover_profile_end(double* ms, long long* count, double* work) {
     g_used = 0;
     return COVER_OK;
 }
+
+// ---- diagnostic: pure streaming read (HBM ceiling for a given byte count and launch shape), not part of the ABI ----
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+__global__ __launch_bounds__(512) void stream_read_k(const u32x4_t* __restrict__ src, size_t n16, unsigned* sink, int nt) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    u32x4_t acc = {0, 0, 0, 0};
+    // each wave reads 1 KiB per instruction, 8 in flight, grid-strided (consecutive waves read consecutive KiB)
+    for (; i + 7 * stride < n16; i += 8 * stride) {
+        u32x4_t v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = nt ? __builtin_nontemporal_load(src + i + u * stride) : src[i + u * stride];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc ^= v[u];
+    }
+    for (; i < n16; i += stride) acc ^= src[i];
+    if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678u) sink[0] = 1;
+}
+extern "C" int cover_debug_stream_read(const void* src, size_t bytes, int blocks, int nt, void* sink, void* stream) {
+    hipLaunchKernelGGL(stream_read_k, dim3(blocks), dim3(512), 0, (hipStream_t)stream, (const u32x4_t*)src, bytes / 16, (unsigned*)sink, nt);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
