@@ -217,11 +217,17 @@ def main():
                                 "one 224x224 RGB frame; CoVer verifier SigLIP2-L/16-384 + 3-member ensemble; random-init weights"),
                    "candidates_per_gpu": N_PROMPTS * N_SAMPLES, "prompts_per_gpu": N_PROMPTS, "parallelism": f"candidate-sharded x{world}"},
     }
+    traffic = None
+    try:  # HBM bytes per launch from the committed PMC pass (rocprofv3 --pmc FETCH_SIZE, x2 gfx950 correction); see profiles/
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+            traffic = round(json.load(f)["hbm_fetch_bytes_per_launch"])
+    except Exception:
+        pass
     if cnt[0] > 0 and ms[0] > 0:
         ach = work[0] / (ms[0] * 1e-3) / 1e9
         out["roofline"] = {"bound": "hbm", "kernel": "gemm_skinny (weight-streaming GEMM of the decode passes) + splitk_reduce",
                            "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-                           "traffic": None, "launches": int(cnt[0]), "avg_launch_us": round(1e3 * ms[0] / cnt[0], 2),
+                           "traffic": traffic, "algorithmic_bytes_per_launch": round(work[0] / cnt[0]), "launches": int(cnt[0]), "avg_launch_us": round(1e3 * ms[0] / cnt[0], 2),
                            "algorithmic_bytes_per_decision": work[0], "kernel_ms_per_decision": round(ms[0], 3)}
     if cnt[1] > 0 and ms[1] > 0:
         tf = work[1] / (ms[1] * 1e-3) / 1e12
