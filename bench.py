@@ -79,7 +79,7 @@ class Pipeline:
             self.inp["img384"] = torch.randn(1, 3, sc["image"], sc["image"], generator=g).to(dev)
             self.inp["text"] = torch.randint(0, sc["vocab"], (1, sc["context_length"]), generator=g).to(dev)
 
-    def decision(self, world=1):
+    def decision(self, world=1, rank=0, cpu_gather=False):
         i = self.inp
         tokens, _ = self.policy.sample(i["frame"], i["toks"], i["lens"], N_SAMPLES, i["u"], 1.0)
         acts = self.policy.tokens_to_actions(tokens.cpu().numpy())            # [N, 7] host (the reference also goes D2H here)
@@ -89,12 +89,12 @@ class Pipeline:
         pf, tf = self.ver.extract_shared_features(i["img384"], i["text"])
         r = self.ver.score_features(pf, tf, hists, N_SAMPLES)
         if world > 1:
-            import torch.distributed as dist
-            from cover_vla_amd import ops
-            allsc = torch.empty(world * r["scores"].numel(), dtype=torch.float32, device=self.dev)
-            dist.all_gather_into_tensor(allsc, r["scores"])
-            res, best = ops.group_argmax(allsc, N_SAMPLES)
-            return int(res[0]), tokens
+            # ONE collective: all-gather of the per-candidate scores (RCCL over xGMI; gloo only in plumbing tests), then the
+            # same deterministic grouped arg-max on every rank (cover_vla_amd/sharding.py)
+            from cover_vla_amd.sharding import gather_scores_and_select
+            sc = r["scores"].cpu() if cpu_gather else r["scores"]
+            sel = gather_scores_and_select(sc, N_SAMPLES, rank, world, n_prompts_total=world * N_PROMPTS)
+            return sel["global_idx"], tokens
         return int(r["result"][0]), tokens
 
 
@@ -164,6 +164,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--small", action="store_true", help="tiny config (plumbing check, not a valid bench line)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="nccl (= RCCL) for real runs; gloo only to test the N>1 plumbing")
+    ap.add_argument("--share-gpu", action="store_true", help="plumbing test: every rank uses cuda:0")
     a = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -171,13 +173,18 @@ def main():
     if not torch.cuda.is_available():
         print(json.dumps({"error": "no GPU: bench.py measures the HIP path only (no CPU fallback)"}))
         sys.exit(2)
+    if a.share_gpu:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device(f"cuda:{local}")
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(a.backend, rank=rank, world_size=world)
     from cover_vla_amd import _lib as L
     pipe = Pipeline(dev, small=a.small)
 
@@ -186,16 +193,17 @@ def main():
         if world > 1:
             torch.distributed.barrier()
 
+    cpu_gather = a.backend != "nccl"
     for _ in range(a.warmup):
-        pipe.decision(world)
+        pipe.decision(world, rank, cpu_gather)
     sync()
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        pipe.decision(world)
+        pipe.decision(world, rank, cpu_gather)
     sync()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], device=dev)
+        t = torch.tensor([dt], device=dev if a.backend == "nccl" else "cpu")
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t[0])
 
@@ -204,7 +212,7 @@ def main():
     h = L.lib()
     ms, cnt, work = (C.c_double * 3)(), (C.c_longlong * 3)(), (C.c_double * 3)()
     L.check(h.cover_profile_begin(16384), "profile_begin")
-    pipe.decision(world)
+    pipe.decision(world, rank, cpu_gather)
     L.check(h.cover_profile_end(ms, cnt, work), "profile_end")
     n_total = world * N_PROMPTS * N_SAMPLES
     out = {
