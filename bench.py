@@ -74,6 +74,7 @@ class Pipeline:
         ck = synth.verifier_checkpoint(3, seed=1234, num_patches=self.enc.num_patches, vision_dim=sc["dim"], text_dim=sc["dim"])
         self.ver = EfficientEnsembleMerged(ck, device=str(dev), encoder=self.enc)
         self.inp = build_inputs(dev, c)
+        self.side = None
         if small:
             g = torch.Generator().manual_seed(1)
             self.inp["img384"] = torch.randn(1, 3, sc["image"], sc["image"], generator=g).to(dev)
@@ -81,13 +82,22 @@ class Pipeline:
 
     def decision(self, world=1, rank=0, cpu_gather=False):
         i = self.inp
+        # the verifier's frozen towers and image-text heads depend only on the observation and the instruction: they run
+        # on a side stream underneath the policy's (HBM-bound, launch-gapped) decode passes
+        main = torch.cuda.current_stream()
+        if self.side is None:
+            self.side = torch.cuda.Stream(device=self.dev)
+        self.side.wait_stream(main)
+        with torch.cuda.stream(self.side):
+            pf, tf = self.ver.extract_shared_features(i["img384"], i["text"])
+            its = self.ver.image_text_embeddings(pf, tf)
         tokens, _ = self.policy.sample(i["frame"], i["toks"], i["lens"], N_SAMPLES, i["u"], 1.0)
         acts = self.policy.tokens_to_actions(tokens.cpu().numpy())            # [N, 7] host (the reference also goes D2H here)
         acts_v = acts.copy()
         acts_v[:, 6] = (acts[:, 6] >= 0.5).astype(np.float64)                  # verifier-format gripper (simpler.py:222-226)
         hists = [np.vstack([i["past"], a[None]]) for a in acts_v]
-        pf, tf = self.ver.extract_shared_features(i["img384"], i["text"])
-        r = self.ver.score_features(pf, tf, hists, N_SAMPLES)
+        main.wait_stream(self.side)
+        r = self.ver.score_histories(its, hists, N_SAMPLES)
         if world > 1:
             # ONE collective: all-gather of the per-candidate scores (RCCL over xGMI; gloo only in plumbing tests), then the
             # same deterministic grouped arg-max on every rank (cover_vla_amd/sharding.py)

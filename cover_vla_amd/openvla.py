@@ -64,6 +64,7 @@ class OpenVLA:
         self.head_ws = ops.gemm_workspace(max_candidates, c["vocab"], D, dev)
         self.zero_slots = torch.zeros(max(max_prompts, max_candidates), dtype=torch.int32, device=dev)
         self.bos = torch.tensor([1], dtype=torch.int64, device=dev)
+        self._side = None
 
     # ---------------------------------------------------------------------------------------------- vision
     def encode_image(self, frame_u8: torch.Tensor) -> torch.Tensor:
@@ -71,10 +72,17 @@ class OpenVLA:
         c, n = self.c, frame_u8.shape[0]
         mul_d = [1.0 / (255.0 * s) for s in IMAGENET_STD]
         add_d = [-m / s for m, s in zip(IMAGENET_MEAN, IMAGENET_STD)]
+        # the two towers are independent and individually too small to fill 256 CUs: run SigLIP on a side stream
+        main = torch.cuda.current_stream()
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.dev)
+        self._side.wait_stream(main)
+        with torch.cuda.stream(self._side):
+            xs = self.siglip.embed(frame_u8, [1.0 / (255.0 * 0.5)] * 3, [-1.0] * 3)
+            xs = self.siglip.forward(xs)
         xd = self.dino.embed(frame_u8, mul_d, add_d)
         xd = self.dino.forward(xd)
-        xs = self.siglip.embed(frame_u8, [1.0 / (255.0 * 0.5)] * 3, [-1.0] * 3)
-        xs = self.siglip.forward(xs)
+        main.wait_stream(self._side)
         P = self.n_patches
         fused = torch.empty(n * P, self.fused, dtype=BF, device=self.dev)
         fused[:, :c["dino_dim"]].copy_(xd[:, c["dino_prefix"]:, :].reshape(n * P, -1))   # channel concat (device copies)

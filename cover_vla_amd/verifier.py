@@ -201,23 +201,32 @@ class EfficientEnsembleMerged:
         act = m.trajectory(hb, pad)
         return it.expand(hb.shape[0], -1), act
 
-    def score_features(self, patch_features, text_features, all_action_histories, group_size=1):
-        """Scores every candidate history against ONE (image, text) pair given its features. Returns a dict with the
-        device tensors (scores [N], result int32[4], best f32[2]) plus per-member embeddings."""
+    def image_text_embeddings(self, patch_features, text_features) -> torch.Tensor:
+        """Per-member image-text embeddings [M, 512] of ONE (image, text) pair. Independent of the candidates, so a caller
+        may run it (and extract_shared_features) on a side stream while the policy is still sampling."""
+        pf = patch_features[0].to(self._dev).contiguous()
+        tf = text_features[0].to(self._dev).contiguous()
+        its = torch.empty(self.num_models, 512, dtype=torch.float32, device=self._dev)
+        for i, m in enumerate(self.trainable_models):
+            its[i] = m.image_text(pf, tf)[0]
+        return its
+
+    def score_histories(self, its: torch.Tensor, all_action_histories, group_size=1):
+        """Trajectory encoder per candidate + fusion + scoring + grouped arg-max against precomputed image-text embeddings."""
         hb = self._pad_histories(all_action_histories)
         N = hb.shape[0]
         pad = (hb[:, :, 0] == self.trainable_models[0].pad_value).to(torch.uint8).to(self._dev).contiguous()
         hb = hb.to(self._dev).contiguous()
-        pf = patch_features[0].to(self._dev).contiguous()
-        tf = text_features[0].to(self._dev).contiguous()
-        M = self.num_models
-        its = torch.empty(M, 512, dtype=torch.float32, device=self._dev)
-        acts = torch.empty(M, N, 512, dtype=torch.float32, device=self._dev)
+        acts = torch.empty(self.num_models, N, 512, dtype=torch.float32, device=self._dev)
         for i, m in enumerate(self.trainable_models):
-            its[i] = m.image_text(pf, tf)[0]
             acts[i] = m.trajectory(hb, pad)
         scores, result, best, fit, fact = ops.score_select(its, acts, group_size)
         return {"scores": scores, "result": result, "best": best, "its": its, "acts": acts, "fused_it": fit, "fused_act": fact}
+
+    def score_features(self, patch_features, text_features, all_action_histories, group_size=1):
+        """Scores every candidate history against ONE (image, text) pair given its features. Returns a dict with the
+        device tensors (scores [N], result int32[4], best f32[2]) plus per-member embeddings."""
+        return self.score_histories(self.image_text_embeddings(patch_features, text_features), all_action_histories, group_size)
 
     def fuse_embeddings(self, image, instruction, action_histories):
         pf, tf = self._encode_pair(image, instruction)
