@@ -75,6 +75,9 @@ class Pipeline:
         self.ver = EfficientEnsembleMerged(ck, device=str(dev), encoder=self.enc)
         self.inp = build_inputs(dev, c)
         self.side = None
+        bins = np.linspace(-1, 1, c["n_bins"])
+        self.centers = torch.tensor((bins[:-1] + bins[1:]) / 2.0, dtype=torch.float32, device=dev)   # float64 -> fp32 table
+        self.past_dev = torch.tensor(self.inp["past"], dtype=torch.float32, device=dev)
         if small:
             g = torch.Generator().manual_seed(1)
             self.inp["img384"] = torch.randn(1, 3, sc["image"], sc["image"], generator=g).to(dev)
@@ -92,12 +95,11 @@ class Pipeline:
             pf, tf = self.ver.extract_shared_features(i["img384"], i["text"])
             its = self.ver.image_text_embeddings(pf, tf)
         tokens, _ = self.policy.sample(i["frame"], i["toks"], i["lens"], N_SAMPLES, i["u"], 1.0)
-        acts = self.policy.tokens_to_actions(tokens.cpu().numpy())            # [N, 7] host (the reference also goes D2H here)
-        acts_v = acts.copy()
-        acts_v[:, 6] = (acts[:, 6] >= 0.5).astype(np.float64)                  # verifier-format gripper (simpler.py:222-226)
-        hists = [np.vstack([i["past"], a[None]]) for a in acts_v]
+        # de-tokenise + assemble the verifier histories on the device: no host sync between sampler and verifier
+        from cover_vla_amd import ops
+        hb, pad = ops.tokens_to_histories(tokens, self.c["tok_vocab"], self.centers, self.past_dev)
         main.wait_stream(self.side)
-        r = self.ver.score_histories(its, hists, N_SAMPLES)
+        r = self.ver.score_histories(its, hb, N_SAMPLES, pad=pad)
         if world > 1:
             # ONE collective: all-gather of the per-candidate scores (RCCL over xGMI; gloo only in plumbing tests), then the
             # same deterministic grouped arg-max on every rank (cover_vla_amd/sharding.py)

@@ -168,6 +168,13 @@ int cover_score_select(const cover_score_select_args* a, void* stream) {
     HIPCHK(launch_score_select(a, ST(stream)), "score_select (N % group_size == 0, fused_*_out required)");
     return COVER_OK;
 }
+int cover_tokens_to_histories(const int64_t* tokens, int ld_tokens, int N, int tok_vocab, const float* centers, int n_centers,
+                              const float* past, int n_past, float pad_value, float* hist_out, uint8_t* pad_out, void* stream) {
+    if (!tokens || !centers || !hist_out || !pad_out || (n_past > 0 && !past)) return fail(COVER_EINVAL, "cover_tokens_to_histories: null pointer");
+    HIPCHK(launch_tokens_to_histories(tokens, ld_tokens, N, tok_vocab, centers, n_centers, past, n_past, pad_value, hist_out, pad_out, ST(stream)),
+           "tokens_to_histories (0 <= n_past <= 9)");
+    return COVER_OK;
+}
 int cover_group_argmax(const float* scores, int N, int group_size, int* result_out, float* best_out, void* stream) {
     HIPCHK(launch_group_argmax(scores, N, group_size, result_out, best_out, ST(stream)), "group_argmax");
     return COVER_OK;

@@ -176,3 +176,42 @@ hipError_t launch_group_argmax(const float* scores, int N, int gs, int* result, 
     hipLaunchKernelGGL(group_argmax_k, dim3(1), dim3(256), 0, st, scores, N, gs, result, best);
     return hipGetLastError();
 }
+
+// ---------------------------------------------------------------------------------------------------
+// tokens -> verifier histories on the device (one thread per (candidate, history row))
+// ---------------------------------------------------------------------------------------------------
+__global__ void tokens_to_histories_k(const int64_t* __restrict__ tokens, int ld_tokens, int N, int tok_vocab,
+                                      const float* __restrict__ centers, int n_centers, const float* __restrict__ past,
+                                      int n_past, float pad_value, float* __restrict__ hist, uint8_t* __restrict__ pad) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= N * 10) return;
+    const int n = idx / 10, t = idx - n * 10;
+    const int n_pad = 10 - n_past - 1;
+    float* o = hist + (size_t)idx * 7;
+    if (t < n_pad) {
+        for (int d = 0; d < 7; ++d) o[d] = pad_value;
+        pad[idx] = 1;
+    } else if (t < 9) {
+        const float* p = past + (size_t)(t - n_pad) * 7;
+        for (int d = 0; d < 7; ++d) o[d] = p[d];
+        pad[idx] = 0;
+    } else {
+        for (int d = 0; d < 7; ++d) {
+            long long b = (long long)tok_vocab - tokens[(size_t)n * ld_tokens + d] - 1;
+            b = b < 0 ? 0 : (b > n_centers - 1 ? n_centers - 1 : b);
+            float a = centers[b];
+            if (d == 6) a = a < 0.5f ? 0.f : 1.f;
+            o[d] = a;
+        }
+        pad[idx] = 0;
+    }
+}
+hipError_t launch_tokens_to_histories(const int64_t* tokens, int ld_tokens, int N, int tok_vocab, const float* centers,
+                                      int n_centers, const float* past, int n_past, float pad_value, float* hist, uint8_t* pad,
+                                      hipStream_t st) {
+    if (N <= 0) return hipSuccess;
+    if (n_past < 0 || n_past > 9) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(tokens_to_histories_k, dim3((N * 10 + 255) / 256), dim3(256), 0, st, tokens, ld_tokens, N, tok_vocab,
+                       centers, n_centers, past, n_past, pad_value, hist, pad);
+    return hipGetLastError();
+}

@@ -400,6 +400,19 @@ def score_select(it, act, group_size):
     return scores, result, best, fit, fact
 
 
+def tokens_to_histories(tokens, tok_vocab, centers, past, pad_value=-5.0):
+    """tokens int64 [N, >=7] (device), centers fp32 [n_centers], past fp32 [n_past, 7] -> (hist fp32 [N,10,7], pad uint8 [N,10])."""
+    _chk_dev(tokens, centers)
+    N = tokens.shape[0]
+    hist = torch.empty(N, 10, 7, dtype=torch.float32, device=tokens.device)
+    pad = torch.empty(N, 10, dtype=torch.uint8, device=tokens.device)
+    n_past = 0 if past is None else past.shape[0]
+    L.check(L.lib().cover_tokens_to_histories(tokens.data_ptr(), tokens.stride(0), N, tok_vocab, centers.data_ptr(),
+                                              centers.numel(), _ptr(past), n_past, pad_value, hist.data_ptr(), pad.data_ptr(),
+                                              _stream()), "tokens_to_histories")
+    return hist, pad
+
+
 def group_argmax(scores, group_size):
     _chk_dev(scores)
     result = torch.empty(4, dtype=torch.int32, device=scores.device)

@@ -211,12 +211,17 @@ class EfficientEnsembleMerged:
             its[i] = m.image_text(pf, tf)[0]
         return its
 
-    def score_histories(self, its: torch.Tensor, all_action_histories, group_size=1):
-        """Trajectory encoder per candidate + fusion + scoring + grouped arg-max against precomputed image-text embeddings."""
-        hb = self._pad_histories(all_action_histories)
+    def score_histories(self, its: torch.Tensor, all_action_histories, group_size=1, pad: Optional[torch.Tensor] = None):
+        """Trajectory encoder per candidate + fusion + scoring + grouped arg-max against precomputed image-text embeddings.
+        all_action_histories: list of [h<=10, 7] host arrays (reference format), OR an already padded DEVICE tensor
+        fp32 [N,10,7] together with its padding mask `pad` uint8 [N,10] (ops.tokens_to_histories): no host round trip."""
+        if torch.is_tensor(all_action_histories) and all_action_histories.is_cuda:
+            hb = all_action_histories.contiguous()
+        else:
+            hb = self._pad_histories(all_action_histories)
+            pad = (hb[:, :, 0] == self.trainable_models[0].pad_value).to(torch.uint8).to(self._dev).contiguous()
+            hb = hb.to(self._dev).contiguous()
         N = hb.shape[0]
-        pad = (hb[:, :, 0] == self.trainable_models[0].pad_value).to(torch.uint8).to(self._dev).contiguous()
-        hb = hb.to(self._dev).contiguous()
         acts = torch.empty(self.num_models, N, 512, dtype=torch.float32, device=self._dev)
         for i, m in enumerate(self.trainable_models):
             acts[i] = m.trajectory(hb, pad)

@@ -265,6 +265,15 @@ typedef struct cover_score_select_args {
     float* fused_act_out;  /* [N][dim] optional */
 } cover_score_select_args;
 int cover_score_select(const cover_score_select_args* args, void* stream);
+/* De-tokenise action tokens and assemble the verifier's candidate histories on the device (no host round trip between
+ * sampler and verifier). For candidate n: hist[n] = [pad rows (= pad_value) | past[0..n_past) | new row], 10 rows total
+ * (efficient_ensemble_merged.py:378-390 front padding), new row d = centers[clip(tok_vocab - token[n][d] - 1, 0, n_centers-1)]
+ * (256-bin arithmetic of policy_wrapper.py:259-266) with the gripper (last dim) mapped to 0/1 at 0.5
+ * (BridgeSimplerAdapter.postprocess_gripper_verifier, simpler.py:222-226). centers: fp32 table computed on the host in
+ * float64. pad_out[n][t] = 1 for padding rows. */
+int cover_tokens_to_histories(const int64_t* tokens, int ld_tokens, int N, int tok_vocab, const float* centers, int n_centers,
+                              const float* past, int n_past, float pad_value, float* hist_out, uint8_t* pad_out, void* stream);
+
 /* grouped arg-max over already-computed (e.g. all-gathered) scores: same selection rule as above */
 int cover_group_argmax(const float* scores, int N, int group_size, int* result_out, float* best_out, void* stream);
 

@@ -467,3 +467,22 @@ def test_gemm_fused_rmsnorm(dev, variant, M, style):
     rstd = torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-6)
     ref_h = bf(nw * bf(xf * rstd).float()) if style == 1 else bf(xf * rstd * (1 + nw))
     assert torch.allclose(h.float().cpu(), ref_h.float(), atol=2e-2, rtol=1e-2)
+
+
+def test_tokens_to_histories_matches_host_path(dev):
+    # device de-tokeniser + history assembly == the host path (numpy float64 -> fp32, front padding with -5)
+    import numpy as np
+    g = torch.Generator().manual_seed(12)
+    N, vocab, nb = 9, 32000, 256
+    tok = torch.randint(vocab - nb - 3, vocab + 2, (N, 7), generator=g)
+    bins = np.linspace(-1, 1, nb)
+    centers = (bins[:-1] + bins[1:]) / 2.0
+    past = (torch.randn(6, 7, generator=g) * 0.02).double().numpy()
+    hb, pad = ops.tokens_to_histories(tok.to(dev), vocab, torch.tensor(centers, dtype=torch.float32, device=dev),
+                                      torch.tensor(past, dtype=torch.float32, device=dev))
+    d = np.clip(vocab - tok.numpy() - 1, 0, centers.shape[0] - 1)
+    a = centers[d]
+    a[:, 6] = (a[:, 6] >= 0.5)
+    ref = np.stack([np.vstack([np.ones((3, 7)) * -5, past, a[n][None]]) for n in range(N)]).astype(np.float32)
+    assert np.array_equal(hb.cpu().numpy(), ref)
+    assert np.array_equal(pad.cpu().numpy(), (ref[:, :, 0] == -5).astype(np.uint8))
