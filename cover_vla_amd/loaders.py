@@ -1,0 +1,121 @@
+"""On-disk formats of the reference -> the neutral state dicts the MI355X classes consume.
+
+pi0: `config.json` + `model.safetensors` written by `PI0Policy.save_pretrained`
+(lerobot_custom/lerobot/common/policies/pretrained.py:77-150). Key layout = what
+`conversion_scripts/convert_pi0_to_hf_lerobot.py:67-245,384-390` produces:
+    model.paligemma_with_expert.paligemma.vision_tower.vision_model.{embeddings.*, encoder.layers.N.*, post_layernorm.*}
+    model.paligemma_with_expert.paligemma.multi_modal_projector.linear.{weight,bias}
+    model.paligemma_with_expert.paligemma.language_model.model.{embed_tokens.weight, layers.N.*, norm.weight}
+    model.paligemma_with_expert.paligemma.language_model.lm_head.weight          (tied, ignored)
+    model.paligemma_with_expert.gemma_expert.model.{layers.N.*, norm.weight}     (embed_tokens / lm_head unused)
+    model.{state_proj, action_in_proj, action_out_proj, action_time_mlp_in, action_time_mlp_out}.{weight,bias}
+The verifier's merged checkpoint needs no conversion (cover_vla_amd.verifier reads its reference layout directly).
+"""
+from __future__ import annotations
+
+import json
+import os
+import re
+from typing import Dict, Tuple
+
+import torch
+
+_PWE = "model.paligemma_with_expert."
+_VT = _PWE + "paligemma.vision_tower.vision_model."
+_LM = _PWE + "paligemma.language_model.model."
+_EX = _PWE + "gemma_expert.model."
+_PROJ = ("state_proj", "action_in_proj", "action_out_proj", "action_time_mlp_in", "action_time_mlp_out")
+_VIT_LAYER = {"layer_norm1": "ln1", "layer_norm2": "ln2", "self_attn.q_proj": "q", "self_attn.k_proj": "k",
+              "self_attn.v_proj": "v", "self_attn.out_proj": "o", "mlp.fc1": "fc1", "mlp.fc2": "fc2"}
+
+
+def pi0_reference_to_neutral(sd: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    out = {}
+    for k, v in sd.items():
+        if not k.startswith("model."):
+            k = "model." + k  # state dicts taken from PI0FlowMatching directly carry no "model." prefix
+        if k.startswith(_VT):
+            r = k[len(_VT):]
+            if r == "embeddings.patch_embedding.weight":
+                out["vision.patch.weight"] = v.reshape(v.shape[0], -1)
+            elif r == "embeddings.patch_embedding.bias":
+                out["vision.patch.bias"] = v
+            elif r == "embeddings.position_embedding.weight":
+                out["vision.pos"] = v
+            elif r.startswith("post_layernorm."):
+                out["vision.post_ln." + r.split(".")[-1]] = v
+            else:
+                m = re.match(r"encoder\.layers\.(\d+)\.(.+)\.(weight|bias)$", r)
+                if m and m.group(2) in _VIT_LAYER:
+                    out[f"vision.blocks.{m.group(1)}.{_VIT_LAYER[m.group(2)]}.{m.group(3)}"] = v
+        elif k.startswith(_PWE + "paligemma.multi_modal_projector.linear."):
+            out["projector." + k.split(".")[-1]] = v
+        elif k.startswith(_LM):
+            out["lm." + k[len(_LM):]] = v
+        elif k.startswith(_EX):
+            r = k[len(_EX):]
+            if not r.startswith("embed_tokens"):
+                out["expert." + r] = v
+        else:
+            m = re.match(r"model\.(%s)\.(weight|bias)$" % "|".join(_PROJ), k)
+            if m:
+                out[f"{m.group(1)}.{m.group(2)}"] = v
+    return out
+
+
+def neutral_to_pi0_reference(sd: Dict[str, torch.Tensor], patch: int) -> Dict[str, torch.Tensor]:
+    """Inverse map (export / tests): neutral -> the reference's safetensors key layout."""
+    inv = {v: k for k, v in _VIT_LAYER.items()}
+    out = {}
+    for k, v in sd.items():
+        if k == "vision.patch.weight":
+            out[_VT + "embeddings.patch_embedding.weight"] = v.reshape(v.shape[0], 3, patch, patch)
+        elif k == "vision.patch.bias":
+            out[_VT + "embeddings.patch_embedding.bias"] = v
+        elif k == "vision.pos":
+            out[_VT + "embeddings.position_embedding.weight"] = v
+        elif k.startswith("vision.post_ln."):
+            out[_VT + "post_layernorm." + k.split(".")[-1]] = v
+        elif k.startswith("vision.blocks."):
+            _, _, i, name, wb = k.split(".")
+            out[f"{_VT}encoder.layers.{i}.{inv[name]}.{wb}"] = v
+        elif k.startswith("projector."):
+            out[_PWE + "paligemma.multi_modal_projector.linear." + k.split(".")[-1]] = v
+        elif k.startswith("lm."):
+            out[_LM + k[3:]] = v
+        elif k.startswith("expert."):
+            out[_EX + k[7:]] = v
+        else:
+            out["model." + k] = v
+    return out
+
+
+def infer_pi0_sizes(n: Dict[str, torch.Tensor], chunk: int) -> dict:
+    """Size dict (cover_vla_amd.synth.PI0_FULL layout) from tensor shapes."""
+    vit_dim = n["vision.patch.bias"].shape[0]
+    patch = int(round((n["vision.patch.weight"].shape[1] // 3) ** 0.5))
+    n_pos = n["vision.pos"].shape[0]
+    layers = 1 + max(int(k.split(".")[2]) for k in n if k.startswith("lm.layers."))
+    vit_layers = 1 + max(int(k.split(".")[2]) for k in n if k.startswith("vision.blocks."))
+    lm_dim = n["lm.norm.weight"].shape[0]
+    ex_dim = n["expert.norm.weight"].shape[0]
+    kD = n["lm.layers.0.self_attn.k_proj.weight"].shape[0]
+    qD = n["lm.layers.0.self_attn.q_proj.weight"].shape[0]
+    return dict(lm_dim=lm_dim, lm_mlp=n["lm.layers.0.mlp.gate_proj.weight"].shape[0], ex_dim=ex_dim,
+                ex_mlp=n["expert.layers.0.mlp.gate_proj.weight"].shape[0], layers=layers, vocab=n["lm.embed_tokens.weight"].shape[0],
+                vit_dim=vit_dim, vit_mlp=n["vision.blocks.0.fc1.weight"].shape[0], vit_layers=vit_layers, patch=patch,
+                image=int(round(n_pos ** 0.5)) * patch, chunk=chunk, _kD=kD, _qD=qD)
+
+
+def load_pi0_pretrained(path: str, head_dim: int = 256, vit_heads: int = 16) -> Tuple[Dict[str, torch.Tensor], dict, dict]:
+    """Directory with config.json + model.safetensors -> (neutral state dict, size dict, raw config)."""
+    from safetensors.torch import load_file
+    with open(os.path.join(path, "config.json")) as f:
+        cfg = json.load(f)
+    n = pi0_reference_to_neutral(load_file(os.path.join(path, "model.safetensors")))
+    c = infer_pi0_sizes(n, int(cfg.get("chunk_size", 50)))
+    c["D"] = head_dim
+    c["Hkv"] = c.pop("_kD") // head_dim
+    c["Hq"] = c.pop("_qD") // head_dim
+    c["vit_heads"] = vit_heads
+    return n, c, cfg

@@ -199,6 +199,22 @@ class PI0Policy:
         self._preprocess_adapter = None
         self.reset()
 
+    @classmethod
+    def from_pretrained(cls, pretrained_name_or_path: str, *, tokenizer: Callable, device="cuda:0", max_batch=64,
+                        max_prompts=16, image_keys=("observation.images.top",), **kwargs) -> "PI0Policy":
+        """Local directory holding the reference's `config.json` + `model.safetensors` (pretrained.py:77-150). The HF
+        tokenizer the reference downloads at modeling_pi0.py:251 is injected (no network on the GPU box)."""
+        from .loaders import load_pi0_pretrained
+        sd, c, cfg = load_pi0_pretrained(pretrained_name_or_path)
+        max_lang = int(cfg.get("tokenizer_max_length", 48))
+        model = PI0FlowMatching(sd, c, device=device, max_batch=max_batch, max_prompts=max_prompts, max_lang=max_lang,
+                                num_steps=int(cfg.get("num_steps", 10)), max_state_dim=int(cfg.get("max_state_dim", 32)),
+                                max_action_dim=int(cfg.get("max_action_dim", 32)))
+        pc = PI0Config(image_keys=image_keys, n_action_steps=int(cfg.get("n_action_steps", c["chunk"])), chunk_size=c["chunk"],
+                       max_state_dim=int(cfg.get("max_state_dim", 32)), max_action_dim=int(cfg.get("max_action_dim", 32)),
+                       tokenizer_max_length=max_lang, num_steps=int(cfg.get("num_steps", 10)), device=device)
+        return cls(pc, model, tokenizer, **kwargs)
+
     def to(self, device):
         return self
 

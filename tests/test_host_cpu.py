@@ -144,3 +144,36 @@ def test_candidate_sharding_gloo_world2():
         assert outs[r]["global_idx"] == bg * S + bi and outs[r]["group"] == bg
         assert abs(outs[r]["max_score"] - float(all_scores[bg, bi])) < 1e-7
     assert outs[0] == outs[1]
+
+
+# ------------------------------------------------------------------------------------------------ checkpoint format
+def test_pi0_checkpoint_key_layout_round_trip(tmp_path):
+    """neutral -> the reference's safetensors key layout (convert_pi0_to_hf_lerobot.py:67-245,384-390) -> neutral."""
+    import json
+    from safetensors.torch import save_file
+    from cover_vla_amd import loaders, synth
+    tiny = dict(lm_dim=64, lm_mlp=128, ex_dim=32, ex_mlp=64, layers=2, Hq=4, Hkv=1, D=16, vocab=96, vit_dim=48, vit_mlp=80,
+                vit_layers=2, vit_heads=4, patch=14, image=56, chunk=4)
+    sd = synth.pi0_state(tiny, seed=3)
+    ref = loaders.neutral_to_pi0_reference(sd, tiny["patch"])
+    # spot-check names against the reference's converter
+    for k in ("model.paligemma_with_expert.paligemma.vision_tower.vision_model.embeddings.patch_embedding.weight",
+              "model.paligemma_with_expert.paligemma.vision_tower.vision_model.encoder.layers.1.self_attn.out_proj.bias",
+              "model.paligemma_with_expert.paligemma.multi_modal_projector.linear.weight",
+              "model.paligemma_with_expert.paligemma.language_model.model.layers.0.mlp.gate_proj.weight",
+              "model.paligemma_with_expert.gemma_expert.model.norm.weight", "model.action_time_mlp_in.bias"):
+        assert k in ref, k
+    assert ref["model.paligemma_with_expert.paligemma.vision_tower.vision_model.embeddings.patch_embedding.weight"].shape == (48, 3, 14, 14)
+    # extras a real checkpoint carries and the loader must ignore
+    ref["model.paligemma_with_expert.paligemma.language_model.lm_head.weight"] = sd["lm.embed_tokens.weight"].clone()
+    ref["model.paligemma_with_expert.gemma_expert.lm_head.weight"] = torch.zeros(4, 4)
+    d = tmp_path / "ckpt"
+    d.mkdir()
+    save_file({k: v.contiguous() for k, v in ref.items()}, str(d / "model.safetensors"))
+    (d / "config.json").write_text(json.dumps({"chunk_size": 4, "n_action_steps": 4, "tokenizer_max_length": 72, "num_steps": 10}))
+    n, c, cfg = loaders.load_pi0_pretrained(str(d), head_dim=16, vit_heads=4)
+    assert set(n) == set(sd)
+    for k in sd:
+        assert torch.equal(n[k], sd[k]), k
+    for k in ("lm_dim", "lm_mlp", "ex_dim", "ex_mlp", "layers", "Hq", "Hkv", "D", "vocab", "vit_dim", "vit_mlp", "vit_layers", "patch", "image", "chunk"):
+        assert c[k] == tiny[k], (k, c[k], tiny[k])

@@ -75,3 +75,52 @@ def test_pi0_sampler_matches_reference_golden(dev, name):
     rel = np.linalg.norm(x - z["actions"]) / np.linalg.norm(upd)
     assert rel < 3e-2, rel
     assert np.abs(x - z["actions"]).max() < 8e-2
+
+
+def test_pi0_policy_api_from_pretrained(dev, tmp_path):
+    """PI0Policy drop-in surface (modeling_pi0.py:226-307): from_pretrained on the reference's on-disk layout, select_action
+    returns the policy-owned deque of n_action_steps [B,7] tensors, tolerates the caller's copy()/clear(), reuses the queue."""
+    import collections
+    import json
+    from safetensors.torch import save_file
+    from cover_vla_amd import loaders
+    from cover_vla_amd.pi0 import PI0FlowMatching, PI0Policy
+    from tests.helpers import pi0_case
+    z, tiny, sd, (images, img_masks, toks, masks, state, noise) = pi0_case(os.path.join(GOLD, "pi0_tiny_b6.npz"))
+    d = tmp_path / "ckpt"
+    d.mkdir()
+    save_file({k: v.contiguous() for k, v in loaders.neutral_to_pi0_reference(sd, tiny["patch"]).items()}, str(d / "model.safetensors"))
+    (d / "config.json").write_text(json.dumps({"chunk_size": 4, "n_action_steps": 4, "tokenizer_max_length": toks.shape[1], "num_steps": 10}))
+    B = state.shape[0]
+    vocab = {}
+
+    def tokenizer(texts, max_length):  # stand-in for the HF PaliGemma tokenizer: text -> the case's token rows
+        ids = torch.stack([toks[vocab[t]] for t in texts])
+        return ids, torch.stack([masks[vocab[t]] for t in texts])
+
+    tasks = []
+    for b in range(B):
+        name = f"prompt-{int(masks[b].sum())}-{int(toks[b, 0])}\n"
+        vocab[name] = b
+        tasks.append(name)
+    import cover_vla_amd.loaders as L2
+    orig = L2.load_pi0_pretrained
+    L2.load_pi0_pretrained = lambda p: orig(p, head_dim=tiny["D"], vit_heads=tiny["vit_heads"])
+    try:
+        pol = PI0Policy.from_pretrained(str(d), tokenizer=tokenizer, device="cuda:0", max_batch=8, max_prompts=8)
+    finally:
+        L2.load_pi0_pretrained = orig
+    batch = {"observation.images.top": images[0].to(dev), "observation.state": state[:, :7].to(dev), "task": tasks}
+    q = pol.select_action(batch, noise=noise.to(dev))
+    assert isinstance(q, collections.deque) and len(q) == 4 and q[0].shape == (B, 7)
+    got = torch.stack(list(q), 1).cpu().numpy()            # [B, 4, 7]
+    ref = z["actions"][:, :4, :7]
+    upd = ref - noise.numpy()[:, :4, :7]
+    assert np.linalg.norm(got - ref) / np.linalg.norm(upd) < 3e-2
+    snapshot = q.copy()
+    q.clear()                                              # what the driver does (run_simpler_eval_with_openpi.py:324-326)
+    assert len(pol._action_queue) == 0 and len(snapshot) == 4
+    q2 = pol.select_action(batch, noise=noise.to(dev))
+    assert len(q2) == 4
+    with pytest.raises(ValueError):
+        pol.select_action({"observation.state": state[:, :7].to(dev), "task": tasks})
