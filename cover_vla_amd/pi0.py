@@ -212,7 +212,8 @@ class PI0Policy:
                                 max_action_dim=int(cfg.get("max_action_dim", 32)))
         pc = PI0Config(image_keys=image_keys, n_action_steps=int(cfg.get("n_action_steps", c["chunk"])), chunk_size=c["chunk"],
                        max_state_dim=int(cfg.get("max_state_dim", 32)), max_action_dim=int(cfg.get("max_action_dim", 32)),
-                       tokenizer_max_length=max_lang, num_steps=int(cfg.get("num_steps", 10)), device=device)
+                       tokenizer_max_length=max_lang, num_steps=int(cfg.get("num_steps", 10)), device=device,
+                       resize_imgs_with_padding=tuple(cfg.get("resize_imgs_with_padding", (c["image"], c["image"]))))
         return cls(pc, model, tokenizer, **kwargs)
 
     def to(self, device):

@@ -122,5 +122,6 @@ def test_pi0_policy_api_from_pretrained(dev, tmp_path):
     assert len(pol._action_queue) == 0 and len(snapshot) == 4
     q2 = pol.select_action(batch, noise=noise.to(dev))
     assert len(q2) == 4
-    with pytest.raises(ValueError):
+    q2.clear()
+    with pytest.raises(ValueError):                        # modeling_pi0.py:354-357: no image feature in the batch
         pol.select_action({"observation.state": state[:, :7].to(dev), "task": tasks})
