@@ -475,36 +475,43 @@ __global__ __launch_bounds__(512) void gemm_skinny2(const bf16_t* __restrict__ A
         comp8(buf[i & 1], acc[i]);
         if (i + 2 < NBW) load8(buf[i & 1], i + 2);  // refill the buffer just consumed: two blocks stay in flight
     }
-    // ---- sum the KS k-slices through LDS (the X chunk is dead now) ----
-    __syncthreads();
-    float* red = (float*)smem;  // [w][i][f][4][64]
-#pragma unroll
-    for (int i = 0; i < NBW; ++i)
-#pragma unroll
-        for (int f = 0; f < MF; ++f)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) red[(((w * NBW + i) * MF + f) * 4 + e) * 64 + lane] = acc[i][f][e];
-    __syncthreads();
+    // ---- sum the KS k-slices through LDS (the X chunk is dead now), RB n-blocks per round (<= 64 KiB of LDS) ----
+    constexpr int RB = (8 / MF) < NBW ? (8 / MF) : NBW;
     const int r = lane & 15, g = lane >> 4;
-    constexpr int NFRAG = NG * NBW * MF;
-    for (int j = w; j < NFRAG; j += 8) {
-        const int f = j % MF, i = (j / MF) % NBW, gsel = j / (MF * NBW);
-        float v[4] = {0.f, 0.f, 0.f, 0.f};
+    float* red = (float*)smem;  // [w][ii][f][4][64]
 #pragma unroll
-        for (int kk = 0; kk < KS; ++kk) {
-            const int ww = gsel * KS + kk;
+    for (int i0 = 0; i0 < NBW; i0 += RB) {
+        __syncthreads();
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] += red[(((ww * NBW + i) * MF + f) * 4 + e) * 64 + lane];
-        }
-        const int nb = nb_begin + gsel + NG * i;
-        const int m = f * 16 + r, n = nb * 16 + 4 * g;
-        if (nb < N16 && m < M && n < N) {
-            float* o = partial + ((size_t)s * M + m) * N + n;
-            if (n + 3 < N && ((((uintptr_t)o) & 15) == 0)) {
-                *(float4*)o = make_float4(v[0], v[1], v[2], v[3]);
-            } else {
-                for (int e = 0; e < 4; ++e)
-                    if (n + e < N) o[e] = v[e];
+        for (int ii = 0; ii < RB; ++ii)
+            if (i0 + ii < NBW) {
+#pragma unroll
+                for (int f = 0; f < MF; ++f)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) red[(((w * RB + ii) * MF + f) * 4 + e) * 64 + lane] = acc[(i0 + ii) < NBW ? (i0 + ii) : 0][f][e];
+            }
+        __syncthreads();
+        constexpr int NFRAG = NG * RB * MF;
+        for (int j = w; j < NFRAG; j += 8) {
+            const int f = j % MF, ii = (j / MF) % RB, gsel = j / (MF * RB);
+            if (i0 + ii >= NBW) continue;
+            const int nb = nb_begin + gsel + NG * (i0 + ii);
+            float v[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk) {
+                const int ww = gsel * KS + kk;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] += red[(((ww * RB + ii) * MF + f) * 4 + e) * 64 + lane];
+            }
+            const int m = f * 16 + r, n = nb * 16 + 4 * g;
+            if (nb < N16 && m < M && n < N) {
+                float* o = partial + ((size_t)s * M + m) * N + n;
+                if (n + 3 < N && ((((uintptr_t)o) & 15) == 0)) {
+                    *(float4*)o = make_float4(v[0], v[1], v[2], v[3]);
+                } else {
+                    for (int e = 0; e < 4; ++e)
+                        if (n + e < N) o[e] = v[e];
+                }
             }
         }
     }
@@ -698,11 +705,24 @@ static Skinny2Plan plan_skinny2(int M, int N, int Kp) {
     const int KC = 256 * p.KS, NG = 8 / p.KS;
     p.S = (Kp + KC - 1) / KC;
     const int N16 = (N + 15) / 16;
-    p.NBW = p.MF <= 2 ? 4 : 2;  // the LDS reduction buffer (8 * NBW * MF KiB) must stay within 64 KiB
-    while (p.NBW > 1 && (long long)((N16 + NG * p.NBW - 1) / (NG * p.NBW)) * p.S < 256) p.NBW >>= 1;
-    if (p.NBW == 1) p.NBW = 2;  // keep >= 2 n-blocks per wave so the activation chunk is amortised
+    // NBW (n-blocks per wave): the smallest of {2,3,4,6} for which the whole grid is ONE wave of resident blocks
+    // (2 blocks per CU x 256 CUs): a second, partially filled wave of blocks leaves CUs idle while the last blocks stream.
+    static const char* slots_env = getenv("COVER_SK_SLOTS");
+    const int slots = slots_env ? atoi(slots_env) : 512;
+    if (p.MF <= 2) {
+        const int cand[4] = {2, 3, 4, 6};
+        p.NBW = 4;
+        bool found = false;
+        for (int c = 0; c < 4 && !found; ++c) {
+            const long long blocks = (long long)((N16 + NG * cand[c] - 1) / (NG * cand[c])) * p.S;
+            if (blocks <= slots) { p.NBW = cand[c]; found = true; }
+        }
+    } else {
+        p.NBW = 2;  // the LDS reduction buffer (8 * NBW * MF KiB per round) and the accumulators bound it
+    }
     p.gx = (N16 + NG * p.NBW - 1) / (NG * p.NBW);
-    const size_t x = (size_t)p.MF * 16 * KC * 2, red = (size_t)8 * p.NBW * p.MF * 4 * 64 * 4;
+    const int rb = (8 / p.MF) < p.NBW ? (8 / p.MF) : p.NBW;
+    const size_t x = (size_t)p.MF * 16 * KC * 2, red = (size_t)8 * rb * p.MF * 4 * 64 * 4;
     p.lds = x > red ? x : red;
     p.ws_bytes = (size_t)p.S * M * N * sizeof(float);
     return p;
@@ -732,10 +752,10 @@ hipError_t launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* Wp, void* C,
         dim3 grid(p.gx, p.S), block(512);
         const int pid = prof_enabled() ? prof_open(st, 0, 2.0 * (double)N * (double)K) : -1;
 #define SK2(MF_, KS_, NBW_) hipLaunchKernelGGL((gemm_skinny2<MF_, KS_, NBW_>), grid, block, p.lds, st, A, lda, Wp, ws, M, N, Kp)
-        if (p.MF == 1) { if (p.NBW == 4) SK2(1, 4, 4); else SK2(1, 4, 2); }
-        else if (p.MF == 2) { if (p.NBW == 4) SK2(2, 4, 4); else SK2(2, 4, 2); }
-        else if (p.MF == 3) { if (p.NBW == 4) SK2(3, 2, 4); else SK2(3, 2, 2); }
-        else { if (p.NBW == 4) SK2(4, 2, 4); else SK2(4, 2, 2); }
+        if (p.MF == 1) { if (p.NBW == 6) SK2(1, 4, 6); else if (p.NBW == 4) SK2(1, 4, 4); else if (p.NBW == 3) SK2(1, 4, 3); else SK2(1, 4, 2); }
+        else if (p.MF == 2) { if (p.NBW == 6) SK2(2, 4, 6); else if (p.NBW == 4) SK2(2, 4, 4); else if (p.NBW == 3) SK2(2, 4, 3); else SK2(2, 4, 2); }
+        else if (p.MF == 3) SK2(3, 2, 2);
+        else SK2(4, 2, 2);
 #undef SK2
         prof_close(st, pid);
         hipError_t e = hipGetLastError();
@@ -865,10 +885,10 @@ hipError_t launch_gemm_skinny_partial(const bf16_t* A, int lda, const bf16_t* Wp
     dim3 grid(p.gx, p.S), block(512);
     const int pid = prof_enabled() ? prof_open(st, 0, 2.0 * (double)N * (double)K) : -1;
 #define SK2(MF_, KS_, NBW_) hipLaunchKernelGGL((gemm_skinny2<MF_, KS_, NBW_>), grid, block, p.lds, st, A, lda, Wp, ws, M, N, Kp)
-    if (p.MF == 1) { if (p.NBW == 4) SK2(1, 4, 4); else SK2(1, 4, 2); }
-    else if (p.MF == 2) { if (p.NBW == 4) SK2(2, 4, 4); else SK2(2, 4, 2); }
-    else if (p.MF == 3) { if (p.NBW == 4) SK2(3, 2, 4); else SK2(3, 2, 2); }
-    else { if (p.NBW == 4) SK2(4, 2, 4); else SK2(4, 2, 2); }
+    if (p.MF == 1) { if (p.NBW == 6) SK2(1, 4, 6); else if (p.NBW == 4) SK2(1, 4, 4); else if (p.NBW == 3) SK2(1, 4, 3); else SK2(1, 4, 2); }
+    else if (p.MF == 2) { if (p.NBW == 6) SK2(2, 4, 6); else if (p.NBW == 4) SK2(2, 4, 4); else if (p.NBW == 3) SK2(2, 4, 3); else SK2(2, 4, 2); }
+    else if (p.MF == 3) SK2(3, 2, 2);
+    else SK2(4, 2, 2);
 #undef SK2
     prof_close(st, pid);
     *S_out = p.S;
