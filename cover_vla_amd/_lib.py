@@ -51,6 +51,13 @@ class AttnArgs(C.Structure):
                 ("state_in_o", c_p), ("state_in_ml", c_p), ("state_out_o", c_p), ("state_out_ml", c_p)]
 
 
+class DecodeAttnArgs(C.Structure):
+    _fields_ = [("qkv", c_p), ("ld_qkv", c_i), ("n_splits", c_i), ("partial", c_p), ("bias", c_p),
+                ("N", c_i), ("H", c_i), ("D", c_i), ("scale", c_f),
+                ("positions", c_p), ("cos_table", c_p), ("sin_table", c_p), ("n_pos", c_i), ("rope_mode", c_i),
+                ("seg", KvSegment * 3), ("write_t", c_i), ("_pad", c_i), ("out", c_p), ("out_row_stride", c_ll)]
+
+
 class RopeArgs(C.Structure):
     _fields_ = [("qkv", c_p), ("ld_qkv", c_i),
                 ("B", c_i), ("T", c_i), ("Hq", c_i), ("Hkv", c_i), ("D", c_i),
@@ -141,7 +148,7 @@ _STRUCTS = {
     "cover_mha_f32_args": MhaF32Args, "cover_token_select_args": TokenSelectArgs,
     "cover_score_select_args": ScoreSelectArgs, "cover_workspace": Workspace, "cover_vit_layer": VitLayer,
     "cover_vit_desc": VitDesc, "cover_dec_layer": DecLayer, "cover_dec_desc": DecDesc, "cover_dec_group": DecGroup,
-    "cover_dec_pass": DecPass,
+    "cover_dec_pass": DecPass, "cover_decode_attn_args": DecodeAttnArgs,
 }
 
 # every symbol include/cover_hip.h declares: (restype, argtypes)
@@ -156,6 +163,7 @@ SYMBOLS = {
     "cover_gemm_workspace_bytes": (C.c_size_t, [c_i, c_i, c_i]),
     "cover_gemm_bf16": (c_i, [c_p, c_i, c_p, c_p, c_i, c_i, c_i, c_i, _P(GemmEpi), c_p, C.c_size_t, c_i, c_p]),
     "cover_attention_bf16": (c_i, [_P(AttnArgs), c_p]),
+    "cover_decode_attention_fused": (c_i, [_P(DecodeAttnArgs), c_p]),
     "cover_layernorm_bf16": (c_i, [c_p, c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_p]),
     "cover_rmsnorm_bf16": (c_i, [c_p, c_i, c_i, c_p, c_f, c_i, c_p, c_i, c_i, c_i, c_f, c_p]),
     "cover_rope_kv_write": (c_i, [_P(RopeArgs), c_p]),

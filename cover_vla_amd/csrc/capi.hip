@@ -68,6 +68,13 @@ int cover_attention_bf16(const cover_attn_args* a, void* stream) {
     return COVER_OK;
 }
 
+int cover_decode_attention_fused(const cover_decode_attn_args* a, void* stream) {
+    if (!a || !a->out || (a->n_splits <= 0 && !a->qkv) || (a->n_splits > 0 && !a->partial))
+        return fail(COVER_EINVAL, "cover_decode_attention_fused: null pointer");
+    HIPCHK(launch_decode_attention_fused(a, ST(stream)), "decode_attention_fused (D in {64,128}, COVER_MASK_LEN segments, 0 <= write_t < seg[2].len)");
+    return COVER_OK;
+}
+
 int cover_layernorm_bf16(const void* x, int ldx, const float* w, const float* b, void* y, int ldy, int rows, int dim,
                          float eps, void* stream) {
     HIPCHK(launch_layernorm_bf16((const bf16_t*)x, ldx, w, b, (bf16_t*)y, ldy, rows, dim, eps, ST(stream)), "layernorm_bf16");
@@ -359,6 +366,28 @@ int cover_decoder_forward(const cover_dec_desc* d, const cover_dec_pass* p, void
             if (G.B * G.T == 0) continue;
             bf16_t* gq = (bf16_t*)qkv + (size_t)row0[g] * nqkv;
             const cover_kv_segment& W = G.segs[G.write_seg];
+            if (G.T == 1 && G.seg0_shared && G.n_seg == 3 && G.write_seg == 2 && Hq == Hkv && (D == 64 || D == 128) &&
+                G.segs[0].mask_mode == COVER_MASK_LEN && G.segs[1].mask_mode == COVER_MASK_LEN && G.segs[2].mask_mode == COVER_MASK_LEN &&
+                G.write_t_offset_of_batch == nullptr && G.segs[2].len_of_batch == nullptr && G.segs[0].len_of_batch == nullptr) {
+                // single-token candidate decode: RoPE + KV append + 3-segment attention in ONE launch
+                cover_decode_attn_args da;
+                memset(&da, 0, sizeof da);
+                da.qkv = gq; da.ld_qkv = nqkv;
+                if (qkv_splits > 0) { da.n_splits = qkv_splits; da.partial = (const float*)sk; da.bias = L.qkv_b; }
+                da.N = G.B; da.H = Hq; da.D = D; da.scale = d->attn_scale;
+                da.positions = G.positions; da.cos_table = d->cos_table; da.sin_table = d->sin_table; da.n_pos = d->n_pos;
+                da.rope_mode = d->rope_mode;
+                for (int s = 0; s < 3; ++s) {
+                    da.seg[s] = G.segs[s];
+                    da.seg[s].k = (const bf16_t*)L.k_cache + G.seg_k_offset[s];
+                    da.seg[s].vt = (const bf16_t*)L.vt_cache + G.seg_vt_offset[s];
+                }
+                da.seg[2].slot_of_batch = G.write_slot_of_batch ? G.write_slot_of_batch : G.segs[2].slot_of_batch;
+                da.write_t = G.write_t_offset;
+                da.out = (bf16_t*)attn + (size_t)row0[g] * HD; da.out_row_stride = HD;
+                HIPCHK(launch_decode_attention_fused(&da, st), "dec fused decode attention");
+                continue;
+            }
             cover_rope_args ra;
             memset(&ra, 0, sizeof ra);
             ra.qkv = gq; ra.ld_qkv = nqkv; ra.B = G.B; ra.T = G.T; ra.Hq = Hq; ra.Hkv = Hkv; ra.D = D;
@@ -487,7 +516,7 @@ size_t cover_sizeof(const char* n) {
     SZ(cover_gemm_epi); SZ(cover_kv_segment); SZ(cover_attn_args); SZ(cover_rope_args); SZ(cover_patchify_args);
     SZ(cover_gemm_f32_args); SZ(cover_mha_f32_args); SZ(cover_token_select_args); SZ(cover_score_select_args);
     SZ(cover_workspace); SZ(cover_vit_layer); SZ(cover_vit_desc); SZ(cover_dec_layer); SZ(cover_dec_desc);
-    SZ(cover_dec_group); SZ(cover_dec_pass);
+    SZ(cover_dec_group); SZ(cover_dec_pass); SZ(cover_decode_attn_args);
 #undef SZ
     return 0;
 }

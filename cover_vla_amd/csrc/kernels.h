@@ -19,6 +19,7 @@ hipError_t launch_pack_weight_bf16(const bf16_t* W, int ldw, int N, int K, bf16_
 
 // ---- attention.hip -------------------------------------------------------------------------------
 hipError_t launch_attention_bf16(const cover_attn_args* a, hipStream_t st);
+hipError_t launch_decode_attention_fused(const cover_decode_attn_args* a, hipStream_t st);
 
 // ---- rowops.hip ----------------------------------------------------------------------------------
 hipError_t launch_layernorm_bf16(const bf16_t* x, int ldx, const float* w, const float* b, bf16_t* y, int ldy, int rows,

@@ -187,6 +187,7 @@ __global__ __launch_bounds__(256) void rope_kv_write_k(cover_rope_args a) {
             o1 = bfround(bfround(x1 * c) + bfround(-x2 * s));
             o2 = bfround(bfround(x2 * c) + bfround(x1 * s));
         } else {  // apply_rope (paligemma_with_expert.py:34-57): fp32, one rounding
+#pragma clang fp contract(off)   // torch rounds each product: no FMA here
             o1 = x1 * c - x2 * s;
             o2 = x2 * c + x1 * s;
         }

@@ -151,6 +151,26 @@ def attention(q: torch.Tensor, q_strides: Sequence[int], out: Optional[torch.Ten
     return out
 
 
+def decode_attention_fused(qkv, N, H, D, scale, segments, write_t, out, *, positions=None, cos=None, sin=None, rope_mode=0,
+                           partial=None, bias=None):
+    """RoPE + KV append + [shared | per-prompt | own] attention for one new token per candidate, one launch."""
+    _chk_dev(qkv, out)
+    a = L.DecodeAttnArgs()
+    a.qkv, a.ld_qkv = qkv.data_ptr(), qkv.stride(0)
+    if partial is not None:
+        a.n_splits, a.partial, a.bias = partial.shape[0], partial.data_ptr(), _ptr(bias)
+    a.N, a.H, a.D, a.scale = N, H, D, scale
+    a.positions, a.cos_table, a.sin_table = _ptr(positions), _ptr(cos), _ptr(sin)
+    a.n_pos = cos.shape[0] if cos is not None else 0
+    a.rope_mode = rope_mode
+    for i, sg in enumerate(segments):
+        fill_segment(a.seg[i], sg)
+    a.write_t = write_t
+    a.out, a.out_row_stride = out.data_ptr(), out.stride(0)
+    L.check(L.lib().cover_decode_attention_fused(C.byref(a), _stream()), "decode_attention_fused")
+    return out
+
+
 # ------------------------------------------------------------------------------------------------ row kernels
 def layernorm(x, w, b, eps, out=None):
     _chk_dev(x, w)

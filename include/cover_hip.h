@@ -130,6 +130,24 @@ typedef struct cover_attn_args {
 } cover_attn_args;
 int cover_attention_bf16(const cover_attn_args* args, void* stream);
 
+/* Fused single-token decode attention (OpenVLA-style candidate decode): RoPE + KV append + attention over
+ * [seg[0]: ONE slot (slot 0) shared by all N candidates | seg[1]: per-prompt slot | seg[2]: the candidate's own tokens,
+ * including the one written here at position write_t] in ONE launch. q/k/v come from the bf16 qkv buffer, or (n_splits > 0)
+ * straight from the split-K partial sums of the weight-streaming QKV GEMM. Requirements: one new token per candidate,
+ * Hq == Hkv == H, D in {64,128}, COVER_MASK_LEN segments. Same results as cover_rope_kv_write + cover_attention_bf16. */
+typedef struct cover_decode_attn_args {
+    const void* qkv; int ld_qkv;           /* bf16 [N][3*H*D] (used when n_splits == 0) */
+    int n_splits;
+    const float* partial; const float* bias; /* fp32 [n_splits][N][3*H*D], bias [3*H*D] or NULL */
+    int N, H, D;
+    float scale;
+    const int* positions; const float* cos_table; const float* sin_table; int n_pos; int rope_mode;
+    cover_kv_segment seg[3];               /* k/vt pointers are the segment bases */
+    int write_t; int _pad;                 /* position of the new token inside seg[2] (slot = seg[2].slot_of_batch[n] or n) */
+    void* out; long long out_row_stride;   /* bf16 [N][H*D] */
+} cover_decode_attn_args;
+int cover_decode_attention_fused(const cover_decode_attn_args* args, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Row kernels (HBM-bound, wave-shuffle reductions, 16-byte vector access)
  * ------------------------------------------------------------------------------------------------ */

@@ -486,3 +486,52 @@ def test_tokens_to_histories_matches_host_path(dev):
     ref = np.stack([np.vstack([np.ones((3, 7)) * -5, past, a[n][None]]) for n in range(N)]).astype(np.float32)
     assert np.array_equal(hb.cpu().numpy(), ref)
     assert np.array_equal(pad.cpu().numpy(), (ref[:, :, 0] == -5).astype(np.uint8))
+
+
+@pytest.mark.parametrize("D,H", [(128, 8), (64, 4)])
+@pytest.mark.parametrize("N,write_t,mode,from_partials", [(32, 0, 1, False), (32, 4, 2, True), (21, 3, 1, True), (5, 6, 0, False),
+                                                         (64, 5, 1, False)])
+def test_decode_attention_fused_matches_three_launch_path(dev, D, H, N, write_t, mode, from_partials):
+    # one launch (RoPE + KV append + [shared | per-prompt | own] attention) == rope_kv_write + attention over 3 segments
+    T0, T1, cap2, npos = 257, 24, 32, 320
+    g = torch.Generator().manual_seed(1000 * N + 10 * write_t + mode)
+    ncol = 3 * H * D
+    if from_partials:
+        part = torch.randn(3, N, ncol, generator=g) * 0.6
+        bias = torch.randn(ncol, generator=g) * 0.1
+        qkv = bf(part.sum(0) + bias)
+    else:
+        part = bias = None
+        qkv = bf(torch.randn(N, ncol, generator=g))
+    pos = torch.randint(0, npos, (N,), generator=g, dtype=torch.int32)
+    inv = 1.0 / (10000.0 ** (torch.arange(0, D, 2).float() / D))
+    ang = torch.arange(npos).float()[:, None] * inv[None]
+    cos, sin = ang.cos().to(dev), ang.sin().to(dev)
+    k0, v0 = bf(torch.randn(1, T0, H, D, generator=g)), bf(torch.randn(1, T0, H, D, generator=g))
+    k1, v1 = bf(torch.randn(8, T1, H, D, generator=g)), bf(torch.randn(8, T1, H, D, generator=g))
+    k2, v2 = bf(torch.randn(N, cap2, H, D, generator=g)), bf(torch.randn(N, cap2, H, D, generator=g))
+    slot1 = (torch.arange(N) // 3 % 8).to(torch.int32)     # prompt groups straddle the 16-candidate tiles
+    len1 = (9 + (slot1 * 5) % 16).to(torch.int32)
+    zero = torch.zeros(N, dtype=torch.int32)
+    c0, c1 = make_cache(k0, v0, dev), make_cache(k1, v1, dev)
+    ca, cb = make_cache(k2, v2, dev, cap2), make_cache(k2, v2, dev, cap2)
+    s0 = ops.Segment(c0[0], c0[1], c0[2], c0[3], length=T0, slot_of_batch=zero.to(dev))
+    s1 = ops.Segment(c1[0], c1[1], c1[2], c1[3], length=T1, slot_of_batch=slot1.to(dev), len_of_batch=len1.to(dev))
+    L2 = write_t + 1
+    # reference path
+    qa = qkv.clone().to(dev)
+    ops.rope_kv_write(qa, N, 1, H, H, D, positions=pos.to(dev), cos=cos, sin=sin, rope_mode=mode, k_cache=ca[0], k_strides=ca[2],
+                      vt_cache=ca[1], vt_strides=ca[3], t_offset=write_t)
+    ref = torch.empty(N, H * D, dtype=torch.bfloat16, device=dev)
+    ops.attention(qa, (ncol, ncol, D), ref, (H * D, H * D, D), N, 1, H, H, D, D ** -0.5,
+                  [s0, s1, ops.Segment(ca[0], ca[1], ca[2], ca[3], length=L2)])
+    # fused path
+    out = torch.full((N, H * D), float("nan"), dtype=torch.bfloat16, device=dev)
+    ops.decode_attention_fused(qkv.to(dev), N, H, D, D ** -0.5, [s0, s1, ops.Segment(cb[0], cb[1], cb[2], cb[3], length=L2)],
+                               write_t, out, positions=pos.to(dev), cos=cos, sin=sin, rope_mode=mode,
+                               partial=None if part is None else part.to(dev), bias=None if bias is None else bias.to(dev))
+    assert torch.equal(ca[0].cpu().view(torch.int16), cb[0].cpu().view(torch.int16))       # appended K rows, bit-exact
+    assert torch.equal(ca[1].cpu().view(torch.int16), cb[1].cpu().view(torch.int16))       # appended V^T columns
+    o, r = out.float().cpu(), ref.float().cpu()
+    assert torch.isfinite(o).all()
+    assert rel_l2(o, r) < 6e-3 and (o - r).abs().max() < 3e-2
