@@ -94,22 +94,33 @@ class OpenVLA:
     # ---------------------------------------------------------------------------------------------- sampler
     def sample(self, frame_u8: torch.Tensor, prompt_tokens: torch.Tensor, prompt_lens: torch.Tensor, n_samples: int,
                uniforms: Optional[torch.Tensor] = None, temperature: float = 1.0, trace: Optional[dict] = None,
-               force_tokens: Optional[torch.Tensor] = None):
+               force_tokens: Optional[torch.Tensor] = None, on_prefill_enqueued=None):
         """frame_u8 [n_cams,H,W,3] uint8; prompt_tokens int64 [P, Lt] right padded, prompt_lens int32 [P] (device);
         n_samples candidates per prompt (N = P*n_samples, candidate i belongs to prompt i // n_samples);
         uniforms fp32 [N, n_gen] in [0,1) for inverse-CDF sampling over the 256 action tokens, None = greedy over the
         tokenizer vocabulary. force_tokens int64 [N, n_gen] (tests): teacher-force the fed-back tokens while still
-        returning this path's own picks. Returns (tokens int64 [N, n_gen], selected-logit fp32 [N, n_gen])."""
+        returning this path's own picks. on_prefill_enqueued: optional callable invoked once the prefill launches are
+        queued -- the point where a caller should queue independent side-stream work (the verifier towers): the
+        HBM-bound decode passes that follow tolerate concurrent kernels, the MFMA-bound prefill does not. Returns (tokens int64 [N, n_gen], selected-logit fp32 [N, n_gen])."""
         c, dev = self.c, self.dev
         P, Lt = prompt_tokens.shape
         N = P * n_samples
+
+        def mark(name):   # optional phase timing (tools/phases.py): trace["events"] collects (name, event) pairs
+            if trace is not None and "events" in trace:
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record()
+                trace["events"].append((name, ev))
+
         if P > self.max_prompts or N > self.max_candidates or Lt > self.max_text:
             raise ValueError("prompts/candidates/text length exceed the sizes this model was built for")
         D, T0 = c["llm_dim"], self.T0
         # ---- prefill input rows: [BOS | patches] then P x Lt text rows
         x = self.x_pre[: T0 + P * Lt]
         ops.embed_gather(self.embed, self.bos, out=x[:1])
+        mark("start")
         x[1:T0].copy_(self.encode_image(frame_u8))
+        mark("vision")
         ops.embed_gather(self.embed, prompt_tokens.reshape(-1).contiguous(), out=x[T0:])
         pos0 = torch.arange(T0, dtype=torch.int32, device=dev)
         pos1 = (T0 + torch.arange(Lt, dtype=torch.int32, device=dev))[None].expand(P, Lt).contiguous()
@@ -118,6 +129,9 @@ class OpenVLA:
                             [dict(region=0, length=T0, slot_of_batch=self.zero_slots),
                              dict(region=1, length=Lt, mask=ops.MASK_CAUSAL)], 1)
         self.llm.forward(x, [g0, g1], final_norm=False)
+        mark("prefill")
+        if on_prefill_enqueued is not None:
+            on_prefill_enqueued()
         # ---- first action token: last valid text position of each candidate's prompt
         prompt_of_cand = (torch.arange(N, device=dev) // n_samples).to(torch.int32)
         cand_len = prompt_lens.to(torch.int32)[prompt_of_cand.long()].contiguous()
@@ -139,13 +153,14 @@ class OpenVLA:
                                 dict(region=2, length=i)], 2, write_t_off=i - 1, seg0_shared=True)
             self.llm.forward(xd, [g], final_norm=False)
             self._head_select(xd, uniforms, i, temperature, tokens, sel, trace)
+            mark(f"decode{i}")
         return tokens, sel
 
     def _head_select(self, h, uniforms, i, temperature, tokens, sel, trace):
         N = h.shape[0]
         hn = ops.rmsnorm(h, self.llm.final_norm, 1e-5, w_offset=0.0, style=1)
         lg = ops.gemm(hn, self.lm_head, out=self.logits[:N], ws=self.head_ws)
-        if trace is not None:
+        if trace is not None and "events" not in trace:
             trace.setdefault("logits", []).append(lg.clone())
         if uniforms is None:
             t, s = ops.token_select(lg, 0, self.c["tok_vocab"])

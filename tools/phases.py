@@ -1,0 +1,45 @@
+"""Phase breakdown of one OpenVLA-7B + CoVer decision (bench.py's pipeline) with HIP events on the main stream:
+vision towers, LLM prefill, the six decode passes, the verifier tail. Usage: python tools/phases.py [--small]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import bench
+from cover_vla_amd import ops
+
+dev = torch.device("cuda:0")
+torch.cuda.set_device(dev)
+pipe = bench.Pipeline(dev, small="--small" in sys.argv)
+for _ in range(3):
+    pipe.decision()
+torch.cuda.synchronize()
+i = pipe.inp
+acc = {}
+R = 5
+for _ in range(R):
+    main = torch.cuda.current_stream()
+    tr = {"events": []}
+    e0 = torch.cuda.Event(enable_timing=True); e0.record()
+    out = {}
+
+    def side_work():
+        ev = torch.cuda.Event(); ev.record(main)
+        pipe.side.wait_event(ev)
+        with torch.cuda.stream(pipe.side):
+            pf, tf = pipe.ver.extract_shared_features(i["img384"], i["text"])
+            out["its"] = pipe.ver.image_text_embeddings(pf, tf)
+
+    tokens, _ = pipe.policy.sample(i["frame"], i["toks"], i["lens"], bench.N_SAMPLES, i["u"], 1.0, trace=tr, on_prefill_enqueued=side_work)
+    its = out["its"]
+    hb, pad = ops.tokens_to_histories(tokens, pipe.c["tok_vocab"], pipe.centers, pipe.past_dev)
+    e1 = torch.cuda.Event(enable_timing=True); e1.record()
+    main.wait_stream(pipe.side)
+    e2 = torch.cuda.Event(enable_timing=True); e2.record()
+    r = pipe.ver.score_histories(its, hb, bench.N_SAMPLES, pad=pad)
+    e3 = torch.cuda.Event(enable_timing=True); e3.record()
+    idx = int(r["result"][0])
+    torch.cuda.synchronize()
+    evs = [("t0", e0)] + tr["events"] + [("histories", e1), ("join_side", e2), ("verifier_tail", e3)]
+    for (n0, a), (n1, b) in zip(evs[:-1], evs[1:]):
+        acc[n1] = acc.get(n1, 0.0) + a.elapsed_time(b)
+    acc["total"] = acc.get("total", 0.0) + e0.elapsed_time(e3)
+print({k: round(v / R, 3) for k, v in acc.items()})
