@@ -127,15 +127,18 @@ __device__ __forceinline__ void epi_store4_glu(const EpiDev& e, void* C, int ldc
 // ---------------------------------------------------------------------------------------------------
 #define BK 64
 
-template <int WM, int WN, bool GLDS, int NST_ = 2>
-__global__ __launch_bounds__(256) void gemm_tiled(const bf16_t* __restrict__ A, int lda,
+template <int WM, int WN, bool GLDS, int NST_ = 2, int WGM = 2, int WGN = 2>
+__global__ __launch_bounds__(64 * WGM * WGN) void gemm_tiled(const bf16_t* __restrict__ A, int lda,
                                                   const bf16_t* __restrict__ Wp, void* C, int ldc, int M, int N,
                                                   int Kp, EpiDev epi, int tiles_m, int tiles_n, int kt_per,
                                                   float* __restrict__ partial) {
-    constexpr int BM_ = 2 * WM * 16, BN_ = 2 * WN * 16;
+    constexpr int NW = WGM * WGN;                // waves: a WGM x WGN grid of (WM*16) x (WN*16) wave tiles
+    constexpr int BM_ = WGM * WM * 16, BN_ = WGN * WN * 16;
     constexpr int A_BYTES = BM_ * BK * 2, B_BYTES = BN_ * BK * 2;
-    constexpr int AI = BM_ / 32, BI = BN_ / 32;  // 1-KiB staging instructions per wave per tile
-    constexpr int NST = GLDS ? NST_ : 2;         // LDS stages (3: one extra k-tile stays in flight across the barrier)
+    constexpr int AI = BM_ / (8 * NW), BI = BN_ / (8 * NW);  // 1-KiB staging instructions per wave per tile
+    constexpr int NST = GLDS ? NST_ : 2;         // LDS stages (NST - 1 k-tiles stay in flight across the barrier)
+    static_assert(BM_ % (8 * NW) == 0 && BN_ % (8 * NW) == 0, "tile rows must split evenly over the waves");
+    static_assert((NST - 2) * (AI + BI) <= 63, "counted vmcnt must fit its 6-bit field");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* As = smem;                   // [NST][A_BYTES]
     char* Bs = smem + NST * A_BYTES;   // [NST][B_BYTES]
@@ -154,7 +157,7 @@ __global__ __launch_bounds__(256) void gemm_tiled(const bf16_t* __restrict__ A, 
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = w >> 1, wn = w & 1;
+    const int wm = w / WGN, wn = w % WGN;
     const int K32 = Kp >> 5;
     const int N16 = (N + 15) >> 4;
     const int nk_total = Kp / BK;
@@ -237,17 +240,23 @@ __global__ __launch_bounds__(256) void gemm_tiled(const bf16_t* __restrict__ A, 
         // 3-stage ring, two k-tiles in flight: tile kt is waited for with a COUNTED vmcnt (the AI+BI loads of tile kt+1
         // stay outstanding across the barrier), a raw s_barrier publishes it, then tile kt+2 is issued into the stage
         // that compute(kt-1) has just released. __syncthreads() would drain vmcnt to 0 here.
-        if (NST == 3) {
-            stage_glds(0, 0);
-            if (nk > 1) stage_glds(1, 1);
+        if (NST >= 3) {
+            // NST-stage ring, NST-1 k-tiles in flight: tile kt is waited for with a COUNTED vmcnt (the loads of the younger
+            // tiles stay outstanding across the barrier), a raw s_barrier publishes it, then tile kt+NST-1 is issued
+            // into the stage that compute(kt-1) has just released. __syncthreads() would drain vmcnt to 0 here.
+#pragma unroll
+            for (int s = 0; s < NST - 1; ++s)
+                if (s < nk) stage_glds(s, s);
             int cur = 0;
             for (int kt = 0; kt < nk; ++kt) {
-                if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AI + BI) : "memory");
+                const int younger = nk - 1 - kt;   // tiles issued after kt that may stay in flight
+                if (NST >= 4 && younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (AI + BI)) : "memory");
+                else if (younger >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AI + BI) : "memory");
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
-                if (kt + 2 < nk) stage_glds(cur >= 1 ? cur - 1 : 2, kt + 2);  // stage (kt+2) % 3 == (kt-1) % 3
+                if (kt + NST - 1 < nk) stage_glds(cur == 0 ? NST - 1 : cur - 1, kt + NST - 1);  // stage (kt-1) % NST
                 compute(cur);
-                cur = cur == 2 ? 0 : cur + 1;
+                cur = cur == NST - 1 ? 0 : cur + 1;
             }
         } else {  // 2 stages: smaller LDS footprint -> one more resident block per CU (better when L2->LDS bandwidth-bound)
             stage_glds(0, 0);
@@ -438,9 +447,14 @@ __global__ __launch_bounds__(512) void gemm_skinny2(const bf16_t* __restrict__ A
         int nb = nb_begin + ng + NG * i;
         nb = nb < N16 ? nb : N16 - 1;
         const u32x4* src = (const u32x4*)(Wp + ((size_t)nb * K32 + ((k0 + kw0) >> 5)) * 512) + lane;
+        if (nsteps == 8) {   // whole k-slice: straight-line issue (per-load branches cost ~20 % of the stream rate)
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
-            if (u < nsteps) dst[u] = __builtin_nontemporal_load(src + u * 64);
+            for (int u = 0; u < 8; ++u) dst[u] = __builtin_nontemporal_load(src + u * 64);
+        } else {
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (u < nsteps) dst[u] = __builtin_nontemporal_load(src + u * 64);
+        }
     };
     load8(buf[0], 0);  // the first two weight blocks are in flight while the activation chunk is staged
     if (NBW > 1) load8(buf[1], 1);
@@ -457,17 +471,22 @@ __global__ __launch_bounds__(512) void gemm_skinny2(const bf16_t* __restrict__ A
     }
     __syncthreads();
     auto comp8 = [&](u32x4(&src)[8], f32x4(&a)[MF]) {
+        auto step = [&](int u) {
+            const bf16x8 wf = __builtin_bit_cast(bf16x8, src[u]);
+            const int kst = (kw0 >> 5) + u;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            if (u < nsteps) {
-                const bf16x8 wf = __builtin_bit_cast(bf16x8, src[u]);
-                const int kst = (kw0 >> 5) + u;
-#pragma unroll
-                for (int f = 0; f < MF; ++f) {
-                    const bf16x8 xf = as_bf16x8(*(const uint4*)(smem + ((kst * MF + f) * 64 + lane) * 16));
-                    a[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf, a[f], 0, 0, 0);
-                }
+            for (int f = 0; f < MF; ++f) {
+                const bf16x8 xf = as_bf16x8(*(const uint4*)(smem + ((kst * MF + f) * 64 + lane) * 16));
+                a[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf, a[f], 0, 0, 0);
             }
+        };
+        if (nsteps == 8) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) step(u);
+        } else {
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (u < nsteps) step(u);
         }
     };
 #pragma unroll
@@ -511,6 +530,183 @@ __global__ __launch_bounds__(512) void gemm_skinny2(const bf16_t* __restrict__ A
                 } else {
                     for (int e = 0; e < 4; ++e)
                         if (n + e < N) o[e] = v[e];
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Weight-streaming kernel, third generation (M <= 32): NO grid-level split-K. A block owns NG*NBW n-blocks for the WHOLE
+// K range, so the output leaves through the fused epilogue (bias / activation / GLU / residual, bf16 or fp32) and the
+// fp32 partial slabs plus the splitk_reduce launch disappear. The activation panel does not fit LDS at once
+// (32 x 4096 bf16 = 256 KiB): it is streamed in KC-wide chunks through a DOUBLE buffer -- the global loads of chunk c+1
+// are issued before chunk c's MFMAs and written to the other buffer after them, one barrier per chunk -- while the
+// weight stream (NBUF x 8 KiB per wave in flight, non-temporal) runs across chunk boundaries without draining.
+// Waves: NG n-groups x KS k-slices of 256 inside every chunk, accumulators live across chunks, KS-way LDS reduction at
+// the end as in the second generation. grid = ceil(N16 / (NG*NBW)).
+// ---------------------------------------------------------------------------------------------------
+template <int MF, int KS, int NBW, int NBUF>
+__global__ __launch_bounds__(512) void gemm_skinny3(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ Wp,
+                                                    void* C, int ldc, int M, int N, int Kp, EpiDev epi) {
+    constexpr int NG = 8 / KS, KC = 256 * KS, NBPB = NG * NBW;
+    constexpr int XB = MF * 16 * KC * 2;          // bytes of one activation chunk (fragment-major)
+    constexpr int XL = XB / (512 * 16);           // 16-B loads per thread per chunk
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][XB]; the reduction buffer aliases it at the end
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ks = w % KS, ng = w / KS;
+    const int K32 = Kp >> 5;
+    const int N16 = (N + 15) >> 4;
+    const int nb_begin = blockIdx.x * NBPB;
+    const int nchunks = (Kp + KC - 1) / KC;
+    const int kw0 = ks * 256;                     // this wave's k-slice inside every chunk
+    f32x4 acc[NBW][MF];
+#pragma unroll
+    for (int i = 0; i < NBW; ++i)
+#pragma unroll
+        for (int f = 0; f < MF; ++f) acc[i][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // weight stream: item t = (chunk c = t / NBW, n-block i = t % NBW) -> 8 x 1 KiB (this wave's 256 k of that chunk)
+    const int items = nchunks * NBW;
+    auto steps_of = [&](int c) { return max(0, min(8, (min(KC, Kp - c * KC) - kw0) >> 5)); };
+    u32x4 buf[NBUF][8];
+    auto load8 = [&](u32x4(&dst)[8], int t) {
+        const int c = t / NBW, i = t - c * NBW;
+        int nb = nb_begin + ng + NG * i;
+        nb = nb < N16 ? nb : N16 - 1;
+        const int nst = steps_of(c);
+        const u32x4* src = (const u32x4*)(Wp + ((size_t)nb * K32 + ((c * KC + kw0) >> 5)) * 512) + lane;
+        if (nst == 8) {   // whole k-slice (every chunk but a ragged last one): straight-line issue
+#pragma unroll
+            for (int u = 0; u < 8; ++u) dst[u] = __builtin_nontemporal_load(src + u * 64);
+        } else {
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (u < nst) dst[u] = __builtin_nontemporal_load(src + u * 64);
+        }
+    };
+    // activation chunk staging through registers (coalesced 16-B reads along k, fragment-major scatter into LDS)
+    uint4 xr[XL];
+    auto x_load = [&](int c) {
+        const int k0 = c * KC, kc = min(KC, Kp - k0);
+        constexpr int cpr = KC >> 3;
+#pragma unroll
+        for (int j = 0; j < XL; ++j) {
+            const int q = tid + j * 512;
+            const int row = q / cpr, kc8 = q - row * cpr;
+            xr[j] = make_uint4(0, 0, 0, 0);
+            if (row < M && kc8 * 8 < kc) xr[j] = *(const uint4*)(A + (size_t)row * lda + k0 + kc8 * 8);
+        }
+    };
+    auto x_write = [&](int b) {
+        constexpr int cpr = KC >> 3;
+#pragma unroll
+        for (int j = 0; j < XL; ++j) {
+            const int q = tid + j * 512;
+            const int row = q / cpr, kc8 = q - row * cpr;
+            const int kst = kc8 >> 2, gg = kc8 & 3, f = row >> 4, rr = row & 15;
+            *(uint4*)(smem + b * XB + (((kst * MF + f) * 64) + rr + 16 * gg) * 16) = xr[j];
+        }
+    };
+    auto comp8 = [&](u32x4(&src)[8], f32x4(&a)[MF], int c) {
+        const int nst = steps_of(c);
+        const char* xb = smem + (c & 1) * XB;
+        auto step = [&](int u) {
+            const bf16x8 wf = __builtin_bit_cast(bf16x8, src[u]);
+            const int kst = (kw0 >> 5) + u;
+#pragma unroll
+            for (int f = 0; f < MF; ++f) {
+                const bf16x8 xf = as_bf16x8(*(const uint4*)(xb + ((kst * MF + f) * 64 + lane) * 16));
+                a[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf, a[f], 0, 0, 0);
+            }
+        };
+        if (nst == 8) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) step(u);
+        } else {
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (u < nst) step(u);
+        }
+    };
+
+    // prologue: the first NBUF weight items are in flight while chunk 0 is staged
+#pragma unroll
+    for (int b = 0; b < NBUF; ++b)
+        if (b < items) load8(buf[b], b);
+    x_load(0);
+    x_write(0);
+    __syncthreads();
+    // main stream, unrolled by NBUF so that buffer indices are compile-time
+    int t = 0;
+    for (int c = 0; c < nchunks; ++c) {
+        if (c + 1 < nchunks) x_load(c + 1);            // lands underneath this chunk's weight stream
+#pragma unroll
+        for (int i = 0; i < NBW; ++i, ++t) {
+            // buffer of item t is t % NBUF; NBW % NBUF == 0 keeps it static per i
+            comp8(buf[i % NBUF], acc[i], c);
+            if (t + NBUF < items) load8(buf[i % NBUF], t + NBUF);
+        }
+        if (c + 1 < nchunks) {
+            x_write((c + 1) & 1);                      // the other buffer: nobody reads it during chunk c
+            // chunk c+1 visible, chunk c's buffer free for c+2. LDS-only barrier: __syncthreads() would also drain
+            // vmcnt, i.e. the NBUF weight items in flight, at every chunk boundary.
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+    }
+
+    // ---- sum the KS k-slices through LDS, RB n-blocks per round, and leave through the fused epilogue ----
+    constexpr int RB = (8 / MF) < NBW ? (8 / MF) : NBW;
+    const int r = lane & 15, g = lane >> 4;
+    float* red = (float*)smem;  // [w][ii][f][4][64]
+#pragma unroll
+    for (int i0 = 0; i0 < NBW; i0 += RB) {
+        __syncthreads();
+#pragma unroll
+        for (int ii = 0; ii < RB; ++ii)
+            if (i0 + ii < NBW) {
+#pragma unroll
+                for (int f = 0; f < MF; ++f)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) red[(((w * RB + ii) * MF + f) * 4 + e) * 64 + lane] = acc[(i0 + ii) < NBW ? (i0 + ii) : 0][f][e];
+            }
+        __syncthreads();
+        auto slice_sum = [&](int gsel, int ii, int f, float (&v)[4]) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = 0.f;
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk) {
+                const int ww = gsel * KS + kk;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] += red[(((ww * RB + ii) * MF + f) * 4 + e) * 64 + lane];
+            }
+        };
+        if (epi.glu) {   // n-groups 0 / 1 hold the gate / up block of one output block (NG == 2, even nb_begin)
+            constexpr int NFRAG = RB * MF;
+            for (int j = w; j < NFRAG; j += 8) {
+                const int f = j % MF, ii = j / MF;
+                if (i0 + ii >= NBW) continue;
+                const int nb = nb_begin + NG * (i0 + ii);   // gate block (even), up = nb + 1
+                const int m = f * 16 + r;
+                if (nb + 1 < N16 + (N16 & 1) && nb < N16 && m < M) {
+                    float gv[4], uv[4];
+                    slice_sum(0, ii, f, gv);
+                    slice_sum(1, ii, f, uv);
+                    epi_store4_glu(epi, C, ldc, m, (nb >> 1) * 16 + 4 * g, N >> 1, gv, uv);
+                }
+            }
+        } else {
+            constexpr int NFRAG = NG * RB * MF;
+            for (int j = w; j < NFRAG; j += 8) {
+                const int f = j % MF, ii = (j / MF) % RB, gsel = j / (MF * RB);
+                if (i0 + ii >= NBW) continue;
+                const int nb = nb_begin + gsel + NG * (i0 + ii);
+                const int m = f * 16 + r;
+                if (nb < N16 && m < M) {
+                    float v[4];
+                    slice_sum(gsel, ii, f, v);
+                    epi_store4(epi, C, ldc, m, nb * 16 + 4 * g, N, v);
                 }
             }
         }
@@ -745,6 +941,40 @@ hipError_t launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* Wp, void* C,
     const int Kp = (K + 127) / 128 * 128;
     EpiDev epi = make_epi(epi_in);
     if (variant == 0) variant = (M <= 64 && ws != nullptr) ? 3 : 1;
+    // Third generation (no split-K, fused epilogue): worth it when the n-blocks alone fill the chip with ONE block per CU
+    // (128 KiB of LDS), i.e. the wide MLP up-projection; narrower outputs keep the split-K kernel + reduction.
+    {
+        const int N16 = (N + 15) / 16;
+        static const char* g3 = getenv("COVER_SKINNY3");   // experiment knob: 0 disables, 1 forces where legal
+        const bool legal = M <= 32 && (N16 % 2) == 0 && Kp >= 2048;
+        const bool want = (N16 + 5) / 6 >= 200 && (N16 + 5) / 6 <= 256;
+        if ((variant == 3 && legal && want && !(g3 && g3[0] == '0')) || (variant == 3 && legal && g3 && g3[0] == '1') ||
+            (variant == 6 && legal)) {
+            const int MF = (M + 15) / 16;
+            const int gx = (N16 + 5) / 6;
+            const size_t lds = (size_t)2 * MF * 16 * 1024 * 2;
+            const int pid = prof_enabled() ? prof_open(st, 0, 2.0 * (double)N * (double)K) : -1;
+            hipError_t e = hipSuccess;
+#define SK3(MF_)                                                                                                             \
+    do {                                                                                                                    \
+        auto kfn = gemm_skinny3<MF_, 4, 3, 3>;                                                                              \
+        if (lds > 64 * 1024) {                                                                                              \
+            static hipError_t attr = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+            e = attr;                                                                                                       \
+        }                                                                                                                   \
+        if (e == hipSuccess) hipLaunchKernelGGL(kfn, dim3(gx), dim3(512), lds, st, A, lda, Wp, C, ldc, M, N, Kp, epi);      \
+    } while (0)
+            if (MF == 1) SK3(1); else SK3(2);
+#undef SK3
+            prof_close(st, pid);
+            if (e == hipSuccess) e = hipGetLastError();
+            if (e == hipSuccess && epi.norm_w != nullptr && epi.norm_out != nullptr)
+                e = launch_rmsnorm(C, 0, ldc, epi.norm_w, epi.norm_w_offset, epi.norm_style, epi.norm_out, epi.ld_norm_out, M,
+                                   epi.glu ? N / 2 : N, epi.norm_eps, st);
+            return e;
+        }
+        if (variant == 6) return hipErrorInvalidValue;
+    }
     if (variant == 3) {  // second-generation weight streaming (in-block k-slices)
         if (M > 64) return hipErrorInvalidValue;
         Skinny2Plan p = plan_skinny2(M, N, Kp);
@@ -808,22 +1038,33 @@ hipError_t launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* Wp, void* C,
         return e;
     }
     // ---- tile / split-K selection: fill >= ~1 block per CU when the problem allows it
-    struct Cand { int wm, wn; };
-    const Cand cands[3] = {{4, 4}, {2, 4}, {2, 2}};
+    // tile configurations: {wave tile (WM, WN) in 16-row units, wave grid, stages}
+    struct Cand { int wm, wn, wgm, wgn, nst; };
+    const Cand cands[7] = {
+        {4, 4, 2, 2, 2},   // 0: 128x128, 4 waves of 64x64, 2 stages (64 KiB)
+        {2, 4, 2, 2, 2},   // 1:  64x128, 4 waves of 32x64, 2 stages (48 KiB)
+        {2, 2, 2, 2, 3},   // 2:  64x64,  4 waves of 32x32, 3 stages (48 KiB)
+        {4, 4, 2, 2, 4},   // 3: 128x128, 4 waves, 4 stages (128 KiB, one block per CU, three k-tiles in flight)
+        {4, 4, 4, 2, 3},   // 4: 256x128, 8 waves of 64x64, 3 stages (144 KiB)
+        {4, 4, 2, 4, 3},   // 5: 128x256, 8 waves of 64x64, 3 stages (144 KiB)
+        {2, 4, 4, 2, 4},   // 6: 128x128, 8 waves of 32x64, 4 stages (128 KiB)
+    };
     // Measured on MI355X (tools/bench_kernels.py, M = 441): this single-barrier-per-k-tile structure is latency-bound per
     // block, so residency beats tile size until the tile grid oversubscribes the chip several times over, while 64x64
     // tiles on a wide N become L2-traffic-bound (the activation panel is re-read N/64 times).
     auto nblocks = [&](int c) {
-        const int bm_ = cands[c].wm * 32, bn_ = cands[c].wn * 32;
+        const int bm_ = cands[c].wm * cands[c].wgm * 16, bn_ = cands[c].wn * cands[c].wgn * 16;
         return (long long)((M + bm_ - 1) / bm_) * ((N + bn_ - 1) / bn_);
     };
     int pick = 0;
     if (nblocks(0) < 1024) pick = (nblocks(1) >= 384) ? 1 : 2;
     {
-        static const char* force = getenv("COVER_TILE_PICK");  // experiment knob: 0 = 128x128, 1 = 64x128, 2 = 64x64
-        if (force && force[0] >= '0' && force[0] <= '2') pick = force[0] - '0';
+        static const char* force = getenv("COVER_TILE_PICK");  // experiment knob: index into cands
+        if (force && force[0] >= '0' && force[0] <= '6') pick = force[0] - '0';
     }
-    const int bm = cands[pick].wm * 32, bn = cands[pick].wn * 32;
+    if (variant == 2 && pick > 2) pick = 0;
+    const Cand cd = cands[pick];
+    const int bm = cd.wm * cd.wgm * 16, bn = cd.wn * cd.wgn * 16;
     const int tiles_m = (M + bm - 1) / bm, tiles_n = (N + bn - 1) / bn;
     const int nk_total = Kp / BK;
     int S = 1;
@@ -836,29 +1077,40 @@ hipError_t launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* Wp, void* C,
     S = (nk_total + kt_per - 1) / kt_per;
     float* partial = S > 1 ? ws : nullptr;
     // stages: measured at M = 441 (tools/bench_kernels.py): the 64x64 tile gains 40-55 % from a third stage (48 KiB, still
-    // 3 blocks/CU); 64x128 and 128x128 are L2->LDS bandwidth-bound (~12.8 TB/s => 42.7 / 64 FLOP per byte) and lose more
-    // from the residency a third stage costs than they gain from it.
-    const int nst = (variant != 2 && pick == 2) ? 3 : 2;
+    // 3 blocks/CU); 64x128 and 128x128 are bound by the bytes a CU keeps in flight (LDS capacity x resident blocks) over
+    // the load latency (~12.8 TB/s chip-wide at 2 stages => 42.7 / 64 FLOP per byte).
+    const int nst = variant == 2 ? 2 : cd.nst;
     const size_t lds = (size_t)nst * (bm + bn) * BK * 2;
-    dim3 grid(tiles_m * tiles_n, S), block(256);
+    dim3 grid(tiles_m * tiles_n, S), block(64 * cd.wgm * cd.wgn);
     const int pid = prof_enabled() ? prof_open(st, 1, 2.0 * (double)M * (double)N * (double)K) : -1;
-#define LAUNCH_TILED(WM_, WN_)                                                                                              \
+    hipError_t e = hipSuccess;
+#define LAUNCH_T(WM_, WN_, G_, NST_, WGM_, WGN_)                                                                            \
     do {                                                                                                                    \
-        if (variant == 2)                                                                                                   \
-            hipLaunchKernelGGL((gemm_tiled<WM_, WN_, false>), grid, block, lds, st, A, lda, Wp, C, ldc, M, N, Kp, epi, tiles_m, \
-                               tiles_n, kt_per, partial);                                                                   \
-        else if (nst == 3)                                                                                                  \
-            hipLaunchKernelGGL((gemm_tiled<WM_, WN_, true, 3>), grid, block, lds, st, A, lda, Wp, C, ldc, M, N, Kp, epi, tiles_m, \
-                               tiles_n, kt_per, partial);                                                                   \
-        else                                                                                                                \
-            hipLaunchKernelGGL((gemm_tiled<WM_, WN_, true, 2>), grid, block, lds, st, A, lda, Wp, C, ldc, M, N, Kp, epi, tiles_m, \
-                               tiles_n, kt_per, partial);                                                                   \
+        auto kfn = gemm_tiled<WM_, WN_, G_, NST_, WGM_, WGN_>;                                                              \
+        if (lds > 64 * 1024) {                                                                                              \
+            static hipError_t attr = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+            e = attr;                                                                                                       \
+        }                                                                                                                   \
+        if (e == hipSuccess)                                                                                                \
+            hipLaunchKernelGGL(kfn, grid, block, lds, st, A, lda, Wp, C, ldc, M, N, Kp, epi, tiles_m, tiles_n, kt_per, partial); \
     } while (0)
-    if (pick == 0) LAUNCH_TILED(4, 4);
-    else if (pick == 1) LAUNCH_TILED(2, 4);
-    else LAUNCH_TILED(2, 2);
-#undef LAUNCH_TILED
-    hipError_t e = hipGetLastError();
+    if (variant == 2) {
+        if (pick == 0) LAUNCH_T(4, 4, false, 2, 2, 2);
+        else if (pick == 1) LAUNCH_T(2, 4, false, 2, 2, 2);
+        else LAUNCH_T(2, 2, false, 2, 2, 2);
+    } else {
+        switch (pick) {
+            case 0: LAUNCH_T(4, 4, true, 2, 2, 2); break;
+            case 1: LAUNCH_T(2, 4, true, 2, 2, 2); break;
+            case 2: LAUNCH_T(2, 2, true, 3, 2, 2); break;
+            case 3: LAUNCH_T(4, 4, true, 4, 2, 2); break;
+            case 4: LAUNCH_T(4, 4, true, 3, 4, 2); break;
+            case 5: LAUNCH_T(4, 4, true, 3, 2, 4); break;
+            default: LAUNCH_T(2, 4, true, 4, 4, 2); break;
+        }
+    }
+#undef LAUNCH_T
+    if (e == hipSuccess) e = hipGetLastError();
     if (e == hipSuccess && S > 1) {
         const int Nout = epi.glu ? N / 2 : N;
         const long long total = (long long)M * ((Nout + 3) / 4);

@@ -72,6 +72,30 @@ def test_gemm_skinny(dev, variant, M, N, K):
     assert torch.allclose(out32.cpu(), bf(ref).float(), atol=0.05, rtol=2e-2)
 
 
+@pytest.mark.parametrize("M", [1, 16, 27, 32])
+@pytest.mark.parametrize("N,K,glu", [(768, 2048, False), (1536, 4096, True), (416, 2176, True), (22016, 4096, True)])
+def test_gemm_skinny_full_k_fused_epilogue(dev, M, N, K, glu):
+    # third-generation weight streaming (variant 6): no split-K slabs, bias / activation / GLU / residual in the kernel
+    g = torch.Generator().manual_seed(M * 13 + N + K)
+    w = bf(torch.randn(N, K, generator=g) * 0.05)
+    a = bf(torch.randn(M, K, generator=g))
+    n_out = N // 2 if glu else N
+    bias = torch.randn(N, generator=g) * 0.1
+    res = bf(torch.randn(M, n_out, generator=g))
+    if glu:
+        bias = torch.zeros(N)   # the GLU epilogue has no bias term (Llama / Gemma MLPs)
+    lin = ops.pack_linear(w.to(dev), None if glu else bias.to(dev), glu=glu)
+    kw = dict(act="silu") if glu else dict(act="gelu_tanh", residual=res.to(dev))
+    out = ops.gemm(a.to(dev), lin, variant=6, **kw)
+    y = a.float() @ w.float().T + bias
+    ref = torch.nn.functional.silu(y[:, :n_out]) * y[:, n_out:] if glu else torch.nn.functional.gelu(y, approximate="tanh") + res.float()
+    assert out.shape == (M, n_out)
+    assert rel_l2(out, ref) < 6e-3
+    # and it agrees with the split-K generation up to the bf16 rounding of differently ordered fp32 sums
+    out3 = ops.gemm(a.to(dev), lin, variant=3, **kw)
+    assert rel_l2(out, out3.float().cpu()) < 4e-3
+
+
 @pytest.mark.parametrize("variant,M", [(1, 150), (2, 150), (3, 32)])
 @pytest.mark.parametrize("act", ["gelu_tanh", "gelu_erf", "silu", "relu"])
 def test_gemm_epilogues(dev, variant, M, act):
