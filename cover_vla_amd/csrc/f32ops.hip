@@ -11,8 +11,7 @@
 // Tile = TM x TN (64x64 or 32x32), BK = 32, 4 waves (2x2), each wave (TM/32)x(TN/32) MFMA fragments. The next k-tile is
 // fetched into registers while the current one is multiplied (these GEMMs have tiny grids, so nothing else hides the
 // global-load latency).
-#define FK 32
-template <int TM, int TN>
+template <int TM, int TN, int FK>
 __global__ __launch_bounds__(256) void gemm_f32_k(cover_gemm_f32_args a) {
     constexpr int FM = TM / 32, FN = TN / 32;
     constexpr int EA = TM * FK / 256, EB = TN * FK / 256;  // elements per thread per tile
@@ -93,16 +92,122 @@ __global__ __launch_bounds__(256) void gemm_f32_k(cover_gemm_f32_args a) {
                 }
             }
 }
+// Small-grid variant for k-contiguous operands (every nn.Linear of the verifier heads): no LDS staging and no barrier in
+// the k loop. A block owns a (16*FM) x 32 output tile, its 4 waves split K in interleaved 16-wide steps and keep UNR steps
+// of 16-byte loads in flight each; lane (r, g) loads k = 16s + 4g .. 4g+3 of its row, and the j-th of four MFMAs per step
+// takes component j from both operands (the 16x16x4 MFMA sums over the four lane groups, so any k <-> (g, j) bijection
+// that is the same for A and B is valid). The four partial tiles meet in LDS and leave through the usual epilogue.
+template <int FM>
+__global__ __launch_bounds__(256) void gemm_f32_direct_k(cover_gemm_f32_args a) {
+    constexpr int UNR = 4;
+    __shared__ float red[4][FM * 2][4][64];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 15, g = lane >> 4;
+    const int m0 = blockIdx.y * (16 * FM), n0 = blockIdx.x * 32;
+    const int bz = blockIdx.z;
+    const float* A = a.A + (size_t)bz * a.a_batch_stride;
+    const float* B = a.B + (size_t)bz * a.b_batch_stride;
+    float* C = a.C + (size_t)bz * a.c_batch_stride;
+    const float* ap[FM];
+    const float* bp[2];
+#pragma unroll
+    for (int f = 0; f < FM; ++f) {
+        int m = m0 + f * 16 + r;
+        m = m < a.M ? m : a.M - 1;
+        ap[f] = A + (size_t)m * a.a_row_stride + 4 * g;
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        int n = n0 + j * 16 + r;
+        n = n < a.N ? n : a.N - 1;
+        bp[j] = B + (size_t)n * a.b_row_stride + 4 * g;
+    }
+    f32x4 acc[FM][2];
+#pragma unroll
+    for (int f = 0; f < FM; ++f)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[f][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int nsteps = a.K >> 4;
+    for (int s0 = w; s0 < nsteps; s0 += 4 * UNR) {
+        float4 av[UNR][FM], bv[UNR][2];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int s = s0 + 4 * u;
+            const int ko = (s < nsteps ? s : s0) * 16;   // out-of-range steps re-read a valid one and are skipped below
+#pragma unroll
+            for (int f = 0; f < FM; ++f) av[u][f] = *(const float4*)(ap[f] + ko);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bv[u][j] = *(const float4*)(bp[j] + ko);
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            if (s0 + 4 * u < nsteps) {
+#pragma unroll
+                for (int f = 0; f < FM; ++f)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        acc[f][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][f].x, bv[u][j].x, acc[f][j], 0, 0, 0);
+                        acc[f][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][f].y, bv[u][j].y, acc[f][j], 0, 0, 0);
+                        acc[f][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][f].z, bv[u][j].z, acc[f][j], 0, 0, 0);
+                        acc[f][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][f].w, bv[u][j].w, acc[f][j], 0, 0, 0);
+                    }
+            }
+        }
+    }
+#pragma unroll
+    for (int f = 0; f < FM; ++f)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) red[w][f * 2 + j][e][lane] = acc[f][j][e];
+    __syncthreads();
+    // D[row = 4g + e][col = r]; thread (e = tid >> 6, lane) finishes element e of every fragment
+    const int e = tid >> 6;
+#pragma unroll
+    for (int q = 0; q < FM * 2; ++q) {
+        float v = red[0][q][e][lane] + red[1][q][e][lane];
+        v += red[2][q][e][lane];
+        v += red[3][q][e][lane];
+        const int m = m0 + (q >> 1) * 16 + 4 * g + e;
+        const int n = n0 + (q & 1) * 16 + r;
+        if (m < a.M && n < a.N) {
+            if (a.bias) v += a.bias[n];
+            v = act_apply(v, a.act);
+            v *= a.alpha;
+            if (a.residual) v += a.residual[(size_t)bz * a.c_batch_stride + (size_t)m * a.ld_residual + n];
+            C[(size_t)m * a.c_row_stride + n] = v;
+        }
+    }
+}
+
 hipError_t launch_gemm_f32(const cover_gemm_f32_args* a, hipStream_t st) {
     if (a->M <= 0 || a->N <= 0) return hipSuccess;
     const int nb = a->batch > 0 ? a->batch : 1;
     const long long blocks64 = (long long)((a->N + 63) / 64) * ((a->M + 63) / 64) * nb;
+    const bool k_contig = a->a_k_stride == 1 && a->b_k_stride == 1 && (a->K & 15) == 0 && a->K >= 64 && (a->a_row_stride & 3) == 0 &&
+                          (a->b_row_stride & 3) == 0 && (a->a_batch_stride & 3) == 0 && (a->b_batch_stride & 3) == 0 &&
+                          (((uintptr_t)a->A | (uintptr_t)a->B) & 15) == 0;
+    if (k_contig && blocks64 < 1024) {
+        if (a->M <= 16) {
+            dim3 grid((a->N + 31) / 32, (a->M + 15) / 16, nb);
+            hipLaunchKernelGGL(gemm_f32_direct_k<1>, grid, dim3(256), 0, st, *a);
+        } else {
+            dim3 grid((a->N + 31) / 32, (a->M + 31) / 32, nb);
+            hipLaunchKernelGGL(gemm_f32_direct_k<2>, grid, dim3(256), 0, st, *a);
+        }
+        return hipGetLastError();
+    }
     if (blocks64 >= 256) {
         dim3 grid((a->N + 63) / 64, (a->M + 63) / 64, nb);
-        hipLaunchKernelGGL((gemm_f32_k<64, 64>), grid, dim3(256), 0, st, *a);
+        hipLaunchKernelGGL((gemm_f32_k<64, 64, 32>), grid, dim3(256), 0, st, *a);
+    } else if (a->K >= 256) {
+        // small grids are bound by one global-load latency per k-step: a 128-deep step puts 4x the loads in flight
+        dim3 grid((a->N + 31) / 32, (a->M + 31) / 32, nb);
+        hipLaunchKernelGGL((gemm_f32_k<32, 32, 128>), grid, dim3(256), 0, st, *a);
     } else {
         dim3 grid((a->N + 31) / 32, (a->M + 31) / 32, nb);
-        hipLaunchKernelGGL((gemm_f32_k<32, 32>), grid, dim3(256), 0, st, *a);
+        hipLaunchKernelGGL((gemm_f32_k<32, 32, 32>), grid, dim3(256), 0, st, *a);
     }
     return hipGetLastError();
 }

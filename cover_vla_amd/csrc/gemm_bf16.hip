@@ -1057,6 +1057,8 @@ hipError_t launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* Wp, void* C,
         return (long long)((M + bm_ - 1) / bm_) * ((N + bn_ - 1) / bn_);
     };
     int pick = 0;
+    // (tools/exp_tiles.py re-reads one weight matrix, i.e. measures Infinity-Cache-warm: there 128x128 wins already at 688
+    // tiles (N = 22016, M = 449); inside the decision, with cold weights, it does not -- 137 vs ~130 us -- so 1024 stays)
     if (nblocks(0) < 1024) pick = (nblocks(1) >= 384) ? 1 : 2;
     {
         static const char* force = getenv("COVER_TILE_PICK");  // experiment knob: index into cands
