@@ -254,7 +254,7 @@ def main():
         pass
     if cnt[0] > 0 and ms[0] > 0:
         ach = work[0] / (ms[0] * 1e-3) / 1e9
-        out["roofline"] = {"bound": "hbm", "kernel": "gemm_skinny (weight-streaming GEMM of the decode passes) + splitk_reduce",
+        out["roofline"] = {"bound": "hbm", "kernel": "gemm_skinny2 / gemm_skinny3 (weight-streaming GEMMs of the decode passes, M = 32)",
                            "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                            "traffic": traffic, "algorithmic_bytes_per_launch": round(work[0] / cnt[0]), "launches": int(cnt[0]), "avg_launch_us": round(1e3 * ms[0] / cnt[0], 2),
                            "algorithmic_bytes_per_decision": work[0], "kernel_ms_per_decision": round(ms[0], 3)}
