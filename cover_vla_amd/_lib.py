@@ -31,7 +31,7 @@ class GemmEpi(C.Structure):
     _fields_ = [("bias", c_p), ("residual", c_p), ("layer_scale", c_p), ("ld_residual", c_i), ("residual_f32", c_i),
                 ("act", c_i), ("glu", c_i), ("out_f32", c_i), ("out_scale", c_f),
                 ("norm_w", c_p), ("norm_out", c_p), ("ld_norm_out", c_i), ("norm_style", c_i), ("norm_w_offset", c_f),
-                ("norm_eps", c_f)]
+                ("norm_eps", c_f), ("norm_b", c_p)]
 
 
 class KvSegment(C.Structure):

@@ -248,9 +248,11 @@ int cover_vit_forward(const cover_vit_desc* d, void* x, int n_seq, int T, void* 
     // the transposed-V scratch must be finite where keys >= T are read under a zero probability
     if (tcap != T) HIPCHK(hipMemsetAsync(vt, 0, (size_t)n_seq * HD * tcap * 2, st), "memset vt");
 
+    // ln1 of layer 0 is its own launch; every later LayerNorm rides on the GEMM that produces its input (folded into the
+    // split-K reduction whenever that GEMM splits K, which the dim-wide outputs of ViT-sized problems do)
+    HIPCHK(launch_layernorm_bf16((const bf16_t*)x, dim, d->layers_host[0].ln1_w, d->layers_host[0].ln1_b, (bf16_t*)h, dim, R, dim, d->ln_eps, st), "vit ln1");
     for (int l = 0; l < d->n_layers; ++l) {
         const cover_vit_layer& L = d->layers_host[l];
-        HIPCHK(launch_layernorm_bf16((const bf16_t*)x, dim, L.ln1_w, L.ln1_b, (bf16_t*)h, dim, R, dim, d->ln_eps, st), "vit ln1");
         cover_gemm_epi e;
         memset(&e, 0, sizeof e);
         e.out_scale = 1.0f;
@@ -279,8 +281,8 @@ int cover_vit_forward(const cover_vit_desc* d, void* x, int n_seq, int T, void* 
             break;
         }
         e.residual = x; e.ld_residual = dim; e.layer_scale = L.ls1;
-        HIPCHK(launch_gemm_bf16((const bf16_t*)attn, HD, (const bf16_t*)L.proj_w, x, dim, R, dim, HD, &e, (float*)sk, skb, variant, st), "vit proj");
-        HIPCHK(launch_layernorm_bf16((const bf16_t*)x, dim, L.ln2_w, L.ln2_b, (bf16_t*)h, dim, R, dim, d->ln_eps, st), "vit ln2");
+        e.norm_w = L.ln2_w; e.norm_b = L.ln2_b; e.norm_out = h; e.ld_norm_out = dim; e.norm_style = 2; e.norm_eps = d->ln_eps;
+        HIPCHK(launch_gemm_bf16((const bf16_t*)attn, HD, (const bf16_t*)L.proj_w, x, dim, R, dim, HD, &e, (float*)sk, skb, variant, st), "vit proj (+ln2)");
         memset(&e, 0, sizeof e);
         e.out_scale = 1.0f;
         e.bias = L.fc1_b; e.act = d->act;
@@ -288,7 +290,11 @@ int cover_vit_forward(const cover_vit_desc* d, void* x, int n_seq, int T, void* 
         memset(&e, 0, sizeof e);
         e.out_scale = 1.0f;
         e.bias = L.fc2_b; e.residual = x; e.ld_residual = dim; e.layer_scale = L.ls2;
-        HIPCHK(launch_gemm_bf16((const bf16_t*)mlp, d->mlp_p, (const bf16_t*)L.fc2_w, x, dim, R, dim, d->mlp_p, &e, (float*)sk, skb, variant, st), "vit fc2");
+        if (l + 1 < d->n_layers) {
+            const cover_vit_layer& Ln = d->layers_host[l + 1];
+            e.norm_w = Ln.ln1_w; e.norm_b = Ln.ln1_b; e.norm_out = h; e.ld_norm_out = dim; e.norm_style = 2; e.norm_eps = d->ln_eps;
+        }
+        HIPCHK(launch_gemm_bf16((const bf16_t*)mlp, d->mlp_p, (const bf16_t*)L.fc2_w, x, dim, R, dim, d->mlp_p, &e, (float*)sk, skb, variant, st), "vit fc2 (+next ln1)");
     }
     return COVER_OK;
 }

@@ -25,6 +25,7 @@ struct EpiDev {
     int ldr, res_f32, act, glu, out_f32;
     float out_scale;
     const float* norm_w;
+    const float* norm_b;
     bf16_t* norm_out;
     int ld_norm_out, norm_style;
     float norm_w_offset, norm_eps;
@@ -749,9 +750,9 @@ __global__ __launch_bounds__(256) void splitk_reduce(const float* __restrict__ p
     }
 }
 
-// out = epi(sum_s partial[s]) AND norm_out = rmsnorm(out): one 256-thread block per output row (N % 8 == 0, N <= 8192,
-// no GLU, bf16 output). The sum of squares is taken over the bf16-ROUNDED outputs, i.e. exactly what the separate
-// rmsnorm kernel would read back.
+// out = epi(sum_s partial[s]) AND norm_out = rmsnorm(out) / layernorm(out): one 512-thread block per output row
+// (N % 8 == 0, N <= 8192, no GLU, bf16 output). The statistics are taken over the bf16-ROUNDED outputs, i.e. exactly what
+// the separate norm kernel would read back, with that kernel's arithmetic.
 __global__ __launch_bounds__(512) void splitk_reduce_norm(const float* __restrict__ partial, int S, bf16_t* C, int ldc, int M,
                                                           int N, EpiDev epi) {
     __shared__ float red[16];
@@ -795,7 +796,28 @@ __global__ __launch_bounds__(512) void splitk_reduce_norm(const float* __restric
             }
         }
     }
-    const float rstd = rsqrtf(block_sum(q, red) / N + epi.norm_eps);
+    float mean = 0.f, rstd;
+    if (epi.norm_style == 2) {   // LayerNorm (layernorm_bf16_k arithmetic: mean, then the centred second moment)
+        float sum = 0.f;
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+            if ((int)(threadIdx.x + c * 512) * 8 < N)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) sum += vals[c][i];
+        mean = block_sum(sum, red) / N;
+        float q2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+            if ((int)(threadIdx.x + c * 512) * 8 < N)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float d = vals[c][i] - mean;
+                    q2 += d * d;
+                }
+        rstd = rsqrtf(block_sum(q2, red) / N + epi.norm_eps);
+    } else {
+        rstd = rsqrtf(block_sum(q, red) / N + epi.norm_eps);
+    }
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
         const int n0 = (threadIdx.x + c * 512) * 8;
@@ -804,7 +826,8 @@ __global__ __launch_bounds__(512) void splitk_reduce_norm(const float* __restric
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const float ww = epi.norm_w[n0 + i];
-                o[i] = epi.norm_style == 1 ? ww * bfround(vals[c][i] * rstd) : vals[c][i] * rstd * (epi.norm_w_offset + ww);
+                if (epi.norm_style == 2) o[i] = (vals[c][i] - mean) * rstd * ww + (epi.norm_b ? epi.norm_b[n0 + i] : 0.f);
+                else o[i] = epi.norm_style == 1 ? ww * bfround(vals[c][i] * rstd) : vals[c][i] * rstd * (epi.norm_w_offset + ww);
             }
             uint4 u;
             u.x = pack_bf2(o[0], o[1]); u.y = pack_bf2(o[2], o[3]); u.z = pack_bf2(o[4], o[5]); u.w = pack_bf2(o[6], o[7]);
@@ -858,6 +881,7 @@ static EpiDev make_epi(const cover_gemm_epi* e) {
     d.out_scale = e ? e->out_scale : 1.0f;
     if (d.out_scale == 0.0f) d.out_scale = 1.0f;
     d.norm_w = e ? e->norm_w : nullptr;
+    d.norm_b = e ? e->norm_b : nullptr;
     d.norm_out = e ? (bf16_t*)e->norm_out : nullptr;
     d.ld_norm_out = e ? e->ld_norm_out : 0;
     d.norm_style = e ? e->norm_style : 0;
@@ -935,6 +959,13 @@ size_t gemm_workspace_bytes(int M, int N, int K) {
     return a > b ? a : b;
 }
 
+// the norm requested through the epilogue, as its own launch (paths that cannot fold it into a split-K reduction)
+static hipError_t run_norm(const EpiDev& epi, void* C, int ldc, int M, int Nout, hipStream_t st) {
+    if (epi.norm_style == 2)
+        return launch_layernorm_bf16((const bf16_t*)C, ldc, epi.norm_w, epi.norm_b, epi.norm_out, epi.ld_norm_out, M, Nout, epi.norm_eps, st);
+    return launch_rmsnorm(C, 0, ldc, epi.norm_w, epi.norm_w_offset, epi.norm_style, epi.norm_out, epi.ld_norm_out, M, Nout, epi.norm_eps, st);
+}
+
 hipError_t launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* Wp, void* C, int ldc, int M, int N, int K,
                             const cover_gemm_epi* epi_in, float* ws, size_t ws_bytes, int variant, hipStream_t st) {
     if (M <= 0 || N <= 0) return hipSuccess;
@@ -969,8 +1000,7 @@ hipError_t launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* Wp, void* C,
             prof_close(st, pid);
             if (e == hipSuccess) e = hipGetLastError();
             if (e == hipSuccess && epi.norm_w != nullptr && epi.norm_out != nullptr)
-                e = launch_rmsnorm(C, 0, ldc, epi.norm_w, epi.norm_w_offset, epi.norm_style, epi.norm_out, epi.ld_norm_out, M,
-                                   epi.glu ? N / 2 : N, epi.norm_eps, st);
+                e = run_norm(epi, C, ldc, M, epi.glu ? N / 2 : N, st);
             return e;
         }
         if (variant == 6) return hipErrorInvalidValue;
@@ -1002,8 +1032,7 @@ hipError_t launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* Wp, void* C,
         hipLaunchKernelGGL(splitk_reduce, dim3(rb), dim3(256), 0, st, (const float*)ws, p.S, C, ldc, M, N, epi);
         e = hipGetLastError();
         if (e == hipSuccess && want_norm)
-            e = launch_rmsnorm(C, 0, ldc, epi.norm_w, epi.norm_w_offset, epi.norm_style, epi.norm_out, epi.ld_norm_out, M,
-                               epi.glu ? N / 2 : N, epi.norm_eps, st);
+            e = run_norm(epi, C, ldc, M, epi.glu ? N / 2 : N, st);
         return e;
     }
     if (variant == 5) {  // first-generation weight streaming (grid-level split-K only), kept for A/B measurements
@@ -1033,8 +1062,7 @@ hipError_t launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* Wp, void* C,
         hipLaunchKernelGGL(splitk_reduce, dim3(rb), dim3(256), 0, st, (const float*)ws, p.S, C, ldc, M, N, epi);
         e = hipGetLastError();
         if (e == hipSuccess && want_norm)
-            e = launch_rmsnorm(C, 0, ldc, epi.norm_w, epi.norm_w_offset, epi.norm_style, epi.norm_out, epi.ld_norm_out, M,
-                               epi.glu ? N / 2 : N, epi.norm_eps, st);
+            e = run_norm(epi, C, ldc, M, epi.glu ? N / 2 : N, st);
         return e;
     }
     // ---- tile / split-K selection: fill >= ~1 block per CU when the problem allows it
@@ -1113,18 +1141,24 @@ hipError_t launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* Wp, void* C,
     }
 #undef LAUNCH_T
     if (e == hipSuccess) e = hipGetLastError();
+    bool norm_done = false;
     if (e == hipSuccess && S > 1) {
-        const int Nout = epi.glu ? N / 2 : N;
-        const long long total = (long long)M * ((Nout + 3) / 4);
-        int rb = (int)((total + 255) / 256);
-        if (rb > 2048) rb = 2048;
-        hipLaunchKernelGGL(splitk_reduce, dim3(rb), dim3(256), 0, st, (const float*)ws, S, C, ldc, M, N, epi);
+        const bool want_norm = epi.norm_w != nullptr && epi.norm_out != nullptr;
+        if (want_norm && !epi.glu && !epi.out_f32 && (N % 8) == 0 && N <= 8192 && (ldc % 8) == 0 && (epi.ld_norm_out % 8) == 0) {
+            hipLaunchKernelGGL(splitk_reduce_norm, dim3(M), dim3(512), 0, st, (const float*)ws, S, (bf16_t*)C, ldc, M, N, epi);
+            norm_done = true;
+        } else {
+            const int Nout = epi.glu ? N / 2 : N;
+            const long long total = (long long)M * ((Nout + 3) / 4);
+            int rb = (int)((total + 255) / 256);
+            if (rb > 2048) rb = 2048;
+            hipLaunchKernelGGL(splitk_reduce, dim3(rb), dim3(256), 0, st, (const float*)ws, S, C, ldc, M, N, epi);
+        }
         e = hipGetLastError();
     }
     prof_close(st, pid);
-    if (e == hipSuccess && epi.norm_w != nullptr && epi.norm_out != nullptr)
-        e = launch_rmsnorm(C, 0, ldc, epi.norm_w, epi.norm_w_offset, epi.norm_style, epi.norm_out, epi.ld_norm_out, M,
-                           epi.glu ? N / 2 : N, epi.norm_eps, st);
+    if (e == hipSuccess && !norm_done && epi.norm_w != nullptr && epi.norm_out != nullptr)
+        e = run_norm(epi, C, ldc, M, epi.glu ? N / 2 : N, st);
     return e;
 }
 

@@ -71,7 +71,8 @@ def gemm_workspace(M: int, N: int, K: int, device) -> Optional[torch.Tensor]:
 def gemm(a: torch.Tensor, lin: PackedLinear, *, act: str = "none", residual: Optional[torch.Tensor] = None,
          layer_scale: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, out_f32: bool = False,
          out_scale: float = 1.0, variant: int = 0, ws: Optional[torch.Tensor] = None, norm_w: Optional[torch.Tensor] = None,
-         norm_out: Optional[torch.Tensor] = None, norm_style: int = 0, norm_w_offset: float = 0.0, norm_eps: float = 1e-6
+         norm_out: Optional[torch.Tensor] = None, norm_style: int = 0, norm_w_offset: float = 0.0, norm_eps: float = 1e-6,
+         norm_b: Optional[torch.Tensor] = None
          ) -> torch.Tensor:
     """out[M, n_out] = epi(a[M, K] @ W^T). `a` is bf16 with row stride >= padded K (zero padded)."""
     _chk_dev(a, residual, out)
@@ -93,6 +94,7 @@ def gemm(a: torch.Tensor, lin: PackedLinear, *, act: str = "none", residual: Opt
     if norm_w is not None:
         e.norm_w, e.norm_out, e.ld_norm_out = norm_w.data_ptr(), norm_out.data_ptr(), norm_out.stride(0)
         e.norm_style, e.norm_w_offset, e.norm_eps = norm_style, norm_w_offset, norm_eps
+        e.norm_b = _ptr(norm_b)
     if ws is None:
         ws = gemm_workspace(M, lin.N, lin.K, a.device)   # None when this shape needs no split-K scratch
     L.check(h.cover_gemm_bf16(a.data_ptr(), a.stride(0), lin.wp.data_ptr(), out.data_ptr(), out.stride(0), M, lin.N,

@@ -60,15 +60,16 @@ typedef struct cover_gemm_epi {
                                  out[m, j] = act(gate[m, j]) * up[m, j], output has N/2 columns */
     int out_f32;              /* 0: bf16 output, 1: fp32 output */
     float out_scale;          /* final multiply (1.0f = none) */
-    /* Optional fused RMSNorm of the (bf16) output rows into a second tensor: norm_out = rmsnorm(C) exactly as
-     * cover_rmsnorm_bf16 computes it from the stored bf16 C. On the weight-streaming path it is folded into the split-K
-     * reduction (one launch less per GEMM); on the LDS-tiled path the library runs the norm kernel after the GEMM. */
+    /* Optional fused RMSNorm / LayerNorm of the (bf16) output rows into a second tensor: norm_out = norm(C) exactly as
+     * cover_rmsnorm_bf16 / cover_layernorm_bf16 compute it from the stored bf16 C. Whenever the GEMM runs split-K it is
+     * folded into the reduction (one launch less per GEMM); otherwise the library runs the norm kernel after the GEMM. */
     const float* norm_w;      /* [N] or NULL = no fused norm */
     void* norm_out;           /* bf16 [M, ld_norm_out] */
     int ld_norm_out;
-    int norm_style;           /* cover_rmsnorm_bf16 style */
+    int norm_style;           /* cover_rmsnorm_bf16 style (0 Gemma, 1 Llama), or 2 = LayerNorm as cover_layernorm_bf16 computes it */
     float norm_w_offset;
     float norm_eps;
+    const float* norm_b;      /* [N] LayerNorm bias (norm_style 2) or NULL */
 } cover_gemm_epi;
 
 /* bytes needed for the packed form of an [N, K] weight (K padded to a multiple of 128, N to 16) */

@@ -493,6 +493,31 @@ def test_gemm_fused_rmsnorm(dev, variant, M, style):
     assert torch.allclose(h.float().cpu(), ref_h.float(), atol=2e-2, rtol=1e-2)
 
 
+@pytest.mark.parametrize("M,N,K", [(257, 1024, 4096), (150, 1152, 1152), (300, 4096, 1024), (32, 1024, 512)])
+def test_gemm_fused_layernorm(dev, M, N, K):
+    # out = residual + ls * (A W^T + b) ; norm_out = LayerNorm(out) with the arithmetic of cover_layernorm_bf16: folded
+    # into the split-K reduction when the GEMM splits K (ViT-sized outputs), a separate launch otherwise -- same values
+    g = torch.Generator().manual_seed(M + N)
+    a = bf(torch.randn(M, K, generator=g))
+    w = bf(torch.randn(N, K, generator=g) * 0.05)
+    bias = torch.randn(N, generator=g) * 0.1
+    res = bf(torch.randn(M, N, generator=g))
+    ls = torch.rand(N, generator=g) + 0.5
+    nw, nb = torch.randn(N, generator=g) * 0.2 + 1.0, torch.randn(N, generator=g) * 0.1
+    lin = ops.pack_linear(w.to(dev), bias.to(dev))
+    x = res.clone().to(dev)
+    h = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+    ops.gemm(a.to(dev), lin, residual=x, layer_scale=ls.to(dev), out=x, norm_w=nw.to(dev), norm_b=nb.to(dev), norm_out=h,
+             norm_style=2, norm_eps=1e-6)
+    ref_x = bf(res.float() + ls * (a.float() @ w.float().T + bias))
+    assert rel_l2(x, ref_x) < 6e-3
+    h2 = ops.layernorm(x, nw.to(dev), nb.to(dev), 1e-6)   # the separate kernel on what was actually stored
+    dh = (h.float() - h2.float()).abs().cpu()   # same arithmetic, different reduction tree: at most a rare 1-ulp flip
+    assert dh.max() <= 0.04 and (dh > 0).float().mean() < 2e-3
+    ref_h = torch.nn.functional.layer_norm(x.float().cpu(), (N,), nw, nb, 1e-6)
+    assert torch.allclose(h.float().cpu(), ref_h, atol=3e-2, rtol=1e-2)
+
+
 def test_tokens_to_histories_matches_host_path(dev):
     # device de-tokeniser + history assembly == the host path (numpy float64 -> fp32, front padding with -5)
     import numpy as np
