@@ -65,6 +65,20 @@ class OpenVLA:
         self.zero_slots = torch.zeros(max(max_prompts, max_candidates), dtype=torch.int32, device=dev)
         self.bos = torch.tensor([1], dtype=torch.int64, device=dev)
         self._side = None
+        self._bos_ready = False
+
+    def _ensure_bos_kv(self):
+        """The BOS token sits at position 0 of a causal prefix: it attends only to itself, so its hidden states and its K/V
+        in every layer depend on nothing but the weights. They are computed once (a 1-row pass) and stay in slot 0 /
+        position 0 of the shared cache segment; every decision then prefills 256 patch rows + the text rows =
+        448 = 7 x 64 rows instead of 449 (a whole 64-row GEMM tile for one row, 12.5 % of the prefill)."""
+        if self._bos_ready:
+            return
+        x = ops.embed_gather(self.embed, self.bos)
+        pos = torch.zeros(1, dtype=torch.int32, device=self.dev)
+        g = self.llm.group(1, 1, pos, [dict(region=0, length=1, mask=ops.MASK_CAUSAL)], 0)
+        self.llm.forward(x, [g], final_norm=False)
+        self._bos_ready = True
 
     # ---------------------------------------------------------------------------------------------- vision
     def encode_image(self, frame_u8: torch.Tensor) -> torch.Tensor:
@@ -115,16 +129,18 @@ class OpenVLA:
         if P > self.max_prompts or N > self.max_candidates or Lt > self.max_text:
             raise ValueError("prompts/candidates/text length exceed the sizes this model was built for")
         D, T0 = c["llm_dim"], self.T0
-        # ---- prefill input rows: [BOS | patches] then P x Lt text rows
-        x = self.x_pre[: T0 + P * Lt]
-        ops.embed_gather(self.embed, self.bos, out=x[:1])
+        Tp = T0 - 1                                   # patch rows; the BOS row is input-independent (see _ensure_bos_kv)
+        self._ensure_bos_kv()
+        # ---- prefill input rows: the patches (positions 1..Tp) then P x Lt text rows
+        x = self.x_pre[: Tp + P * Lt]
         mark("start")
-        x[1:T0].copy_(self.encode_image(frame_u8))
+        x[:Tp].copy_(self.encode_image(frame_u8))
         mark("vision")
-        ops.embed_gather(self.embed, prompt_tokens.reshape(-1).contiguous(), out=x[T0:])
-        pos0 = torch.arange(T0, dtype=torch.int32, device=dev)
+        ops.embed_gather(self.embed, prompt_tokens.reshape(-1).contiguous(), out=x[Tp:])
+        pos0 = 1 + torch.arange(Tp, dtype=torch.int32, device=dev)
         pos1 = (T0 + torch.arange(Lt, dtype=torch.int32, device=dev))[None].expand(P, Lt).contiguous()
-        g0 = self.llm.group(1, T0, pos0, [dict(region=0, length=T0, mask=ops.MASK_CAUSAL)], 0)
+        # patch row t (position t+1) sees keys 0..t+1 of the shared segment: BOS (cached) + patches up to itself
+        g0 = self.llm.group(1, Tp, pos0, [dict(region=0, length=T0, mask=ops.MASK_CAUSAL, causal_offset=1)], 0, write_t_off=1)
         g1 = self.llm.group(P, Lt, pos1.view(-1),
                             [dict(region=0, length=T0, slot_of_batch=self.zero_slots),
                              dict(region=1, length=Lt, mask=ops.MASK_CAUSAL)], 1)
@@ -135,7 +151,7 @@ class OpenVLA:
         # ---- first action token: last valid text position of each candidate's prompt
         prompt_of_cand = (torch.arange(N, device=dev) // n_samples).to(torch.int32)
         cand_len = prompt_lens.to(torch.int32)[prompt_of_cand.long()].contiguous()
-        last_row = (T0 + prompt_of_cand * Lt + cand_len - 1).to(torch.int32)
+        last_row = (Tp + prompt_of_cand * Lt + cand_len - 1).to(torch.int32)
         ops.copy_rows(x, self.h_sel, N, D, last_row, None)
         tokens = torch.empty(N, self.n_gen, dtype=torch.int64, device=dev)
         sel = torch.empty(N, self.n_gen, dtype=torch.float32, device=dev)
