@@ -1068,7 +1068,7 @@ hipError_t launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* Wp, void* C,
     // ---- tile / split-K selection: fill >= ~1 block per CU when the problem allows it
     // tile configurations: {wave tile (WM, WN) in 16-row units, wave grid, stages}
     struct Cand { int wm, wn, wgm, wgn, nst; };
-    const Cand cands[7] = {
+    const Cand cands[9] = {
         {4, 4, 2, 2, 2},   // 0: 128x128, 4 waves of 64x64, 2 stages (64 KiB)
         {2, 4, 2, 2, 2},   // 1:  64x128, 4 waves of 32x64, 2 stages (48 KiB)
         {2, 2, 2, 2, 3},   // 2:  64x64,  4 waves of 32x32, 3 stages (48 KiB)
@@ -1076,6 +1076,8 @@ hipError_t launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* Wp, void* C,
         {4, 4, 4, 2, 3},   // 4: 256x128, 8 waves of 64x64, 3 stages (144 KiB)
         {4, 4, 2, 4, 3},   // 5: 128x256, 8 waves of 64x64, 3 stages (144 KiB)
         {2, 4, 4, 2, 4},   // 6: 128x128, 8 waves of 32x64, 4 stages (128 KiB)
+        {2, 4, 2, 2, 3},   // 7:  64x128, 4 waves, 3 stages (72 KiB, two blocks per CU, two k-tiles in flight each)
+        {4, 4, 2, 2, 3},   // 8: 128x128, 4 waves, 3 stages (96 KiB, one block per CU)
     };
     // Measured on MI355X (tools/bench_kernels.py, M = 441): this single-barrier-per-k-tile structure is latency-bound per
     // block, so residency beats tile size until the tile grid oversubscribes the chip several times over, while 64x64
@@ -1088,9 +1090,12 @@ hipError_t launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* Wp, void* C,
     // (tools/exp_tiles.py re-reads one weight matrix, i.e. measures Infinity-Cache-warm: there 128x128 wins already at 688
     // tiles (N = 22016, M = 449); inside the decision, with cold weights, it does not -- 137 vs ~130 us -- so 1024 stays)
     if (nblocks(0) < 1024) pick = (nblocks(1) >= 384) ? 1 : 2;
+    // a 64x128 grid of about one block per CU on a long K (M = 448: o_proj / down of a 7B decoder) is latency-bound per block:
+    // the third stage (two k-tiles in flight) beats the 64x64 tile there (cold weights: down 90.9 -> 81.9 us, o_proj equal)
+    if (pick == 2 && nblocks(1) >= 192 && Kp >= 4096) pick = 7;
     {
         static const char* force = getenv("COVER_TILE_PICK");  // experiment knob: index into cands
-        if (force && force[0] >= '0' && force[0] <= '6') pick = force[0] - '0';
+        if (force && force[0] >= '0' && force[0] <= '8') pick = force[0] - '0';
     }
     if (variant == 2 && pick > 2) pick = 0;
     const Cand cd = cands[pick];
@@ -1136,6 +1141,8 @@ hipError_t launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* Wp, void* C,
             case 3: LAUNCH_T(4, 4, true, 4, 2, 2); break;
             case 4: LAUNCH_T(4, 4, true, 3, 4, 2); break;
             case 5: LAUNCH_T(4, 4, true, 3, 2, 4); break;
+            case 7: LAUNCH_T(2, 4, true, 3, 2, 2); break;
+            case 8: LAUNCH_T(4, 4, true, 3, 2, 2); break;
             default: LAUNCH_T(2, 4, true, 4, 4, 2); break;
         }
     }
