@@ -231,7 +231,7 @@ def main():
     # ---- roofline of the dominant kernel, live hipEvent timing of every launch of one extra decision
     import ctypes as C
     h = L.lib()
-    ms, cnt, work = (C.c_double * 3)(), (C.c_longlong * 3)(), (C.c_double * 3)()
+    ms, cnt, work = (C.c_double * 4)(), (C.c_longlong * 4)(), (C.c_double * 4)()
     L.check(h.cover_profile_begin(16384), "profile_begin")
     pipe.decision(world, rank, cpu_gather)
     L.check(h.cover_profile_end(ms, cnt, work), "profile_end")
@@ -254,7 +254,7 @@ def main():
         pass
     if cnt[0] > 0 and ms[0] > 0:
         ach = work[0] / (ms[0] * 1e-3) / 1e9
-        out["roofline"] = {"bound": "hbm", "kernel": "gemm_skinny2 / gemm_skinny3 (weight-streaming GEMMs of the decode passes, M = 32)",
+        out["roofline"] = {"bound": "hbm", "kernel": "gemm_skinny2 / gemm_skinny3 (weight-streaming GEMMs of the 7B decode passes and lm_head, M = 32, >= 16 MB of weights each)",
                            "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                            "traffic": traffic, "algorithmic_bytes_per_launch": round(work[0] / cnt[0]), "launches": int(cnt[0]), "avg_launch_us": round(1e3 * ms[0] / cnt[0], 2),
                            "algorithmic_bytes_per_decision": work[0], "kernel_ms_per_decision": round(ms[0], 3)}
@@ -263,6 +263,9 @@ def main():
         out["mfma_kernels"] = {"kernel": "gemm_tiled (prefill / ViT GEMMs)", "achieved": round(tf, 1), "peak": MFMA_PEAK_TF,
                                "unit": "TFLOP/s", "frac": round(tf / MFMA_PEAK_TF, 4), "launches": int(cnt[1]),
                                "kernel_ms_per_decision": round(ms[1], 3)}
+    if cnt[3] > 0:
+        out["small_streaming_gemms"] = {"kernel": "gemm_skinny2 launches with < 16 MB of weights (verifier text tower etc.)", "launches": int(cnt[3]),
+                                        "kernel_ms_per_decision": round(ms[3], 3)}
     if cnt[2] > 0:
         out["attention_kernels"] = {"launches": int(cnt[2]), "kernel_ms_per_decision": round(ms[2], 3)}
     if rank == 0 and world == 1 and not a.no_cpu_baseline:

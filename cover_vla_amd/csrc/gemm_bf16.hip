@@ -890,6 +890,10 @@ static EpiDev make_epi(const cover_gemm_epi* e) {
     return d;
 }
 
+// profiling class of a weight-streaming launch: 0 = the large (>= 16 MB of weights) GEMMs of an LLM decode pass, i.e. the
+// kernel bench.py's roofline object is about; 3 = small ones (verifier / pi0-expert sized) that are latency-, not HBM-bound
+static inline int sk_class(int N, int K) { return 2.0 * (double)N * (double)K >= 16.0e6 ? 0 : 3; }
+
 struct SkinnyPlan {
     int MF, KC, S, nbpb, gx;
     size_t lds, ws_bytes;
@@ -984,7 +988,7 @@ hipError_t launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* Wp, void* C,
             const int MF = (M + 15) / 16;
             const int gx = (N16 + 5) / 6;
             const size_t lds = (size_t)2 * MF * 16 * 1024 * 2;
-            const int pid = prof_enabled() ? prof_open(st, 0, 2.0 * (double)N * (double)K) : -1;
+            const int pid = prof_enabled() ? prof_open(st, sk_class(N, K), 2.0 * (double)N * (double)K) : -1;
             hipError_t e = hipSuccess;
 #define SK3(MF_)                                                                                                             \
     do {                                                                                                                    \
@@ -1010,7 +1014,7 @@ hipError_t launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* Wp, void* C,
         Skinny2Plan p = plan_skinny2(M, N, Kp);
         if (ws == nullptr || ws_bytes < p.ws_bytes) return hipErrorInvalidValue;
         dim3 grid(p.gx, p.S), block(512);
-        const int pid = prof_enabled() ? prof_open(st, 0, 2.0 * (double)N * (double)K) : -1;
+        const int pid = prof_enabled() ? prof_open(st, sk_class(N, K), 2.0 * (double)N * (double)K) : -1;
 #define SK2(MF_, KS_, NBW_) hipLaunchKernelGGL((gemm_skinny2<MF_, KS_, NBW_>), grid, block, p.lds, st, A, lda, Wp, ws, M, N, Kp)
         if (p.MF == 1) { if (p.NBW == 6) SK2(1, 4, 6); else if (p.NBW == 4) SK2(1, 4, 4); else if (p.NBW == 3) SK2(1, 4, 3); else SK2(1, 4, 2); }
         else if (p.MF == 2) { if (p.NBW == 6) SK2(2, 4, 6); else if (p.NBW == 4) SK2(2, 4, 4); else if (p.NBW == 3) SK2(2, 4, 3); else SK2(2, 4, 2); }
@@ -1040,7 +1044,7 @@ hipError_t launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* Wp, void* C,
         SkinnyPlan p = plan_skinny(M, N, Kp);
         if (ws == nullptr || ws_bytes < p.ws_bytes) return hipErrorInvalidValue;
         dim3 grid(p.gx, p.S), block(512);
-        const int pid = prof_enabled() ? prof_open(st, 0, 2.0 * (double)N * (double)K) : -1;
+        const int pid = prof_enabled() ? prof_open(st, sk_class(N, K), 2.0 * (double)N * (double)K) : -1;
         switch (p.MF) {
             case 1: hipLaunchKernelGGL(gemm_skinny<1>, grid, block, p.lds, st, A, lda, Wp, ws, M, N, Kp, p.KC, p.nbpb); break;
             case 2: hipLaunchKernelGGL(gemm_skinny<2>, grid, block, p.lds, st, A, lda, Wp, ws, M, N, Kp, p.KC, p.nbpb); break;
@@ -1178,7 +1182,7 @@ hipError_t launch_gemm_skinny_partial(const bf16_t* A, int lda, const bf16_t* Wp
     Skinny2Plan p = plan_skinny2(M, N, Kp);
     if (ws == nullptr || ws_bytes < p.ws_bytes) return hipErrorInvalidValue;
     dim3 grid(p.gx, p.S), block(512);
-    const int pid = prof_enabled() ? prof_open(st, 0, 2.0 * (double)N * (double)K) : -1;
+    const int pid = prof_enabled() ? prof_open(st, sk_class(N, K), 2.0 * (double)N * (double)K) : -1;
 #define SK2(MF_, KS_, NBW_) hipLaunchKernelGGL((gemm_skinny2<MF_, KS_, NBW_>), grid, block, p.lds, st, A, lda, Wp, ws, M, N, Kp)
     if (p.MF == 1) { if (p.NBW == 6) SK2(1, 4, 6); else if (p.NBW == 4) SK2(1, 4, 4); else if (p.NBW == 3) SK2(1, 4, 3); else SK2(1, 4, 2); }
     else if (p.MF == 2) { if (p.NBW == 6) SK2(2, 4, 6); else if (p.NBW == 4) SK2(2, 4, 4); else if (p.NBW == 3) SK2(2, 4, 3); else SK2(2, 4, 2); }

@@ -1,6 +1,7 @@
 // Optional in-library kernel timing with hipEvents on the launch stream (bench.py's `roofline` object):
 // when enabled, the GEMM / attention launchers bracket each launch with an event pair taken from a pre-created pool.
-// Classes: 0 = weight-streaming GEMM (work = weight bytes), 1 = LDS-tiled GEMM (work = FLOPs), 2 = attention (work = 0).
+// Classes: 0 = weight-streaming GEMM with >= 16 MB of weights (work = weight bytes), 1 = LDS-tiled GEMM (work = FLOPs),
+// 2 = attention (work = 0), 3 = small weight-streaming GEMMs (work = weight bytes).
 #include <hip/hip_runtime.h>
 #include <vector>
 #include "kernels.h"
@@ -38,16 +39,16 @@ extern "C" int cover_profile_begin(int max_events) {
     return COVER_OK;
 }
 
-// ms[3], count[3], work[3]; synchronises the device
+// ms[4], count[4], work[4]; synchronises the device
 extern "C" int cover_profile_end(double* ms, long long* count, double* work) {
     g_on = false;
     if (hipDeviceSynchronize() != hipSuccess) return COVER_EHIP;
-    for (int c = 0; c < 3; ++c) { ms[c] = 0; count[c] = 0; work[c] = 0; }
+    for (int c = 0; c < 4; ++c) { ms[c] = 0; count[c] = 0; work[c] = 0; }
     for (size_t i = 0; i < g_used; ++i) {
         float t = 0.f;
         if (hipEventElapsedTime(&t, g_pool[i].a, g_pool[i].b) != hipSuccess) continue;
         const int c = g_pool[i].cls;
-        if (c < 0 || c > 2) continue;
+        if (c < 0 || c > 3) continue;
         ms[c] += t;
         count[c] += 1;
         work[c] += g_pool[i].work;

@@ -389,8 +389,9 @@ int cover_timer_destroy(void* timer);
 int cover_stream_sync(void* stream);
 
 /* Per-launch kernel timing for bench.py's roofline object: between begin/end every GEMM / attention launch issued by
- * this library is bracketed by a hipEvent pair on its own stream. Classes: 0 = weight-streaming GEMM (work = weight bytes),
- * 1 = LDS-tiled GEMM (work = FLOPs), 2 = attention. end() synchronises the device and fills ms[3], count[3], work[3]. */
+ * this library is bracketed by a hipEvent pair on its own stream. Classes: 0 = weight-streaming GEMM with >= 16 MB of
+ * weights (work = weight bytes), 1 = LDS-tiled GEMM (work = FLOPs), 2 = attention, 3 = small weight-streaming GEMMs.
+ * end() synchronises the device and fills ms[4], count[4], work[4]. */
 int cover_profile_begin(int max_events);
 int cover_profile_end(double* ms, long long* count, double* work);
 

@@ -17,7 +17,8 @@ for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
     if shown < 40:
         print(f"{k[0]:62s} {str(k[1])+'x'+str(k[2]):>12s} {len(v):6d} {avg:10.0f} {2*avg/1024:14.1f}")
         shown += 1
-    if "gemm_skinny2" in k[0] or "gemm_skinny3" in k[0]:
+    # bench.py's roofline class: weight-streaming launches with >= 16 MB of weights (the 7B decode GEMMs and lm_head)
+    if ("gemm_skinny2" in k[0] or "gemm_skinny3" in k[0]) and 2 * avg * 1024 >= 16.0e6:
         sk_bytes += 2 * sum(v) * 1024
         sk_n += len(v)
 if len(sys.argv) > 2 and sk_n:
