@@ -15,6 +15,7 @@
 //                (no LDS round trip for the streamed operand), split-K over grid.y with fp32 partials that a
 //                small reduce kernel folds together with the epilogue.
 #include <stdlib.h>
+#include <hip/hip_ext.h>
 #include "common.h"
 #include "kernels.h"
 
@@ -549,7 +550,8 @@ __global__ __launch_bounds__(512) void gemm_skinny2(const bf16_t* __restrict__ A
 // ---------------------------------------------------------------------------------------------------
 template <int MF, int KS, int NBW, int NBUF>
 __global__ __launch_bounds__(512) void gemm_skinny3(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ Wp,
-                                                    void* C, int ldc, int M, int N, int Kp, EpiDev epi) {
+                                                    void* C, int ldc, int M, int N, int Kp, EpiDev epi,
+                                                    float* __restrict__ partial, int kper) {
     constexpr int NG = 8 / KS, KC = 256 * KS, NBPB = NG * NBW;
     constexpr int XB = MF * 16 * KC * 2;          // bytes of one activation chunk (fragment-major)
     constexpr int XL = XB / (512 * 16);           // 16-B loads per thread per chunk
@@ -560,7 +562,11 @@ __global__ __launch_bounds__(512) void gemm_skinny3(const bf16_t* __restrict__ A
     const int K32 = Kp >> 5;
     const int N16 = (N + 15) >> 4;
     const int nb_begin = blockIdx.x * NBPB;
-    const int nchunks = (Kp + KC - 1) / KC;
+    // optional grid-level split-K (narrow outputs: n-blocks alone cannot fill the chip): slice s = blockIdx.y owns
+    // k in [kb, ke) and leaves raw fp32 partial sums [s][M][N] for the reduction / the fused decode attention
+    const int kb = blockIdx.y * kper;
+    const int ke = min(Kp, kb + kper);
+    const int nchunks = (ke - kb + KC - 1) / KC;
     const int kw0 = ks * 256;                     // this wave's k-slice inside every chunk
     f32x4 acc[NBW][MF];
 #pragma unroll
@@ -570,14 +576,14 @@ __global__ __launch_bounds__(512) void gemm_skinny3(const bf16_t* __restrict__ A
 
     // weight stream: item t = (chunk c = t / NBW, n-block i = t % NBW) -> 8 x 1 KiB (this wave's 256 k of that chunk)
     const int items = nchunks * NBW;
-    auto steps_of = [&](int c) { return max(0, min(8, (min(KC, Kp - c * KC) - kw0) >> 5)); };
+    auto steps_of = [&](int c) { return max(0, min(8, (min(KC, ke - kb - c * KC) - kw0) >> 5)); };
     u32x4 buf[NBUF][8];
     auto load8 = [&](u32x4(&dst)[8], int t) {
         const int c = t / NBW, i = t - c * NBW;
         int nb = nb_begin + ng + NG * i;
         nb = nb < N16 ? nb : N16 - 1;
         const int nst = steps_of(c);
-        const u32x4* src = (const u32x4*)(Wp + ((size_t)nb * K32 + ((c * KC + kw0) >> 5)) * 512) + lane;
+        const u32x4* src = (const u32x4*)(Wp + ((size_t)nb * K32 + ((kb + c * KC + kw0) >> 5)) * 512) + lane;
         if (nst == 8) {   // whole k-slice (every chunk but a ragged last one): straight-line issue
 #pragma unroll
             for (int u = 0; u < 8; ++u) dst[u] = __builtin_nontemporal_load(src + u * 64);
@@ -590,7 +596,7 @@ __global__ __launch_bounds__(512) void gemm_skinny3(const bf16_t* __restrict__ A
     // activation chunk staging through registers (coalesced 16-B reads along k, fragment-major scatter into LDS)
     uint4 xr[XL];
     auto x_load = [&](int c) {
-        const int k0 = c * KC, kc = min(KC, Kp - k0);
+        const int k0 = kb + c * KC, kc = min(KC, ke - k0);
         constexpr int cpr = KC >> 3;
 #pragma unroll
         for (int j = 0; j < XL; ++j) {
@@ -683,7 +689,26 @@ __global__ __launch_bounds__(512) void gemm_skinny3(const bf16_t* __restrict__ A
                 for (int e = 0; e < 4; ++e) v[e] += red[(((ww * RB + ii) * MF + f) * 4 + e) * 64 + lane];
             }
         };
-        if (epi.glu) {   // n-groups 0 / 1 hold the gate / up block of one output block (NG == 2, even nb_begin)
+        if (partial) {   // split-K slice: raw sums, the epilogue belongs to whoever folds the slabs
+            constexpr int NFRAG = NG * RB * MF;
+            for (int j = w; j < NFRAG; j += 8) {
+                const int f = j % MF, ii = (j / MF) % RB, gsel = j / (MF * RB);
+                if (i0 + ii >= NBW) continue;
+                const int nb = nb_begin + gsel + NG * (i0 + ii);
+                const int m = f * 16 + r, n = nb * 16 + 4 * g;
+                if (nb < N16 && m < M && n < N) {
+                    float v[4];
+                    slice_sum(gsel, ii, f, v);
+                    float* o = partial + ((size_t)blockIdx.y * M + m) * N + n;
+                    if (n + 3 < N && ((((uintptr_t)o) & 15) == 0)) {
+                        *(float4*)o = make_float4(v[0], v[1], v[2], v[3]);
+                    } else {
+                        for (int e = 0; e < 4; ++e)
+                            if (n + e < N) o[e] = v[e];
+                    }
+                }
+            }
+        } else if (epi.glu) {   // n-groups 0 / 1 hold the gate / up block of one output block (NG == 2, even nb_begin)
             constexpr int NFRAG = RB * MF;
             for (int j = w; j < NFRAG; j += 8) {
                 const int f = j % MF, ii = j / MF;
@@ -892,6 +917,55 @@ static EpiDev make_epi(const cover_gemm_epi* e) {
 
 // profiling class of a weight-streaming launch: 0 = the large (>= 16 MB of weights) GEMMs of an LLM decode pass, i.e. the
 // kernel bench.py's roofline object is about; 3 = small ones (verifier / pi0-expert sized) that are latency-, not HBM-bound
+// Third-generation plan: NBW n-blocks per wave (x NG = 2 n-groups) and S grid-level K slices such that the grid is as close
+// to ONE block per CU (128 KiB of LDS) as possible; every block must see at least two 1024-wide chunks (otherwise the
+// second generation does the same work with two blocks per CU).
+struct Skinny3Plan {
+    bool ok;
+    int MF, NBW, S, kper, gx;
+    size_t lds, ws_bytes;
+};
+static Skinny3Plan plan_skinny3(int M, int N, int Kp) {
+    Skinny3Plan best;
+    best.ok = false;
+    best.MF = (M + 15) / 16;
+    const int N16 = (N + 15) / 16;
+    if (M > 32 || (N16 & 1) || Kp < 2048) return best;
+    int best_blocks = 0;
+    const int nbws[3] = {4, 3, 2};
+    for (int bi = 0; bi < 3; ++bi) {
+        const int nbw = nbws[bi];
+        const int gx = (N16 + 2 * nbw - 1) / (2 * nbw);
+        for (int S = 1; S <= 8; ++S) {
+            if ((long long)gx * S > 256) break;
+            int kper = (Kp + S - 1) / S;
+            kper = (kper + 255) / 256 * 256;
+            if (kper < 2048) break;                      // fewer than two chunks per block
+            if ((long long)kper * (S - 1) >= Kp) continue;  // an empty last slice
+            const int blocks = gx * S;
+            // more blocks first; then fewer slices (less partial traffic); then more n-blocks per wave (longer streams)
+            if (blocks > best_blocks) {
+                best_blocks = blocks;
+                best.ok = true; best.NBW = nbw; best.S = S; best.kper = kper; best.gx = gx;
+            }
+        }
+    }
+    if (!best.ok || best_blocks < 190) { best.ok = false; return best; }
+    best.lds = (size_t)2 * best.MF * 16 * 1024 * 2;
+    best.ws_bytes = best.S > 1 ? (size_t)best.S * M * N * sizeof(float) : 0;
+    return best;
+}
+
+// weight-streaming launches: with profiling on, the kernel's own start / stop timestamps go into a reserved event pair
+template <typename F, typename... Args>
+static inline void launch_streaming(int cls, double work, F kfn, dim3 grid, dim3 block, size_t lds, hipStream_t st, Args... args) {
+    hipEvent_t ea, eb;
+    if (prof_enabled() && prof_reserve(cls, work, &ea, &eb) >= 0)
+        hipExtLaunchKernelGGL(kfn, grid, block, (uint32_t)lds, st, ea, eb, 0, args...);
+    else
+        hipLaunchKernelGGL(kfn, grid, block, lds, st, args...);
+}
+
 static inline int sk_class(int N, int K) { return 2.0 * (double)N * (double)K >= 16.0e6 ? 0 : 3; }
 
 struct SkinnyPlan {
@@ -960,7 +1034,32 @@ size_t gemm_workspace_bytes(int M, int N, int K) {
         return blocks64 < 192 ? (size_t)8 * M * N * sizeof(float) : 0;
     }
     const size_t a = plan_skinny(M, N, Kp).ws_bytes, b = plan_skinny2(M, N, Kp).ws_bytes;
-    return a > b ? a : b;
+    size_t c = plan_skinny3(M, N, Kp).ws_bytes;
+    const size_t one = (size_t)M * N * sizeof(float);   // launch_gemm_skinny_partial with an unsplit third-generation plan
+    if (c < one) c = one;
+    const size_t ab = a > b ? a : b;
+    return ab > c ? ab : c;
+}
+
+static hipError_t launch_skinny3(const Skinny3Plan& p, const bf16_t* A, int lda, const bf16_t* Wp, void* C, int ldc, int M, int N,
+                                 int Kp, const EpiDev& epi, float* partial, hipStream_t st) {
+    hipError_t e = hipSuccess;
+    dim3 grid(p.gx, p.S), block(512);
+#define SK3(MF_, NBW_)                                                                                                       \
+    do {                                                                                                                    \
+        auto kfn = gemm_skinny3<MF_, 4, NBW_, NBW_>;                                                                        \
+        if (p.lds > 64 * 1024) {                                                                                            \
+            static hipError_t attr = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+            e = attr;                                                                                                       \
+        }                                                                                                                   \
+        if (e == hipSuccess)                                                                                                \
+            launch_streaming(sk_class(N, Kp), 2.0 * (double)N * (double)Kp, kfn, grid, block, p.lds, st, A, lda, Wp, C, ldc, M, N, Kp, epi, partial, p.kper); \
+    } while (0)
+    if (p.MF == 1) { if (p.NBW == 4) SK3(1, 4); else if (p.NBW == 3) SK3(1, 3); else SK3(1, 2); }
+    else { if (p.NBW == 4) SK3(2, 4); else if (p.NBW == 3) SK3(2, 3); else SK3(2, 2); }
+#undef SK3
+    if (e == hipSuccess) e = hipGetLastError();
+    return e;
 }
 
 // the norm requested through the epilogue, as its own launch (paths that cannot fold it into a split-K reduction)
@@ -976,67 +1075,61 @@ hipError_t launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* Wp, void* C,
     const int Kp = (K + 127) / 128 * 128;
     EpiDev epi = make_epi(epi_in);
     if (variant == 0) variant = (M <= 64 && ws != nullptr) ? 3 : 1;
-    // Third generation (no split-K, fused epilogue): worth it when the n-blocks alone fill the chip with ONE block per CU
-    // (128 KiB of LDS), i.e. the wide MLP up-projection; narrower outputs keep the split-K kernel + reduction.
-    {
+    // Third generation (full-K chunk loop per block, one block per CU): used whenever its plan fills the chip -- with the
+    // epilogue fused when no grid split is needed (wide outputs), else leaving S (< the second generation's) partial slabs.
+    int S3 = 0;   // > 0: the third generation has left S3 slabs in ws, fall through to the shared reduction
+    if (variant == 3 || variant == 6) {
+        static const char* g3 = getenv("COVER_SKINNY3");   // experiment knob: 0 disables the automatic choice
+        Skinny3Plan p3 = plan_skinny3(M, N, Kp);
         const int N16 = (N + 15) / 16;
-        static const char* g3 = getenv("COVER_SKINNY3");   // experiment knob: 0 disables, 1 forces where legal
-        const bool legal = M <= 32 && (N16 % 2) == 0 && Kp >= 2048;
-        const bool want = (N16 + 5) / 6 >= 200 && (N16 + 5) / 6 <= 256;
-        if ((variant == 3 && legal && want && !(g3 && g3[0] == '0')) || (variant == 3 && legal && g3 && g3[0] == '1') ||
-            (variant == 6 && legal)) {
-            const int MF = (M + 15) / 16;
-            const int gx = (N16 + 5) / 6;
-            const size_t lds = (size_t)2 * MF * 16 * 1024 * 2;
-            const int pid = prof_enabled() ? prof_open(st, sk_class(N, K), 2.0 * (double)N * (double)K) : -1;
-            hipError_t e = hipSuccess;
-#define SK3(MF_)                                                                                                             \
-    do {                                                                                                                    \
-        auto kfn = gemm_skinny3<MF_, 4, 3, 3>;                                                                              \
-        if (lds > 64 * 1024) {                                                                                              \
-            static hipError_t attr = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-            e = attr;                                                                                                       \
-        }                                                                                                                   \
-        if (e == hipSuccess) hipLaunchKernelGGL(kfn, dim3(gx), dim3(512), lds, st, A, lda, Wp, C, ldc, M, N, Kp, epi);      \
-    } while (0)
-            if (MF == 1) SK3(1); else SK3(2);
-#undef SK3
-            prof_close(st, pid);
-            if (e == hipSuccess) e = hipGetLastError();
-            if (e == hipSuccess && epi.norm_w != nullptr && epi.norm_out != nullptr)
-                e = run_norm(epi, C, ldc, M, epi.glu ? N / 2 : N, st);
-            return e;
+        if (variant == 6 && !p3.ok) {   // forced (tests): any legal problem, unsplit
+            if (M > 32 || (N16 & 1) || Kp < 2048) return hipErrorInvalidValue;
+            p3.ok = true; p3.NBW = 3; p3.S = 1; p3.kper = Kp; p3.gx = (N16 + 5) / 6;
+            p3.lds = (size_t)2 * p3.MF * 16 * 1024 * 2; p3.ws_bytes = 0;
         }
-        if (variant == 6) return hipErrorInvalidValue;
+        if (p3.ok && p3.S > 1 && (ws == nullptr || ws_bytes < p3.ws_bytes)) p3.ok = false;
+        if (p3.ok && (variant == 6 || !(g3 && g3[0] == '0'))) {
+            hipError_t e = launch_skinny3(p3, A, lda, Wp, C, ldc, M, N, Kp, epi, p3.S > 1 ? ws : nullptr, st);
+            if (e != hipSuccess) return e;
+            if (p3.S == 1) {
+                if (epi.norm_w != nullptr && epi.norm_out != nullptr) e = run_norm(epi, C, ldc, M, epi.glu ? N / 2 : N, st);
+                return e;
+            }
+            S3 = p3.S;
+        } else if (variant == 6) {
+            return hipErrorInvalidValue;
+        }
+        variant = 3;
     }
-    if (variant == 3) {  // second-generation weight streaming (in-block k-slices)
+    if (variant == 3) {  // second-generation weight streaming (in-block k-slices), or the reduction of either generation
         if (M > 64) return hipErrorInvalidValue;
-        Skinny2Plan p = plan_skinny2(M, N, Kp);
-        if (ws == nullptr || ws_bytes < p.ws_bytes) return hipErrorInvalidValue;
-        dim3 grid(p.gx, p.S), block(512);
-        const int pid = prof_enabled() ? prof_open(st, sk_class(N, K), 2.0 * (double)N * (double)K) : -1;
-#define SK2(MF_, KS_, NBW_) hipLaunchKernelGGL((gemm_skinny2<MF_, KS_, NBW_>), grid, block, p.lds, st, A, lda, Wp, ws, M, N, Kp)
-        if (p.MF == 1) { if (p.NBW == 6) SK2(1, 4, 6); else if (p.NBW == 4) SK2(1, 4, 4); else if (p.NBW == 3) SK2(1, 4, 3); else SK2(1, 4, 2); }
-        else if (p.MF == 2) { if (p.NBW == 6) SK2(2, 4, 6); else if (p.NBW == 4) SK2(2, 4, 4); else if (p.NBW == 3) SK2(2, 4, 3); else SK2(2, 4, 2); }
-        else if (p.MF == 3) SK2(3, 2, 2);
-        else SK2(4, 2, 2);
+        int S = S3;
+        if (S == 0) {
+            Skinny2Plan p = plan_skinny2(M, N, Kp);
+            if (ws == nullptr || ws_bytes < p.ws_bytes) return hipErrorInvalidValue;
+            dim3 grid(p.gx, p.S), block(512);
+#define SK2(MF_, KS_, NBW_) launch_streaming(sk_class(N, K), 2.0 * (double)N * (double)K, gemm_skinny2<MF_, KS_, NBW_>, grid, block, p.lds, st, A, lda, Wp, ws, M, N, Kp)
+            if (p.MF == 1) { if (p.NBW == 6) SK2(1, 4, 6); else if (p.NBW == 4) SK2(1, 4, 4); else if (p.NBW == 3) SK2(1, 4, 3); else SK2(1, 4, 2); }
+            else if (p.MF == 2) { if (p.NBW == 6) SK2(2, 4, 6); else if (p.NBW == 4) SK2(2, 4, 4); else if (p.NBW == 3) SK2(2, 4, 3); else SK2(2, 4, 2); }
+            else if (p.MF == 3) SK2(3, 2, 2);
+            else SK2(4, 2, 2);
 #undef SK2
-        prof_close(st, pid);
+            S = p.S;
+        }
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
         const bool want_norm = epi.norm_w != nullptr && epi.norm_out != nullptr;
         if (want_norm && !epi.glu && !epi.out_f32 && (N % 8) == 0 && N <= 8192 && (ldc % 8) == 0 && (epi.ld_norm_out % 8) == 0) {
-            hipLaunchKernelGGL(splitk_reduce_norm, dim3(M), dim3(512), 0, st, (const float*)ws, p.S, (bf16_t*)C, ldc, M, N, epi);
+            hipLaunchKernelGGL(splitk_reduce_norm, dim3(M), dim3(512), 0, st, (const float*)ws, S, (bf16_t*)C, ldc, M, N, epi);
             return hipGetLastError();
         }
         const int Nout = epi.glu ? N / 2 : N;
         const long long total = (long long)M * ((Nout + 3) / 4);
         int rb = (int)((total + 255) / 256);
         if (rb > 2048) rb = 2048;
-        hipLaunchKernelGGL(splitk_reduce, dim3(rb), dim3(256), 0, st, (const float*)ws, p.S, C, ldc, M, N, epi);
+        hipLaunchKernelGGL(splitk_reduce, dim3(rb), dim3(256), 0, st, (const float*)ws, S, C, ldc, M, N, epi);
         e = hipGetLastError();
-        if (e == hipSuccess && want_norm)
-            e = run_norm(epi, C, ldc, M, epi.glu ? N / 2 : N, st);
+        if (e == hipSuccess && want_norm) e = run_norm(epi, C, ldc, M, epi.glu ? N / 2 : N, st);
         return e;
     }
     if (variant == 5) {  // first-generation weight streaming (grid-level split-K only), kept for A/B measurements
@@ -1179,17 +1272,26 @@ hipError_t launch_gemm_skinny_partial(const bf16_t* A, int lda, const bf16_t* Wp
                                       int K, int* S_out, hipStream_t st) {
     if (M <= 0 || M > 64 || N <= 0) return hipErrorInvalidValue;
     const int Kp = (K + 127) / 128 * 128;
+    {
+        static const char* g3 = getenv("COVER_SKINNY3");
+        Skinny3Plan p3 = plan_skinny3(M, N, Kp);
+        const size_t need = (size_t)p3.S * M * N * sizeof(float);
+        if (p3.ok && !(g3 && g3[0] == '0') && ws != nullptr && ws_bytes >= need) {
+            EpiDev none = make_epi(nullptr);
+            hipError_t e = launch_skinny3(p3, A, lda, Wp, nullptr, 0, M, N, Kp, none, ws, st);
+            *S_out = p3.S;
+            return e;
+        }
+    }
     Skinny2Plan p = plan_skinny2(M, N, Kp);
     if (ws == nullptr || ws_bytes < p.ws_bytes) return hipErrorInvalidValue;
     dim3 grid(p.gx, p.S), block(512);
-    const int pid = prof_enabled() ? prof_open(st, sk_class(N, K), 2.0 * (double)N * (double)K) : -1;
-#define SK2(MF_, KS_, NBW_) hipLaunchKernelGGL((gemm_skinny2<MF_, KS_, NBW_>), grid, block, p.lds, st, A, lda, Wp, ws, M, N, Kp)
+#define SK2(MF_, KS_, NBW_) launch_streaming(sk_class(N, K), 2.0 * (double)N * (double)K, gemm_skinny2<MF_, KS_, NBW_>, grid, block, p.lds, st, A, lda, Wp, ws, M, N, Kp)
     if (p.MF == 1) { if (p.NBW == 6) SK2(1, 4, 6); else if (p.NBW == 4) SK2(1, 4, 4); else if (p.NBW == 3) SK2(1, 4, 3); else SK2(1, 4, 2); }
     else if (p.MF == 2) { if (p.NBW == 6) SK2(2, 4, 6); else if (p.NBW == 4) SK2(2, 4, 4); else if (p.NBW == 3) SK2(2, 4, 3); else SK2(2, 4, 2); }
     else if (p.MF == 3) SK2(3, 2, 2);
     else SK2(4, 2, 2);
 #undef SK2
-    prof_close(st, pid);
     *S_out = p.S;
     return hipGetLastError();
 }

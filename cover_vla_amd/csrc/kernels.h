@@ -64,3 +64,6 @@ size_t gemm_workspace_bytes(int M, int N, int K);
 bool prof_enabled();
 int prof_open(hipStream_t st, int cls, double work);
 void prof_close(hipStream_t st, int id);
+// reserve a record whose two events the caller hands to hipExtLaunchKernelGGL (kernel start / stop timestamps, no event
+// packets around the launch); returns -1 when profiling is off
+int prof_reserve(int cls, double work, hipEvent_t* start, hipEvent_t* stop);

@@ -1,5 +1,7 @@
 // Optional in-library kernel timing with hipEvents on the launch stream (bench.py's `roofline` object):
-// when enabled, the GEMM / attention launchers bracket each launch with an event pair taken from a pre-created pool.
+// when enabled, the tiled-GEMM / attention launchers bracket each launch with an event pair taken from a pre-created pool;
+// the weight-streaming launchers pass the pair to hipExtLaunchKernelGGL instead, which stamps the kernel's own start and
+// stop (an event packet on either side of a 20-40 us kernel adds ~3 us to what it measures).
 // Classes: 0 = weight-streaming GEMM with >= 16 MB of weights (work = weight bytes), 1 = LDS-tiled GEMM (work = FLOPs),
 // 2 = attention (work = 0), 3 = small weight-streaming GEMMs (work = weight bytes).
 #include <hip/hip_runtime.h>
@@ -21,6 +23,15 @@ int prof_open(hipStream_t st, int cls, double work) {
     r.cls = cls;
     r.work = work;
     if (hipEventRecord(r.a, st) != hipSuccess) return -1;
+    return (int)g_used++;
+}
+int prof_reserve(int cls, double work, hipEvent_t* start, hipEvent_t* stop) {
+    if (!g_on || g_used >= g_pool.size()) return -1;
+    Rec& r = g_pool[g_used];
+    r.cls = cls;
+    r.work = work;
+    *start = r.a;
+    *stop = r.b;
     return (int)g_used++;
 }
 void prof_close(hipStream_t st, int id) {
