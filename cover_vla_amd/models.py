@@ -105,25 +105,41 @@ class VitTower:
         d.last_attn_only = 1 if last_attn_only else 0
         return d
 
-    def embed(self, pixels: torch.Tensor, mul=(1.0, 1.0, 1.0), add=(0.0, 0.0, 0.0)) -> torch.Tensor:
-        """pixels: fp32 [n,3,H,W] (normalised) or uint8 [n,H,W,3] (+ per-channel mul/add) -> bf16 [n, prefix+P, dim]."""
+    def static_bufs(self, n: int, H: int, W: int) -> dict:
+        """Persistent buffers for embed() of n images of H x W: nothing is allocated per call, so the tower can be recorded
+        into a hipGraph (fixed addresses) and its host launch cost paid once."""
+        P = (H // self.patch) * (W // self.patch)
+        T = P + self.prefix_tokens
+        dev = self.dev
+        b = dict(rows=torch.empty(n * P, self.kpatch_p, dtype=BF, device=dev), x=torch.empty(n, T, self.dim, dtype=BF, device=dev),
+                 ws=ops.gemm_workspace(n * P, self.patch_lin.N, self.patch_lin.K, dev))
+        if self.prefix_tokens:
+            b["tok"] = torch.empty(n * P, self.dim, dtype=BF, device=dev)
+            b["idx_dst"] = (torch.arange(n, device=dev)[:, None] * T + self.prefix_tokens +
+                            torch.arange(P, device=dev)[None]).reshape(-1).to(torch.int32)
+            b["pidx"] = (torch.arange(n, device=dev)[:, None] * T + torch.arange(self.prefix_tokens, device=dev)[None]
+                         ).reshape(-1).to(torch.int32)
+            b["psrc"] = torch.arange(self.prefix_tokens, device=dev).repeat(n).to(torch.int32)
+        return b
+
+    def embed(self, pixels: torch.Tensor, mul=(1.0, 1.0, 1.0), add=(0.0, 0.0, 0.0), bufs: Optional[dict] = None) -> torch.Tensor:
+        """pixels: fp32 [n,3,H,W] (normalised) or uint8 [n,H,W,3] (+ per-channel mul/add) -> bf16 [n, prefix+P, dim].
+        bufs: static_bufs(...) of the same geometry (no allocation; pixels must be contiguous)."""
         n = pixels.shape[0]
-        rows = ops.patchify(pixels, self.patch, mul, add, self.kpatch_p)
+        if bufs is None:
+            H, W = (pixels.shape[1], pixels.shape[2]) if pixels.dtype == torch.uint8 else (pixels.shape[2], pixels.shape[3])
+            bufs = self.static_bufs(n, H, W)
+        rows = ops.patchify(pixels, self.patch, mul, add, self.kpatch_p, out=bufs["rows"])
         P = rows.shape[0] // n
         T = P + self.prefix_tokens
-        x = torch.empty(n, T, self.dim, dtype=BF, device=self.dev)
+        x = bufs["x"]
         if self.prefix_tokens:
-            tok = ops.gemm(rows, self.patch_lin)
+            tok = ops.gemm(rows, self.patch_lin, out=bufs["tok"], ws=bufs["ws"])
             xv = x.view(n * T, self.dim)
-            idx_dst = (torch.arange(n, device=self.dev)[:, None] * T + self.prefix_tokens +
-                       torch.arange(P, device=self.dev)[None]).reshape(-1).to(torch.int32)
-            ops.copy_rows(tok, xv, n * P, self.dim, None, idx_dst)
-            pidx = (torch.arange(n, device=self.dev)[:, None] * T + torch.arange(self.prefix_tokens, device=self.dev)[None]
-                    ).reshape(-1).to(torch.int32)
-            psrc = torch.arange(self.prefix_tokens, device=self.dev).repeat(n).to(torch.int32)
-            ops.copy_rows(self.prefix, xv, n * self.prefix_tokens, self.dim, psrc, pidx)
+            ops.copy_rows(tok, xv, n * P, self.dim, None, bufs["idx_dst"])
+            ops.copy_rows(self.prefix, xv, n * self.prefix_tokens, self.dim, bufs["psrc"], bufs["pidx"])
         else:
-            ops.gemm(rows, self.patch_lin, out=x.view(n * T, self.dim))
+            ops.gemm(rows, self.patch_lin, out=x.view(n * T, self.dim), ws=bufs["ws"])
         ops.add_rows(x.view(n * T, self.dim), self.pos[:T])
         return x
 

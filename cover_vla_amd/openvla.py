@@ -18,6 +18,8 @@ from __future__ import annotations
 
 from typing import Dict, Optional
 
+import os
+
 import numpy as np
 import torch
 
@@ -65,6 +67,8 @@ class OpenVLA:
         self.zero_slots = torch.zeros(max(max_prompts, max_candidates), dtype=torch.int32, device=dev)
         self.bos = torch.tensor([1], dtype=torch.int64, device=dev)
         self._side = None
+        self._cap = None
+        self._vis = {}
         self._bos_ready = False
 
     def _ensure_bos_kv(self):
@@ -81,9 +85,23 @@ class OpenVLA:
         self._bos_ready = True
 
     # ---------------------------------------------------------------------------------------------- vision
-    def encode_image(self, frame_u8: torch.Tensor) -> torch.Tensor:
-        """frame uint8 [n_cams, H, W, 3] -> projected patch embeddings bf16 [n_cams*256, llm_dim]."""
-        c, n = self.c, frame_u8.shape[0]
+    def _vision_static(self, n, H, W):
+        key = (n, H, W)
+        st = self._vis.get(key)
+        if st is None:
+            c, P, dev = self.c, self.n_patches, self.dev
+            st = dict(frame=torch.empty(n, H, W, 3, dtype=torch.uint8, device=dev),
+                      d=self.dino.static_bufs(n, H, W), s=self.siglip.static_bufs(n, H, W),
+                      fused=torch.empty(n * P, self.fused, dtype=BF, device=dev),
+                      h=[torch.empty(n * P, lin.n_out, dtype=BF, device=dev) for lin in self.proj],
+                      ws=[ops.gemm_workspace(n * P, lin.N, lin.K, dev) for lin in self.proj], graph=None)
+            self._vis[key] = st
+        return st
+
+    def _encode_static(self, st) -> torch.Tensor:
+        """Both towers + projector on persistent buffers (no allocation: recordable into a hipGraph)."""
+        c = self.c
+        n, P = st["frame"].shape[0], self.n_patches
         mul_d = [1.0 / (255.0 * s) for s in IMAGENET_STD]
         add_d = [-m / s for m, s in zip(IMAGENET_MEAN, IMAGENET_STD)]
         # the two towers are independent and individually too small to fill 256 CUs: run SigLIP on a side stream
@@ -92,18 +110,40 @@ class OpenVLA:
             self._side = torch.cuda.Stream(device=self.dev)
         self._side.wait_stream(main)
         with torch.cuda.stream(self._side):
-            xs = self.siglip.embed(frame_u8, [1.0 / (255.0 * 0.5)] * 3, [-1.0] * 3)
+            xs = self.siglip.embed(st["frame"], [1.0 / (255.0 * 0.5)] * 3, [-1.0] * 3, bufs=st["s"])
             xs = self.siglip.forward(xs)
-        xd = self.dino.embed(frame_u8, mul_d, add_d)
+        xd = self.dino.embed(st["frame"], mul_d, add_d, bufs=st["d"])
         xd = self.dino.forward(xd)
         main.wait_stream(self._side)
-        P = self.n_patches
-        fused = torch.empty(n * P, self.fused, dtype=BF, device=self.dev)
-        fused[:, :c["dino_dim"]].copy_(xd[:, c["dino_prefix"]:, :].reshape(n * P, -1))   # channel concat (device copies)
-        fused[:, c["dino_dim"]:].copy_(xs.reshape(n * P, -1))
-        h = ops.gemm(fused, self.proj[0], act="gelu_erf")
-        h = ops.gemm(h, self.proj[1], act="gelu_erf")
-        return ops.gemm(h, self.proj[2])
+        fused = st["fused"].view(n, P, self.fused)                       # channel concat (strided device copies)
+        fused[:, :, :c["dino_dim"]].copy_(xd[:, c["dino_prefix"]:, :])
+        fused[:, :, c["dino_dim"]:].copy_(xs)
+        h = ops.gemm(st["fused"], self.proj[0], act="gelu_erf", out=st["h"][0], ws=st["ws"][0])
+        h = ops.gemm(h, self.proj[1], act="gelu_erf", out=st["h"][1], ws=st["ws"][1])
+        return ops.gemm(h, self.proj[2], out=st["h"][2], ws=st["ws"][2])
+
+    def encode_image(self, frame_u8: torch.Tensor) -> torch.Tensor:
+        """frame uint8 [n_cams, H, W, 3] -> projected patch embeddings bf16 [n_cams*256, llm_dim] (a persistent buffer,
+        overwritten by the next call). The ~400 launches of the two towers are recorded into a hipGraph on first use
+        (COVER_VISION_GRAPH=0 disables): queued one after the other from the host, the second tower starts ~1 ms late."""
+        n, H, W, _ = frame_u8.shape
+        st = self._vision_static(n, H, W)
+        st["frame"].copy_(frame_u8)
+        if st["graph"] is not None:
+            st["graph"].launch()
+            return st["h"][2]
+        out = self._encode_static(st)                                    # eager (also sizes the towers' workspaces)
+        if os.environ.get("COVER_VISION_GRAPH", "1") != "0":
+            cur = torch.cuda.current_stream()
+            if self._cap is None:
+                self._cap = torch.cuda.Stream(device=self.dev)
+            self._cap.wait_stream(cur)
+            with torch.cuda.stream(self._cap):
+                with ops.Graph() as g:
+                    self._encode_static(st)
+            st["graph"] = g
+            cur.wait_stream(self._cap)
+        return out
 
     # ---------------------------------------------------------------------------------------------- sampler
     def sample(self, frame_u8: torch.Tensor, prompt_tokens: torch.Tensor, prompt_lens: torch.Tensor, n_samples: int,

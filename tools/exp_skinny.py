@@ -14,7 +14,7 @@ st = torch.cuda.Stream()
 with torch.cuda.stream(st):
     for K, N in [(4096, 12288), (4096, 4096), (4096, 22016), (11008, 4096), (4096, 32064)]:
         glu = N == 22016
-        ncopy = max(2, int(600e6 // (2 * N * K)) + 1)
+        ncopy = 1 if os.environ.get("WARM", "0") == "1" else max(2, int(600e6 // (2 * N * K)) + 1)
         lins = [ops.pack_linear((torch.randn(N, K, device=dev) * 0.02).bfloat16(), glu=glu) for _ in range(ncopy)]
         a = torch.randn(M, K, device=dev).bfloat16()
         o = torch.empty(M, lins[0].n_out, dtype=torch.bfloat16, device=dev)
