@@ -39,11 +39,15 @@ struct DecAttnDev {
 
 constexpr int DA_NW = 16;
 
-template <int D>
+// VS = 2: the value / output columns of a (16 candidates, head) unit are split over two blocks (blockIdx.z): both compute
+// the scores from the full K, each loads, multiplies and merges only its D/2 columns of V. The tile phase is bound by the
+// bytes one CU can pull in (64 blocks read 11.5 MB at N = 32, H = 32); two CUs at 0.75x the bytes each finish it sooner.
+template <int D, int VS>
 __global__ __launch_bounds__(1024) void decode_attn_fused_k(DecAttnDev a) {
-    constexpr int KS = D / 32, DB = D / 16, HALF = D / 2;
+    constexpr int KS = D / 32, DB = D / 16 / VS, HALF = D / 2, DV = D / VS;
     constexpr int OW = DB * 4 * 64;                    // floats of one wave's O state
-    constexpr int IPW = DB * 4 / DA_NW;                // (db, e) output items merged per wave (2 for D=128, 1 for D=64)
+    constexpr int IPW = (DB * 4 + DA_NW - 1) / DA_NW;  // (db, e) output items merged per wave
+    static_assert(DB * 4 % DA_NW == 0 || DB * 4 < DA_NW, "merge items must split evenly over the waves");
     __shared__ __attribute__((aligned(16))) bf16_t qs[16 * D];
     __shared__ __attribute__((aligned(16))) bf16_t kn[16 * D];   // k_new / v_new of the block's candidates (pool C reads them)
     __shared__ __attribute__((aligned(16))) bf16_t vn[16 * D];
@@ -53,6 +57,7 @@ __global__ __launch_bounds__(1024) void decode_attn_fused_k(DecAttnDev a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tile = blockIdx.x, h = blockIdx.y;
+    const int dv0 = blockIdx.z * DV;                  // first value / output column of this block
     const int r = lane & 15, g = lane >> 4;
     const int ncols = 3 * a.H * D;
     const int WB = DA_NW - a.WA - a.WC;
@@ -210,7 +215,7 @@ __global__ __launch_bounds__(1024) void decode_attn_fused_k(DecAttnDev a) {
             kr1[ks] = *(const u32x4*)(kbase + ko1 + ks * 32);
         }
 #pragma unroll
-        for (int db = 0; db < DB; ++db) vr[db] = *(const u32x4*)(vbase + vo + db * vstep);
+        for (int db = 0; db < DB; ++db) vr[db] = *(const u32x4*)(vbase + vo + (db + (dv0 >> 4)) * vstep);
     };
     // ---------------- phase 1b: RoPE, q / k_new / v_new -> LDS, k_new / v_new -> own cache segment ----------------
     if (p1) {
@@ -229,10 +234,11 @@ __global__ __launch_bounds__(1024) void decode_attn_fused_k(DecAttnDev a) {
             {
                 bf16_t* kd = a.k2 + a.write_t * a.k2_t + h * a.k2_h;
                 const unsigned kof = (unsigned)pslot2 * (unsigned)a.k2_slot + pi;
-                kd[kof] = f2bf(x[2]); kd[kof + HALF] = f2bf(x[3]);
+                if (blockIdx.z == 0) { kd[kof] = f2bf(x[2]); kd[kof + HALF] = f2bf(x[3]); }
                 bf16_t* vd = a.vt2 + h * a.vt2_h + a.write_t;
                 const unsigned vof = (unsigned)pslot2 * (unsigned)a.vt2_slot + pi * a.vt2_d;
-                vd[vof] = f2bf(x[4]); vd[vof + HALF * a.vt2_d] = f2bf(x[5]);
+                if (pi >= dv0 && pi < dv0 + DV) vd[vof] = f2bf(x[4]);
+                if (pi + HALF >= dv0 && pi + HALF < dv0 + DV) vd[vof + HALF * a.vt2_d] = f2bf(x[5]);
             }
         }
         qs[pc * D + pi] = f2bf(x[0]);
@@ -273,7 +279,7 @@ __global__ __launch_bounds__(1024) void decode_attn_fused_k(DecAttnDev a) {
                 const int sh = (e & 1) ? 16 : 0, wi = e >> 1;
 #pragma unroll
                 for (int db = 0; db < DB; ++db) {
-                    const unsigned nv = (unsigned)vn[(cl + g) * D + db * 16 + r] << sh;
+                    const unsigned nv = (unsigned)vn[(cl + g) * D + dv0 + db * 16 + r] << sh;
 #pragma unroll
                     for (int q = 0; q < 4; ++q) vr[db][q] = (q == wi) ? ((vr[db][q] & keep) | nv) : vr[db][q];
                     asm volatile("" ::: "memory");
@@ -359,6 +365,7 @@ __global__ __launch_bounds__(1024) void decode_attn_fused_k(DecAttnDev a) {
     }
     const float inv = lt > 0.f ? 1.f / lt : 0.f;
     const int item0 = w * IPW, db = item0 >> 2, e0 = item0 & 3;
+    if (item0 >= DB * 4) return;                       // fewer merge items than waves (small D / VS = 2)
     float o[IPW];
 #pragma unroll
     for (int e = 0; e < IPW; ++e) {
@@ -367,7 +374,7 @@ __global__ __launch_bounds__(1024) void decode_attn_fused_k(DecAttnDev a) {
         for (int i = 0; i < DA_NW; ++i) acc += so[i * OW + (item0 + e) * 64 + lane] * f[i];
         o[e] = acc * inv;
     }
-    bf16_t* op = a.out + (long long)cand_r * a.o_row + (long long)h * D + db * 16 + 4 * g + e0;
+    bf16_t* op = a.out + (long long)cand_r * a.o_row + (long long)h * D + dv0 + db * 16 + 4 * g + e0;
     if constexpr (IPW == 2) {
         *(uint32_t*)op = pack_bf2(o[0], o[1]);
     } else {
@@ -414,12 +421,19 @@ hipError_t launch_decode_attention_fused(const cover_decode_attn_args* x, hipStr
     const int nA = (s0.len + 31) / 32;
     a.WC = 4;
     a.WA = nA < 9 ? nA : 9;
-    dim3 grid((x->N + 15) / 16, x->H), block(64 * DA_NW);
+    // few (candidate tile, head) units: split the value columns over two blocks each (see the kernel's VS comment)
+    static const char* vs_env = getenv("COVER_DA_VSPLIT");
+    const int units = ((x->N + 15) / 16) * x->H;
+    const int VS = vs_env ? (atoi(vs_env) == 2 ? 2 : 1) : (units <= 128 ? 2 : 1);
+    dim3 grid((x->N + 15) / 16, x->H, VS), block(64 * DA_NW);
     const int pid = prof_enabled() ? prof_open(st, 2, 0.0) : -1;
-    if (x->D == 128)
-        hipLaunchKernelGGL(decode_attn_fused_k<128>, grid, block, 0, st, a);
-    else
-        hipLaunchKernelGGL(decode_attn_fused_k<64>, grid, block, 0, st, a);
+    if (x->D == 128) {
+        if (VS == 2) hipLaunchKernelGGL((decode_attn_fused_k<128, 2>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((decode_attn_fused_k<128, 1>), grid, block, 0, st, a);
+    } else {
+        if (VS == 2) hipLaunchKernelGGL((decode_attn_fused_k<64, 2>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((decode_attn_fused_k<64, 1>), grid, block, 0, st, a);
+    }
     prof_close(st, pid);
     return hipGetLastError();
 }

@@ -539,9 +539,10 @@ def test_tokens_to_histories_matches_host_path(dev):
 
 @pytest.mark.parametrize("D,H", [(128, 8), (64, 4)])
 @pytest.mark.parametrize("N,write_t,mode,from_partials", [(32, 0, 1, False), (32, 4, 2, True), (21, 3, 1, True), (5, 6, 0, False),
-                                                         (64, 5, 1, False)])
+                                                         (64, 5, 1, False), (144, 2, 2, True)])
 def test_decode_attention_fused_matches_three_launch_path(dev, D, H, N, write_t, mode, from_partials):
     # one launch (RoPE + KV append + [shared | per-prompt | own] attention) == rope_kv_write + attention over 3 segments
+    # (N = 144: more than 128 (candidate tile, head) units for H = 8, i.e. the unsplit VS = 1 variant; fewer: VS = 2)
     T0, T1, cap2, npos = 257, 24, 32, 320
     g = torch.Generator().manual_seed(1000 * N + 10 * write_t + mode)
     ncol = 3 * H * D
