@@ -80,9 +80,12 @@ int cover_packed_k(int K);
 int cover_pack_weight_bf16(const void* W, int ldw, int N, int K, void* Wp, int glu_interleave, void* stream);
 
 /* variant: 0 = auto, 1 = LDS-tiled with async global->LDS (global_load_lds), 2 = LDS-tiled register-staged,
- *          3 = weight-streaming split-K (requires M <= 64).  K = TRUE reduction length (A has >= cover_packed_k(K)
- *          readable, zero-padded columns when K is not a multiple of 128).
- * splitk_ws: fp32 scratch (cover_gemm_workspace_bytes) used by variant 3. */
+ *          3 = weight-streaming (requires M <= 64; the library picks the second-generation split-K kernel or, for
+ *              M <= 32 when its plan fills the chip, the third-generation full-K chunk-loop kernel),
+ *          5 = first-generation weight streaming (kept for A/B measurements), 6 = third generation forced (tests).
+ *          K = TRUE reduction length (A has >= cover_packed_k(K) readable, zero-padded columns when K is not a
+ *          multiple of 128).
+ * splitk_ws: fp32 scratch (cover_gemm_workspace_bytes) used by the weight-streaming variants and by split-K tiles. */
 size_t cover_gemm_workspace_bytes(int M, int N, int K);
 int cover_gemm_bf16(const void* A, int lda, const void* Wp, void* C, int ldc, int M, int N, int K,
                     const cover_gemm_epi* epi, void* splitk_ws, size_t splitk_ws_bytes, int variant, void* stream);
