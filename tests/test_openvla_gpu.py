@@ -100,3 +100,29 @@ def test_siglip2_features_match_oracle(dev):
     assert torch.allclose(tf.cpu(), rtf, atol=1e-2)
     assert (pf.cpu() * rpf).sum(-1).min() > 0.999
     assert (tf.cpu() * rtf).sum(-1).min() > 0.999
+
+
+def test_openvla_vision_graph_replay_equals_eager_and_cached_bos(dev):
+    """The first encode_image call runs eagerly and records both towers + projector into a hipGraph; later calls replay it
+    on the persistent buffers. Replays must reproduce the eager result bit for bit, follow a NEW frame, and sample()
+    (448-row prefill over the cached BOS K/V) must be repeatable across calls."""
+    from cover_vla_amd.openvla import OpenVLA
+    c, sd, frame, toks, lens, u = _case(seed=11)
+    model = OpenVLA(sd, c, device="cuda:0", max_prompts=4, max_candidates=8, max_text=toks.shape[1])
+    f0 = frame.to(dev)
+    e0 = model.encode_image(f0).clone()            # eager + capture
+    e1 = model.encode_image(f0).clone()            # replay
+    assert torch.equal(e0.view(torch.int16), e1.view(torch.int16))
+    f1 = (255 - frame).to(dev)
+    e2 = model.encode_image(f1).clone()            # replay on another frame: the graph reads the persistent frame buffer
+    assert not torch.equal(e0.view(torch.int16), e2.view(torch.int16))
+    fresh = OpenVLA(sd, c, device="cuda:0", max_prompts=4, max_candidates=8, max_text=toks.shape[1])
+    os.environ["COVER_VISION_GRAPH"] = "0"
+    try:
+        e3 = fresh.encode_image(f1).clone()        # never captured
+    finally:
+        os.environ.pop("COVER_VISION_GRAPH", None)
+    assert torch.equal(e2.view(torch.int16), e3.view(torch.int16))
+    t0, _ = model.sample(f0, toks.to(dev), lens.to(dev), 2, u.to(dev), 1.0)
+    t1, _ = model.sample(f0, toks.to(dev), lens.to(dev), 2, u.to(dev), 1.0)
+    assert torch.equal(t0, t1)

@@ -22,7 +22,7 @@ for K, N in [(4096, 12288), (4096, 4096), (4096, 22016), (11008, 4096)]:
     a = torch.randn(M, K, device=dev, generator=g).bfloat16()
     o = torch.empty(M, lin.n_out, dtype=torch.bfloat16, device=dev)
     ws = ops.gemm_workspace(M, N, K, dev)
-    f = lambda: ops.gemm(a, lin, act="silu" if glu else "none", out=o, variant=1, ws=ws)
+    f = lambda: ops.gemm(a, lin, act="silu" if glu else "none", out=o, variant=int(os.environ.get("VARIANT", "1")), ws=ws)
     f(); torch.cuda.synchronize()
     # correctness against fp32 matmul of the same bf16 operands
     y = a.float() @ w.float().T
@@ -33,7 +33,7 @@ for K, N in [(4096, 12288), (4096, 4096), (4096, 22016), (11008, 4096)]:
     reps = max(10, 2 * ncopy)
     with ops.Graph() as gr:
         for i in range(reps):
-            ops.gemm(a, lins[i % ncopy], act="silu" if glu else "none", out=o, variant=1, ws=ws)
+            ops.gemm(a, lins[i % ncopy], act="silu" if glu else "none", out=o, variant=int(os.environ.get("VARIANT", "1")), ws=ws)
     gr.launch(); torch.cuda.synchronize()
     t = ops.Timer(); t.start()
     for _ in range(5):
