@@ -80,7 +80,8 @@ class GemmF32Args(C.Structure):
                 ("C", c_p), ("c_row_stride", c_ll),
                 ("bias", c_p), ("residual", c_p), ("ld_residual", c_ll),
                 ("M", c_i), ("N", c_i), ("K", c_i), ("act", c_i), ("alpha", c_f),
-                ("batch", c_i), ("a_batch_stride", c_ll), ("b_batch_stride", c_ll), ("c_batch_stride", c_ll)]
+                ("batch", c_i), ("a_batch_stride", c_ll), ("b_batch_stride", c_ll), ("c_batch_stride", c_ll),
+                ("bias_batch_stride", c_ll)]
 
 
 class MhaF32Args(C.Structure):
@@ -176,6 +177,7 @@ SYMBOLS = {
     "cover_cast_bf16_to_f32": (c_i, [c_p, c_i, c_p, c_i, c_i, c_i, c_p]),
     "cover_gemm_f32": (c_i, [_P(GemmF32Args), c_p]),
     "cover_layernorm_f32": (c_i, [c_p, c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_p]),
+    "cover_layernorm_f32_grouped": (c_i, [c_p, c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_i, c_ll, c_p]),
     "cover_softmax_rows_f32": (c_i, [c_p, c_i, c_i, c_i, c_f, c_p]),
     "cover_l2norm_rows_f32": (c_i, [c_p, c_i, c_p, c_i, c_i, c_i, c_p]),
     "cover_add_f32": (c_i, [c_p, c_i, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_p]),

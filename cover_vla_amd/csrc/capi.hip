@@ -135,6 +135,12 @@ int cover_layernorm_f32(const float* x, int ldx, const float* w, const float* b,
     HIPCHK(launch_layernorm_f32(x, ldx, w, b, y, ldy, rows, dim, eps, ST(stream)), "layernorm_f32");
     return COVER_OK;
 }
+int cover_layernorm_f32_grouped(const float* x, int ldx, const float* w, const float* b, float* y, int ldy, int rows, int dim,
+                                float eps, int rows_per_group, long long wb_group_stride, void* stream) {
+    if (rows_per_group <= 0) return fail(COVER_EINVAL, "cover_layernorm_f32_grouped: rows_per_group");
+    HIPCHK(launch_layernorm_f32(x, ldx, w, b, y, ldy, rows, dim, eps, ST(stream), rows_per_group, wb_group_stride), "layernorm_f32_grouped");
+    return COVER_OK;
+}
 int cover_softmax_rows_f32(float* x, int ldx, int rows, int cols, float scale, void* stream) {
     HIPCHK(launch_softmax_rows_f32(x, ldx, rows, cols, scale, ST(stream)), "softmax_rows_f32");
     return COVER_OK;

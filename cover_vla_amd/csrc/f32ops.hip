@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256) void gemm_f32_k(cover_gemm_f32_args a) {
                 const int n = n0 + wn * (TN / 2) + j * 16 + r;
                 if (m < a.M && n < a.N) {
                     float v = acc[i][j][e];
-                    if (a.bias) v += a.bias[n];
+                    if (a.bias) v += a.bias[(size_t)bz * a.bias_batch_stride + n];
                     v = act_apply(v, a.act);
                     v *= a.alpha;
                     if (a.residual) v += a.residual[(size_t)bz * a.c_batch_stride + (size_t)m * a.ld_residual + n];
@@ -172,7 +172,7 @@ __global__ __launch_bounds__(256) void gemm_f32_direct_k(cover_gemm_f32_args a) 
         const int m = m0 + (q >> 1) * 16 + 4 * g + e;
         const int n = n0 + (q & 1) * 16 + r;
         if (m < a.M && n < a.N) {
-            if (a.bias) v += a.bias[n];
+            if (a.bias) v += a.bias[(size_t)bz * a.bias_batch_stride + n];
             v = act_apply(v, a.act);
             v *= a.alpha;
             if (a.residual) v += a.residual[(size_t)bz * a.c_batch_stride + (size_t)m * a.ld_residual + n];
@@ -217,8 +217,13 @@ hipError_t launch_gemm_f32(const cover_gemm_f32_args* a, hipStream_t st) {
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void layernorm_f32_k(const float* __restrict__ x, int ldx, const float* __restrict__ w,
                                                        const float* __restrict__ b, float* __restrict__ y, int ldy,
-                                                       int dim, float eps) {
+                                                       int dim, float eps, int rows_per_group, long long wb_group_stride) {
     __shared__ float red[16];
+    {   // stacked row groups with their own affine parameters
+        const long long go = (long long)(blockIdx.x / rows_per_group) * wb_group_stride;
+        if (w) w += go;
+        if (b) b += go;
+    }
     const float* xr = x + (size_t)blockIdx.x * ldx;
     float s = 0.f;
     for (int c = threadIdx.x; c < dim; c += 256) s += xr[c];
@@ -233,9 +238,10 @@ __global__ __launch_bounds__(256) void layernorm_f32_k(const float* __restrict__
     for (int c = threadIdx.x; c < dim; c += 256) yr[c] = (xr[c] - mean) * rstd * (w ? w[c] : 1.f) + (b ? b[c] : 0.f);
 }
 hipError_t launch_layernorm_f32(const float* x, int ldx, const float* w, const float* b, float* y, int ldy, int rows,
-                                int dim, float eps, hipStream_t st) {
+                                int dim, float eps, hipStream_t st, int rows_per_group, long long wb_group_stride) {
     if (rows <= 0) return hipSuccess;
-    hipLaunchKernelGGL(layernorm_f32_k, dim3(rows), dim3(256), 0, st, x, ldx, w, b, y, ldy, dim, eps);
+    if (rows_per_group <= 0) rows_per_group = rows;
+    hipLaunchKernelGGL(layernorm_f32_k, dim3(rows), dim3(256), 0, st, x, ldx, w, b, y, ldy, dim, eps, rows_per_group, wb_group_stride);
     return hipGetLastError();
 }
 

@@ -41,7 +41,7 @@ hipError_t launch_cast_bf16_to_f32(const bf16_t* x, int ldx, float* y, int ldy, 
 // ---- f32ops.hip ----------------------------------------------------------------------------------
 hipError_t launch_gemm_f32(const cover_gemm_f32_args* a, hipStream_t st);
 hipError_t launch_layernorm_f32(const float* x, int ldx, const float* w, const float* b, float* y, int ldy, int rows,
-                                int dim, float eps, hipStream_t st);
+                                int dim, float eps, hipStream_t st, int rows_per_group = 0, long long wb_group_stride = 0);
 hipError_t launch_softmax_rows_f32(float* x, int ldx, int rows, int cols, float scale, hipStream_t st);
 hipError_t launch_l2norm_rows_f32(const float* x, int ldx, float* y, int ldy, int rows, int cols, hipStream_t st);
 hipError_t launch_add_f32(const float* a, int lda, const float* b, int ldb, float* y, int ldy, int rows, int cols,

@@ -286,7 +286,7 @@ def cast_bf16_to_f32(x, out=None):
 
 # ------------------------------------------------------------------------------------------------ fp32 kernels
 def gemm_f32(a, b, *, bias=None, act="none", alpha=1.0, residual=None, out=None, b_is_kn=False, batch=1,
-             a_bs=0, b_bs=0, c_bs=0, M=None, N=None, K=None):
+             a_bs=0, b_bs=0, c_bs=0, M=None, N=None, K=None, bias_bs=0):
     """C[m,n] = residual + alpha*act(sum_k a[m,k] b[n,k] + bias[n]). b_is_kn: b given as [K, N] (k-major)."""
     _chk_dev(a, b)
     g = L.GemmF32Args()
@@ -308,6 +308,7 @@ def gemm_f32(a, b, *, bias=None, act="none", alpha=1.0, residual=None, out=None,
     g.ld_residual = residual.stride(-2) if residual is not None else 0
     g.M, g.N, g.K, g.act, g.alpha = M, N, K, ACT[act], alpha
     g.batch, g.a_batch_stride, g.b_batch_stride, g.c_batch_stride = batch, a_bs, b_bs, c_bs
+    g.bias_batch_stride = bias_bs
     L.check(L.lib().cover_gemm_f32(C.byref(g), _stream()), "gemm_f32")
     return out
 
@@ -330,6 +331,16 @@ def layernorm_f32(x, w, b, eps=1e-5, out=None):
     out = torch.empty_like(x) if out is None else out
     L.check(L.lib().cover_layernorm_f32(x.data_ptr(), x.stride(0), _ptr(w), _ptr(b), out.data_ptr(), out.stride(0),
                                         x.shape[0], x.shape[1], eps, _stream()), "layernorm_f32")
+    return out
+
+
+def layernorm_f32_grouped(x, w, b, rows_per_group, eps=1e-5, out=None):
+    """x fp32 [G * rows_per_group, dim]; w, b fp32 [G, dim]: group g's rows use w[g], b[g] (ensemble members in one launch)."""
+    _chk_dev(x, w)
+    out = torch.empty_like(x) if out is None else out
+    L.check(L.lib().cover_layernorm_f32_grouped(x.data_ptr(), x.stride(0), w.data_ptr(), _ptr(b), out.data_ptr(), out.stride(0),
+                                                x.shape[0], x.shape[1], eps, rows_per_group, w.stride(0), _stream()),
+            "layernorm_f32_grouped")
     return out
 
 

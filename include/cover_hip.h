@@ -230,10 +230,15 @@ typedef struct cover_gemm_f32_args {
     int act;
     float alpha;            /* C = residual + alpha * act(A.B^T + bias) */
     int batch; long long a_batch_stride, b_batch_stride, c_batch_stride;
+    long long bias_batch_stride; /* bias of batch z = bias + z * bias_batch_stride (0: one bias for every batch) */
 } cover_gemm_f32_args;
 int cover_gemm_f32(const cover_gemm_f32_args* args, void* stream);
 int cover_layernorm_f32(const float* x, int ldx, const float* w, const float* b, float* y, int ldy, int rows, int dim,
                         float eps, void* stream);
+/* the same over stacked row groups with their own affine parameters (ensemble members batched into one launch):
+ * row r uses w + (r / rows_per_group) * wb_group_stride (and b likewise) */
+int cover_layernorm_f32_grouped(const float* x, int ldx, const float* w, const float* b, float* y, int ldy, int rows, int dim,
+                                float eps, int rows_per_group, long long wb_group_stride, void* stream);
 /* in place: x[r] = softmax(x[r] * scale) */
 int cover_softmax_rows_f32(float* x, int ldx, int rows, int cols, float scale, void* stream);
 /* y[r] = x[r] / ||x[r]||_2  (finetune_trajectory_bridge_ddp.py:329-330,352-354; efficient_ensemble_merged.py:223,245) */

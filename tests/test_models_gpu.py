@@ -46,6 +46,24 @@ def test_verifier_ties_and_short_histories(dev):
     assert abs(float(r["best"][0]) - float(z["max_score"])) < 1e-5
 
 
+def test_verifier_members_batched_equals_member_loop(dev):
+    """All members' trajectory encoders as batched launches (member = batch index) == the per-member loop, bit for bit."""
+    from cover_vla_amd.verifier import EfficientEnsembleMerged
+    ckpt = synth.verifier_checkpoint(3, seed=5)
+    pf, tf, hists = synth.verifier_inputs(32, seed=5)
+    ens = EfficientEnsembleMerged(ckpt, device="cuda:0")
+    assert ens._traj_stack is not None and ens._traj_stack.ok
+    its = ens.image_text_embeddings(pf, tf)
+    rb = ens.score_histories(its, hists, 4)
+    os.environ["COVER_MEMBER_BATCH"] = "0"
+    try:
+        rl = ens.score_histories(its, hists, 4)
+    finally:
+        os.environ.pop("COVER_MEMBER_BATCH", None)
+    assert torch.equal(rb["acts"], rl["acts"]) and torch.equal(rb["scores"], rl["scores"])
+    assert int(rb["result"][0]) == int(rl["result"][0])
+
+
 # ------------------------------------------------------------------------------------------------ pi0 sampler
 @pytest.mark.parametrize("name", ["pi0_tiny_b6", "pi0_tiny_b1", "pi0_tiny_b40"])
 def test_pi0_sampler_matches_reference_golden(dev, name):
