@@ -33,6 +33,24 @@ def test_fullsize_gemm_kernels_agree(dev):
             assert torch.equal(y2, 2 * y3)
 
 
+@pytest.mark.parametrize("M,N,K", [(32, 12288, 4224), (7, 8192, 6272), (32, 32064, 4096), (20, 4096, 11008)])
+def test_fullsize_streaming_plans_with_ragged_k(dev, M, N, K):
+    """Third-generation weight streaming with K slices / chunks that do not divide evenly (ragged last chunk and slice),
+    M < 32 and the fused-epilogue (unsplit) plan of the lm_head shape: vs the LDS-tiled kernel and an fp32 matmul."""
+    g = torch.Generator(device=dev).manual_seed(M + N + K)
+    w = (torch.randn(N, K, device=dev, generator=g) * 0.02).bfloat16()
+    bias = torch.randn(N, device=dev, generator=g) * 0.1
+    lin = ops.pack_linear(w, bias)
+    a = torch.randn(M, K, device=dev, generator=g).bfloat16()
+    y3 = ops.gemm(a, lin, variant=3).float()
+    y1 = ops.gemm(a, lin, variant=1).float()
+    ref = a.float() @ w.float().T + bias
+    assert ((y3 - ref).norm() / ref.norm()).item() < 4e-3
+    assert ((y3 - y1).norm() / y1.norm()).item() < 4e-3
+    y32 = ops.gemm(a, lin, variant=3, out_f32=True)
+    assert torch.allclose(y32, ref.bfloat16().float(), atol=0.03, rtol=2e-2)
+
+
 def test_fullsize_attention_rows_are_convex_combinations(dev):
     """V = all-ones -> every output element is exactly 1 (softmax rows sum to 1) at the decode shape, 3 segments."""
     N, H, D = 32, 32, 128

@@ -541,6 +541,15 @@ def test_tokens_to_histories_matches_host_path(dev):
 @pytest.mark.parametrize("N,write_t,mode,from_partials", [(32, 0, 1, False), (32, 4, 2, True), (21, 3, 1, True), (5, 6, 0, False),
                                                          (64, 5, 1, False), (144, 2, 2, True)])
 def test_decode_attention_fused_matches_three_launch_path(dev, D, H, N, write_t, mode, from_partials):
+    _decode_attention_case(dev, D, H, N, write_t, mode, from_partials, permute_slots=False)
+
+
+def test_decode_attention_fused_with_an_explicit_own_slot_table(dev):
+    # candidates' own-token segments live in permuted cache slots (write_slot_of_batch / seg[2].slot_of_batch)
+    _decode_attention_case(dev, 128, 8, 29, 3, 2, True, permute_slots=True)
+
+
+def _decode_attention_case(dev, D, H, N, write_t, mode, from_partials, permute_slots):
     # one launch (RoPE + KV append + [shared | per-prompt | own] attention) == rope_kv_write + attention over 3 segments
     # (N = 144: more than 128 (candidate tile, head) units for H = 8, i.e. the unsplit VS = 1 variant; fewer: VS = 2)
     T0, T1, cap2, npos = 257, 24, 32, 320
@@ -568,16 +577,17 @@ def test_decode_attention_fused_matches_three_launch_path(dev, D, H, N, write_t,
     s0 = ops.Segment(c0[0], c0[1], c0[2], c0[3], length=T0, slot_of_batch=zero.to(dev))
     s1 = ops.Segment(c1[0], c1[1], c1[2], c1[3], length=T1, slot_of_batch=slot1.to(dev), len_of_batch=len1.to(dev))
     L2 = write_t + 1
+    slot2 = torch.randperm(N, generator=g).to(torch.int32).to(dev) if permute_slots else None
     # reference path
     qa = qkv.clone().to(dev)
     ops.rope_kv_write(qa, N, 1, H, H, D, positions=pos.to(dev), cos=cos, sin=sin, rope_mode=mode, k_cache=ca[0], k_strides=ca[2],
-                      vt_cache=ca[1], vt_strides=ca[3], t_offset=write_t)
+                      vt_cache=ca[1], vt_strides=ca[3], t_offset=write_t, slot_of_batch=slot2)
     ref = torch.empty(N, H * D, dtype=torch.bfloat16, device=dev)
     ops.attention(qa, (ncol, ncol, D), ref, (H * D, H * D, D), N, 1, H, H, D, D ** -0.5,
-                  [s0, s1, ops.Segment(ca[0], ca[1], ca[2], ca[3], length=L2)])
+                  [s0, s1, ops.Segment(ca[0], ca[1], ca[2], ca[3], length=L2, slot_of_batch=slot2)])
     # fused path
     out = torch.full((N, H * D), float("nan"), dtype=torch.bfloat16, device=dev)
-    ops.decode_attention_fused(qkv.to(dev), N, H, D, D ** -0.5, [s0, s1, ops.Segment(cb[0], cb[1], cb[2], cb[3], length=L2)],
+    ops.decode_attention_fused(qkv.to(dev), N, H, D, D ** -0.5, [s0, s1, ops.Segment(cb[0], cb[1], cb[2], cb[3], length=L2, slot_of_batch=slot2)],
                                write_t, out, positions=pos.to(dev), cos=cos, sin=sin, rope_mode=mode,
                                partial=None if part is None else part.to(dev), bias=None if bias is None else bias.to(dev))
     assert torch.equal(ca[0].cpu().view(torch.int16), cb[0].cpu().view(torch.int16))       # appended K rows, bit-exact
