@@ -121,6 +121,46 @@ __device__ __forceinline__ void epi_store4_glu(const EpiDev& e, void* C, int ldc
     }
 }
 
+// Epilogue of one wave's (WM*16) x (WN*16) tile at (mw, nw): split-K partial slab, GLU, or bias/act/residual store.
+template <int WM, int WN>
+__device__ __forceinline__ void tiled_epilogue(f32x4 (&acc)[WN][WM], const EpiDev& epi, void* C, int ldc, int M, int N, int mw,
+                                               int nw, int r, int g, float* __restrict__ partial) {
+#pragma unroll
+    for (int f = 0; f < WM; ++f) {
+        const int m = mw + f * 16 + r;
+        if (m >= M) continue;
+        if (partial) {  // split-K: raw fp32 partial sums, epilogue applied by splitk_reduce
+#pragma unroll
+            for (int b = 0; b < WN; ++b) {
+                const int n = nw + b * 16 + 4 * g;
+                if (n < N) {
+                    float* o = partial + ((size_t)blockIdx.y * M + m) * N + n;
+                    if (n + 3 < N && ((((uintptr_t)o) & 15) == 0)) {
+                        *(float4*)o = make_float4(acc[b][f][0], acc[b][f][1], acc[b][f][2], acc[b][f][3]);
+                    } else {
+                        for (int i = 0; i < 4; ++i)
+                            if (n + i < N) o[i] = acc[b][f][i];
+                    }
+                }
+            }
+        } else if (epi.glu) {
+#pragma unroll
+            for (int b = 0; b < WN; b += 2) {
+                const int nblk = (nw >> 4) + b;  // even block = gate, odd = up
+                float gv[4] = {acc[b][f][0], acc[b][f][1], acc[b][f][2], acc[b][f][3]};
+                float uv[4] = {acc[b + 1][f][0], acc[b + 1][f][1], acc[b + 1][f][2], acc[b + 1][f][3]};
+                epi_store4_glu(epi, C, ldc, m, (nblk >> 1) * 16 + 4 * g, N >> 1, gv, uv);
+            }
+        } else {
+#pragma unroll
+            for (int b = 0; b < WN; ++b) {
+                float v[4] = {acc[b][f][0], acc[b][f][1], acc[b][f][2], acc[b][f][3]};
+                epi_store4(epi, C, ldc, m, nw + b * 16 + 4 * g, N, v);
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // Tiled kernel: tile = (2*WM*16) x (2*WN*16) x 64, 4 waves in 2x2, each wave WM x WN MFMA fragments.
 //   <4,4> 128x128 (large GEMMs), <2,4> 64x128, <2,2> 64x64 (ViT-sized GEMMs whose 128x128 grid cannot fill 256 CUs).
@@ -281,40 +321,124 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_tiled(const bf16_t* __res
     }
 
     // ---- epilogue ----
-#pragma unroll
-    for (int f = 0; f < WM; ++f) {
-        const int m = m0 + wm * (WM * 16) + f * 16 + r;
-        if (m >= M) continue;
-        if (partial) {  // split-K: raw fp32 partial sums, epilogue applied by splitk_reduce
-#pragma unroll
-            for (int b = 0; b < WN; ++b) {
-                const int n = n0 + wn * (WN * 16) + b * 16 + 4 * g;
-                if (n < N) {
-                    float* o = partial + ((size_t)blockIdx.y * M + m) * N + n;
-                    if (n + 3 < N && ((((uintptr_t)o) & 15) == 0)) {
-                        *(float4*)o = make_float4(acc[b][f][0], acc[b][f][1], acc[b][f][2], acc[b][f][3]);
-                    } else {
-                        for (int i = 0; i < 4; ++i)
-                            if (n + i < N) o[i] = acc[b][f][i];
-                    }
-                }
-            }
-        } else if (epi.glu) {
-#pragma unroll
-            for (int b = 0; b < WN; b += 2) {
-                const int nblk = (n0 >> 4) + wn * WN + b;  // even block = gate, odd = up
-                float gv[4] = {acc[b][f][0], acc[b][f][1], acc[b][f][2], acc[b][f][3]};
-                float uv[4] = {acc[b + 1][f][0], acc[b + 1][f][1], acc[b + 1][f][2], acc[b + 1][f][3]};
-                epi_store4_glu(epi, C, ldc, m, (nblk >> 1) * 16 + 4 * g, N >> 1, gv, uv);
-            }
-        } else {
-#pragma unroll
-            for (int b = 0; b < WN; ++b) {
-                float v[4] = {acc[b][f][0], acc[b][f][1], acc[b][f][2], acc[b][f][3]};
-                epi_store4(epi, C, ldc, m, n0 + wn * (WN * 16) + b * 16 + 4 * g, N, v);
-            }
-        }
+    tiled_epilogue<WM, WN>(acc, epi, C, ldc, M, N, m0 + wm * (WM * 16), n0 + wn * (WN * 16), r, g, partial);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Producer / consumer variant of the tiled kernel: 4 MFMA waves (2 x 2) + ONE loader wave per block.
+// Cycle counters in gemm_tiled's k-loop (64x128, M = 448) show an MFMA wave spending ~30 % of every k-tile ISSUING its
+// LDS-DMA instructions (the CU's address path is shared, and all waves issue right after their barriers) and ~40 %
+// waiting for the tile issued one iteration earlier. Here the loader wave owns every LDS-DMA of the block and runs
+// NST-1 k-tiles ahead with a counted vmcnt; the MFMA waves only pass one barrier per k-tile and compute:
+//   loader:   wait (tile kt landed) -> barrier kt -> issue tile kt+NST-1 into the stage freed by compute(kt-1)
+//   consumer: barrier kt -> compute(stage kt % NST)
+// A consumer reaching barrier kt has finished compute(kt-1), so the stage the loader refills after that barrier is free;
+// LDS-DMA data is ordered for the consumers by the loader's vmcnt wait followed by the barrier they pass.
+// ---------------------------------------------------------------------------------------------------
+template <int WM, int WN, int NST>
+__global__ __launch_bounds__(320) void gemm_tiled_pc(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ Wp,
+                                                     void* C, int ldc, int M, int N, int Kp, EpiDev epi, int tiles_m,
+                                                     int tiles_n, int kt_per, float* __restrict__ partial) {
+    constexpr int BM_ = 2 * WM * 16, BN_ = 2 * WN * 16;
+    constexpr int A_BYTES = BM_ * BK * 2, B_BYTES = BN_ * BK * 2;
+    constexpr int AT = A_BYTES / 1024, BT = B_BYTES / 1024;   // 1-KiB LDS-DMA instructions per k-tile (all by the loader)
+    static_assert((NST - 2) * (AT + BT) <= 63, "counted vmcnt must fit its 6-bit field");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* As = smem;                   // [NST][A_BYTES]
+    char* Bs = smem + NST * A_BYTES;   // [NST][B_BYTES]
+    const int nwg = tiles_m * tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+        const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+        bid = base + (bid >> 3);
     }
+    const int tn = bid / tiles_m, tm = bid % tiles_m;
+    const int m0 = tm * BM_, n0 = tn * BN_;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int K32 = Kp >> 5;
+    const int N16 = (N + 15) >> 4;
+    const int nk_total = Kp / BK;
+    const int kt0 = blockIdx.y * kt_per;
+    const int nk = min(kt_per, nk_total - kt0);
+
+    if (w == 4) {   // ---------------- loader wave ----------------
+        const bf16_t* a_src[AT];
+        const bf16_t* b_src[BT];
+#pragma unroll
+        for (int j = 0; j < AT; ++j) {   // A: LDS chunk position p = j*64 + lane: row = p>>3, c = p&7 holds global chunk c ^ (row&7)
+            const int row = j * 8 + (lane >> 3), c = lane & 7;
+            int gr = m0 + row;
+            gr = gr < M ? gr : M - 1;
+            a_src[j] = A + (size_t)gr * lda + (size_t)kt0 * BK + ((c ^ (row & 7)) << 3);
+        }
+#pragma unroll
+        for (int j = 0; j < BT; ++j) {
+            const int nbi = j >> 1, kbi = j & 1;
+            int nb = (n0 >> 4) + nbi;
+            nb = nb < N16 ? nb : N16 - 1;
+            b_src[j] = Wp + ((size_t)nb * K32 + (size_t)kt0 * 2 + kbi) * 512 + lane * 8;
+        }
+        const uint32_t as_u32 = __builtin_amdgcn_readfirstlane(lds_addr_u32(As));
+        const uint32_t bs_u32 = __builtin_amdgcn_readfirstlane(lds_addr_u32(Bs));
+        auto issue = [&](int buf, int kt) {
+#pragma unroll
+            for (int j = 0; j < AT; ++j) glds16_asm(a_src[j] + kt * BK, as_u32 + buf * A_BYTES + j * 1024);
+#pragma unroll
+            for (int j = 0; j < BT; ++j) glds16_asm(b_src[j] + (size_t)kt * 2 * 512, bs_u32 + buf * B_BYTES + j * 1024);
+        };
+#pragma unroll
+        for (int s = 0; s < NST - 1; ++s)
+            if (s < nk) issue(s, s);
+        int cur = 0;
+        for (int kt = 0; kt < nk; ++kt) {
+            const int younger = min(nk - 1 - kt, NST - 2);   // tiles issued after kt that may stay in flight
+            if (NST >= 4 && younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (AT + BT)) : "memory");
+            else if (younger >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AT + BT) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (kt + NST - 1 < nk) issue(cur == 0 ? NST - 1 : cur - 1, kt + NST - 1);   // stage (kt-1) % NST
+            cur = cur == NST - 1 ? 0 : cur + 1;
+        }
+        return;
+    }
+    // ---------------- MFMA waves ----------------
+    const int wm = w >> 1, wn = w & 1;
+    const int r = lane & 15, g = lane >> 4;
+    f32x4 acc[WN][WM];  // [n-block b][m-frag f]
+#pragma unroll
+    for (int b = 0; b < WN; ++b)
+#pragma unroll
+        for (int f = 0; f < WM; ++f) acc[b][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    int cur = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        __builtin_amdgcn_s_barrier();
+        const char* Ab = As + cur * A_BYTES;
+        const char* Bb = Bs + cur * B_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 xf[WM], wf[WN];
+#pragma unroll
+            for (int f = 0; f < WM; ++f) {
+                const int row = wm * (WM * 16) + f * 16 + r;
+                const int c = (ks * 4 + g) ^ (row & 7);
+                xf[f] = as_bf16x8(*(const uint4*)(Ab + (row * 8 + c) * 16));
+            }
+#pragma unroll
+            for (int b = 0; b < WN; ++b)
+                wf[b] = as_bf16x8(*(const uint4*)(Bb + (((wn * WN + b) * 2 + ks) * 64 + lane) * 16));
+#pragma unroll
+            for (int b = 0; b < WN; ++b)
+#pragma unroll
+                for (int f = 0; f < WM; ++f)
+                    acc[b][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[b], xf[f], acc[b][f], 0, 0, 0);
+        }
+        // the LDS reads of this tile must have returned before this wave reaches the next barrier (after which the
+        // loader may refill the stage): the MFMAs above consumed them, i.e. lgkmcnt is already drained
+        cur = cur == NST - 1 ? 0 : cur + 1;
+    }
+    tiled_epilogue<WM, WN>(acc, epi, C, ldc, M, N, m0 + wm * (WM * 16), n0 + wn * (WN * 16), r, g, partial);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1165,7 +1289,7 @@ hipError_t launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* Wp, void* C,
     // ---- tile / split-K selection: fill >= ~1 block per CU when the problem allows it
     // tile configurations: {wave tile (WM, WN) in 16-row units, wave grid, stages}
     struct Cand { int wm, wn, wgm, wgn, nst; };
-    const Cand cands[9] = {
+    const Cand cands[12] = {
         {4, 4, 2, 2, 2},   // 0: 128x128, 4 waves of 64x64, 2 stages (64 KiB)
         {2, 4, 2, 2, 2},   // 1:  64x128, 4 waves of 32x64, 2 stages (48 KiB)
         {2, 2, 2, 2, 3},   // 2:  64x64,  4 waves of 32x32, 3 stages (48 KiB)
@@ -1175,6 +1299,9 @@ hipError_t launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* Wp, void* C,
         {2, 4, 4, 2, 4},   // 6: 128x128, 8 waves of 32x64, 4 stages (128 KiB)
         {2, 4, 2, 2, 3},   // 7:  64x128, 4 waves, 3 stages (72 KiB, two blocks per CU, two k-tiles in flight each)
         {4, 4, 2, 2, 3},   // 8: 128x128, 4 waves, 3 stages (96 KiB, one block per CU)
+        {2, 4, 2, 2, 3},   // 9:  64x128, loader wave + 4 MFMA waves, 3 stages (72 KiB)
+        {2, 4, 2, 2, 4},   // a:  64x128, loader wave + 4 MFMA waves, 4 stages (96 KiB)
+        {4, 4, 2, 2, 3},   // b: 128x128, loader wave + 4 MFMA waves, 3 stages (96 KiB)
     };
     // Measured on MI355X (tools/bench_kernels.py, M = 441): this single-barrier-per-k-tile structure is latency-bound per
     // block, so residency beats tile size until the tile grid oversubscribes the chip several times over, while 64x64
@@ -1188,11 +1315,14 @@ hipError_t launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* Wp, void* C,
     // tiles (N = 22016, M = 449); inside the decision, with cold weights, it does not -- 137 vs ~130 us -- so 1024 stays)
     if (nblocks(0) < 1024) pick = (nblocks(1) >= 384) ? 1 : 2;
     // a 64x128 grid of about one block per CU on a long K (M = 448: o_proj / down of a 7B decoder) is latency-bound per block:
-    // the third stage (two k-tiles in flight) beats the 64x64 tile there (cold weights: down 90.9 -> 81.9 us, o_proj equal)
-    if (pick == 2 && nblocks(1) >= 192 && Kp >= 4096) pick = 7;
+    // deeper rings beat the 64x64 tile there (cold weights, down / o_proj: 64x64 90.9 / 35.7 us, 64x128 3-stage 81.9 / 35.6,
+    // 64x128 with a loader wave and 4 stages 78.2 / 34.6). For the multi-round grids (qkv, gate_up) neither the deeper ring
+    // nor the loader wave helps (they cost a resident block per CU): 2 stages x 3 blocks stays.
+    if (pick == 2 && nblocks(1) >= 192 && Kp >= 4096) pick = 10;   // loader-wave variant, 4 stages: 83.4 -> 78.2 us (down), 35.9 -> 34.6 (o_proj)
     {
         static const char* force = getenv("COVER_TILE_PICK");  // experiment knob: index into cands
-        if (force && force[0] >= '0' && force[0] <= '8') pick = force[0] - '0';
+        if (force && force[0] >= '0' && force[0] <= '9') pick = force[0] - '0';
+        if (force && (force[0] == 'a' || force[0] == 'b')) pick = 10 + (force[0] - 'a');
     }
     if (variant == 2 && pick > 2) pick = 0;
     const Cand cd = cands[pick];
@@ -1213,7 +1343,8 @@ hipError_t launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* Wp, void* C,
     // the load latency (~12.8 TB/s chip-wide at 2 stages => 42.7 / 64 FLOP per byte).
     const int nst = variant == 2 ? 2 : cd.nst;
     const size_t lds = (size_t)nst * (bm + bn) * BK * 2;
-    dim3 grid(tiles_m * tiles_n, S), block(64 * cd.wgm * cd.wgn);
+    const bool pc = pick >= 9;
+    dim3 grid(tiles_m * tiles_n, S), block(pc ? 320 : 64 * cd.wgm * cd.wgn);
     const int pid = prof_enabled() ? prof_open(st, 1, 2.0 * (double)M * (double)N * (double)K) : -1;
     hipError_t e = hipSuccess;
 #define LAUNCH_T(WM_, WN_, G_, NST_, WGM_, WGN_)                                                                            \
@@ -1226,7 +1357,21 @@ hipError_t launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* Wp, void* C,
         if (e == hipSuccess)                                                                                                \
             hipLaunchKernelGGL(kfn, grid, block, lds, st, A, lda, Wp, C, ldc, M, N, Kp, epi, tiles_m, tiles_n, kt_per, partial); \
     } while (0)
-    if (variant == 2) {
+#define LAUNCH_PC(WM_, WN_, NST_)                                                                                           \
+    do {                                                                                                                    \
+        auto kfn = gemm_tiled_pc<WM_, WN_, NST_>;                                                                           \
+        if (lds > 64 * 1024) {                                                                                              \
+            static hipError_t attr = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+            e = attr;                                                                                                       \
+        }                                                                                                                   \
+        if (e == hipSuccess)                                                                                                \
+            hipLaunchKernelGGL(kfn, grid, block, lds, st, A, lda, Wp, C, ldc, M, N, Kp, epi, tiles_m, tiles_n, kt_per, partial); \
+    } while (0)
+    if (pc) {
+        if (pick == 9) LAUNCH_PC(2, 4, 3);
+        else if (pick == 10) LAUNCH_PC(2, 4, 4);
+        else LAUNCH_PC(4, 4, 3);
+    } else if (variant == 2) {
         if (pick == 0) LAUNCH_T(4, 4, false, 2, 2, 2);
         else if (pick == 1) LAUNCH_T(2, 4, false, 2, 2, 2);
         else LAUNCH_T(2, 2, false, 2, 2, 2);
