@@ -584,15 +584,17 @@ __global__ __launch_bounds__(512) void gemm_skinny2(const bf16_t* __restrict__ A
     };
     load8(buf[0], 0);  // the first two weight blocks are in flight while the activation chunk is staged
     if (NBW > 1) load8(buf[1], 1);
-    {   // stage the activation chunk (fragment-major), zero beyond kc
-        const int cpr = KC >> 3;
-        const int total = MF * 16 * cpr;
-        for (int c = tid; c < total; c += 512) {
-            const int row = c / cpr, kc8 = c - row * cpr;
+    {   // stage the activation chunk (fragment-major), zero beyond kc: wave w moves fragments fi = w, w + 8, ... (fi =
+        // kst*MF + f); lane (rr, gg) owns row f*16 + rr, k = kst*32 + gg*8 -> lane-linear, conflict-free LDS stores
+        constexpr int NFR = (KC / 32) * MF;
+        const int rr = lane & 15, gg = lane >> 4;
+#pragma unroll 4
+        for (int fi = w; fi < NFR; fi += 8) {
+            const int kst = fi / MF, f = fi - kst * MF;
+            const int row = f * 16 + rr, kk = kst * 32 + gg * 8;
             uint4 v = make_uint4(0, 0, 0, 0);
-            if (row < M && kc8 * 8 < kc) v = *(const uint4*)(A + (size_t)row * lda + k0 + kc8 * 8);
-            const int kst = kc8 >> 2, gg = kc8 & 3, f = row >> 4, rr = row & 15;
-            *(uint4*)(smem + (((kst * MF + f) * 64) + rr + 16 * gg) * 16) = v;
+            if (row < M && kk < kc) v = *(const uint4*)(A + (size_t)row * lda + k0 + kk);
+            *(uint4*)(smem + fi * 1024 + lane * 16) = v;
         }
     }
     __syncthreads();
@@ -717,28 +719,26 @@ __global__ __launch_bounds__(512) void gemm_skinny3(const bf16_t* __restrict__ A
                 if (u < nst) dst[u] = __builtin_nontemporal_load(src + u * 64);
         }
     };
-    // activation chunk staging through registers (coalesced 16-B reads along k, fragment-major scatter into LDS)
+    // activation chunk staging through registers: wave w moves fragments fi = j*8 + w (fi = kst*MF + f); lane
+    // (rr, gg) = (lane & 15, lane >> 4) owns the 16 bytes of row f*16 + rr, k = kst*32 + gg*8, so the LDS image of a
+    // fragment is lane-linear and a wave's 16-byte stores are one contiguous KiB (a row-major thread map lands 16 lanes
+    // of every store on one bank)
+    static_assert(XL * 8 == (KC / 32) * MF, "fragments must split evenly over the waves");
     uint4 xr[XL];
+    const int srr = lane & 15, sgg = lane >> 4;
     auto x_load = [&](int c) {
         const int k0 = kb + c * KC, kc = min(KC, ke - k0);
-        constexpr int cpr = KC >> 3;
 #pragma unroll
         for (int j = 0; j < XL; ++j) {
-            const int q = tid + j * 512;
-            const int row = q / cpr, kc8 = q - row * cpr;
+            const int fi = j * 8 + w, kst = fi / MF, f = fi - kst * MF;
+            const int row = f * 16 + srr, kk = kst * 32 + sgg * 8;
             xr[j] = make_uint4(0, 0, 0, 0);
-            if (row < M && kc8 * 8 < kc) xr[j] = *(const uint4*)(A + (size_t)row * lda + k0 + kc8 * 8);
+            if (row < M && kk < kc) xr[j] = *(const uint4*)(A + (size_t)row * lda + k0 + kk);
         }
     };
     auto x_write = [&](int b) {
-        constexpr int cpr = KC >> 3;
 #pragma unroll
-        for (int j = 0; j < XL; ++j) {
-            const int q = tid + j * 512;
-            const int row = q / cpr, kc8 = q - row * cpr;
-            const int kst = kc8 >> 2, gg = kc8 & 3, f = row >> 4, rr = row & 15;
-            *(uint4*)(smem + b * XB + (((kst * MF + f) * 64) + rr + 16 * gg) * 16) = xr[j];
-        }
+        for (int j = 0; j < XL; ++j) *(uint4*)(smem + b * XB + (j * 8 + w) * 1024 + lane * 16) = xr[j];
     };
     auto comp8 = [&](u32x4(&src)[8], f32x4(&a)[MF], int c) {
         const int nst = steps_of(c);
