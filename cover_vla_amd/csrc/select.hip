@@ -112,7 +112,7 @@ __device__ void group_argmax_dev(const float* scores, int N, int gs, int* result
     }
 }
 
-__global__ __launch_bounds__(256) void score_select_k(cover_score_select_args a, float* fit_ws, float* fact_ws) {
+__global__ __launch_bounds__(1024) void score_select_k(cover_score_select_args a, float* fit_ws, float* fact_ws) {
     __shared__ float red[16];
     __shared__ float sv[16];
     __shared__ int si[16];
@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256) void score_select_k(cover_score_select_args a,
     // fused image-text embedding
     {
         float q = 0.f;
-        for (int d = threadIdx.x; d < dim; d += 256) {
+        for (int d = threadIdx.x; d < dim; d += blockDim.x) {
             float s = 0.f;
             for (int m = 0; m < a.n_members; ++m) s += a.it[(size_t)m * dim + d];
             s /= (float)a.n_members;
@@ -129,12 +129,12 @@ __global__ __launch_bounds__(256) void score_select_k(cover_score_select_args a,
             q += s * s;
         }
         const float nrm = sqrtf(block_sum(q, red));
-        for (int d = threadIdx.x; d < dim; d += 256) fit_ws[d] = fit_ws[d] / nrm;
+        for (int d = threadIdx.x; d < dim; d += blockDim.x) fit_ws[d] = fit_ws[d] / nrm;
     }
     __syncthreads();
     // per candidate: fused action embedding + score (one wave per candidate)
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    for (int n = w; n < a.N; n += 4) {
+    for (int n = w; n < a.N; n += (int)(blockDim.x >> 6)) {   // one wave per candidate, 16 waves
         float q = 0.f;
         for (int d = lane; d < dim; d += 64) {
             float s = 0.f;
@@ -161,7 +161,7 @@ hipError_t launch_score_select(const cover_score_select_args* a, hipStream_t st)
     if (a->N <= 0 || a->group_size <= 0 || a->N % a->group_size != 0 || a->N / a->group_size > 4096)
         return hipErrorInvalidValue;
     if (!a->fused_it_out || !a->fused_act_out) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(score_select_k, dim3(1), dim3(256), 0, st, *a, a->fused_it_out, a->fused_act_out);
+    hipLaunchKernelGGL(score_select_k, dim3(1), dim3(1024), 0, st, *a, a->fused_it_out, a->fused_act_out);
     return hipGetLastError();
 }
 
