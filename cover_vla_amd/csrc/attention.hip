@@ -43,15 +43,14 @@ struct AttnDev {
 };
 
 template <int D, bool KSPLIT>
-__global__ __launch_bounds__(512) void attn_kernel(AttnDev a) {
+__device__ __forceinline__ void attn_body(const AttnDev& a, int bx, int kvh, int b) {
     constexpr int KS = D / 32;  // k-steps of QK^T
     constexpr int DB = D / 16;  // 16-row d blocks of O^T
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nw = blockDim.x >> 6;
-    const int b = blockIdx.z, kvh = blockIdx.y;
-    const int tile = KSPLIT ? blockIdx.x : blockIdx.x * nw + w;
+    const int tile = KSPLIT ? bx : bx * nw + w;
     const int r = lane & 15, g = lane >> 4;
 
     const int qi = tile * 16 + r;
@@ -245,6 +244,34 @@ __global__ __launch_bounds__(512) void attn_kernel(AttnDev a) {
     }
 }
 
+template <int D, bool KSPLIT>
+__global__ __launch_bounds__(512) void attn_kernel(AttnDev a) {
+    attn_body<D, KSPLIT>(a, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// Two independent attention problems (the two row groups of a prefill pass: shared-prefix rows and the prompts' text rows)
+// in ONE launch: both are far too small to fill the chip, so back to back they cost two latency floors. Key-split mode
+// only; blockIdx.x enumerates (tile, batch) of problem 0, then of problem 1.
+template <int D>
+__global__ __launch_bounds__(512) void attn_kernel_dual(AttnDev a0, AttnDev a1, int tiles0, int n0, int tiles1) {
+    int idx = blockIdx.x;
+    if (idx < n0) {
+        attn_body<D, true>(a0, idx % tiles0, blockIdx.y, idx / tiles0);
+    } else {
+        idx -= n0;
+        attn_body<D, true>(a1, idx % tiles1, blockIdx.y, idx / tiles1);
+    }
+}
+
+template <int D>
+static hipError_t launch_dual_d(const AttnDev& a0, const AttnDev& a1, hipStream_t st) {
+    const int t0 = (a0.R + 15) / 16, t1 = (a1.R + 15) / 16;
+    const size_t lds = (size_t)(4 * (D / 16) * 4 * 64 + 2 * 4 * 16) * sizeof(float);
+    dim3 grid(t0 * a0.B + t1 * a1.B, a0.Hkv), block(256);
+    hipLaunchKernelGGL((attn_kernel_dual<D>), grid, block, lds, st, a0, a1, t0, t0 * a0.B, t1);
+    return hipGetLastError();
+}
+
 template <int D>
 static hipError_t launch_d(const AttnDev& a, hipStream_t st) {
     const int tiles = (a.R + 15) / 16;
@@ -267,9 +294,8 @@ static hipError_t launch_d(const AttnDev& a, hipStream_t st) {
     return hipGetLastError();
 }
 
-hipError_t launch_attention_bf16(const cover_attn_args* x, hipStream_t st) {
+static hipError_t build_attn_dev(const cover_attn_args* x, AttnDev& a) {
     if (x->n_seg < 1 || x->n_seg > 3 || x->Hq % x->Hkv != 0) return hipErrorInvalidValue;
-    AttnDev a;
     a.q = (const bf16_t*)x->q;
     a.out = (bf16_t*)x->out;
     a.q_b = x->q_b_stride; a.q_t = x->q_t_stride; a.q_h = x->q_h_stride;
@@ -291,15 +317,47 @@ hipError_t launch_attention_bf16(const cover_attn_args* x, hipStream_t st) {
         d.len = s.len; d.mode = s.mask_mode; d.causal_off = s.causal_offset;
         if (d.mode == COVER_MASK_VISLEN && d.vis_len == nullptr) return hipErrorInvalidValue;
     }
+    return hipSuccess;
+}
+
+hipError_t launch_attention_bf16(const cover_attn_args* x, hipStream_t st) {
+    AttnDev a;
+    hipError_t e = build_attn_dev(x, a);
+    if (e != hipSuccess) return e;
     if (a.B <= 0 || a.R <= 0) return hipSuccess;
     const int pid = prof_enabled() ? prof_open(st, 2, 0.0) : -1;
-    hipError_t e;
     switch (x->D) {
         case 64: e = launch_d<64>(a, st); break;
         case 96: e = launch_d<96>(a, st); break;
         case 128: e = launch_d<128>(a, st); break;
         case 256: e = launch_d<256>(a, st); break;
         default: e = hipErrorInvalidValue;
+    }
+    prof_close(st, pid);
+    return e;
+}
+
+// Both problems in one launch when both would run in key-split mode with 4 waves (else: two launches).
+hipError_t launch_attention_bf16_pair(const cover_attn_args* x0, const cover_attn_args* x1, hipStream_t st) {
+    AttnDev a0, a1;
+    hipError_t e = build_attn_dev(x0, a0);
+    if (e == hipSuccess) e = build_attn_dev(x1, a1);
+    if (e != hipSuccess) return e;
+    static const char* e_max = getenv("COVER_ATTN_KSPLIT_MAX");
+    static const char* e_pair = getenv("COVER_ATTN_PAIR");
+    const long long ks_max = e_max ? atoll(e_max) : 1023;
+    const long long q0 = (long long)((a0.R + 15) / 16) * a0.Hkv * a0.B, q1 = (long long)((a1.R + 15) / 16) * a1.Hkv * a1.B;
+    const bool pair = x0->D == x1->D && a0.Hkv == a1.Hkv && a0.B > 0 && a1.B > 0 && a0.R > 0 && a1.R > 0 && q0 <= ks_max && q1 <= ks_max &&
+                      (x0->D == 64 || x0->D == 96 || x0->D == 128) && !(e_pair && e_pair[0] == '0');
+    if (!pair) {
+        e = launch_attention_bf16(x0, st);
+        return e == hipSuccess ? launch_attention_bf16(x1, st) : e;
+    }
+    const int pid = prof_enabled() ? prof_open(st, 2, 0.0) : -1;
+    switch (x0->D) {
+        case 64: e = launch_dual_d<64>(a0, a1, st); break;
+        case 96: e = launch_dual_d<96>(a0, a1, st); break;
+        default: e = launch_dual_d<128>(a0, a1, st); break;
     }
     prof_close(st, pid);
     return e;

@@ -373,6 +373,12 @@ int cover_decoder_forward(const cover_dec_desc* d, const cover_dec_pass* p, void
             HIPCHK(launch_gemm_skinny_partial((const bf16_t*)h, dim, (const bf16_t*)L.qkv_w, (float*)sk, skb, rows, nqkv, dim, &qkv_splits, st), "dec qkv (partials)");
         else
             HIPCHK(launch_gemm_bf16((const bf16_t*)h, dim, (const bf16_t*)L.qkv_w, qkv, nqkv, rows, nqkv, dim, &e, (float*)sk, skb, variant, st), "dec qkv");
+        cover_rope_args ras[2];
+        cover_attn_args aas[2];
+        bool pending[2] = {false, false};
+        // both groups in one RoPE and one attention launch: plain multi-token groups only (no shared-prefix phase split)
+        const bool pair_ok = p->n_groups == 2 && qkv_splits == 0 && !(p->groups[0].seg0_shared && p->groups[0].T == 1) &&
+                             !(p->groups[1].seg0_shared && p->groups[1].T == 1);
         for (int g = 0; g < p->n_groups; ++g) {
             const cover_dec_group& G = p->groups[g];
             if (G.B * G.T == 0) continue;
@@ -400,7 +406,7 @@ int cover_decoder_forward(const cover_dec_desc* d, const cover_dec_pass* p, void
                 HIPCHK(launch_decode_attention_fused(&da, st), "dec fused decode attention");
                 continue;
             }
-            cover_rope_args ra;
+            cover_rope_args& ra = ras[g];
             memset(&ra, 0, sizeof ra);
             ra.qkv = gq; ra.ld_qkv = nqkv; ra.B = G.B; ra.T = G.T; ra.Hq = Hq; ra.Hkv = Hkv; ra.D = D;
             ra.positions = G.positions; ra.cos_table = d->cos_table; ra.sin_table = d->sin_table; ra.n_pos = d->n_pos;
@@ -413,8 +419,7 @@ int cover_decoder_forward(const cover_dec_desc* d, const cover_dec_pass* p, void
             if (qkv_splits > 0) {
                 ra.n_splits = qkv_splits; ra.partial = (const float*)sk; ra.bias = L.qkv_b;
             }
-            HIPCHK(launch_rope_kv_write(&ra, st), "dec rope/kv");
-            cover_attn_args aa;
+            cover_attn_args& aa = aas[g];
             memset(&aa, 0, sizeof aa);
             aa.q = gq; aa.q_b_stride = (long long)G.T * nqkv; aa.q_t_stride = nqkv; aa.q_h_stride = D;
             aa.out = (bf16_t*)attn + (size_t)row0[g] * HD; aa.o_b_stride = (long long)G.T * HD; aa.o_t_stride = HD; aa.o_h_stride = D;
@@ -424,6 +429,9 @@ int cover_decoder_forward(const cover_dec_desc* d, const cover_dec_pass* p, void
                 aa.seg[s].k = (const bf16_t*)L.k_cache + G.seg_k_offset[s];
                 aa.seg[s].vt = (const bf16_t*)L.vt_cache + G.seg_vt_offset[s];
             }
+            pending[g] = true;
+            if (pair_ok) continue;   // both groups: launched together below
+            HIPCHK(launch_rope_kv_write(&ra, st), "dec rope/kv");
             if (G.seg0_shared && G.T == 1 && G.n_seg >= 2 && G.segs[0].mask_mode == COVER_MASK_LEN) {
                 // phase A: the shared segment, candidates as the query rows of one "sequence"
                 cover_attn_args pa = aa;
@@ -440,6 +448,18 @@ int cover_decoder_forward(const cover_dec_desc* d, const cover_dec_pass* p, void
                 aa.state_in_ml = pa.state_out_ml;
             }
             HIPCHK(launch_attention_bf16(&aa, st), "dec attention");
+        }
+        if (pair_ok && pending[0] && pending[1]) {
+            // two row groups of one pass (prefill: shared-prefix rows + the prompts' text rows): RoPE / KV placement of both,
+            // then attention of both, one launch each -- the second group attends keys the first one writes
+            HIPCHK(launch_rope_kv_write_pair(&ras[0], &ras[1], st), "dec rope/kv (both groups)");
+            HIPCHK(launch_attention_bf16_pair(&aas[0], &aas[1], st), "dec attention (both groups)");
+        } else if (pair_ok) {
+            for (int g = 0; g < 2; ++g)
+                if (pending[g]) {
+                    HIPCHK(launch_rope_kv_write(&ras[g], st), "dec rope/kv");
+                    HIPCHK(launch_attention_bf16(&aas[g], st), "dec attention");
+                }
         }
         memset(&e, 0, sizeof e);
         e.out_scale = 1.0f;

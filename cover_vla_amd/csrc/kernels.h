@@ -19,6 +19,7 @@ hipError_t launch_pack_weight_bf16(const bf16_t* W, int ldw, int N, int K, bf16_
 
 // ---- attention.hip -------------------------------------------------------------------------------
 hipError_t launch_attention_bf16(const cover_attn_args* a, hipStream_t st);
+hipError_t launch_attention_bf16_pair(const cover_attn_args* a0, const cover_attn_args* a1, hipStream_t st);
 hipError_t launch_decode_attention_fused(const cover_decode_attn_args* a, hipStream_t st);
 
 // ---- rowops.hip ----------------------------------------------------------------------------------
@@ -27,6 +28,7 @@ hipError_t launch_layernorm_bf16(const bf16_t* x, int ldx, const float* w, const
 hipError_t launch_rmsnorm(const void* x, int x_f32, int ldx, const float* w, float w_offset, int style, bf16_t* y, int ldy,
                           int rows, int dim, float eps, hipStream_t st);
 hipError_t launch_rope_kv_write(const cover_rope_args* a, hipStream_t st);
+hipError_t launch_rope_kv_write_pair(const cover_rope_args* a0, const cover_rope_args* a1, hipStream_t st);
 hipError_t launch_embed_gather(const bf16_t* table, int dim, const int64_t* ids, int n, float scale, bf16_t* out,
                                int ldo, hipStream_t st);
 hipError_t launch_patchify(const cover_patchify_args* a, hipStream_t st);

@@ -134,9 +134,8 @@ hipError_t launch_rmsnorm(const void* x, int x_f32, int ldx, const float* w, flo
 // ---------------------------------------------------------------------------------------------------
 // RoPE + KV placement: one wave per (row, head) of the fused qkv buffer
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void rope_kv_write_k(cover_rope_args a) {
+__device__ __forceinline__ void rope_kv_body(const cover_rope_args& a, int wid) {
     const int lane = threadIdx.x & 63;
-    const int wid = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int nh = a.Hq + 2 * a.Hkv;
     const int rows = a.B * a.T;
     if (wid >= rows * nh) return;
@@ -194,6 +193,27 @@ __global__ __launch_bounds__(256) void rope_kv_write_k(cover_rope_args a) {
         dst[i] = f2bf(o1);
         dst[i + half] = f2bf(o2);
     }
+}
+__global__ __launch_bounds__(256) void rope_kv_write_k(cover_rope_args a) {
+    rope_kv_body(a, blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+}
+// two row groups of one pass in one launch (waves [0, waves0) belong to the first)
+__global__ __launch_bounds__(256) void rope_kv_write2_k(cover_rope_args a0, cover_rope_args a1, int waves0) {
+    const int wid = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (wid < waves0) rope_kv_body(a0, wid);
+    else rope_kv_body(a1, wid - waves0);
+}
+static bool rope_args_ok(const cover_rope_args* a) {
+    return a->vt_cache && !(a->D & 1) && (a->rope_mode == 0 || (a->cos_table && a->sin_table));
+}
+hipError_t launch_rope_kv_write_pair(const cover_rope_args* a0, const cover_rope_args* a1, hipStream_t st) {
+    const long long w0 = (long long)a0->B * a0->T * (a0->Hq + 2 * a0->Hkv), w1 = (long long)a1->B * a1->T * (a1->Hq + 2 * a1->Hkv);
+    if (w0 <= 0) return launch_rope_kv_write(a1, st);
+    if (w1 <= 0) return launch_rope_kv_write(a0, st);
+    if (!rope_args_ok(a0) || !rope_args_ok(a1)) return hipErrorInvalidValue;
+    const int blocks = (int)((w0 + w1 + 3) / 4);
+    hipLaunchKernelGGL(rope_kv_write2_k, dim3(blocks), dim3(256), 0, st, *a0, *a1, (int)w0);
+    return hipGetLastError();
 }
 hipError_t launch_rope_kv_write(const cover_rope_args* a, hipStream_t st) {
     const long long waves = (long long)a->B * a->T * (a->Hq + 2 * a->Hkv);
