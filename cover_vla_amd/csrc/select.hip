@@ -54,19 +54,31 @@ __global__ __launch_bounds__(256) void token_select_k(cover_token_select_args a)
     const float inv_t = 1.0f / a.temperature;
     for (int c = threadIdx.x; c < n; c += 256) probs[c] = expf((lg[a.lo + c] - v) * inv_t);
     __syncthreads();
+    // sequential fp32 sums in index order (the oracle's arithmetic), but without a data-dependent exit inside the chain:
+    // thread 0 leaves the running sums in LDS (loads pipeline, only the adds are serial), then everyone searches them
+    __shared__ float csum[4096];
+    __shared__ float tgt;
     if (threadIdx.x == 0) {
         float total = 0.f;
         for (int c = 0; c < n; ++c) total += probs[c];
-        const float target = a.uniform[row] * total;
+        tgt = a.uniform[row] * total;
         float cs = 0.f;
-        int pick = n - 1;
         for (int c = 0; c < n; ++c) {
             cs += probs[c];
-            if (cs > target) {
-                pick = c;
-                break;
-            }
+            csum[c] = cs;
         }
+    }
+    __syncthreads();
+    int pick = n - 1;   // first index whose running sum exceeds the target (n - 1 if none does)
+    for (int c = threadIdx.x; c < n; c += 256)
+        if (csum[c] > tgt) { pick = c < pick ? c : pick; break; }
+    {   // block-wide minimum of the per-thread first hits (max of the negated index; indices < 4096 are exact in fp32)
+        float nv = -(float)pick;
+        int pi = pick;
+        block_argmax(nv, pi, sv, si);
+        pick = (int)(-nv);
+    }
+    if (threadIdx.x == 0) {
         a.token_out[row] = a.lo + pick;
         if (a.logit_out) a.logit_out[row] = lg[a.lo + pick];
     }
