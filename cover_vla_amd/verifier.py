@@ -116,6 +116,85 @@ class _Member:
         return ops.l2norm_rows_f32(m)
 
 
+class _PoolingStack:
+    """`_Pooling` of all members in batched launches (member = batch index)."""
+
+    def __init__(self, pools: List["_Pooling"]):
+        p0 = pools[0]
+        self.G, self.L, self.E, self.H = len(pools), p0.n_layers, p0.dim, p0.heads
+        st = lambda k: torch.stack([pp.sd[k] for pp in pools]).contiguous()
+        self.sd = {k: st(k) for k in p0.sd if torch.is_tensor(p0.sd[k])}
+        self.w_kv = torch.stack([pp.w_kv for pp in pools]).contiguous()
+        self.b_kv = torch.stack([pp.b_kv for pp in pools]).contiguous()
+        self.q_b = [torch.stack([pp.sd[f"blocks.{i}.attention.in_proj_bias"][:p0.dim] for pp in pools]).contiguous()
+                    for i in range(p0.n_layers)]
+
+    def __call__(self, x: torch.Tensor, shared: bool) -> torch.Tensor:
+        """x fp32 [T, Din] (shared by every member) or [G, T, Din] -> [G, E]."""
+        sd, G, E, H = self.sd, self.G, self.E, self.H
+        T, Din = x.shape[-2], x.shape[-1]
+        ld = self.w_kv.shape[1]
+        kv = ops.gemm_f32(x, self.w_kv, bias=self.b_kv, batch=G, a_bs=0 if shared else T * Din, b_bs=ld * Din, c_bs=T * ld,
+                          bias_bs=ld, M=T, N=ld, K=Din)                                  # [G, T, L*2E]
+        q = sd["query"].reshape(G, E)
+        bg = lambda a_, w_, b_, N_, K_, **kw: ops.gemm_f32(a_, w_, bias=b_, batch=G, a_bs=K_, b_bs=N_ * K_, c_bs=N_, bias_bs=N_,
+                                                           M=1, N=N_, K=K_, **kw).view(G, N_)
+        for i in range(self.L):
+            p = f"blocks.{i}."
+            q = ops.layernorm_f32_grouped(q, sd[p + "q_layer_norm.weight"], sd[p + "q_layer_norm.bias"], 1)
+            qp = bg(q.view(G, 1, E), sd[p + "attention.q_proj_weight"], self.q_b[i], E, E)
+            k = kv[:, :, (2 * i) * E:(2 * i + 1) * E]
+            v = kv[:, :, (2 * i + 1) * E:(2 * i + 2) * E]
+            a = ops.mha_f32(qp, k, v, G, 1, T, H, E // H, (E, E), (T * ld, ld), (T * ld, ld))
+            q = bg(a.view(G, 1, E), sd[p + "attention.out_proj.weight"], sd[p + "attention.out_proj.bias"], E, E, residual=q.view(G, 1, E))
+            q = ops.layernorm_f32_grouped(q, sd[p + "layer_norm.weight"], sd[p + "layer_norm.bias"], 1)
+            F = sd[p + "mlp.fc1.weight"].shape[1]
+            h = bg(q.view(G, 1, E), sd[p + "mlp.fc1.weight"], sd[p + "mlp.fc1.bias"], F, E, act="gelu_erf")
+            q = bg(h.view(G, 1, F), sd[p + "mlp.fc2.weight"], sd[p + "mlp.fc2.bias"], E, F, residual=q.view(G, 1, E))
+        return ops.layernorm_f32_grouped(q, sd["layer_norm.weight"], sd["layer_norm.bias"], 1)
+
+
+class _ImageTextStack:
+    """`_Member.image_text` of all members in batched launches: a third of the ~150 tiny fp32 launches of the member loop,
+    same per-element arithmetic (bit-identical)."""
+
+    def __init__(self, members: List["_Member"]):
+        m0 = members[0]
+        self.G, self.dev = len(members), m0.dev
+        same = lambda a, b: set(a) == set(b) and all((not torch.is_tensor(a[k])) or a[k].shape == b[k].shape for k in a)
+        self.ok = all(same(m0.vision.sd, mm.vision.sd) and same(m0.text.sd, mm.text.sd) and mm.pos_emb.shape == m0.pos_emb.shape and
+                      mm.ip["weight"].shape == m0.ip["weight"].shape and mm.vision.heads == m0.vision.heads and
+                      mm.text.heads == m0.text.heads for mm in members)
+        if not self.ok:
+            return
+        self.inv_temp = [mm.inv_temp for mm in members]
+        self.pos = torch.cat([mm.pos_emb.reshape(-1, mm.pos_emb.shape[-1]) for mm in members], 0).contiguous()   # [G*P, D]
+        self.vision, self.text = _PoolingStack([mm.vision for mm in members]), _PoolingStack([mm.text for mm in members])
+        self.ip_w = torch.stack([mm.ip["weight"] for mm in members]).contiguous()
+        self.ip_b = torch.stack([mm.ip["bias"] for mm in members]).contiguous()
+
+    def __call__(self, pf: torch.Tensor, tf: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+        """pf fp32 [P, D], tf fp32 [T, D] unit rows -> out fp32 [G, 512] unit rows."""
+        G = self.G
+        P, D = pf.shape
+        T = tf.shape[0]
+        sim = ops.gemm_f32(tf, pf, batch=G, a_bs=0, b_bs=0, c_bs=T * P, M=T, N=P, K=D)   # the same product, one copy per member
+        for gi in range(G):
+            ops.softmax_rows_f32(sim[gi], self.inv_temp[gi])
+        pfpe = ops.add_f32(self.pos, pf)                                                 # pos_emb[g] + pf (b rows cycle)
+        taf = ops.gemm_f32(sim, pfpe.view(G, P, D), b_is_kn=True, batch=G, a_bs=T * P, b_bs=P * D, c_bs=T * D, M=T, N=D, K=P)
+        vt = self.vision(taf, shared=False)
+        tt = self.text(tf, shared=True)
+        E1, E2 = tt.shape[1], vt.shape[1]
+        comb = torch.empty(G, E1 + E2, dtype=torch.float32, device=self.dev)
+        comb[:, :E1].copy_(tt)     # cat([text_token, vision_token]) (device copies, no arithmetic)
+        comb[:, E1:].copy_(vt)
+        No = self.ip_w.shape[1]
+        y = ops.gemm_f32(comb.view(G, 1, E1 + E2), self.ip_w, bias=self.ip_b, batch=G, a_bs=E1 + E2, b_bs=No * (E1 + E2), c_bs=No,
+                         bias_bs=No, M=1, N=No, K=E1 + E2)
+        return ops.l2norm_rows_f32(y.view(G, No), out=out)
+
+
 class _TrajectoryStack:
     """The trajectory encoders of ALL ensemble members as batched launches (members have one architecture): every GEMM /
     attention / norm of `_Member.trajectory` runs once with the member index as the batch dimension, i.e. a third of the
@@ -224,6 +303,7 @@ class EfficientEnsembleMerged:
             raise NotImplementedError("MLP action encoder variant (complex_action_encoder) is not on the evaluated path")
         self.trainable_models = [_Member(c, dev) for c in ck["ensemble_components"]]
         self._traj_stack = _TrajectoryStack(self.trainable_models) if self.num_models > 1 else None
+        self._it_stack = _ImageTextStack(self.trainable_models) if self.num_models > 1 else None
         self.encoder, self.preprocess, self.tokenizer = encoder, preprocess, tokenizer
         self._dev = dev
 
@@ -257,7 +337,8 @@ class EfficientEnsembleMerged:
         pf = patch_features[0].to(self._dev).contiguous()
         tf = text_features[0].to(self._dev).contiguous()
         its = torch.empty(self.num_models, 512, dtype=torch.float32, device=self._dev)
-
+        if self._it_stack is not None and self._it_stack.ok and os.environ.get("COVER_MEMBER_BATCH", "1") != "0":
+            return self._it_stack(pf, tf, its)          # all members per launch
         for i, m in enumerate(self.trainable_models):
             its[i] = m.image_text(pf, tf)[0]
         return its

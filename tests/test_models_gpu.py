@@ -53,13 +53,16 @@ def test_verifier_members_batched_equals_member_loop(dev):
     pf, tf, hists = synth.verifier_inputs(32, seed=5)
     ens = EfficientEnsembleMerged(ckpt, device="cuda:0")
     assert ens._traj_stack is not None and ens._traj_stack.ok
+    assert ens._it_stack is not None and ens._it_stack.ok
     its = ens.image_text_embeddings(pf, tf)
     rb = ens.score_histories(its, hists, 4)
     os.environ["COVER_MEMBER_BATCH"] = "0"
     try:
+        its_loop = ens.image_text_embeddings(pf, tf)
         rl = ens.score_histories(its, hists, 4)
     finally:
         os.environ.pop("COVER_MEMBER_BATCH", None)
+    assert torch.equal(its, its_loop)
     assert torch.equal(rb["acts"], rl["acts"]) and torch.equal(rb["scores"], rl["scores"])
     assert int(rb["result"][0]) == int(rl["result"][0])
 
