@@ -75,6 +75,7 @@ class Pipeline:
         self.ver = EfficientEnsembleMerged(ck, device=str(dev), encoder=self.enc)
         self.inp = build_inputs(dev, c)
         self.side = None
+        self.pool = None
         bins = np.linspace(-1, 1, c["n_bins"])
         self.centers = torch.tensor((bins[:-1] + bins[1:]) / 2.0, dtype=torch.float32, device=dev)   # float64 -> fp32 table
         self.past_dev = torch.tensor(self.inp["past"], dtype=torch.float32, device=dev)
@@ -85,25 +86,47 @@ class Pipeline:
 
     def decision(self, world=1, rank=0, cpu_gather=False):
         i = self.inp
-        # The verifier's frozen towers and image-text heads depend only on the observation and the instruction: they run
-        # on a side stream underneath the policy's HBM-bound, launch-gapped decode passes. The host queues them from the
-        # sampler's on_prefill_enqueued hook: queued first they cost ~3.5 ms of host launch time with the main stream
-        # idle, queued before the prefill they steal CUs from its MFMA-bound GEMMs (12.9 -> 14.6 ms).
+        # The verifier's frozen towers and image-text heads depend only on the observation and the instruction: they run on
+        # a side stream while the policy samples. Who queues them matters as much as where they run: queued by this
+        # thread before the policy they cost ~2.6 ms of host launch time with the main stream idle; queued from the
+        # sampler's after-prefill hook they run underneath the decode passes, whose one-block-per-CU weight-streaming
+        # grids lose ~1.4 ms to the co-tenants. A second host thread queues them from t = 0 instead (ctypes releases
+        # the GIL inside the library's composites): they overlap the launch-bound vision phase and the start of the
+        # prefill, and the decode passes run alone (42.2 -> 41.8 ms). COVER_SIDE_THREAD=0 selects the hook.
         main = torch.cuda.current_stream()
         if self.side is None:
             self.side = torch.cuda.Stream(device=self.dev)
         out = {}
 
         def side_work():
-            ev = torch.cuda.Event()
-            ev.record(main)
-            self.side.wait_event(ev)
             with torch.cuda.stream(self.side):
                 pf, tf = self.ver.extract_shared_features(i["img384"], i["text"])
-                out["its"] = self.ver.image_text_embeddings(pf, tf)
+                return self.ver.image_text_embeddings(pf, tf)
 
-        tokens, _ = self.policy.sample(i["frame"], i["toks"], i["lens"], N_SAMPLES, i["u"], 1.0, on_prefill_enqueued=side_work)
-        its = out["its"]
+        if os.environ.get("COVER_SIDE_THREAD", "1") != "0":
+            if self.pool is None:
+                import concurrent.futures
+                self.pool = concurrent.futures.ThreadPoolExecutor(max_workers=1)
+            ev = torch.cuda.Event()
+            ev.record(main)
+
+            def threaded():
+                torch.cuda.set_device(self.dev)
+                self.side.wait_event(ev)
+                return side_work()
+
+            fut = self.pool.submit(threaded)
+            tokens, _ = self.policy.sample(i["frame"], i["toks"], i["lens"], N_SAMPLES, i["u"], 1.0)
+            its = fut.result()
+        else:
+            def hook():
+                ev = torch.cuda.Event()
+                ev.record(main)
+                self.side.wait_event(ev)
+                out["its"] = side_work()
+
+            tokens, _ = self.policy.sample(i["frame"], i["toks"], i["lens"], N_SAMPLES, i["u"], 1.0, on_prefill_enqueued=hook)
+            its = out["its"]
         # de-tokenise + assemble the verifier histories on the device: no host sync between sampler and verifier
         from cover_vla_amd import ops
         hb, pad = ops.tokens_to_histories(tokens, self.c["tok_vocab"], self.centers, self.past_dev)

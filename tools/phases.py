@@ -38,7 +38,27 @@ for _ in range(R):
                 out["its"] = pipe.ver.image_text_embeddings(pf, tf)
                 _cache["its"] = out["its"]
 
-    tokens, _ = pipe.policy.sample(i["frame"], i["toks"], i["lens"], bench.N_SAMPLES, i["u"], 1.0, trace=tr, on_prefill_enqueued=side_work)
+    fut = None
+    if MODE == 3:   # diagnostic: side work queued BEFORE the policy (overlaps the vision phase and the start of the prefill)
+        side_work()
+    if MODE == 4:   # side work queued by a second host thread while this one queues the policy
+        import concurrent.futures
+        if "pool" not in _cache:
+            _cache["pool"] = concurrent.futures.ThreadPoolExecutor(max_workers=1)
+        ev0 = torch.cuda.Event(); ev0.record(main)
+
+        def threaded():
+            torch.cuda.set_device(dev)
+            pipe.side.wait_event(ev0)
+            with torch.cuda.stream(pipe.side):
+                pf, tf = pipe.ver.extract_shared_features(i["img384"], i["text"])
+                return pipe.ver.image_text_embeddings(pf, tf)
+
+        fut = _cache["pool"].submit(threaded)
+    tokens, _ = pipe.policy.sample(i["frame"], i["toks"], i["lens"], bench.N_SAMPLES, i["u"], 1.0, trace=tr,
+                                   on_prefill_enqueued=None if MODE in (3, 4) else side_work)
+    if fut is not None:
+        out["its"] = fut.result()
     if "its" not in out:
         main.wait_stream(pipe.side)
         out["its"] = pipe.ver.image_text_embeddings(out["pf"], out["tf"])
