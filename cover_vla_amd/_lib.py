@@ -188,6 +188,7 @@ SYMBOLS = {
     "cover_score_select": (c_i, [_P(ScoreSelectArgs), c_p]),
     "cover_group_argmax": (c_i, [c_p, c_i, c_i, c_p, c_p, c_p]),
     "cover_tokens_to_histories": (c_i, [c_p, c_i, c_i, c_i, c_p, c_i, c_p, c_i, c_f, c_p, c_p, c_p]),
+    "cover_actions_to_histories": (c_i, [c_p, c_ll, c_ll, c_i, c_i, c_p, c_p, c_i, c_f, c_p, c_p, c_p]),
     "cover_vit_workspace_bytes": (C.c_size_t, [_P(VitDesc), c_i, c_i]),
     "cover_vit_forward": (c_i, [_P(VitDesc), c_p, c_i, c_i, c_p, Workspace, c_i, c_p]),
     "cover_decoder_workspace_bytes": (C.c_size_t, [_P(DecDesc), c_i]),

@@ -188,6 +188,13 @@ int cover_tokens_to_histories(const int64_t* tokens, int ld_tokens, int N, int t
            "tokens_to_histories (0 <= n_past <= 9)");
     return COVER_OK;
 }
+int cover_actions_to_histories(const float* actions, long long n_stride, long long t_stride, int N, int n_use, const float* lo_hi,
+                               const float* past, int n_past, float pad_value, float* hist_out, uint8_t* pad_out, void* stream) {
+    if (!actions || !hist_out || !pad_out || (n_past > 0 && !past)) return fail(COVER_EINVAL, "cover_actions_to_histories: null pointer");
+    HIPCHK(launch_actions_to_histories(actions, n_stride, t_stride, N, n_use, lo_hi, past, n_past, pad_value, hist_out, pad_out, ST(stream)),
+           "actions_to_histories (n_use >= 1, n_past + n_use <= 10)");
+    return COVER_OK;
+}
 int cover_group_argmax(const float* scores, int N, int group_size, int* result_out, float* best_out, void* stream) {
     HIPCHK(launch_group_argmax(scores, N, group_size, result_out, best_out, ST(stream)), "group_argmax");
     return COVER_OK;

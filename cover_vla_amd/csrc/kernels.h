@@ -59,6 +59,9 @@ hipError_t launch_score_select(const cover_score_select_args* a, hipStream_t st)
 hipError_t launch_tokens_to_histories(const int64_t* tokens, int ld_tokens, int N, int tok_vocab, const float* centers,
                                       int n_centers, const float* past, int n_past, float pad_value, float* hist, uint8_t* pad,
                                       hipStream_t st);
+hipError_t launch_actions_to_histories(const float* actions, long long n_stride, long long t_stride, int N, int n_use,
+                                       const float* lo_hi, const float* past, int n_past, float pad_value, float* hist,
+                                       uint8_t* pad, hipStream_t st);
 hipError_t launch_group_argmax(const float* scores, int N, int gs, int* result, float* best, hipStream_t st);
 size_t gemm_workspace_bytes(int M, int N, int K);
 

@@ -227,3 +227,40 @@ hipError_t launch_tokens_to_histories(const int64_t* tokens, int ld_tokens, int 
                        centers, n_centers, past, n_past, pad_value, hist, pad);
     return hipGetLastError();
 }
+
+// flow-matching chunks -> verifier histories on the device (one thread per (candidate, history row))
+__global__ void actions_to_histories_k(const float* __restrict__ actions, long long n_stride, long long t_stride, int N, int n_use,
+                                       const float* __restrict__ lo_hi, const float* __restrict__ past, int n_past,
+                                       float pad_value, float* __restrict__ hist, uint8_t* __restrict__ pad) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= N * 10) return;
+    const int n = idx / 10, t = idx - n * 10;
+    const int n_pad = 10 - n_past - n_use;
+    float* o = hist + (size_t)idx * 7;
+    if (t < n_pad) {
+        for (int d = 0; d < 7; ++d) o[d] = pad_value;
+        pad[idx] = 1;
+    } else if (t < n_pad + n_past) {
+        const float* p = past + (size_t)(t - n_pad) * 7;
+        for (int d = 0; d < 7; ++d) o[d] = p[d];
+        pad[idx] = 0;
+    } else {
+        const float* a = actions + (size_t)n * n_stride + (size_t)(t - n_pad - n_past) * t_stride;
+        for (int d = 0; d < 6; ++d) {
+            float v = a[d];
+            if (lo_hi) v = (v - (-1.0f)) / (1.0f - (-1.0f)) * (lo_hi[6 + d] - lo_hi[d]) + lo_hi[d];   // denormalize_bound
+            o[d] = v;
+        }
+        o[6] = a[6] < 0.5f ? 0.f : 1.f;
+        pad[idx] = 0;
+    }
+}
+hipError_t launch_actions_to_histories(const float* actions, long long n_stride, long long t_stride, int N, int n_use,
+                                       const float* lo_hi, const float* past, int n_past, float pad_value, float* hist,
+                                       uint8_t* pad, hipStream_t st) {
+    if (N <= 0) return hipSuccess;
+    if (n_past < 0 || n_use < 1 || n_past + n_use > 10) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(actions_to_histories_k, dim3((N * 10 + 255) / 256), dim3(256), 0, st, actions, n_stride, t_stride, N, n_use,
+                       lo_hi, past, n_past, pad_value, hist, pad);
+    return hipGetLastError();
+}

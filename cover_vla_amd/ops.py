@@ -446,6 +446,21 @@ def tokens_to_histories(tokens, tok_vocab, centers, past, pad_value=-5.0):
     return hist, pad
 
 
+def actions_to_histories(actions, n_use, past, lo_hi=None, pad_value=-5.0):
+    """actions fp32 [N, chunk, >=7] (device, normalised policy output), past fp32 [n_past, 7], lo_hi fp32 [12] (p01[:6] | p99[:6])
+    or None -> (hist fp32 [N,10,7], pad uint8 [N,10]): the verifier histories of a flow-matching policy's chunks."""
+    _chk_dev(actions)
+    assert actions.dtype == torch.float32 and actions.stride(2) == 1
+    N = actions.shape[0]
+    hist = torch.empty(N, 10, 7, dtype=torch.float32, device=actions.device)
+    pad = torch.empty(N, 10, dtype=torch.uint8, device=actions.device)
+    n_past = 0 if past is None else past.shape[0]
+    L.check(L.lib().cover_actions_to_histories(actions.data_ptr(), actions.stride(0), actions.stride(1), N, n_use, _ptr(lo_hi),
+                                               _ptr(past), n_past, pad_value, hist.data_ptr(), pad.data_ptr(), _stream()),
+            "actions_to_histories")
+    return hist, pad
+
+
 def group_argmax(scores, group_size):
     _chk_dev(scores)
     result = torch.empty(4, dtype=torch.int32, device=scores.device)

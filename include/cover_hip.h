@@ -301,6 +301,15 @@ int cover_score_select(const cover_score_select_args* args, void* stream);
 int cover_tokens_to_histories(const int64_t* tokens, int ld_tokens, int N, int tok_vocab, const float* centers, int n_centers,
                               const float* past, int n_past, float pad_value, float* hist_out, uint8_t* pad_out, void* stream);
 
+/* The same for a flow-matching policy's action chunks (pi0): candidate n contributes the first n_use actions of its chunk
+ * (actions fp32 [N][chunk][>=7], strides in elements) after the verifier post-processing of the reference adapter
+ * (INT-ACT .../simpler.py:96-121, base.py:20-31): dims 0-5 un-normalised (a + 1) / 2 * (hi - lo) + lo with the dataset's
+ * p01 / p99 (lo_hi = fp32 [12] = lo[6] | hi[6], NULL = pass through), gripper 0 if a < 0.5 else 1.
+ * hist[n] = [pad rows | past[0..n_past) | n_use chunk rows], n_past + n_use <= 10. fp32 arithmetic (the reference does this
+ * in float64 on the host and converts: results agree to fp32 rounding). */
+int cover_actions_to_histories(const float* actions, long long n_stride, long long t_stride, int N, int n_use, const float* lo_hi,
+                               const float* past, int n_past, float pad_value, float* hist_out, uint8_t* pad_out, void* stream);
+
 /* grouped arg-max over already-computed (e.g. all-gathered) scores: same selection rule as above */
 int cover_group_argmax(const float* scores, int N, int group_size, int* result_out, float* best_out, void* stream);
 

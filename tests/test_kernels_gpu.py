@@ -537,6 +537,38 @@ def test_tokens_to_histories_matches_host_path(dev):
     assert np.array_equal(pad.cpu().numpy(), (ref[:, :, 0] == -5).astype(np.uint8))
 
 
+@pytest.mark.parametrize("n_past,n_use,denorm", [(6, 4, True), (0, 4, True), (2, 1, False), (6, 1, True), (0, 10, False)])
+def test_actions_to_histories_matches_host_path(dev, n_past, n_use, denorm):
+    # device post-processing of flow-matching chunks == host.process_inputs(verifier_action=True) + front padding
+    import numpy as np
+    from cover_vla_amd import host
+    g = torch.Generator().manual_seed(100 + n_past * 16 + n_use)
+    N, chunk, width = 13, max(n_use, 4), 32
+    x = torch.rand(N, chunk, width, generator=g) * 2.4 - 1.2
+    x[0, 0, 6] = 0.5                                     # the gripper threshold itself binarises to 1
+    history = [(torch.randn(7, generator=g) * 0.02).double().numpy() for _ in range(n_past)]
+    past = torch.tensor(np.stack(history), dtype=torch.float32, device=dev) if n_past else None
+    st = host.bridge_statistics()["action"]
+    lo_hi = torch.tensor(list(st["p01"][:6]) + list(st["p99"][:6]), dtype=torch.float32, device=dev) if denorm else None
+    hb, pad = ops.actions_to_histories(x.to(dev)[:, :, :7] if n_use % 2 else x.to(dev), n_use, past, lo_hi)
+    if denorm:
+        queue = [x[:, t, :7].numpy() for t in range(n_use)]
+        rows = host.process_inputs(queue, True, history, n_use)
+    else:
+        a = x[:, :n_use, :7].double().numpy().copy()
+        a[..., 6] = np.where(a[..., 6] < 0.5, 0, 1)
+        rows = [np.vstack(history + [a[n]]) if n_past else a[n] for n in range(N)]
+    n_pad = 10 - n_past - n_use
+    ref = np.stack([np.vstack([np.full((n_pad, 7), -5.0), r]) for r in rows])
+    got = hb.cpu().numpy()
+    assert np.array_equal(got[:, :n_pad + n_past], ref[:, :n_pad + n_past].astype(np.float32))
+    assert np.array_equal(got[..., 6], ref[..., 6].astype(np.float32))
+    assert np.abs(got - ref).max() <= 5e-7               # fp32 arithmetic vs float64 on the host (|values| < 0.5)
+    assert np.array_equal(pad.cpu().numpy(), (ref[:, :, 0] == -5).astype(np.uint8))
+    with pytest.raises(Exception):
+        ops.actions_to_histories(x.to(dev), 7, torch.zeros(6, 7, device=dev), None)
+
+
 @pytest.mark.parametrize("D,H", [(128, 8), (64, 4)])
 @pytest.mark.parametrize("N,write_t,mode,from_partials", [(32, 0, 1, False), (32, 4, 2, True), (21, 3, 1, True), (5, 6, 0, False),
                                                          (64, 5, 1, False), (144, 2, 2, True)])

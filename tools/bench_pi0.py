@@ -49,19 +49,40 @@ img384 = torch.randn(1, 3, 384, 384, generator=gen).to(dev); text = torch.randin
 past = (torch.randn(6, 7, generator=gen) * 0.02).double().numpy()
 toks, masks, state, noise = toks.to(dev), masks.to(dev), state.to(dev), noise.to(dev)
 side = torch.cuda.Stream()
+from concurrent.futures import ThreadPoolExecutor
+from cover_vla_amd import host
+pool = ThreadPoolExecutor(1)
+st = host.bridge_statistics()["action"]
+lo_hi = torch.tensor(list(st["p01"][:6]) + list(st["p99"][:6]), dtype=torch.float32, device=dev)
+past_d = torch.tensor(past, dtype=torch.float32, device=dev)
+history = [past[i] for i in range(6)]
+MODE = os.environ.get("PI0_MODE", "device")     # "host": chunks -> host numpy post-processing -> histories (reference flow)
+all_valid = torch.ones(B, dtype=torch.bool, device=dev)
+
+def side_work(ev):
+    torch.cuda.set_device(0)
+    with torch.cuda.stream(side):
+        side.wait_event(ev)
+        pf, tf = ver.extract_shared_features(img384, text)
+        return ver.image_text_embeddings(pf, tf)
 
 def decision():
     main = torch.cuda.current_stream()
-    side.wait_stream(main)
-    with torch.cuda.stream(side):
-        pf, tf = ver.extract_shared_features(img384, text)
-        its = ver.image_text_embeddings(pf, tf)
-    x = model.sample_actions([img], [torch.ones(B, dtype=torch.bool, device=dev)], toks, masks, state, noise=noise)
-    a = x[:, :4, :7].cpu().numpy().astype(np.float64)
-    a[..., 6] = (a[..., 6] >= 0.5)
-    hists = [np.vstack([past, a[i]]) for i in range(B)]
+    ev = torch.cuda.Event(); ev.record(main)
+    if MODE == "host":
+        its = side_work(ev)
+    else:
+        fut = pool.submit(side_work, ev)            # queued from a second host thread while this one queues the policy
+    x = model.sample_actions([img], [all_valid], toks, masks, state, noise=noise)
+    if MODE == "host":
+        xa = x[:, :4, :7].cpu().numpy()
+        hists = host.process_inputs([xa[:, t] for t in range(4)], True, history, 4)
+        pad = None
+    else:
+        hists, pad = ops.actions_to_histories(x, 4, past_d, lo_hi)
+        its = fut.result()
     main.wait_stream(side)
-    r = ver.score_histories(its, hists, B // P)
+    r = ver.score_histories(its, hists, B // P, pad=pad)
     return int(r["result"][0]), x
 
 idx, x = decision()
@@ -70,5 +91,5 @@ torch.cuda.synchronize()
 t = time.perf_counter(); K = 5
 for _ in range(K): decision()
 torch.cuda.synchronize(); dt = (time.perf_counter() - t) / K
-print(json.dumps({"profile": "pi0-cover (P1)", "B": B, "prompts": P, "L": L, "ms_per_decision": round(dt * 1e3, 2),
+print(json.dumps({"profile": "pi0-cover (P1)", "mode": MODE, "B": B, "prompts": P, "L": L, "ms_per_decision": round(dt * 1e3, 2),
                   "candidates_per_s": round(B / dt, 1), "selected": idx, "action_absmax": float(x.abs().max())}))
