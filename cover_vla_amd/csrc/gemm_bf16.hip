@@ -325,18 +325,19 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_tiled(const bf16_t* __res
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Producer / consumer variant of the tiled kernel: 4 MFMA waves (2 x 2) + ONE loader wave per block.
+// Producer / consumer variant of the tiled kernel: 4 MFMA waves (2 x 2) + NL loader waves per block.
 // Cycle counters in gemm_tiled's k-loop (64x128, M = 448) show an MFMA wave spending ~30 % of every k-tile ISSUING its
 // LDS-DMA instructions (the CU's address path is shared, and all waves issue right after their barriers) and ~40 %
-// waiting for the tile issued one iteration earlier. Here the loader wave owns every LDS-DMA of the block and runs
-// NST-1 k-tiles ahead with a counted vmcnt; the MFMA waves only pass one barrier per k-tile and compute:
-//   loader:   wait (tile kt landed) -> barrier kt -> issue tile kt+NST-1 into the stage freed by compute(kt-1)
-//   consumer: barrier kt -> compute(stage kt % NST)
-// A consumer reaching barrier kt has finished compute(kt-1), so the stage the loader refills after that barrier is free;
-// LDS-DMA data is ordered for the consumers by the loader's vmcnt wait followed by the barrier they pass.
+// waiting for the tile issued one iteration earlier. Here the loader waves own every LDS-DMA of the block (piece j of a
+// tile belongs to loader j mod NL) and run NST-1 k-tiles ahead with a counted vmcnt; the MFMA waves only pass one barrier
+// per k-tile and compute:
+//   loader:   wait (own pieces of tile kt landed) -> barrier kt -> issue tile kt+NST-1 into the stage of tile kt-1
+//   consumer: barrier kt sits in the MIDDLE of tile kt-1 (see the software pipeline below); a consumer reaching it holds
+//             every fragment of tile kt-1 in registers, so that stage is free
+// LDS-DMA data is ordered for the consumers by the loaders' vmcnt waits followed by the barrier they pass.
 // ---------------------------------------------------------------------------------------------------
-template <int WM, int WN, int NST>
-__global__ __launch_bounds__(320) void gemm_tiled_pc(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ Wp,
+template <int WM, int WN, int NST, int NL = 1>
+__global__ __launch_bounds__(256 + 64 * NL) void gemm_tiled_pc(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ Wp,
                                                      void* C, int ldc, int M, int N, int Kp, EpiDev epi, int tiles_m,
                                                      int tiles_n, int kt_per, float* __restrict__ partial) {
     constexpr int BM_ = 2 * WM * 16, BN_ = 2 * WN * 16;
@@ -363,30 +364,42 @@ __global__ __launch_bounds__(320) void gemm_tiled_pc(const bf16_t* __restrict__ 
     const int kt0 = blockIdx.y * kt_per;
     const int nk = min(kt_per, nk_total - kt0);
 
-    if (w == 4) {   // ---------------- loader wave ----------------
-        const bf16_t* a_src[AT];
-        const bf16_t* b_src[BT];
-#pragma unroll
-        for (int j = 0; j < AT; ++j) {   // A: LDS chunk position p = j*64 + lane: row = p>>3, c = p&7 holds global chunk c ^ (row&7)
-            const int row = j * 8 + (lane >> 3), c = lane & 7;
-            int gr = m0 + row;
-            gr = gr < M ? gr : M - 1;
-            a_src[j] = A + (size_t)gr * lda + (size_t)kt0 * BK + ((c ^ (row & 7)) << 3);
-        }
-#pragma unroll
-        for (int j = 0; j < BT; ++j) {
-            const int nbi = j >> 1, kbi = j & 1;
-            int nb = (n0 >> 4) + nbi;
-            nb = nb < N16 ? nb : N16 - 1;
-            b_src[j] = Wp + ((size_t)nb * K32 + (size_t)kt0 * 2 + kbi) * 512 + lane * 8;
-        }
+    if (w >= 4) {   // ---------------- loader waves: NL of them, loader l owns the pieces j = l, l + NL, ... of every tile ----------------
+        // (one wave issues an LDS-DMA piece every ~60 cycles; the CU's vector memory path takes 1 KiB per 16 cycles, so a
+        // single loader caps the fill at a quarter of what the CU can pull)
+        constexpr int PT = (AT + BT) / NL;
+        static_assert((AT + BT) % NL == 0 && AT % NL == 0, "pieces must split evenly over the loader waves");
+        static_assert((NST - 2) * PT <= 63, "counted vmcnt must fit its 6-bit field");
+        const int l = w - 4;
+        const bf16_t* src[PT];
+        uint32_t dst[PT];
+        size_t step[PT];
         const uint32_t as_u32 = __builtin_amdgcn_readfirstlane(lds_addr_u32(As));
         const uint32_t bs_u32 = __builtin_amdgcn_readfirstlane(lds_addr_u32(Bs));
+#pragma unroll
+        for (int i = 0; i < PT; ++i) {
+            const int j = l + i * NL;
+            if (j < AT) {   // A: LDS chunk position p = j*64 + lane: row = p>>3, c = p&7 holds global chunk c ^ (row&7)
+                const int row = j * 8 + (lane >> 3), c = lane & 7;
+                int gr = m0 + row;
+                gr = gr < M ? gr : M - 1;
+                src[i] = A + (size_t)gr * lda + (size_t)kt0 * BK + ((c ^ (row & 7)) << 3);
+                dst[i] = as_u32 + j * 1024;
+                step[i] = BK;
+            } else {
+                const int jb = j - AT;
+                const int nbi = jb >> 1, kbi = jb & 1;
+                int nb = (n0 >> 4) + nbi;
+                nb = nb < N16 ? nb : N16 - 1;
+                src[i] = Wp + ((size_t)nb * K32 + (size_t)kt0 * 2 + kbi) * 512 + lane * 8;
+                dst[i] = bs_u32 + jb * 1024;
+                step[i] = 2 * 512;
+            }
+        }
         auto issue = [&](int buf, int kt) {
 #pragma unroll
-            for (int j = 0; j < AT; ++j) glds16_asm(a_src[j] + kt * BK, as_u32 + buf * A_BYTES + j * 1024);
-#pragma unroll
-            for (int j = 0; j < BT; ++j) glds16_asm(b_src[j] + (size_t)kt * 2 * 512, bs_u32 + buf * B_BYTES + j * 1024);
+            for (int i = 0; i < PT; ++i)
+                glds16_asm(src[i] + kt * step[i], dst[i] + buf * ((l + i * NL) < AT ? A_BYTES : B_BYTES));
         };
 #pragma unroll
         for (int s = 0; s < NST - 1; ++s)
@@ -394,8 +407,8 @@ __global__ __launch_bounds__(320) void gemm_tiled_pc(const bf16_t* __restrict__ 
         int cur = 0;
         for (int kt = 0; kt < nk; ++kt) {
             const int younger = min(nk - 1 - kt, NST - 2);   // tiles issued after kt that may stay in flight
-            if (NST >= 4 && younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (AT + BT)) : "memory");
-            else if (younger >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AT + BT) : "memory");
+            if (NST >= 4 && younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PT) : "memory");
+            else if (younger >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PT) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             if (kt + NST - 1 < nk) issue(cur == 0 ? NST - 1 : cur - 1, kt + NST - 1);   // stage (kt-1) % NST
@@ -411,32 +424,60 @@ __global__ __launch_bounds__(320) void gemm_tiled_pc(const bf16_t* __restrict__ 
     for (int b = 0; b < WN; ++b)
 #pragma unroll
         for (int f = 0; f < WM; ++f) acc[b][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // Software-pipelined over the two 32-wide k-steps of a tile: the fragments of the NEXT step (the next tile's first step
+    // after the mid-tile barrier) are read from LDS before the MFMAs of the current one, so a wave alone on its SIMD
+    // never exposes LDS latency or the barrier between its MFMA groups.
+    //   prologue: barrier 0, read(tile 0, step 0) -> set A
+    //   tile kt:  read(kt, 1) -> B | MFMA(A) | reads returned, barrier kt+1, read(kt+1, 0) -> A | MFMA(B)
+    // A consumer reaching barrier kt+1 holds every fragment of tile kt - 1 and of tile kt in registers (lgkmcnt drained), so
+    // the loader may refill stage (kt-1) % NST... and stage kt % NST is only refilled after barrier kt+2.
+    // The LDS reads are inline asm with hand-counted lgkmcnt waits (the compiler's own bookkeeping drains lgkmcnt to 0
+    // before the first MFMA of a group, i.e. it also waits for the fragments just requested for the NEXT group).
+    const uint32_t a_addr0 = lds_addr_u32(As) + ((wm * (WM * 16) + r) * 8 + ((0 * 4 + g) ^ (r & 7))) * 16;
+    const uint32_t a_addr1 = lds_addr_u32(As) + ((wm * (WM * 16) + r) * 8 + ((1 * 4 + g) ^ (r & 7))) * 16;
+    const uint32_t b_addr = lds_addr_u32(Bs) + (wn * WN * 2 * 64 + lane) * 16;
+    auto read_frags = [&](int stage, int ks, u32x4(&xf)[WM], u32x4(&wf)[WN]) {
+        const uint32_t aa = (ks ? a_addr1 : a_addr0) + stage * A_BYTES;
+        const uint32_t ba = b_addr + stage * B_BYTES + ks * 1024;
+#pragma unroll
+        for (int f = 0; f < WM; ++f) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(xf[f]) : "v"(aa), "n"(f * 2048));
+#pragma unroll
+        for (int b = 0; b < WN; ++b) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(wf[b]) : "v"(ba), "n"(b * 2048));
+    };
+    auto landed = [&](u32x4(&xf)[WM], u32x4(&wf)[WN]) {   // ties the fragments to the wait that precedes this call
+#pragma unroll
+        for (int f = 0; f < WM; ++f) asm volatile("" : "+v"(xf[f]));
+#pragma unroll
+        for (int b = 0; b < WN; ++b) asm volatile("" : "+v"(wf[b]));
+    };
+    auto mfmas = [&](const u32x4(&xf)[WM], const u32x4(&wf)[WN]) {
+#pragma unroll
+        for (int b = 0; b < WN; ++b)
+#pragma unroll
+            for (int f = 0; f < WM; ++f)
+                acc[b][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[b]), __builtin_bit_cast(bf16x8, xf[f]), acc[b][f], 0, 0, 0);
+    };
+    u32x4 xa[WM], wa[WN], xb[WM], wb[WN];
     int cur = 0;
+    __builtin_amdgcn_s_barrier();
+    read_frags(0, 0, xa, wa);
     for (int kt = 0; kt < nk; ++kt) {
-        __builtin_amdgcn_s_barrier();
-        const char* Ab = As + cur * A_BYTES;
-        const char* Bb = Bs + cur * B_BYTES;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 xf[WM], wf[WN];
-#pragma unroll
-            for (int f = 0; f < WM; ++f) {
-                const int row = wm * (WM * 16) + f * 16 + r;
-                const int c = (ks * 4 + g) ^ (row & 7);
-                xf[f] = as_bf16x8(*(const uint4*)(Ab + (row * 8 + c) * 16));
-            }
-#pragma unroll
-            for (int b = 0; b < WN; ++b)
-                wf[b] = as_bf16x8(*(const uint4*)(Bb + (((wn * WN + b) * 2 + ks) * 64 + lane) * 16));
-#pragma unroll
-            for (int b = 0; b < WN; ++b)
-#pragma unroll
-                for (int f = 0; f < WM; ++f)
-                    acc[b][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[b], xf[f], acc[b][f], 0, 0, 0);
-        }
-        // the LDS reads of this tile must have returned before this wave reaches the next barrier (after which the
-        // loader may refill the stage): the MFMAs above consumed them, i.e. lgkmcnt is already drained
+        read_frags(cur, 1, xb, wb);
+        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(WM + WN));   // set A (older) has landed, set B stays in flight
+        landed(xa, wa);
+        mfmas(xa, wa);
+        __builtin_amdgcn_sched_barrier(0);
         cur = cur == NST - 1 ? 0 : cur + 1;
+        if (kt + 1 < nk) {
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            read_frags(cur, 0, xa, wa);
+            asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(WM + WN));
+        } else {
+            asm volatile("s_waitcnt lgkmcnt(0)");
+        }
+        landed(xb, wb);
+        mfmas(xb, wb);
+        __builtin_amdgcn_sched_barrier(0);
     }
     tiled_epilogue<WM, WN>(acc, epi, C, ldc, M, N, m0 + wm * (WM * 16), n0 + wn * (WN * 16), r, g, partial);
 }
@@ -1357,9 +1398,9 @@ hipError_t launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* Wp, void* C,
         if (e == hipSuccess)                                                                                                \
             hipLaunchKernelGGL(kfn, grid, block, lds, st, A, lda, Wp, C, ldc, M, N, Kp, epi, tiles_m, tiles_n, kt_per, partial); \
     } while (0)
-#define LAUNCH_PC(WM_, WN_, NST_)                                                                                           \
+#define LAUNCH_PC(WM_, WN_, NST_, NL_)                                                                                      \
     do {                                                                                                                    \
-        auto kfn = gemm_tiled_pc<WM_, WN_, NST_>;                                                                           \
+        auto kfn = gemm_tiled_pc<WM_, WN_, NST_, NL_>;                                                                         \
         if (lds > 64 * 1024) {                                                                                              \
             static hipError_t attr = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
             e = attr;                                                                                                       \
@@ -1368,9 +1409,14 @@ hipError_t launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* Wp, void* C,
             hipLaunchKernelGGL(kfn, grid, block, lds, st, A, lda, Wp, C, ldc, M, N, Kp, epi, tiles_m, tiles_n, kt_per, partial); \
     } while (0)
     if (pc) {
-        if (pick == 9) LAUNCH_PC(2, 4, 3);
-        else if (pick == 10) LAUNCH_PC(2, 4, 4);
-        else LAUNCH_PC(4, 4, 3);
+        // loader waves: one wave issues an LDS-DMA piece every ~60 cycles, four keep the CU's vector memory path busy
+        // (cold weights, M = 448: o_proj 36.0 -> 32.3 us, down 84.2 -> 76.0 us)
+        static const char* nl_env = getenv("COVER_PC_LOADERS");
+        const int nl = nl_env ? atoi(nl_env) : 4;
+        block = dim3(256 + 64 * (nl == 4 ? 4 : nl == 2 ? 2 : 1));
+        if (pick == 9) { if (nl == 4) LAUNCH_PC(2, 4, 3, 4); else if (nl == 2) LAUNCH_PC(2, 4, 3, 2); else LAUNCH_PC(2, 4, 3, 1); }
+        else if (pick == 10) { if (nl == 4) LAUNCH_PC(2, 4, 4, 4); else if (nl == 2) LAUNCH_PC(2, 4, 4, 2); else LAUNCH_PC(2, 4, 4, 1); }
+        else { if (nl == 4) LAUNCH_PC(4, 4, 3, 4); else LAUNCH_PC(4, 4, 3, 1); }
     } else if (variant == 2) {
         if (pick == 0) LAUNCH_T(4, 4, false, 2, 2, 2);
         else if (pick == 1) LAUNCH_T(2, 4, false, 2, 2, 2);

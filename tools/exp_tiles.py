@@ -19,13 +19,14 @@ for K, N in [(4096, 12288), (4096, 4096), (4096, 22016), (11008, 4096)]:
     # COLD=1: rotate over enough distinct weight copies (> 512 MB) that neither L2 nor the 256 MB Infinity Cache holds them
     ncopy = max(2, int(600e6 // (2 * N * K)) + 1) if os.environ.get("COLD", "0") == "1" else 1
     lins = [lin] + [ops.pack_linear((torch.randn(N, K, device=dev, generator=g) * 0.02).bfloat16(), glu=glu) for _ in range(ncopy - 1)]
-    a = torch.randn(M, K, device=dev, generator=g).bfloat16()
+    pad = int(os.environ.get("LDA_PAD", "0"))   # break power-of-two row strides of the activation panel
+    a = torch.randn(M, K + pad, device=dev, generator=g).bfloat16()[:, :K]
     o = torch.empty(M, lin.n_out, dtype=torch.bfloat16, device=dev)
     ws = ops.gemm_workspace(M, N, K, dev)
     f = lambda: ops.gemm(a, lin, act="silu" if glu else "none", out=o, variant=int(os.environ.get("VARIANT", "1")), ws=ws)
     f(); torch.cuda.synchronize()
     # correctness against fp32 matmul of the same bf16 operands
-    y = a.float() @ w.float().T
+    y = a.float().contiguous() @ w.float().T
     ref = torch.nn.functional.silu(y[:, : N // 2]) * y[:, N // 2:] if glu else y
     if glu:   # packed GLU interleaves gate/up in 16-row blocks of the ORIGINAL [gate; up] stacking
         ref = torch.nn.functional.silu(y[:, : N // 2]) * y[:, N // 2:]
