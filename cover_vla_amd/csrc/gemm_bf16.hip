@@ -943,12 +943,37 @@ __global__ __launch_bounds__(256) void splitk_reduce(const float* __restrict__ p
 // out = epi(sum_s partial[s]) AND norm_out = rmsnorm(out) / layernorm(out): one 512-thread block per output row
 // (N % 8 == 0, N <= 8192, no GLU, bf16 output). The statistics are taken over the bf16-ROUNDED outputs, i.e. exactly what
 // the separate norm kernel would read back, with that kernel's arithmetic.
+// block sum of a 512-thread block through LDS with an LDS-ONLY barrier: __syncthreads() would also wait for the stores
+// of C still in flight (their acknowledgement is ~1 us on the critical path of a kernel that lasts ~6). `red` is written
+// once per call: a second call in the same kernel takes a different slice.
+__device__ __forceinline__ float block_sum_lds(float v, float* red) {
+    v = wave_sum(v);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) red[w] = v;
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t += red[i];
+    return t;
+}
+
 __global__ __launch_bounds__(512) void splitk_reduce_norm(const float* __restrict__ partial, int S, bf16_t* C, int ldc, int M,
                                                           int N, EpiDev epi) {
     __shared__ float red[16];
     const int m = blockIdx.x;
     float vals[2][8];
     float q = 0.f;
+    // the norm weights do not depend on anything: requested first, so their latency hides under the slab loads instead
+    // of following the block reduction (the stores to C in between keep the compiler from hoisting them itself)
+    float4 nw[2][2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const int n0 = (threadIdx.x + c * 512) * 8;
+        if (n0 < N) {
+            nw[c][0] = *(const float4*)(epi.norm_w + n0);
+            nw[c][1] = *(const float4*)(epi.norm_w + n0 + 4);
+        }
+    }
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
         const int n0 = (threadIdx.x + c * 512) * 8;
@@ -994,7 +1019,7 @@ __global__ __launch_bounds__(512) void splitk_reduce_norm(const float* __restric
             if ((int)(threadIdx.x + c * 512) * 8 < N)
 #pragma unroll
                 for (int i = 0; i < 8; ++i) sum += vals[c][i];
-        mean = block_sum(sum, red) / N;
+        mean = block_sum_lds(sum, red) / N;
         float q2 = 0.f;
 #pragma unroll
         for (int c = 0; c < 2; ++c)
@@ -1004,18 +1029,19 @@ __global__ __launch_bounds__(512) void splitk_reduce_norm(const float* __restric
                     const float d = vals[c][i] - mean;
                     q2 += d * d;
                 }
-        rstd = rsqrtf(block_sum(q2, red) / N + epi.norm_eps);
+        rstd = rsqrtf(block_sum_lds(q2, red + 8) / N + epi.norm_eps);
     } else {
-        rstd = rsqrtf(block_sum(q, red) / N + epi.norm_eps);
+        rstd = rsqrtf(block_sum_lds(q, red) / N + epi.norm_eps);
     }
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
         const int n0 = (threadIdx.x + c * 512) * 8;
         if (n0 < N) {
             float o[8];
+            const float wv[8] = {nw[c][0].x, nw[c][0].y, nw[c][0].z, nw[c][0].w, nw[c][1].x, nw[c][1].y, nw[c][1].z, nw[c][1].w};
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                const float ww = epi.norm_w[n0 + i];
+                const float ww = wv[i];
                 if (epi.norm_style == 2) o[i] = (vals[c][i] - mean) * rstd * ww + (epi.norm_b ? epi.norm_b[n0 + i] : 0.f);
                 else o[i] = epi.norm_style == 1 ? ww * bfround(vals[c][i] * rstd) : vals[c][i] * rstd * (epi.norm_w_offset + ww);
             }
@@ -1284,7 +1310,7 @@ hipError_t launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* Wp, void* C,
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
         const bool want_norm = epi.norm_w != nullptr && epi.norm_out != nullptr;
-        if (want_norm && !epi.glu && !epi.out_f32 && (N % 8) == 0 && N <= 8192 && (ldc % 8) == 0 && (epi.ld_norm_out % 8) == 0) {
+        if (want_norm && !epi.glu && !epi.out_f32 && (N % 8) == 0 && N <= 8192 && (ldc % 8) == 0 && (epi.ld_norm_out % 8) == 0 && (((uintptr_t)epi.norm_w) & 15) == 0) {
             hipLaunchKernelGGL(splitk_reduce_norm, dim3(M), dim3(512), 0, st, (const float*)ws, S, (bf16_t*)C, ldc, M, N, epi);
             return hipGetLastError();
         }
@@ -1313,7 +1339,7 @@ hipError_t launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* Wp, void* C,
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
         const bool want_norm = epi.norm_w != nullptr && epi.norm_out != nullptr;
-        if (want_norm && !epi.glu && !epi.out_f32 && (N % 8) == 0 && N <= 8192 && (ldc % 8) == 0 && (epi.ld_norm_out % 8) == 0) {
+        if (want_norm && !epi.glu && !epi.out_f32 && (N % 8) == 0 && N <= 8192 && (ldc % 8) == 0 && (epi.ld_norm_out % 8) == 0 && (((uintptr_t)epi.norm_w) & 15) == 0) {
             hipLaunchKernelGGL(splitk_reduce_norm, dim3(M), dim3(512), 0, st, (const float*)ws, p.S, (bf16_t*)C, ldc, M, N, epi);
             return hipGetLastError();
         }
@@ -1439,7 +1465,7 @@ hipError_t launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* Wp, void* C,
     bool norm_done = false;
     if (e == hipSuccess && S > 1) {
         const bool want_norm = epi.norm_w != nullptr && epi.norm_out != nullptr;
-        if (want_norm && !epi.glu && !epi.out_f32 && (N % 8) == 0 && N <= 8192 && (ldc % 8) == 0 && (epi.ld_norm_out % 8) == 0) {
+        if (want_norm && !epi.glu && !epi.out_f32 && (N % 8) == 0 && N <= 8192 && (ldc % 8) == 0 && (epi.ld_norm_out % 8) == 0 && (((uintptr_t)epi.norm_w) & 15) == 0) {
             hipLaunchKernelGGL(splitk_reduce_norm, dim3(M), dim3(512), 0, st, (const float*)ws, S, (bf16_t*)C, ldc, M, N, epi);
             norm_done = true;
         } else {
