@@ -1,7 +1,7 @@
 """Calibration only (NOT a product path): what torch.matmul (hipBLASLt / rocBLAS) reaches at the prefill GEMM shapes."""
-import torch, time
+import os, torch, time
 dev = torch.device("cuda:0")
-M = 449
+M = int(os.environ.get("M", "449"))
 for K, N in [(4096, 12288), (4096, 4096), (4096, 22016), (11008, 4096)]:
     a = torch.randn(M, K, device=dev).bfloat16()
     w = torch.randn(N, K, device=dev).bfloat16()
