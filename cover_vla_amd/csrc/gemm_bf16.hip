@@ -122,13 +122,13 @@ __device__ __forceinline__ void epi_store4_glu(const EpiDev& e, void* C, int ldc
 }
 
 // Epilogue of one wave's (WM*16) x (WN*16) tile at (mw, nw): split-K partial slab, GLU, or bias/act/residual store.
-template <int WM, int WN>
-__device__ __forceinline__ void tiled_epilogue(f32x4 (&acc)[WN][WM], const EpiDev& epi, void* C, int ldc, int M, int N, int mw,
-                                               int nw, int r, int g, float* __restrict__ partial) {
-#pragma unroll
-    for (int f = 0; f < WM; ++f) {
-        const int m = mw + f * 16 + r;
-        if (m >= M) continue;
+// The m-fragment index is a template parameter: left as a loop the compiler keeps it rolled for WM = 4 and the
+// accumulators end up in scratch (dynamic indexing).
+template <int WM, int WN, int F>
+__device__ __forceinline__ void tiled_epilogue_row(f32x4 (&acc)[WN][WM], const EpiDev& epi, void* C, int ldc, int M, int N, int mw,
+                                                   int nw, int r, int g, float* __restrict__ partial) {
+    const int m = mw + F * 16 + r;
+    if (m < M) {
         if (partial) {  // split-K: raw fp32 partial sums, epilogue applied by splitk_reduce
 #pragma unroll
             for (int b = 0; b < WN; ++b) {
@@ -136,10 +136,12 @@ __device__ __forceinline__ void tiled_epilogue(f32x4 (&acc)[WN][WM], const EpiDe
                 if (n < N) {
                     float* o = partial + ((size_t)blockIdx.y * M + m) * N + n;
                     if (n + 3 < N && ((((uintptr_t)o) & 15) == 0)) {
-                        *(float4*)o = make_float4(acc[b][f][0], acc[b][f][1], acc[b][f][2], acc[b][f][3]);
+                        *(float4*)o = make_float4(acc[b][F][0], acc[b][F][1], acc[b][F][2], acc[b][F][3]);
                     } else {
+                        const float v[4] = {acc[b][F][0], acc[b][F][1], acc[b][F][2], acc[b][F][3]};
+#pragma unroll
                         for (int i = 0; i < 4; ++i)
-                            if (n + i < N) o[i] = acc[b][f][i];
+                            if (n + i < N) o[i] = v[i];
                     }
                 }
             }
@@ -147,18 +149,24 @@ __device__ __forceinline__ void tiled_epilogue(f32x4 (&acc)[WN][WM], const EpiDe
 #pragma unroll
             for (int b = 0; b < WN; b += 2) {
                 const int nblk = (nw >> 4) + b;  // even block = gate, odd = up
-                float gv[4] = {acc[b][f][0], acc[b][f][1], acc[b][f][2], acc[b][f][3]};
-                float uv[4] = {acc[b + 1][f][0], acc[b + 1][f][1], acc[b + 1][f][2], acc[b + 1][f][3]};
+                float gv[4] = {acc[b][F][0], acc[b][F][1], acc[b][F][2], acc[b][F][3]};
+                float uv[4] = {acc[b + 1][F][0], acc[b + 1][F][1], acc[b + 1][F][2], acc[b + 1][F][3]};
                 epi_store4_glu(epi, C, ldc, m, (nblk >> 1) * 16 + 4 * g, N >> 1, gv, uv);
             }
         } else {
 #pragma unroll
             for (int b = 0; b < WN; ++b) {
-                float v[4] = {acc[b][f][0], acc[b][f][1], acc[b][f][2], acc[b][f][3]};
+                float v[4] = {acc[b][F][0], acc[b][F][1], acc[b][F][2], acc[b][F][3]};
                 epi_store4(epi, C, ldc, m, nw + b * 16 + 4 * g, N, v);
             }
         }
     }
+    if constexpr (F + 1 < WM) tiled_epilogue_row<WM, WN, F + 1>(acc, epi, C, ldc, M, N, mw, nw, r, g, partial);
+}
+template <int WM, int WN>
+__device__ __forceinline__ void tiled_epilogue(f32x4 (&acc)[WN][WM], const EpiDev& epi, void* C, int ldc, int M, int N, int mw,
+                                               int nw, int r, int g, float* __restrict__ partial) {
+    tiled_epilogue_row<WM, WN, 0>(acc, epi, C, ldc, M, N, mw, nw, r, g, partial);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -336,13 +344,14 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_tiled(const bf16_t* __res
 //             every fragment of tile kt-1 in registers, so that stage is free
 // LDS-DMA data is ordered for the consumers by the loaders' vmcnt waits followed by the barrier they pass.
 // ---------------------------------------------------------------------------------------------------
-template <int WM, int WN, int NST, int NL = 1>
-__global__ __launch_bounds__(256 + 64 * NL) void gemm_tiled_pc(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ Wp,
+template <int WM, int WN, int NST, int NL = 1, int CGM = 2, int CGN = 2>
+__global__ __launch_bounds__(64 * (CGM * CGN + NL)) void gemm_tiled_pc(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ Wp,
                                                      void* C, int ldc, int M, int N, int Kp, EpiDev epi, int tiles_m,
                                                      int tiles_n, int kt_per, float* __restrict__ partial) {
-    constexpr int BM_ = 2 * WM * 16, BN_ = 2 * WN * 16;
+    constexpr int NCW = CGM * CGN;                            // MFMA waves: a CGM x CGN grid of (WM*16) x (WN*16) wave tiles
+    constexpr int BM_ = CGM * WM * 16, BN_ = CGN * WN * 16;
     constexpr int A_BYTES = BM_ * BK * 2, B_BYTES = BN_ * BK * 2;
-    constexpr int AT = A_BYTES / 1024, BT = B_BYTES / 1024;   // 1-KiB LDS-DMA instructions per k-tile (all by the loader)
+    constexpr int AT = A_BYTES / 1024, BT = B_BYTES / 1024;   // 1-KiB LDS-DMA instructions per k-tile (all by the loaders)
     static_assert((NST - 2) * (AT + BT) <= 63, "counted vmcnt must fit its 6-bit field");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* As = smem;                   // [NST][A_BYTES]
@@ -364,13 +373,13 @@ __global__ __launch_bounds__(256 + 64 * NL) void gemm_tiled_pc(const bf16_t* __r
     const int kt0 = blockIdx.y * kt_per;
     const int nk = min(kt_per, nk_total - kt0);
 
-    if (w >= 4) {   // ---------------- loader waves: NL of them, loader l owns the pieces j = l, l + NL, ... of every tile ----------------
+    if (w >= NCW) {   // ---------------- loader waves: NL of them, loader l owns the pieces j = l, l + NL, ... of every tile ----------------
         // (one wave issues an LDS-DMA piece every ~60 cycles; the CU's vector memory path takes 1 KiB per 16 cycles, so a
         // single loader caps the fill at a quarter of what the CU can pull)
         constexpr int PT = (AT + BT) / NL;
         static_assert((AT + BT) % NL == 0 && AT % NL == 0, "pieces must split evenly over the loader waves");
         static_assert((NST - 2) * PT <= 63, "counted vmcnt must fit its 6-bit field");
-        const int l = w - 4;
+        const int l = w - NCW;
         const bf16_t* src[PT];
         uint32_t dst[PT];
         size_t step[PT];
@@ -417,7 +426,7 @@ __global__ __launch_bounds__(256 + 64 * NL) void gemm_tiled_pc(const bf16_t* __r
         return;
     }
     // ---------------- MFMA waves ----------------
-    const int wm = w >> 1, wn = w & 1;
+    const int wm = w / CGN, wn = w % CGN;
     const int r = lane & 15, g = lane >> 4;
     f32x4 acc[WN][WM];  // [n-block b][m-frag f]
 #pragma unroll
@@ -1356,7 +1365,7 @@ hipError_t launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* Wp, void* C,
     // ---- tile / split-K selection: fill >= ~1 block per CU when the problem allows it
     // tile configurations: {wave tile (WM, WN) in 16-row units, wave grid, stages}
     struct Cand { int wm, wn, wgm, wgn, nst; };
-    const Cand cands[12] = {
+    const Cand cands[14] = {
         {4, 4, 2, 2, 2},   // 0: 128x128, 4 waves of 64x64, 2 stages (64 KiB)
         {2, 4, 2, 2, 2},   // 1:  64x128, 4 waves of 32x64, 2 stages (48 KiB)
         {2, 2, 2, 2, 3},   // 2:  64x64,  4 waves of 32x32, 3 stages (48 KiB)
@@ -1369,6 +1378,8 @@ hipError_t launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* Wp, void* C,
         {2, 4, 2, 2, 3},   // 9:  64x128, loader wave + 4 MFMA waves, 3 stages (72 KiB)
         {2, 4, 2, 2, 4},   // a:  64x128, loader wave + 4 MFMA waves, 4 stages (96 KiB)
         {4, 4, 2, 2, 3},   // b: 128x128, loader wave + 4 MFMA waves, 3 stages (96 KiB)
+        {4, 4, 4, 2, 3},   // c: 256x128, 4 loader waves + 8 MFMA waves of 64x64, 3 stages (144 KiB)
+        {4, 4, 2, 4, 3},   // d: 128x256, 4 loader waves + 8 MFMA waves of 64x64, 3 stages (144 KiB)
     };
     // Measured on MI355X (tools/bench_kernels.py, M = 441): this single-barrier-per-k-tile structure is latency-bound per
     // block, so residency beats tile size until the tile grid oversubscribes the chip several times over, while 64x64
@@ -1386,10 +1397,20 @@ hipError_t launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* Wp, void* C,
     // 64x128 with a loader wave and 4 stages 78.2 / 34.6). For the multi-round grids (qkv, gate_up) neither the deeper ring
     // nor the loader wave helps (they cost a resident block per CU): 2 stages x 3 blocks stays.
     if (pick == 2 && nblocks(1) >= 192 && Kp >= 4096) pick = 10;   // loader-wave variant, 4 stages: 83.4 -> 78.2 us (down), 35.9 -> 34.6 (o_proj)
+    // 8 MFMA waves of 64x64 + 4 loader waves on 256x128 / 128x256 tiles (3 stages, one block per CU): per k-tile a SIMD has 1024
+    // cycles of MFMA against 768 cycles of LDS-DMA on the CU's address path, and none of the DMA issue sits in an MFMA wave.
+    // Cold weights: M = 2624 qkv 715 -> 867 TF, gate_up 792 -> 1026 TF, down 660 -> 833 TF (M = 448 in isolation: qkv 80.5 ->
+    // 75.1 us, gate_up 125.8 -> 119.1 us). Narrow outputs keep the smaller tiles (o_proj: 664 vs 701 TF at M = 2624).
+    static const char* big_env = getenv("COVER_BIG_TILES");   // experiment knob: 0 disables the 12-wave tiles
+    // (at M = 448 the micro-benchmark gain does not survive inside the decision -- 41.22 vs 40.98 ms -- so: long panels only)
+    if (variant != 2 && Kp >= 2048 && M >= 1024 && !(big_env && big_env[0] == '0')) {
+        if (N > 4096 && nblocks(13) >= 176) pick = N >= 16384 ? 12 : 13;
+        else if (N <= 4096 && Kp >= 8192 && nblocks(12) >= 256) pick = 12;
+    }
     {
         static const char* force = getenv("COVER_TILE_PICK");  // experiment knob: index into cands
         if (force && force[0] >= '0' && force[0] <= '9') pick = force[0] - '0';
-        if (force && (force[0] == 'a' || force[0] == 'b')) pick = 10 + (force[0] - 'a');
+        if (force && force[0] >= 'a' && force[0] <= 'd') pick = 10 + (force[0] - 'a');
     }
     if (variant == 2 && pick > 2) pick = 0;
     const Cand cd = cands[pick];
@@ -1424,9 +1445,9 @@ hipError_t launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* Wp, void* C,
         if (e == hipSuccess)                                                                                                \
             hipLaunchKernelGGL(kfn, grid, block, lds, st, A, lda, Wp, C, ldc, M, N, Kp, epi, tiles_m, tiles_n, kt_per, partial); \
     } while (0)
-#define LAUNCH_PC(WM_, WN_, NST_, NL_)                                                                                      \
+#define LAUNCH_PC(WM_, WN_, NST_, NL_, ...)                                                                                 \
     do {                                                                                                                    \
-        auto kfn = gemm_tiled_pc<WM_, WN_, NST_, NL_>;                                                                         \
+        auto kfn = gemm_tiled_pc<WM_, WN_, NST_, NL_, ##__VA_ARGS__>;                                                                         \
         if (lds > 64 * 1024) {                                                                                              \
             static hipError_t attr = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
             e = attr;                                                                                                       \
@@ -1439,10 +1460,12 @@ hipError_t launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* Wp, void* C,
         // (cold weights, M = 448: o_proj 36.0 -> 32.3 us, down 84.2 -> 76.0 us)
         static const char* nl_env = getenv("COVER_PC_LOADERS");
         const int nl = nl_env ? atoi(nl_env) : 4;
-        block = dim3(256 + 64 * (nl == 4 ? 4 : nl == 2 ? 2 : 1));
+        block = dim3(64 * cd.wgm * cd.wgn + 64 * (pick >= 12 || nl == 4 ? 4 : nl == 2 ? 2 : 1));
         if (pick == 9) { if (nl == 4) LAUNCH_PC(2, 4, 3, 4); else if (nl == 2) LAUNCH_PC(2, 4, 3, 2); else LAUNCH_PC(2, 4, 3, 1); }
         else if (pick == 10) { if (nl == 4) LAUNCH_PC(2, 4, 4, 4); else if (nl == 2) LAUNCH_PC(2, 4, 4, 2); else LAUNCH_PC(2, 4, 4, 1); }
-        else { if (nl == 4) LAUNCH_PC(4, 4, 3, 4); else LAUNCH_PC(4, 4, 3, 1); }
+        else if (pick == 11) { if (nl == 4) LAUNCH_PC(4, 4, 3, 4); else LAUNCH_PC(4, 4, 3, 1); }
+        else if (pick == 12) LAUNCH_PC(4, 4, 3, 4, 4, 2);
+        else LAUNCH_PC(4, 4, 3, 4, 2, 4);
     } else if (variant == 2) {
         if (pick == 0) LAUNCH_T(4, 4, false, 2, 2, 2);
         else if (pick == 1) LAUNCH_T(2, 4, false, 2, 2, 2);

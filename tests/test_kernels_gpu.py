@@ -45,6 +45,29 @@ def test_gemm_tiled(dev, variant, M, N, K):
     assert torch.allclose(out.float().cpu(), ref, atol=0.05, rtol=2e-2)
 
 
+@pytest.mark.parametrize("M,N,K,glu", [(1100, 6144, 2048, False), (1037, 16384, 2048, True), (2304, 4096, 8192, False), (1025, 4352, 2176, False)])
+def test_gemm_long_panel_tiles(dev, M, N, K, glu):
+    # M >= 1024: the 12-wave kernels (8 MFMA waves on 128x256 / 256x128 tiles + 4 loader waves), ragged M and N tiles,
+    # bias / activation / GLU / residual epilogues -- against fp32 matmul of the same bf16 operands (computed on the device)
+    g = torch.Generator(device=dev).manual_seed(M + N)
+    a = (torch.randn(M, K, device=dev, generator=g)).bfloat16()
+    w = (torch.randn(N, K, device=dev, generator=g) * 0.03).bfloat16()
+    y = a.float() @ w.float().T
+    if glu:
+        lin = ops.pack_linear(w, glu=True)
+        out = ops.gemm(a, lin, act="silu")
+        ref = torch.nn.functional.silu(y[:, : N // 2]) * y[:, N // 2:]
+    else:
+        bias = torch.randn(N, device=dev, generator=g) * 0.3
+        res = torch.randn(M, N, device=dev, generator=g).bfloat16()
+        lin = ops.pack_linear(w, bias)
+        out = ops.gemm(a, lin, residual=res)
+        ref = res.float() + y + bias
+    assert rel_l2(out, ref) < 6e-3
+    d = (out.float() - ref).abs()
+    assert (d <= 0.06 + 2e-2 * ref.abs()).all()
+
+
 def test_gemm_transpose_detecting(dev):
     # A = I with an asymmetric W: out must equal W^T exactly (bf16 values are exact here)
     K = N = 256
