@@ -344,6 +344,15 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_tiled(const bf16_t* __res
 //             every fragment of tile kt-1 in registers, so that stage is free
 // LDS-DMA data is ordered for the consumers by the loaders' vmcnt waits followed by the barrier they pass.
 // ---------------------------------------------------------------------------------------------------
+#ifdef COVER_PC_DEBUG
+__device__ unsigned long long g_pc_dbg[8];   // loader: wait, barrier, issue; consumer: barrier, rest; counts
+extern "C" int cover_pc_debug(unsigned long long* out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pc_dbg), sizeof(g_pc_dbg)) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_pc_dbg), z, sizeof(z)); }
+    return 0;
+}
+#define PCT() __builtin_readcyclecounter()
+#endif
 template <int WM, int WN, int NST, int NL = 1, int CGM = 2, int CGN = 2>
 __global__ __launch_bounds__(64 * (CGM * CGN + NL)) void gemm_tiled_pc(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ Wp,
                                                      void* C, int ldc, int M, int N, int Kp, EpiDev epi, int tiles_m,
@@ -405,6 +414,11 @@ __global__ __launch_bounds__(64 * (CGM * CGN + NL)) void gemm_tiled_pc(const bf1
                 step[i] = 2 * 512;
             }
         }
+        // (Register-staged loaders -- plain global loads into two register sets, ds_write_b128 into a 2-stage ring -- were
+        // built and measured: 64x128 o_proj 45 -> 62 us, down 87 -> 151 us, 128x256 at M = 2624 831 -> 641 TF. The LDS-DMA
+        // piece stays, at 64-100 cycles of issue per wave: cycle counters (-DCOVER_PC_DEBUG, tools/exp_pc_debug.py) give per
+        // k-tile of the 128x256 kernel: loader issue 770-1200, data wait 70-100, barrier 270-500; MFMA wave: 900 compute +
+        // 540-690 at the barrier. s_setprio 3 on the loaders changes nothing.)
         auto issue = [&](int buf, int kt) {
 #pragma unroll
             for (int i = 0; i < PT; ++i)
@@ -414,15 +428,34 @@ __global__ __launch_bounds__(64 * (CGM * CGN + NL)) void gemm_tiled_pc(const bf1
         for (int s = 0; s < NST - 1; ++s)
             if (s < nk) issue(s, s);
         int cur = 0;
+#ifdef COVER_PC_DEBUG
+        unsigned long long tw = 0, tb = 0, ti = 0;
+#endif
         for (int kt = 0; kt < nk; ++kt) {
+#ifdef COVER_PC_DEBUG
+            const unsigned long long c0 = PCT();
+#endif
             const int younger = min(nk - 1 - kt, NST - 2);   // tiles issued after kt that may stay in flight
             if (NST >= 4 && younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PT) : "memory");
             else if (younger >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PT) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef COVER_PC_DEBUG
+            const unsigned long long c1 = PCT();
+#endif
             __builtin_amdgcn_s_barrier();
+#ifdef COVER_PC_DEBUG
+            const unsigned long long c2 = PCT();
+#endif
             if (kt + NST - 1 < nk) issue(cur == 0 ? NST - 1 : cur - 1, kt + NST - 1);   // stage (kt-1) % NST
             cur = cur == NST - 1 ? 0 : cur + 1;
+#ifdef COVER_PC_DEBUG
+            const unsigned long long c3 = PCT();
+            tw += c1 - c0; tb += c2 - c1; ti += c3 - c2;
+#endif
         }
+#ifdef COVER_PC_DEBUG
+        if (lane == 0 && l == 0) { atomicAdd(&g_pc_dbg[0], tw); atomicAdd(&g_pc_dbg[1], tb); atomicAdd(&g_pc_dbg[2], ti); atomicAdd(&g_pc_dbg[5], (unsigned long long)nk); }
+#endif
         return;
     }
     // ---------------- MFMA waves ----------------
@@ -469,6 +502,10 @@ __global__ __launch_bounds__(64 * (CGM * CGN + NL)) void gemm_tiled_pc(const bf1
     u32x4 xa[WM], wa[WN], xb[WM], wb[WN];
     int cur = 0;
     __builtin_amdgcn_s_barrier();
+#ifdef COVER_PC_DEBUG
+    unsigned long long dbg_bar = 0;
+    const unsigned long long dbg_t0 = PCT();
+#endif
     read_frags(0, 0, xa, wa);
     for (int kt = 0; kt < nk; ++kt) {
         read_frags(cur, 1, xb, wb);
@@ -478,7 +515,13 @@ __global__ __launch_bounds__(64 * (CGM * CGN + NL)) void gemm_tiled_pc(const bf1
         __builtin_amdgcn_sched_barrier(0);
         cur = cur == NST - 1 ? 0 : cur + 1;
         if (kt + 1 < nk) {
+#ifdef COVER_PC_DEBUG
+            const unsigned long long c0 = PCT();
+#endif
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#ifdef COVER_PC_DEBUG
+            dbg_bar += PCT() - c0;
+#endif
             read_frags(cur, 0, xa, wa);
             asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(WM + WN));
         } else {
@@ -488,6 +531,9 @@ __global__ __launch_bounds__(64 * (CGM * CGN + NL)) void gemm_tiled_pc(const bf1
         mfmas(xb, wb);
         __builtin_amdgcn_sched_barrier(0);
     }
+#ifdef COVER_PC_DEBUG
+    if (lane == 0 && w == 0) { atomicAdd(&g_pc_dbg[3], dbg_bar); atomicAdd(&g_pc_dbg[4], PCT() - dbg_t0); }
+#endif
     tiled_epilogue<WM, WN>(acc, epi, C, ldc, M, N, m0 + wm * (WM * 16), n0 + wn * (WN * 16), r, g, partial);
 }
 
