@@ -1,0 +1,112 @@
+"""Serving boundary: wire format against bytes produced by the reference's own msgpack_numpy module
+(tests/golden/wire_msgpack.npz, generator: tests/golden/make_wire_golden.py) and the per-connection protocol."""
+import os
+
+import numpy as np
+import pytest
+
+from cover_vla_amd import server
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "wire_msgpack.npz")
+
+
+def _objects():
+    rng = np.random.default_rng(7)   # the generator script's objects, in its order of draws
+    return {
+        "observation": {"observation.images.top": rng.integers(0, 256, (6, 8, 3), dtype=np.uint8),
+                        "observation.state": rng.standard_normal(7).astype(np.float32),
+                        "task": "put the spoon on the towel", "step": 3},
+        "action_chunk": rng.standard_normal((4, 7)).astype(np.float64),
+        "scalars": {"score": np.float32(0.125), "idx": np.int64(17), "flag": np.bool_(True), "plain": [1, 2.5, None, "x", b"raw"]},
+        "reset": {"reset": True},
+        "switch": {"new_model_path": "/ckpt/step_20000"},
+        "status": {"status": "model switched"},
+        "empty_and_strided": {"e": np.zeros((0, 7), dtype=np.float32), "t": np.arange(12, dtype=np.int16).reshape(3, 4).T},
+    }
+
+
+def _same(a, b):
+    if isinstance(a, dict):
+        return isinstance(b, dict) and a.keys() == b.keys() and all(_same(a[k], b[k]) for k in a)
+    if isinstance(a, (list, tuple)):
+        return len(a) == len(b) and all(_same(x, y) for x, y in zip(a, b))
+    if isinstance(a, np.ndarray):
+        return isinstance(b, np.ndarray) and a.dtype == b.dtype and a.shape == b.shape and np.array_equal(a, b)
+    if isinstance(a, np.generic):
+        return isinstance(b, np.generic) and a.dtype == b.dtype and a == b
+    return type(a) == type(b) and a == b
+
+
+def test_wire_format_matches_reference_bytes():
+    gold = np.load(GOLD)
+    objs = _objects()
+    assert set(gold.files) == set(objs)
+    for name, obj in objs.items():
+        ref_bytes = gold[name].tobytes()
+        assert server.pack(obj) == ref_bytes, name                 # encoder: byte for byte what the reference sends
+        assert _same(obj, server.unpack(ref_bytes)), name           # decoder: what the reference sends comes back as sent
+    back = server.unpack(gold["empty_and_strided"].tobytes())
+    assert back["t"].flags["C_CONTIGUOUS"] and back["t"].shape == (4, 3)   # a strided array travels in C order
+
+
+@pytest.mark.parametrize("bad", [np.array([1 + 2j]), np.array([object()], dtype=object), np.zeros(2, dtype=[("a", "i4")])])
+def test_wire_format_refuses_what_the_reference_refuses(bad):
+    with pytest.raises(ValueError):
+        server.pack({"x": bad})
+
+
+class _FakePolicy:
+    def __init__(self):
+        self.calls = []
+
+    def select_action(self, obs):
+        self.calls.append(("infer", obs["step"]))
+        if obs.get("explode"):
+            raise RuntimeError("boom")
+        return {"action": np.full((4, 7), float(obs["step"]), dtype=np.float32), "idx": np.int64(obs["step"])}
+
+    def reset(self):
+        self.calls.append(("reset",))
+
+    def switch_model(self, path):
+        self.calls.append(("switch", path))
+
+
+def test_session_protocol():
+    pol = _FakePolicy()
+    s = server.PolicySession(pol, {"policy": "cover", "n_action_steps": 4})
+    assert server.unpack(s.greeting()) == {"policy": "cover", "n_action_steps": 4}
+    r, close = s.handle(server.pack({"reset": True}))
+    assert server.unpack(r) == {"status": "reset"} and not close
+    r, close = s.handle(server.pack({"new_model_path": "/ckpt/a"}))
+    assert server.unpack(r) == {"status": "model switched"} and not close
+    r, close = s.handle(server.pack({"step": 5, "observation.state": np.zeros(7, np.float32)}))
+    out = server.unpack(r)
+    assert not close and out["idx"] == 5 and np.array_equal(out["action"], np.full((4, 7), 5.0, np.float32))
+    r, close = s.handle(server.pack({"step": 6, "explode": True}))      # the traceback text goes out, then the connection closes
+    assert close and isinstance(r, str) and "RuntimeError: boom" in r
+    r, close = s.handle(b"\\xc1 not msgpack")
+    assert close and isinstance(r, str)
+    assert pol.calls == [("reset",), ("switch", "/ckpt/a"), ("infer", 5), ("infer", 6)]
+
+
+def test_verified_policy_composes_sampler_and_verifier():
+    seen = {}
+
+    def sample(obs):
+        return np.arange(8 * 7, dtype=np.float32).reshape(8, 7), {"groups": 4}
+
+    def choose(cands, ctx, obs):
+        seen["ctx"] = ctx
+        return cands[obs["pick"]]
+
+    pol = server.VerifiedPolicy(sample, choose)
+    s = server.PolicySession(pol)
+    out = server.unpack(s.handle(server.pack({"pick": 3}))[0])
+    assert np.array_equal(out, np.arange(21, 28, dtype=np.float32)) and seen["ctx"] == {"groups": 4}
+    r, close = s.handle(server.pack({"new_model_path": "x"}))           # one checkpoint: refused loudly, connection closed
+    assert close and "NotImplementedError" in r
+    import importlib.util
+    if importlib.util.find_spec("websockets") is None:
+        with pytest.raises(ImportError):
+            server.serve_websocket(pol)                                  # no silent fallback transport in this image
