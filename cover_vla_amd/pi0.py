@@ -16,6 +16,7 @@ from __future__ import annotations
 
 import collections
 import math
+import os
 from typing import Callable, Dict, List, Optional
 
 import numpy as np
@@ -56,6 +57,8 @@ class PI0FlowMatching:
                   for n in ("state_proj", "action_in_proj", "action_out_proj", "action_time_mlp_in", "action_time_mlp_out")}
         self.vis_len = torch.tensor([1] + [S] * self.chunk, dtype=torch.int32, device=dev)
         self.max_batch, self.max_prompts, self.max_lang = max_batch, max_prompts, max_lang
+        self._den = {}     # static buffers (+ hipGraph) of the denoise loop per batch size
+        self._cap = None   # capture stream
 
     # ---------------------------------------------------------------------------------------------- prefix
     def _image_tokens(self, img: torch.Tensor) -> torch.Tensor:
@@ -116,49 +119,83 @@ class PI0FlowMatching:
         g0 = self.lm.group(U, Tp, ppos.view(-1), [dict(region=0, length=Tp, len_of_batch=plen)], 0)
         self.lm.forward(prefix.view(U * Tp, D), [g0], final_norm=False)
 
-        # ---- suffix constants
+        # ---- suffix constants: persistent buffers per batch size. With COVER_PI0_GRAPH=1 the ten Euler steps (~190 launches
+        # each) are replayed as ONE hipGraph from the third call on (call 1 runs eagerly and sizes every workspace, call 2
+        # captures): bit-identical, but measured no faster at B = 40 (37.0 vs 36.7 ms per decision -- the loop is bound by
+        # the GPU's ~1 us per kernel boundary, not by the host), so it stays off by default.
         S, W, A = 1 + self.chunk, self.W, self.max_action_dim
-        row_prompt = prompt_of_row.to(torch.int32).contiguous()
-        row_plen = plen[prompt_of_row].contiguous()
-        spos = (row_plen[:, None] + torch.arange(S, device=dev, dtype=torch.int32)[None]).contiguous()
-        g1 = self.expert.group(B, S, spos.view(-1),
-                               [dict(region=0, length=Tp, len_of_batch=row_plen, slot_of_batch=row_prompt),
-                                dict(region=1, length=S, mask=ops.MASK_VISLEN, vis_len=self.vis_len)], 1)
-        suffix = torch.empty(B, S, W, dtype=torch.float32, device=dev)
-        st = ops.gemm_f32(state.float().contiguous(), self.p["state_proj"][0], bias=self.p["state_proj"][1])
-        ops.cast_bf16_to_f32(ops.cast_f32_to_bf16(st), out=suffix.view(B, S * W)[:, :W])  # bf16-rounded state token
-        x_t = noise.to(torch.float32).clone().contiguous()
-        cat = torch.empty(B * self.chunk, 2 * W, dtype=torch.float32, device=dev)
-        hid = torch.empty(B * self.chunk, W, dtype=torch.float32, device=dev)
-        xb = torch.empty(B * S, W, dtype=BF, device=dev)
-        out32 = torch.empty(B, S, W, dtype=torch.float32, device=dev)
-        tvec = torch.empty(B * self.chunk, dtype=torch.float32, device=dev)
+        st = self._den.get(B)
+        if st is None:
+            st = dict(calls=0, graph=None,
+                      row_prompt=torch.empty(B, dtype=torch.int32, device=dev), row_plen=torch.empty(B, dtype=torch.int32, device=dev),
+                      spos=torch.empty(B, S, dtype=torch.int32, device=dev),
+                      suffix=torch.empty(B, S, W, dtype=torch.float32, device=dev),
+                      x_t=torch.empty(B, self.chunk, A, dtype=torch.float32, device=dev),
+                      cat=torch.empty(B * self.chunk, 2 * W, dtype=torch.float32, device=dev),
+                      hid=torch.empty(B * self.chunk, W, dtype=torch.float32, device=dev),
+                      xb=torch.empty(B * S, W, dtype=BF, device=dev), out32=torch.empty(B, S, W, dtype=torch.float32, device=dev),
+                      tvec=torch.empty(B * self.chunk, dtype=torch.float32, device=dev),
+                      temb=torch.empty(B * self.chunk, W, dtype=BF, device=dev))
+            st["g1"] = self.expert.group(B, S, st["spos"].view(-1),
+                                         [dict(region=0, length=Tp, len_of_batch=st["row_plen"], slot_of_batch=st["row_prompt"]),
+                                          dict(region=1, length=S, mask=ops.MASK_VISLEN, vis_len=self.vis_len)], 1)
+            self._den[B] = st
+        st["calls"] += 1
+        if st.get("Tp") != Tp:                      # the prefix width is baked into the group (and into a captured graph)
+            st["g1"].segs[0].len = Tp
+            st["Tp"], st["graph"] = Tp, None
+        st["row_prompt"].copy_(prompt_of_row)
+        st["row_plen"].copy_(plen[prompt_of_row])
+        st["spos"].copy_(st["row_plen"][:, None] + torch.arange(S, device=dev, dtype=torch.int32)[None])
+        suffix, x_t, cat, hid, xb, out32, tvec, temb, g1 = (st[k] for k in ("suffix", "x_t", "cat", "hid", "xb", "out32", "tvec", "temb", "g1"))
+        stp = ops.gemm_f32(state.float().contiguous(), self.p["state_proj"][0], bias=self.p["state_proj"][1])
+        ops.cast_bf16_to_f32(ops.cast_f32_to_bf16(stp), out=suffix.view(B, S * W)[:, :W])  # bf16-rounded state token
+        x_t.copy_(noise.to(torch.float32))
         dt = -1.0 / self.num_steps
-        # the reference loops `while time >= -dt/2` on an fp32 tensor: exactly num_steps iterations (modeling_pi0.py:697-715)
-        time = torch.tensor(1.0, dtype=torch.float32)
-        dt32 = torch.tensor(dt, dtype=torch.float32)
         vs = []
-        while time >= -dt32 / 2:
-            tvec.fill_(float(time))
-            temb = ops.sincos_time_embed(tvec, W, 4e-3, 4.0)
-            ops.cast_bf16_to_f32(temb, out=cat[:, W:])
-            ops.gemm_f32(x_t.view(B * self.chunk, A), self.p["action_in_proj"][0], bias=self.p["action_in_proj"][1], out=cat[:, :W])
-            ops.gemm_f32(cat, self.p["action_time_mlp_in"][0], bias=self.p["action_time_mlp_in"][1], act="silu", out=hid)
-            wo, bo = self.p["action_time_mlp_out"]
-            ops.gemm_f32_raw(hid.data_ptr(), W, 1, wo.data_ptr(), W, 1, suffix.data_ptr() + 4 * W, W, self.chunk, W, W,
-                             bias=bo, batch=B, a_bs=self.chunk * W, c_bs=S * W)  # rows 1..chunk of every suffix
-            if trace is not None and not vs:
-                trace["suffix_embs_t1"] = suffix.clone()
-            self.expert.forward(xb, [g1], final_norm=True, x_f32=suffix.view(B * S, W))
-            ops.cast_bf16_to_f32(xb, out=out32.view(B * S, W))
-            # v_t = action_out_proj(suffix_out[:, -chunk:]) ; x_t += dt * v_t   (modeling_pi0.py:748-751, 713)
-            wp, bp = self.p["action_out_proj"]
-            ops.gemm_f32_raw(out32.data_ptr() + 4 * W, W, 1, wp.data_ptr(), W, 1, x_t.data_ptr(), A, self.chunk, A, W,
-                             bias=bp, residual_ptr=x_t.data_ptr(), ld_res=A, alpha=float(dt32), batch=B, a_bs=S * W,
-                             c_bs=self.chunk * A)
-            if trace is not None:
-                vs.append(x_t.clone())
-            time = time + dt32
+
+        def euler_loop():
+            # the reference loops `while time >= -dt/2` on an fp32 tensor: exactly num_steps iterations (modeling_pi0.py:697-715)
+            time = torch.tensor(1.0, dtype=torch.float32)
+            dt32 = torch.tensor(dt, dtype=torch.float32)
+            while time >= -dt32 / 2:
+                tvec.fill_(float(time))
+                ops.sincos_time_embed(tvec, W, 4e-3, 4.0, out=temb)
+                ops.cast_bf16_to_f32(temb, out=cat[:, W:])
+                ops.gemm_f32(x_t.view(B * self.chunk, A), self.p["action_in_proj"][0], bias=self.p["action_in_proj"][1], out=cat[:, :W])
+                ops.gemm_f32(cat, self.p["action_time_mlp_in"][0], bias=self.p["action_time_mlp_in"][1], act="silu", out=hid)
+                wo, bo = self.p["action_time_mlp_out"]
+                ops.gemm_f32_raw(hid.data_ptr(), W, 1, wo.data_ptr(), W, 1, suffix.data_ptr() + 4 * W, W, self.chunk, W, W,
+                                 bias=bo, batch=B, a_bs=self.chunk * W, c_bs=S * W)  # rows 1..chunk of every suffix
+                if trace is not None and not vs:
+                    trace["suffix_embs_t1"] = suffix.clone()
+                self.expert.forward(xb, [g1], final_norm=True, x_f32=suffix.view(B * S, W))
+                ops.cast_bf16_to_f32(xb, out=out32.view(B * S, W))
+                # v_t = action_out_proj(suffix_out[:, -chunk:]) ; x_t += dt * v_t   (modeling_pi0.py:748-751, 713)
+                wp, bp = self.p["action_out_proj"]
+                ops.gemm_f32_raw(out32.data_ptr() + 4 * W, W, 1, wp.data_ptr(), W, 1, x_t.data_ptr(), A, self.chunk, A, W,
+                                 bias=bp, residual_ptr=x_t.data_ptr(), ld_res=A, alpha=float(dt32), batch=B, a_bs=S * W,
+                                 c_bs=self.chunk * A)
+                if trace is not None:
+                    vs.append(x_t.clone())
+                time = time + dt32
+
+        use_graph = trace is None and os.environ.get("COVER_PI0_GRAPH", "0") == "1" and st["calls"] >= 2
+        if not use_graph:
+            euler_loop()
+        else:
+            if st["graph"] is None:
+                cur = torch.cuda.current_stream()
+                if self._cap is None:
+                    self._cap = torch.cuda.Stream(device=dev)
+                self._cap.wait_stream(cur)
+                with torch.cuda.stream(self._cap):
+                    with ops.Graph() as gr:
+                        euler_loop()
+                cur.wait_stream(self._cap)
+                st["graph"] = gr
+            st["graph"].launch()
+        x_t = x_t.clone()   # the static buffer is overwritten by the next decision
         if trace is not None:
             trace["x_steps"] = vs
         return x_t

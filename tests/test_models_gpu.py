@@ -96,6 +96,21 @@ def test_pi0_sampler_matches_reference_golden(dev, name):
     rel = np.linalg.norm(x - z["actions"]) / np.linalg.norm(upd)
     assert rel < 3e-2, rel
     assert np.abs(x - z["actions"]).max() < 8e-2
+    # the denoise loop as a replayed hipGraph (call 2 captures, call 3 replays) == the eager loop, bit for bit; and a
+    # different noise / prompt assignment flows through the same graph
+    args = ([im.to(dev) for im in images], [m.to(dev) for m in img_masks], toks.to(dev), masks.to(dev), state.to(dev))
+    noise2 = torch.flip(noise, dims=[0]).contiguous()
+    x3e = model.sample_actions(*args, noise=noise2.to(dev))
+    os.environ["COVER_PI0_GRAPH"] = "1"
+    try:
+        x1 = model.sample_actions(*args, noise=noise.to(dev))
+        x2 = model.sample_actions(*args, noise=noise.to(dev))
+        assert model._den[B]["graph"] is not None
+        x3 = model.sample_actions(*args, noise=noise2.to(dev))
+    finally:
+        os.environ.pop("COVER_PI0_GRAPH", None)
+    assert np.array_equal(x1.cpu().numpy(), x) and np.array_equal(x2.cpu().numpy(), x)
+    assert torch.equal(x3, x3e)
 
 
 def test_pi0_policy_api_from_pretrained(dev, tmp_path):
