@@ -15,7 +15,7 @@ import os
 import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcover_hip.so")
+LIB_PATH = os.environ.get("COVER_LIB_PATH") or os.path.join(_HERE, "libcover_hip.so")   # override: A/B runs of two builds
 
 c_p = C.c_void_p
 c_ll = C.c_longlong

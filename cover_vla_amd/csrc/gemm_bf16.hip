@@ -678,22 +678,49 @@ __global__ __launch_bounds__(512) void gemm_skinny2(const bf16_t* __restrict__ A
                 if (u < nsteps) dst[u] = __builtin_nontemporal_load(src + u * 64);
         }
     };
-    load8(buf[0], 0);  // the first two weight blocks are in flight while the activation chunk is staged
-    if (NBW > 1) load8(buf[1], 1);
-    {   // stage the activation chunk (fragment-major), zero beyond kc: wave w moves fragments fi = w, w + 8, ... (fi =
-        // kst*MF + f); lane (rr, gg) owns row f*16 + rr, k = kst*32 + gg*8 -> lane-linear, conflict-free LDS stores
-        constexpr int NFR = (KC / 32) * MF;
+    constexpr int NFR = (KC / 32) * MF;
+    if (kc == KC && nsteps == 8 && NBW > 1) {
+        // whole chunk, whole k-slice: the activation fragments are requested BEFORE the weight blocks (loads return in order:
+        // behind the weights they would hold the first MFMA back until both blocks have landed), without per-element
+        // conditions (rows beyond M re-read row M-1; their outputs are never stored)
+        constexpr int XL = NFR / 8;
+        uint4 xr[XL];
         const int rr = lane & 15, gg = lane >> 4;
-#pragma unroll 4
-        for (int fi = w; fi < NFR; fi += 8) {
-            const int kst = fi / MF, f = fi - kst * MF;
-            const int row = f * 16 + rr, kk = kst * 32 + gg * 8;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (row < M && kk < kc) v = *(const uint4*)(A + (size_t)row * lda + k0 + kk);
-            *(uint4*)(smem + fi * 1024 + lane * 16) = v;
+#pragma unroll
+        for (int j = 0; j < XL; ++j) {
+            const int fi = j * 8 + w, kst = fi / MF, f = fi - kst * MF;
+            int row = f * 16 + rr;
+            row = row < M ? row : M - 1;
+            xr[j] = *(const uint4*)(A + (size_t)row * lda + k0 + kst * 32 + gg * 8);
         }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int nb = nb_begin + ng + NG * i;
+            nb = nb < N16 ? nb : N16 - 1;
+            const u32x4* src = (const u32x4*)(Wp + ((size_t)nb * K32 + ((k0 + kw0) >> 5)) * 512) + lane;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) buf[i][u] = __builtin_nontemporal_load(src + u * 64);
+        }
+#pragma unroll
+        for (int j = 0; j < XL; ++j) *(uint4*)(smem + (j * 8 + w) * 1024 + lane * 16) = xr[j];
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // LDS-only: the weight blocks stay in flight
+    } else {
+        load8(buf[0], 0);  // the first two weight blocks are in flight while the activation chunk is staged
+        if (NBW > 1) load8(buf[1], 1);
+        {   // stage the activation chunk (fragment-major), zero beyond kc: wave w moves fragments fi = w, w + 8, ... (fi =
+            // kst*MF + f); lane (rr, gg) owns row f*16 + rr, k = kst*32 + gg*8 -> lane-linear, conflict-free LDS stores
+            const int rr = lane & 15, gg = lane >> 4;
+#pragma unroll 4
+            for (int fi = w; fi < NFR; fi += 8) {
+                const int kst = fi / MF, f = fi - kst * MF;
+                const int row = f * 16 + rr, kk = kst * 32 + gg * 8;
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (row < M && kk < kc) v = *(const uint4*)(A + (size_t)row * lda + k0 + kk);
+                *(uint4*)(smem + fi * 1024 + lane * 16) = v;
+            }
+        }
+        __syncthreads();
     }
-    __syncthreads();
     auto comp8 = [&](u32x4(&src)[8], f32x4(&a)[MF]) {
         auto step = [&](int u) {
             const bf16x8 wf = __builtin_bit_cast(bf16x8, src[u]);
@@ -858,13 +885,37 @@ __global__ __launch_bounds__(512) void gemm_skinny3(const bf16_t* __restrict__ A
         }
     };
 
-    // prologue: the first NBUF weight items are in flight while chunk 0 is staged
+    // prologue. The activation chunk is requested BEFORE the first NBUF weight items: loads return in order, so with the
+    // weights first the chunk (and with it the first MFMA, and with that the first REFILL of a weight buffer) would wait for
+    // all NBUF x 8 KiB per wave to land -- the stream would drain its whole initial window before issuing anything new.
+    if (items >= NBUF && min(KC, ke - kb) == KC) {   // straight-line: the compiler counts the weight loads behind the chunk's
+        {   // whole first chunk: no per-element conditions (rows beyond M re-read row M-1; their outputs are never stored)
 #pragma unroll
-    for (int b = 0; b < NBUF; ++b)
-        if (b < items) load8(buf[b], b);
-    x_load(0);
-    x_write(0);
-    __syncthreads();
+            for (int j = 0; j < XL; ++j) {
+                const int fi = j * 8 + w, kst = fi / MF, f = fi - kst * MF;
+                int row = f * 16 + srr;
+                row = row < M ? row : M - 1;
+                xr[j] = *(const uint4*)(A + (size_t)row * lda + kb + kst * 32 + sgg * 8);
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < NBUF; ++b) {
+            int nb = nb_begin + ng + NG * b;
+            nb = nb < N16 ? nb : N16 - 1;
+            const u32x4* src = (const u32x4*)(Wp + ((size_t)nb * K32 + ((kb + kw0) >> 5)) * 512) + lane;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) buf[b][u] = __builtin_nontemporal_load(src + u * 64);
+        }
+        x_write(0);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // LDS-only: the weight items stay in flight
+    } else {
+#pragma unroll
+        for (int b = 0; b < NBUF; ++b)
+            if (b < items) load8(buf[b], b);
+        x_load(0);
+        x_write(0);
+        __syncthreads();
+    }
     // main stream, unrolled by NBUF so that buffer indices are compile-time
     int t = 0;
     for (int c = 0; c < nchunks; ++c) {
