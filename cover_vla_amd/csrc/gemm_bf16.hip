@@ -916,9 +916,70 @@ __global__ __launch_bounds__(512) void gemm_skinny3(const bf16_t* __restrict__ A
         x_write(0);
         __syncthreads();
     }
-    // main stream, unrolled by NBUF so that buffer indices are compile-time
-    int t = 0;
-    for (int c = 0; c < nchunks; ++c) {
+    // Steady state: chunk c is full and so is chunk c+1. Everything in the body is straight-line (unconditional loads, fixed
+    // step counts), so the compiler's s_waitcnt before the first MFMA of an item counts exactly the loads issued after that
+    // item's (two younger items + the next activation chunk stay in flight). With the refill behind an `if`, it emitted
+    // vmcnt(0) at every item: the wave drained its whole window 3-4 times per chunk.
+    int c0 = 0;
+    if (items >= NBUF && min(KC, ke - kb) == KC) {
+        const bool last_full = ((ke - kb) % KC) == 0;
+        const int nfast = last_full ? nchunks - 1 : nchunks - 2;   // chunks whose successor is a full chunk
+        for (; c0 < nfast; ++c0) {
+            const int k1 = kb + (c0 + 1) * KC;
+#pragma unroll
+            for (int j = 0; j < XL; ++j) {
+                const int fi = j * 8 + w, kst = fi / MF, f = fi - kst * MF;
+                int row = f * 16 + srr;
+                row = row < M ? row : M - 1;
+                xr[j] = *(const uint4*)(A + (size_t)row * lda + k1 + kst * 32 + sgg * 8);
+            }
+            __builtin_amdgcn_sched_barrier(0);   // (the scheduler otherwise hoists the first MFMAs of all items and sinks the refills)
+            const char* xb = smem + (c0 & 1) * XB;
+#pragma unroll
+            for (int i = 0; i < NBW; ++i) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const bf16x8 wf = __builtin_bit_cast(bf16x8, buf[i % NBUF][u]);
+                    const int kst = (kw0 >> 5) + u;
+#pragma unroll
+                    for (int f = 0; f < MF; ++f) {
+                        const bf16x8 xf = as_bf16x8(*(const uint4*)(xb + ((kst * MF + f) * 64 + lane) * 16));
+                        acc[i][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf, acc[i][f], 0, 0, 0);
+                    }
+                }
+                int nb = nb_begin + ng + NG * i;
+                nb = nb < N16 ? nb : N16 - 1;
+                const u32x4* src = (const u32x4*)(Wp + ((size_t)nb * K32 + ((k1 + kw0) >> 5)) * 512) + lane;
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) buf[i % NBUF][u] = __builtin_nontemporal_load(src + u * 64);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            x_write((c0 + 1) & 1);
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+        if (last_full && c0 == nchunks - 1) {   // the last chunk, full: the same straight-line items without refills
+            const char* xb = smem + (c0 & 1) * XB;
+#pragma unroll
+            for (int i = 0; i < NBW; ++i) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const bf16x8 wf = __builtin_bit_cast(bf16x8, buf[i % NBUF][u]);
+                    const int kst = (kw0 >> 5) + u;
+#pragma unroll
+                    for (int f = 0; f < MF; ++f) {
+                        const bf16x8 xf = as_bf16x8(*(const uint4*)(xb + ((kst * MF + f) * 64 + lane) * 16));
+                        acc[i][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf, acc[i][f], 0, 0, 0);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            ++c0;
+        }
+    }
+    // remaining chunks (ragged last chunk and its predecessor, or everything for short K): generic bookkeeping
+    int t = c0 * NBW;
+    for (int c = c0; c < nchunks; ++c) {
         if (c + 1 < nchunks) x_load(c + 1);            // lands underneath this chunk's weight stream
 #pragma unroll
         for (int i = 0; i < NBW; ++i, ++t) {
