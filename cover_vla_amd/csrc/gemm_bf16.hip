@@ -679,6 +679,7 @@ __global__ __launch_bounds__(512) void gemm_skinny2(const bf16_t* __restrict__ A
         }
     };
     constexpr int NFR = (KC / 32) * MF;
+    bool items_done = false;
     if (kc == KC && nsteps == 8 && NBW > 1) {
         // whole chunk, whole k-slice: the activation fragments are requested BEFORE the weight blocks (loads return in order:
         // behind the weights they would hold the first MFMA back until both blocks have landed), without per-element
@@ -704,6 +705,31 @@ __global__ __launch_bounds__(512) void gemm_skinny2(const bf16_t* __restrict__ A
 #pragma unroll
         for (int j = 0; j < XL; ++j) *(uint4*)(smem + (j * 8 + w) * 1024 + lane * 16) = xr[j];
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // LDS-only: the weight blocks stay in flight
+        // the items straight-line as well (fixed step count, unconditional refills): s_waitcnt then counts the younger block
+        // still in flight instead of draining both before the first MFMA
+#pragma unroll
+        for (int i = 0; i < NBW; ++i) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const bf16x8 wf = __builtin_bit_cast(bf16x8, buf[i & 1][u]);
+                const int kst = (kw0 >> 5) + u;
+#pragma unroll
+                for (int f = 0; f < MF; ++f) {
+                    const bf16x8 xf = as_bf16x8(*(const uint4*)(smem + ((kst * MF + f) * 64 + lane) * 16));
+                    acc[i][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf, acc[i][f], 0, 0, 0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (i + 2 < NBW) {
+                int nb = nb_begin + ng + NG * (i + 2);
+                nb = nb < N16 ? nb : N16 - 1;
+                const u32x4* src = (const u32x4*)(Wp + ((size_t)nb * K32 + ((k0 + kw0) >> 5)) * 512) + lane;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) buf[i & 1][u] = __builtin_nontemporal_load(src + u * 64);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        items_done = true;
     } else {
         load8(buf[0], 0);  // the first two weight blocks are in flight while the activation chunk is staged
         if (NBW > 1) load8(buf[1], 1);
@@ -740,10 +766,12 @@ __global__ __launch_bounds__(512) void gemm_skinny2(const bf16_t* __restrict__ A
                 if (u < nsteps) step(u);
         }
     };
+    if (!items_done) {
 #pragma unroll
-    for (int i = 0; i < NBW; ++i) {
-        comp8(buf[i & 1], acc[i]);
-        if (i + 2 < NBW) load8(buf[i & 1], i + 2);  // refill the buffer just consumed: two blocks stay in flight
+        for (int i = 0; i < NBW; ++i) {
+            comp8(buf[i & 1], acc[i]);
+            if (i + 2 < NBW) load8(buf[i & 1], i + 2);  // refill the buffer just consumed: two blocks stay in flight
+        }
     }
     // ---- sum the KS k-slices through LDS (the X chunk is dead now), RB n-blocks per round (<= 64 KiB of LDS) ----
     constexpr int RB = (8 / MF) < NBW ? (8 / MF) : NBW;
