@@ -35,6 +35,43 @@ struct EpiDev {
 // val[4] are 4 consecutive columns n0..n0+3 of row m: bias / activation / layer-scale / residual / scale, in place.
 __device__ __forceinline__ void epi_value4(const EpiDev& e, int m, int n0, int N, float v[4]) {
     const bool full = (n0 + 3 < N);
+    if (full) {
+        // Whole group of four columns: every operand load is unconditional and issued before the first use. With the
+        // per-element `n0 + i < N` guards below, each bias / layer-scale / residual element became its own branch + load +
+        // s_waitcnt vmcnt(0): up to 12 dependent L2 round trips per group in the epilogue of every GEMM and reduction.
+        float b[4] = {0.f, 0.f, 0.f, 0.f}, ls[4] = {1.f, 1.f, 1.f, 1.f}, r[4] = {0.f, 0.f, 0.f, 0.f};
+        if (e.bias) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) b[i] = e.bias[n0 + i];
+        }
+        if (e.lscale) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ls[i] = e.lscale[n0 + i];
+        }
+        if (e.residual) {
+            if (e.res_f32) {
+                const float* rp = (const float*)e.residual + (size_t)m * e.ldr + n0;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) r[i] = rp[i];
+            } else {
+                const bf16_t* rp = (const bf16_t*)e.residual + (size_t)m * e.ldr + n0;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) r[i] = bf2f(rp[i]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {   // the arithmetic and its rounding points are those of the generic path below
+            float x = v[i];
+            if (e.bias) x += b[i];
+            x = bfround(x);
+            if (e.act != ACT_NONE) x = bfround(act_apply(x, e.act));
+            if (e.lscale) x = bfround(x * ls[i]);
+            if (e.residual) x = x + r[i];
+            if (e.out_scale != 1.0f) x *= e.out_scale;
+            v[i] = x;
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         float x = v[i];
