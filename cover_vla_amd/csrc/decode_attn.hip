@@ -42,8 +42,16 @@ constexpr int DA_NW = 16;
 // VS = 2: the value / output columns of a (16 candidates, head) unit are split over two blocks (blockIdx.z): both compute
 // the scores from the full K, each loads, multiplies and merges only its D/2 columns of V. The tile phase is bound by the
 // bytes one CU can pull in (64 blocks read 11.5 MB at N = 32, H = 32); two CUs at 0.75x the bytes each finish it sooner.
+#ifdef COVER_DA_DEBUG
+__device__ unsigned long long g_da_dbg[512 * 8];   // per block: start, phase 1 done (LDS hand-off), tile phase done, end
+extern "C" int cover_da_debug(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_da_dbg), sizeof(g_da_dbg)); }
+#define DAT(slot) do { if (threadIdx.x == 0) g_da_dbg[(((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) & 511) * 8 + (slot)] = wall_clock64(); } while (0)
+#else
+#define DAT(slot) do { } while (0)
+#endif
 template <int D, int VS>
 __global__ __launch_bounds__(1024) void decode_attn_fused_k(DecAttnDev a) {
+    DAT(0);
     constexpr int KS = D / 32, DB = D / 16 / VS, HALF = D / 2, DV = D / VS;
     constexpr int OW = DB * 4 * 64;                    // floats of one wave's O state
     constexpr int IPW = (DB * 4 + DA_NW - 1) / DA_NW;  // (db, e) output items merged per wave
@@ -77,6 +85,8 @@ __global__ __launch_bounds__(1024) void decode_attn_fused_k(DecAttnDev a) {
         if (a.slot2) pslot2 = a.slot2[pcand];
     }
 
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    DAT(4);
     // ---------------- phase 1a: q / k / v elements (i, i + HALF) of one candidate, summed over the split-K partials ----------------
     float x[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};      // q1 q2 k1 k2 v1 v2
     float cs = 1.f, sn = 0.f;
@@ -119,6 +129,8 @@ __global__ __launch_bounds__(1024) void decode_attn_fused_k(DecAttnDev a) {
         }
     }
 
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    DAT(5);
     // ---------------- tile iterator: every role describes its tile by per-lane K-row / V^T-row pointers and a mask ----------------
     const int prev_slot1 = __shfl(my_slot1, (lane & 48) | ((r + 15) & 15));
     const bool leader = q_ok && (r == 0 || my_slot1 != prev_slot1);
@@ -250,11 +262,13 @@ __global__ __launch_bounds__(1024) void decode_attn_fused_k(DecAttnDev a) {
     }
     // the first tile's K and V go in flight only now and land behind the barrier; issuing them before phase 1 measured
     // slower (22.9 -> 24.4 / 26.9 us per layer at N=32, H=32: the tile phase is bound by per-CU load throughput)
+    DAT(6);
     bool have = next_tile();
     if (have) load_tile();
     // LDS-only barrier: q / k_new / v_new are exchanged through LDS, so neither the cache stores nor the tile loads
     // still in flight are waited for here
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    DAT(1);
 
     // ---------------- phase 2 ----------------
     // Every tile is computed as an independent softmax state (m, l, O) and parked in the wave's LDS slot; a further tile
@@ -352,6 +366,7 @@ __global__ __launch_bounds__(1024) void decode_attn_fused_k(DecAttnDev a) {
 
     // ---------------- phase 3: merge the waves' states in wave order ----------------
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // LDS-only again: the cache stores drain behind the merge
+    DAT(2);
     if (!q_ok) return;
     float mx = -INFINITY;
 #pragma unroll
@@ -380,6 +395,7 @@ __global__ __launch_bounds__(1024) void decode_attn_fused_k(DecAttnDev a) {
     } else {
         *op = f2bf(o[0]);
     }
+    DAT(3);
 }
 
 hipError_t launch_decode_attention_fused(const cover_decode_attn_args* x, hipStream_t st) {
