@@ -103,6 +103,34 @@ __device__ __forceinline__ void epi_value4(const EpiDev& e, int m, int n0, int N
         for (int i = 0; i < 4; ++i) v[i] *= e.out_scale;
     }
 }
+// the store half of epi_store4 (values already through epi_value4)
+__device__ __forceinline__ void epi_put4(const EpiDev& e, void* C, int ldc, int m, int n0, int N, const float v[4]) {
+    if (n0 >= N) return;
+    const bool full = (n0 + 3 < N);
+    if (e.out_f32) {
+        float* o = (float*)C + (size_t)m * ldc + n0;
+        if (full && ((((uintptr_t)o) & 15) == 0)) {
+            *(float4*)o = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (n0 + i < N) o[i] = v[i];
+        }
+    } else {
+        bf16_t* o = (bf16_t*)C + (size_t)m * ldc + n0;
+        if (full && ((((uintptr_t)o) & 7) == 0)) {
+            uint2 p;
+            p.x = pack_bf2(v[0], v[1]);
+            p.y = pack_bf2(v[2], v[3]);
+            *(uint2*)o = p;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (n0 + i < N) o[i] = f2bf(v[i]);
+        }
+    }
+}
+
 __device__ __forceinline__ void epi_store4(const EpiDev& e, void* C, int ldc, int m, int n0, int N, float v[4]) {
     if (n0 >= N) return;
     const bool full = (n0 + 3 < N);
@@ -191,11 +219,18 @@ __device__ __forceinline__ void tiled_epilogue_row(f32x4 (&acc)[WN][WM], const E
                 epi_store4_glu(epi, C, ldc, m, (nblk >> 1) * 16 + 4 * g, N >> 1, gv, uv);
             }
         } else {
+            // values of the whole row first, stores after: the operand loads (bias, layer scale, residual) of all WN groups
+            // then share one round trip -- behind a store they cannot be hoisted (C may alias the residual)
+            float vv[WN][4];
 #pragma unroll
             for (int b = 0; b < WN; ++b) {
-                float v[4] = {acc[b][F][0], acc[b][F][1], acc[b][F][2], acc[b][F][3]};
-                epi_store4(epi, C, ldc, m, nw + b * 16 + 4 * g, N, v);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) vv[b][i] = acc[b][F][i];
+                const int n = nw + b * 16 + 4 * g;
+                if (n < N) epi_value4(epi, m, n, N, vv[b]);
             }
+#pragma unroll
+            for (int b = 0; b < WN; ++b) epi_put4(epi, C, ldc, m, nw + b * 16 + 4 * g, N, vv[b]);
         }
     }
     if constexpr (F + 1 < WM) tiled_epilogue_row<WM, WN, F + 1>(acc, epi, C, ldc, M, N, mw, nw, r, g, partial);
