@@ -9,7 +9,8 @@
 //            other waves through LDS and appends k_new / v_new to the candidate's own cache segment (nobody waits for
 //            those stores: both block barriers are LDS-only);
 //   phase 2  32-key tiles, one (rarely two) per wave, waves split into three pools with FIXED roles:
-//            pool A  segment 0, tile t -> wave t mod WA; the 16 candidates are the query rows of the tile,
+//            pool A  segment 0, tile t -> wave t mod WA; the 16 candidates are the query rows of the tile (a ninth, mostly
+//                    empty tile of a 257-key segment goes to the first pool-C wave and a state slot of its own: launcher),
 //            pool B  segment 1, the p-th distinct prompt slot of the block -> wave p mod WB, with a column mask,
 //            pool C  segment 2: a tile is 4 candidates x 8 own tokens (key slot 8g+e <-> candidate c0+g, token e, so the
 //                    V^T operand is ONE 16-byte load per lane) with a block-diagonal mask, candidates 4w..4w+3 -> wave w;
@@ -35,6 +36,7 @@ struct DecAttnDev {
     bf16_t* k2; bf16_t* vt2; long long k2_slot, vt2_slot; int k2_t, k2_h, vt2_h, vt2_d; const int* slot2; int len2, write_t;
     bf16_t* out; long long o_row;
     int WA, WC;   // wave pools: [0, WA) segment 0, [WA, 16 - WC) segment 1, [16 - WC, 16) segment 2
+    int tail_tile; // >= 0: this segment-0 tile is taken by the first pool-C wave into the EXTRA state slot (see the launcher)
 };
 
 constexpr int DA_NW = 16;
@@ -59,9 +61,9 @@ __global__ __launch_bounds__(1024) void decode_attn_fused_k(DecAttnDev a) {
     __shared__ __attribute__((aligned(16))) bf16_t qs[16 * D];
     __shared__ __attribute__((aligned(16))) bf16_t kn[16 * D];   // k_new / v_new of the block's candidates (pool C reads them)
     __shared__ __attribute__((aligned(16))) bf16_t vn[16 * D];
-    __shared__ float so[DA_NW * OW];
-    __shared__ float sm[DA_NW * 16];
-    __shared__ float sl[DA_NW * 16];
+    __shared__ float so[(DA_NW + 1) * OW];            // slot DA_NW: the segment-0 tail tile (empty when there is none)
+    __shared__ float sm[(DA_NW + 1) * 16];
+    __shared__ float sl[(DA_NW + 1) * 16];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tile = blockIdx.x, h = blockIdx.y;
@@ -147,11 +149,13 @@ __global__ __launch_bounds__(1024) void decode_attn_fused_k(DecAttnDev a) {
     unsigned vstep = 0;
     unsigned vmask = 0;                               // bit e: this lane's e-th score is visible
     int it = -1, bcol = -1, bslot = 0, blen = 0;      // iterator state: tile index inside the current run; pool B run
+    // (only in the value-split variant: the unsplit one is at its 128-register budget, and its blocks are not the few-units case)
+    bool tail_pending = (VS == 2 && role == 2 && wl == 0 && a.tail_tile >= 0), is_tail = false;
     auto next_tile = [&]() -> bool {
         if (role == 0) {            // segment 0: tiles wl, wl + WA, ...
             it = it < 0 ? wl : it + a.WA;
             const int t0 = 32 * it;
-            if (t0 >= a.len0) return false;
+            if (t0 >= a.len0 || it == a.tail_tile) return false;   // (the tail tile belongs to the first pool-C wave)
             int key0 = t0 + 8 * (r >> 2) + (r & 3), key1 = key0 + 4;
             key0 = key0 < a.len0 ? key0 : a.len0 - 1;
             key1 = key1 < a.len0 ? key1 : a.len0 - 1;
@@ -200,7 +204,26 @@ __global__ __launch_bounds__(1024) void decode_attn_fused_k(DecAttnDev a) {
         // K operand row i of half X <-> key slot 8*(i>>2) + 4X + (i&3) = candidate cl + (i>>2), token tb + 4X + (i&3)
         ++it;
         const int tb = 8 * it;
-        if (tb >= a.len2) return false;
+        if (tb >= a.len2) {
+            if (VS != 2 || !tail_pending) return false;
+            // the segment-0 tail tile (pool A has exactly one wave per FULL tile): described like a pool-A tile
+            tail_pending = false;
+            is_tail = true;
+            const int t0 = 32 * a.tail_tile;
+            int key0 = t0 + 8 * (r >> 2) + (r & 3), key1 = key0 + 4;
+            key0 = key0 < a.len0 ? key0 : a.len0 - 1;
+            key1 = key1 < a.len0 ? key1 : a.len0 - 1;
+            kbase = a.k0 + h * a.k0_h;
+            ko0 = key0 * a.k0_t + g * 8;
+            ko1 = key1 * a.k0_t + g * 8;
+            vbase = a.vt0 + h * a.vt0_h + t0;
+            vo = r * a.vt0_d + g * 8;
+            vstep = 16 * a.vt0_d;
+            vmask = 0;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) vmask |= (q_ok && t0 + 8 * g + e < a.len0) ? (1u << e) : 0u;
+            return true;
+        }
         int cg = tile * 16 + cl + (r >> 2), cv = tile * 16 + cl + g;
         cg = cg < a.N ? cg : a.N - 1;
         cv = cv < a.N ? cv : a.N - 1;
@@ -275,9 +298,22 @@ __global__ __launch_bounds__(1024) void decode_attn_fused_k(DecAttnDev a) {
     // of the same wave (rare: more tiles than waves in the pool) is folded into the slot. No O accumulator lives across
     // tiles, which keeps the kernel inside the 128-register budget of a 16-wave block with K and V of a tile in flight.
     bool first = true;
+    int sw = w;                                        // state slot this wave is writing
 #pragma clang loop unroll(disable)
     while (have) {
-        if (role == 2) {   // the token written by this pass comes from LDS (its cache stores may still be in flight)
+        if (VS == 2 && is_tail && sw == w) {   // switching to the extra slot: close this wave's own slot first
+            if (first) {
+#pragma unroll
+                for (int i = 0; i < DB * 4; ++i) so[w * OW + i * 64 + lane] = 0.f;
+                if (g == 0) {
+                    sm[w * 16 + r] = -INFINITY;
+                    sl[w * 16 + r] = 0.f;
+                }
+            }
+            sw = DA_NW;
+            first = true;
+        }
+        if (role == 2 && !is_tail) {   // the token written by this pass comes from LDS (its cache stores may still be in flight)
             const int e = a.write_t - 8 * it;
             if (e >= 0 && e < 8) {
                 const bf16_t* kp = kn + (cl + (r >> 2)) * D + g * 8;
@@ -327,10 +363,10 @@ __global__ __launch_bounds__(1024) void decode_attn_fused_k(DecAttnDev a) {
         uint4 pp;
         pp.x = pack_bf2(p[0], p[1]); pp.y = pack_bf2(p[2], p[3]); pp.z = pack_bf2(p[4], p[5]); pp.w = pack_bf2(p[6], p[7]);
         const bf16x8 pf = as_bf16x8(pp);
-        float* slot = so + w * OW + lane;
+        float* slot = so + sw * OW + lane;
         float fo = 0.f, ft = 1.f;
         if (!first) {
-            const float mo = sm[w * 16 + r], lo = sl[w * 16 + r];
+            const float mo = sm[sw * 16 + r], lo = sl[sw * 16 + r];
             const float mx = fmaxf(mo, m);
             fo = (mo == -INFINITY) ? 0.f : exp2f(mo - mx);
             ft = (m == -INFINITY) ? 0.f : exp2f(m - mx);
@@ -348,19 +384,27 @@ __global__ __launch_bounds__(1024) void decode_attn_fused_k(DecAttnDev a) {
             asm volatile("" ::: "memory");   // keep the LDS reads of the fold next to their use (register budget)
         }
         if (g == 0) {
-            sm[w * 16 + r] = m;
-            sl[w * 16 + r] = l;
+            sm[sw * 16 + r] = m;
+            sl[sw * 16 + r] = l;
         }
         first = false;
         have = next_tile();
         if (have) load_tile();
     }
-    if (first) {   // a wave without a tile contributes the empty state
+    if (first && sw == w) {   // a wave without a tile contributes the empty state
 #pragma unroll
         for (int i = 0; i < DB * 4; ++i) so[w * OW + i * 64 + lane] = 0.f;
         if (g == 0) {
             sm[w * 16 + r] = -INFINITY;
             sl[w * 16 + r] = 0.f;
+        }
+    }
+    if (role == 2 && wl == 0 && sw == w) {   // no tail tile: the extra slot is empty
+#pragma unroll
+        for (int i = 0; i < DB * 4; ++i) so[DA_NW * OW + i * 64 + lane] = 0.f;
+        if (g == 0) {
+            sm[DA_NW * 16 + r] = -INFINITY;
+            sl[DA_NW * 16 + r] = 0.f;
         }
     }
 
@@ -370,10 +414,10 @@ __global__ __launch_bounds__(1024) void decode_attn_fused_k(DecAttnDev a) {
     if (!q_ok) return;
     float mx = -INFINITY;
 #pragma unroll
-    for (int i = 0; i < DA_NW; ++i) mx = fmaxf(mx, sm[i * 16 + r]);
-    float lt = 0.f, f[DA_NW];
+    for (int i = 0; i < DA_NW + 1; ++i) mx = fmaxf(mx, sm[i * 16 + r]);
+    float lt = 0.f, f[DA_NW + 1];
 #pragma unroll
-    for (int i = 0; i < DA_NW; ++i) {
+    for (int i = 0; i < DA_NW + 1; ++i) {
         const float mi = sm[i * 16 + r];
         f[i] = (mi == -INFINITY) ? 0.f : exp2f(mi - mx);
         lt += sl[i * 16 + r] * f[i];
@@ -386,7 +430,7 @@ __global__ __launch_bounds__(1024) void decode_attn_fused_k(DecAttnDev a) {
     for (int e = 0; e < IPW; ++e) {
         float acc = 0.f;
 #pragma unroll
-        for (int i = 0; i < DA_NW; ++i) acc += so[i * OW + (item0 + e) * 64 + lane] * f[i];
+        for (int i = 0; i < DA_NW + 1; ++i) acc += so[i * OW + (item0 + e) * 64 + lane] * f[i];
         o[e] = acc * inv;
     }
     bf16_t* op = a.out + (long long)cand_r * a.o_row + (long long)h * D + dv0 + db * 16 + 4 * g + e0;
@@ -437,10 +481,17 @@ hipError_t launch_decode_attention_fused(const cover_decode_attn_args* x, hipStr
     const int nA = (s0.len + 31) / 32;
     a.WC = 4;
     a.WA = nA < 9 ? nA : 9;
+    a.tail_tile = -1;
+    // Nine segment-0 tiles (257 keys = BOS + 256 patches: eight full tiles and ONE key) would cost pool A a ninth wave and leave
+    // pool B three waves for the four prompts of a block -- one of them then runs two tiles back to back, each a full
+    // global round trip, and the whole block waits for it. The ninth tile goes to the first pool-C wave instead (its own
+    // tile is 8 short keys), into a state slot of its own so that the merge order stays independent of where a candidate sits.
     // few (candidate tile, head) units: split the value columns over two blocks each (see the kernel's VS comment)
     static const char* vs_env = getenv("COVER_DA_VSPLIT");
     const int units = ((x->N + 15) / 16) * x->H;
     const int VS = vs_env ? (atoi(vs_env) == 2 ? 2 : 1) : (units <= 128 ? 2 : 1);
+    static const char* tail_env = getenv("COVER_DA_TAIL");   // experiment knob: 0 keeps nine pool-A waves
+    if (nA == 9 && VS == 2 && !(tail_env && tail_env[0] == '0')) { a.WA = 8; a.tail_tile = 8; }
     dim3 grid((x->N + 15) / 16, x->H, VS), block(64 * DA_NW);
     const int pid = prof_enabled() ? prof_open(st, 2, 0.0) : -1;
     if (x->D == 128) {
