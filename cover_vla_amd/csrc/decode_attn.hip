@@ -41,7 +41,7 @@ struct DecAttnDev {
 
 constexpr int DA_NW = 16;
 
-// VS = 2: the value / output columns of a (16 candidates, head) unit are split over two blocks (blockIdx.z): both compute
+// VS = 2 / 4: the value / output columns of a (16 candidates, head) unit are split over two / four blocks (blockIdx.z): all compute
 // the scores from the full K, each loads, multiplies and merges only its D/2 columns of V. The tile phase is bound by the
 // bytes one CU can pull in (64 blocks read 11.5 MB at N = 32, H = 32); two CUs at 0.75x the bytes each finish it sooner.
 #ifdef COVER_DA_DEBUG
@@ -150,7 +150,7 @@ __global__ __launch_bounds__(1024) void decode_attn_fused_k(DecAttnDev a) {
     unsigned vmask = 0;                               // bit e: this lane's e-th score is visible
     int it = -1, bcol = -1, bslot = 0, blen = 0;      // iterator state: tile index inside the current run; pool B run
     // (only in the value-split variant: the unsplit one is at its 128-register budget, and its blocks are not the few-units case)
-    bool tail_pending = (VS == 2 && role == 2 && wl == 0 && a.tail_tile >= 0), is_tail = false;
+    bool tail_pending = (VS >= 2 && role == 2 && wl == 0 && a.tail_tile >= 0), is_tail = false;
     auto next_tile = [&]() -> bool {
         if (role == 0) {            // segment 0: tiles wl, wl + WA, ...
             it = it < 0 ? wl : it + a.WA;
@@ -205,7 +205,7 @@ __global__ __launch_bounds__(1024) void decode_attn_fused_k(DecAttnDev a) {
         ++it;
         const int tb = 8 * it;
         if (tb >= a.len2) {
-            if (VS != 2 || !tail_pending) return false;
+            if (VS < 2 || !tail_pending) return false;
             // the segment-0 tail tile (pool A has exactly one wave per FULL tile): described like a pool-A tile
             tail_pending = false;
             is_tail = true;
@@ -301,7 +301,7 @@ __global__ __launch_bounds__(1024) void decode_attn_fused_k(DecAttnDev a) {
     int sw = w;                                        // state slot this wave is writing
 #pragma clang loop unroll(disable)
     while (have) {
-        if (VS == 2 && is_tail && sw == w) {   // switching to the extra slot: close this wave's own slot first
+        if (VS >= 2 && is_tail && sw == w) {   // switching to the extra slot: close this wave's own slot first
             if (first) {
 #pragma unroll
                 for (int i = 0; i < DB * 4; ++i) so[w * OW + i * 64 + lane] = 0.f;
@@ -489,13 +489,18 @@ hipError_t launch_decode_attention_fused(const cover_decode_attn_args* x, hipStr
     // few (candidate tile, head) units: split the value columns over two blocks each (see the kernel's VS comment)
     static const char* vs_env = getenv("COVER_DA_VSPLIT");
     const int units = ((x->N + 15) / 16) * x->H;
-    const int VS = vs_env ? (atoi(vs_env) == 2 ? 2 : 1) : (units <= 128 ? 2 : 1);
+    // units <= 64 (N = 32 at 32 heads): four blocks per unit put one block on every CU; the score part is computed four times
+    // over, but a block then pulls 10 instead of 12 KiB per wave-tile and merges a quarter of the columns (decode pass 3.655 ->
+    // 3.58 ms). D = 64 heads have too few columns to split in four.
+    int VS = vs_env ? (atoi(vs_env) == 4 ? 4 : atoi(vs_env) == 2 ? 2 : 1) : (units <= 64 ? 4 : units <= 128 ? 2 : 1);
+    if (x->D != 128 && VS == 4) VS = 2;
     static const char* tail_env = getenv("COVER_DA_TAIL");   // experiment knob: 0 keeps nine pool-A waves
-    if (nA == 9 && VS == 2 && !(tail_env && tail_env[0] == '0')) { a.WA = 8; a.tail_tile = 8; }
+    if (nA == 9 && VS >= 2 && !(tail_env && tail_env[0] == '0')) { a.WA = 8; a.tail_tile = 8; }
     dim3 grid((x->N + 15) / 16, x->H, VS), block(64 * DA_NW);
     const int pid = prof_enabled() ? prof_open(st, 2, 0.0) : -1;
     if (x->D == 128) {
-        if (VS == 2) hipLaunchKernelGGL((decode_attn_fused_k<128, 2>), grid, block, 0, st, a);
+        if (VS == 4) hipLaunchKernelGGL((decode_attn_fused_k<128, 4>), grid, block, 0, st, a);
+        else if (VS == 2) hipLaunchKernelGGL((decode_attn_fused_k<128, 2>), grid, block, 0, st, a);
         else hipLaunchKernelGGL((decode_attn_fused_k<128, 1>), grid, block, 0, st, a);
     } else {
         if (VS == 2) hipLaunchKernelGGL((decode_attn_fused_k<64, 2>), grid, block, 0, st, a);
