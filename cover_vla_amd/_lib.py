@@ -204,6 +204,7 @@ SYMBOLS = {
     "cover_stream_sync": (c_i, [c_p]),
     "cover_profile_begin": (c_i, [c_i]),
     "cover_profile_end": (c_i, [_P(C.c_double), _P(C.c_longlong), _P(C.c_double)]),
+    "cover_profile_end_n": (c_i, [_P(C.c_double), _P(C.c_longlong), _P(C.c_double), c_i]),
     "cover_sizeof": (C.c_size_t, [C.c_char_p]),
 }
 

@@ -1594,14 +1594,14 @@ hipError_t launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* Wp, void* C,
         if (e != hipSuccess) return e;
         const bool want_norm = epi.norm_w != nullptr && epi.norm_out != nullptr;
         if (want_norm && !epi.glu && !epi.out_f32 && (N % 8) == 0 && N <= 8192 && (ldc % 8) == 0 && (epi.ld_norm_out % 8) == 0 && (((uintptr_t)epi.norm_w) & 15) == 0) {
-            hipLaunchKernelGGL(splitk_reduce_norm, dim3(M), dim3(512), 0, st, (const float*)ws, S, (bf16_t*)C, ldc, M, N, epi);
+            launch_streaming(5, 0.0, splitk_reduce_norm, dim3(M), dim3(512), 0, st, (const float*)ws, S, (bf16_t*)C, ldc, M, N, epi);
             return hipGetLastError();
         }
         const int Nout = epi.glu ? N / 2 : N;
         const long long total = (long long)M * ((Nout + 3) / 4);
         int rb = (int)((total + 255) / 256);
         if (rb > 2048) rb = 2048;
-        hipLaunchKernelGGL(splitk_reduce, dim3(rb), dim3(256), 0, st, (const float*)ws, S, C, ldc, M, N, epi);
+        launch_streaming(5, 0.0, splitk_reduce, dim3(rb), dim3(256), 0, st, (const float*)ws, S, C, ldc, M, N, epi);
         e = hipGetLastError();
         if (e == hipSuccess && want_norm) e = run_norm(epi, C, ldc, M, epi.glu ? N / 2 : N, st);
         return e;
@@ -1707,7 +1707,9 @@ hipError_t launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* Wp, void* C,
     const size_t lds = (size_t)nst * (bm + bn) * BK * 2;
     const bool pc = pick >= 9;
     dim3 grid(tiles_m * tiles_n, S), block(pc ? 320 : 64 * cd.wgm * cd.wgn);
-    const int pid = prof_enabled() ? prof_open(st, 1, 2.0 * (double)M * (double)N * (double)K) : -1;
+    // profiling: the GEMM kernel's own start / stop stamps; class 4 = LLM-sized weight matrix (prefill), 1 = ViT-sized
+    const int tcls = (double)N * (double)Kp >= 16.0e6 ? 4 : 1;
+    const double twork = 2.0 * (double)M * (double)N * (double)K;
     hipError_t e = hipSuccess;
 #define LAUNCH_T(WM_, WN_, G_, NST_, WGM_, WGN_)                                                                            \
     do {                                                                                                                    \
@@ -1717,7 +1719,7 @@ hipError_t launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* Wp, void* C,
             e = attr;                                                                                                       \
         }                                                                                                                   \
         if (e == hipSuccess)                                                                                                \
-            hipLaunchKernelGGL(kfn, grid, block, lds, st, A, lda, Wp, C, ldc, M, N, Kp, epi, tiles_m, tiles_n, kt_per, partial); \
+            launch_streaming(tcls, twork, kfn, grid, block, lds, st, A, lda, Wp, C, ldc, M, N, Kp, epi, tiles_m, tiles_n, kt_per, partial); \
     } while (0)
 #define LAUNCH_PC(WM_, WN_, NST_, NL_, ...)                                                                                 \
     do {                                                                                                                    \
@@ -1727,7 +1729,7 @@ hipError_t launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* Wp, void* C,
             e = attr;                                                                                                       \
         }                                                                                                                   \
         if (e == hipSuccess)                                                                                                \
-            hipLaunchKernelGGL(kfn, grid, block, lds, st, A, lda, Wp, C, ldc, M, N, Kp, epi, tiles_m, tiles_n, kt_per, partial); \
+            launch_streaming(tcls, twork, kfn, grid, block, lds, st, A, lda, Wp, C, ldc, M, N, Kp, epi, tiles_m, tiles_n, kt_per, partial); \
     } while (0)
     if (pc) {
         // loader waves: one wave issues an LDS-DMA piece every ~60 cycles, four keep the CU's vector memory path busy
@@ -1763,18 +1765,17 @@ hipError_t launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* Wp, void* C,
     if (e == hipSuccess && S > 1) {
         const bool want_norm = epi.norm_w != nullptr && epi.norm_out != nullptr;
         if (want_norm && !epi.glu && !epi.out_f32 && (N % 8) == 0 && N <= 8192 && (ldc % 8) == 0 && (epi.ld_norm_out % 8) == 0 && (((uintptr_t)epi.norm_w) & 15) == 0) {
-            hipLaunchKernelGGL(splitk_reduce_norm, dim3(M), dim3(512), 0, st, (const float*)ws, S, (bf16_t*)C, ldc, M, N, epi);
+            launch_streaming(6, 0.0, splitk_reduce_norm, dim3(M), dim3(512), 0, st, (const float*)ws, S, (bf16_t*)C, ldc, M, N, epi);
             norm_done = true;
         } else {
             const int Nout = epi.glu ? N / 2 : N;
             const long long total = (long long)M * ((Nout + 3) / 4);
             int rb = (int)((total + 255) / 256);
             if (rb > 2048) rb = 2048;
-            hipLaunchKernelGGL(splitk_reduce, dim3(rb), dim3(256), 0, st, (const float*)ws, S, C, ldc, M, N, epi);
+            launch_streaming(6, 0.0, splitk_reduce, dim3(rb), dim3(256), 0, st, (const float*)ws, S, C, ldc, M, N, epi);
         }
         e = hipGetLastError();
     }
-    prof_close(st, pid);
     if (e == hipSuccess && !norm_done && epi.norm_w != nullptr && epi.norm_out != nullptr)
         e = run_norm(epi, C, ldc, M, epi.glu ? N / 2 : N, st);
     return e;

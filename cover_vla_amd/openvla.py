@@ -70,6 +70,10 @@ class OpenVLA:
         self._cap = None
         self._vis = {}
         self._bos_ready = False
+        # measurement switches (bench.py's profiled decision): hipGraph replay hides launches from the in-library kernel
+        # timer, and the SigLIP tower on a side stream inflates the durations of the kernels it overlaps
+        self.vision_graph = os.environ.get("COVER_VISION_GRAPH", "1") != "0"
+        self.vision_overlap = True
 
     def _ensure_bos_kv(self):
         """The BOS token sits at position 0 of a causal prefix: it attends only to itself, so its hidden states and its K/V
@@ -108,13 +112,14 @@ class OpenVLA:
         main = torch.cuda.current_stream()
         if self._side is None:
             self._side = torch.cuda.Stream(device=self.dev)
-        self._side.wait_stream(main)
-        with torch.cuda.stream(self._side):
+        side = self._side if self.vision_overlap else main
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
             xs = self.siglip.embed(st["frame"], [1.0 / (255.0 * 0.5)] * 3, [-1.0] * 3, bufs=st["s"])
             xs = self.siglip.forward(xs)
         xd = self.dino.embed(st["frame"], mul_d, add_d, bufs=st["d"])
         xd = self.dino.forward(xd)
-        main.wait_stream(self._side)
+        main.wait_stream(side)
         fused = st["fused"].view(n, P, self.fused)                       # channel concat (strided device copies)
         fused[:, :, :c["dino_dim"]].copy_(xd[:, c["dino_prefix"]:, :])
         fused[:, :, c["dino_dim"]:].copy_(xs)
@@ -129,11 +134,11 @@ class OpenVLA:
         n, H, W, _ = frame_u8.shape
         st = self._vision_static(n, H, W)
         st["frame"].copy_(frame_u8)
-        if st["graph"] is not None:
+        if st["graph"] is not None and self.vision_graph:
             st["graph"].launch()
             return st["h"][2]
         out = self._encode_static(st)                                    # eager (also sizes the towers' workspaces)
-        if os.environ.get("COVER_VISION_GRAPH", "1") != "0":
+        if self.vision_graph and st["graph"] is None:
             cur = torch.cuda.current_stream()
             if self._cap is None:
                 self._cap = torch.cuda.Stream(device=self.dev)

@@ -2,14 +2,19 @@
 xGMI on the GPU box, "gloo" in the CPU tests).
 
 Candidates are independent given the observation (run_simpler_eval_with_openpi.py:305-319; the verifier scores each
-history independently, efficient_ensemble_merged.py:226-245), so the path shards with ONE exchange: an all-gather of the
-per-candidate fp32 scores (128 B per rank at 32 candidates: latency-bound, no weight or activation traffic), after
-which every rank applies the same deterministic grouped arg-max (efficient_ensemble_merged.py:417-448 semantics need
-every group's mean). Rank r owns prompt groups r, r+W, r+2W, ...; global candidate index = prompt_index * S + sample.
+history independently, efficient_ensemble_merged.py:226-245), so the path shards with ONE exchange: an all-gather of one
+fp32 RECORD per candidate -- its score followed by its payload (the sampled action tokens / the action chunk, a few
+dozen floats) -- after which every rank applies the same deterministic grouped arg-max
+(efficient_ensemble_merged.py:417-448 semantics need every group's mean) and therefore holds, without a second
+collective, everything the driver needs on the rank that steps the environment
+(run_simpler_eval_with_openpi.py:365-401): the winner's index and score, the winner's chunk, and the chunks of the
+winner's whole prompt group (the gripper majority vote of :374-392 runs over that group). N = 256 candidates x
+(1 + 28) floats = 29 KB in total: latency-bound, no weight or activation traffic over xGMI, no all-reduce.
+Rank r owns prompt groups r, r+W, r+2W, ...; global candidate index = prompt_index * S + sample.
 """
 from __future__ import annotations
 
-from typing import List, Sequence
+from typing import List, Optional, Sequence
 
 import torch
 import torch.distributed as dist
@@ -19,28 +24,61 @@ def shard_prompts(prompts: Sequence, rank: int, world: int) -> List:
     return [p for i, p in enumerate(prompts) if i % world == rank]
 
 
-def gather_scores_and_select(local_scores: torch.Tensor, samples_per_prompt: int, rank: int, world: int,
-                             n_prompts_total: int) -> dict:
-    """local_scores: fp32 [n_local_prompts * S] in this rank's prompt order. Returns the GLOBAL selection (identical on
-    every rank): dict(global_idx, group, in_group, max_score, group_mean, scores)."""
-    S = samples_per_prompt
-    n_local = local_scores.numel() // S
-    if world > 1:
-        # equal shards are the contract (prompts % world == 0); a ragged tail would need all_gather with padding
-        assert n_prompts_total % world == 0, "prompt count must be a multiple of the world size"
-        buf = torch.empty(world * local_scores.numel(), dtype=torch.float32, device=local_scores.device)
-        dist.all_gather_into_tensor(buf, local_scores.contiguous())
-        # rank r's j-th prompt is global prompt r + j*world  -> scatter back into global prompt order
-        g = buf.view(world, n_local, S).permute(1, 0, 2).reshape(n_prompts_total, S)
-    else:
-        g = local_scores.view(n_local, S)
+def _select(g: torch.Tensor, S: int) -> dict:
+    """g fp32 [G, S] in global prompt order -> first-maximum-wins grouped arg-max (torch.max semantics)."""
     if g.is_cuda:
         from . import ops
         res, best = ops.group_argmax(g.reshape(-1).contiguous(), S)
         res, best = res.cpu(), best.cpu()
         return dict(global_idx=int(res[0]), group=int(res[1]), in_group=int(res[2]), max_score=float(best[0]),
-                    group_mean=float(best[1]), scores=g.reshape(-1))
-    # CPU process groups (tests): same rule, first maximum wins (torch.max semantics)
+                    group_mean=float(best[1]))
     gm, bg = g.mean(dim=1).max(dim=0)
     mx, bi = g[bg].max(dim=0)
     return dict(global_idx=int(bg) * S + int(bi), group=int(bg), in_group=int(bi), max_score=float(mx), group_mean=float(gm))
+
+
+def gather_records_and_select(local_scores: torch.Tensor, samples_per_prompt: int, rank: int, world: int,
+                              n_prompts_total: int, local_payload: Optional[torch.Tensor] = None) -> dict:
+    """local_scores fp32 [n_local_prompts * S] in this rank's prompt order; local_payload [n_local * S, P] (any dtype
+    exactly representable in fp32: token ids < 2^24, fp32 action chunks) or None.
+    ONE all-gather of [n_local * S, 1 + P] fp32 records. Returns, identically on every rank:
+    dict(global_idx, group, in_group, max_score, group_mean, scores [N], payload [N, P] | None,
+         winner_payload [P] | None, group_payload [S, P] | None)."""
+    S = samples_per_prompt
+    n_loc = local_scores.numel()
+    n_local_prompts = n_loc // S
+    P = 0 if local_payload is None else int(local_payload.reshape(n_loc, -1).shape[1])
+    rec = local_scores.reshape(n_loc, 1).to(torch.float32)
+    if P:
+        rec = torch.cat([rec, local_payload.reshape(n_loc, P).to(torch.float32)], dim=1)
+    rec = rec.contiguous()
+    if world > 1:
+        # equal shards are the contract (prompts % world == 0); a ragged tail would need all_gather with padding
+        assert n_prompts_total % world == 0 and n_local_prompts * world == n_prompts_total, \
+            "prompt count must be a multiple of the world size"
+        buf = torch.empty(world * n_loc, 1 + P, dtype=torch.float32, device=rec.device)
+        dist.all_gather_into_tensor(buf, rec)
+        # rank r's j-th prompt is global prompt r + j*world  -> scatter back into global prompt order
+        allrec = buf.view(world, n_local_prompts, S, 1 + P).permute(1, 0, 2, 3).reshape(n_prompts_total * S, 1 + P)
+    else:
+        allrec = rec
+    scores = allrec[:, 0].contiguous()
+    sel = _select(scores.view(-1, S), S)
+    sel["scores"] = scores
+    if P:
+        pay = allrec[:, 1:]
+        if local_payload.dtype != torch.float32:
+            pay = pay.round().to(local_payload.dtype)
+        gi, gg = sel["global_idx"], sel["group"]
+        sel["payload"] = pay
+        sel["winner_payload"] = pay[gi]
+        sel["group_payload"] = pay[gg * S:(gg + 1) * S]
+    else:
+        sel["payload"] = sel["winner_payload"] = sel["group_payload"] = None
+    return sel
+
+
+def gather_scores_and_select(local_scores: torch.Tensor, samples_per_prompt: int, rank: int, world: int,
+                             n_prompts_total: int) -> dict:
+    """Scores only (no payload): kept for callers that hold the candidates everywhere already."""
+    return gather_records_and_select(local_scores, samples_per_prompt, rank, world, n_prompts_total, None)

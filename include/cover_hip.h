@@ -405,12 +405,18 @@ int cover_timer_stop(void* timer, void* stream, float* ms_out);
 int cover_timer_destroy(void* timer);
 int cover_stream_sync(void* stream);
 
-/* Per-launch kernel timing for bench.py's roofline object: between begin/end every GEMM / attention launch issued by
- * this library is bracketed by a hipEvent pair on its own stream. Classes: 0 = weight-streaming GEMM with >= 16 MB of
- * weights (work = weight bytes), 1 = LDS-tiled GEMM (work = FLOPs), 2 = attention, 3 = small weight-streaming GEMMs.
- * end() synchronises the device and fills ms[4], count[4], work[4]. */
+/* Per-launch kernel timing for bench.py's roofline objects: between begin/end every GEMM / attention launch issued by
+ * this library carries a hipEvent pair stamped with the kernel's own start / stop on its stream. Classes:
+ *   0 weight-streaming GEMM with >= 16 MB of weights (work = weight bytes)   1 LDS-tiled GEMM, ViT-sized (work = FLOPs)
+ *   2 attention (work = 0)   3 small weight-streaming GEMMs (work = weight bytes)
+ *   4 LDS-tiled GEMM, LLM-sized (N*K >= 16 M; work = FLOPs)   5 / 6 split-K reductions behind a weight-streaming / an LDS-tiled GEMM (work = 0)
+ * Thread-safe (records are claimed atomically). Launches replayed from a hipGraph are not seen (neither time nor work).
+ * end_n() synchronises the device and fills ms[n], count[n], work[n] (n <= COVER_PROF_CLASSES); it returns
+ * COVER_EWORKSPACE when more launches were issued than max_events (sums incomplete). end() = end_n(.., 4). */
+#define COVER_PROF_CLASSES 7
 int cover_profile_begin(int max_events);
 int cover_profile_end(double* ms, long long* count, double* work);
+int cover_profile_end_n(double* ms, long long* count, double* work, int n_classes);
 
 /* sizeof() of every struct above by name ("cover_attn_args", ...): lets a foreign-language binding check its
  * mirrored layouts at load time. Returns 0 for unknown names. */

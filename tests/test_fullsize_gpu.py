@@ -70,13 +70,13 @@ def test_fullsize_attention_rows_are_convex_combinations(dev):
     assert torch.allclose(out.float(), torch.ones_like(out.float()), atol=8e-3)   # bf16 P rounding only
 
 
-def test_fullsize_decision_properties(pipe, dev):
+def _decision_properties(pipe, dev, P, S):
     i = pipe.inp
-    P, S = 8, 4
     # (a) determinism: bit-identical tokens and scores on a repeat
-    idx1, tok1 = pipe.decision()
-    idx2, tok2 = pipe.decision()
+    idx1, tok1, _ = pipe.decision()
+    idx2, tok2, _ = pipe.decision()
     assert idx1 == idx2 and torch.equal(tok1, tok2)
+    assert 0 <= idx1 < P * S
     assert tok1.shape == (P * S, 7)
     lo, hi = pipe.c["tok_vocab"] - pipe.c["n_bins"], pipe.c["tok_vocab"]
     assert int(tok1.min()) >= lo and int(tok1.max()) < hi
@@ -93,6 +93,50 @@ def test_fullsize_decision_properties(pipe, dev):
     g8, _ = pipe.policy.sample(i["frame"], i["toks"], i["lens"], 1)
     g1, _ = pipe.policy.sample(i["frame"], i["toks"][:1], i["lens"][:1], 1)
     assert torch.equal(g1[0], g8[0])
+    # (e) the serialised decision bench.py profiles (one stream, no hipGraph replay, both towers on one stream) selects the same
+    idx3, tok3, _ = pipe.decision(serial=True)
+    assert idx3 == idx1 and torch.equal(tok3, tok1)
+
+
+def test_fullsize_decision_properties(pipe, dev):
+    """Headline configuration: OpenVLA-7B, N = 32 = 8 prompts x 4 samples, one camera, 3-member ensemble."""
+    _decision_properties(pipe, dev, 8, 4)
+
+
+def test_fullsize_config2_n16(pipe, dev):
+    """BASELINE config 2: OpenVLA-7B N = 16 = 8 prompts x 2 samples, bf16, one MI355X (same weights, M = 16 decode rows)."""
+    keep = (pipe.n_samples, pipe.inp["u"])
+    pipe.n_samples = 2
+    pipe.inp["u"] = keep[1].view(8, 4, 7)[:, :2].reshape(16, 7).contiguous()
+    try:
+        _decision_properties(pipe, dev, 8, 2)
+        # candidate (p, s) of the N = 16 run draws the uniforms of candidate (p, s) of the N = 32 run: same tokens
+        _, tok16, _ = pipe.decision()
+        pipe.n_samples, pipe.inp["u"] = keep
+        _, tok32, _ = pipe.decision()
+        assert torch.equal(tok16.view(8, 2, 7), tok32.view(8, 4, 7)[:, :2])
+    finally:
+        pipe.n_samples, pipe.inp["u"] = keep
+
+
+def test_fullsize_config4_two_cameras_n64_ensemble2(dev):
+    """BASELINE config 4: Prismatic dual encoder, 2-camera 224^2 observation (512 patch rows in the shared prefix), N = 64 =
+    8 prompts x 8 samples, verifier ensemble = 2. Size-independent properties at full size (small-size oracle parity with
+    two cameras: tests/test_openvla_gpu.py; 2-member verifier vs the reference golden: tests/test_models_gpu.py)."""
+    import bench
+    torch.cuda.empty_cache()
+    p4 = bench.Pipeline(dev, small=False, n_samples=8, n_cams=2, members=2)
+    assert p4.policy.T0 == 1 + 512 and len(p4.ver.trainable_models) == 2
+    _decision_properties(p4, dev, 8, 8)
+    # the second camera matters: another frame in camera 1 changes the sampled tokens of at least one candidate
+    i = p4.inp
+    _, t0, _ = p4.decision()
+    f2 = i["frame"].clone()
+    f2[1] = 255 - f2[1]
+    t1, _ = p4.policy.sample(f2, i["toks"], i["lens"], 8, i["u"], 1.0)
+    assert not torch.equal(t0, t1)
+    del p4
+    torch.cuda.empty_cache()
 
 
 def test_fullsize_verifier_permutation(pipe, dev):

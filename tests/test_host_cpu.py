@@ -113,19 +113,25 @@ def _worker(rank, world, port, q):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from cover_vla_amd.sharding import gather_scores_and_select, shard_prompts
+    from cover_vla_amd.sharding import gather_records_and_select, shard_prompts
     prompts = [f"p{i}" for i in range(8)]
     mine = shard_prompts(prompts, rank, world)
-    # rank r scores its candidates with a known function of the GLOBAL candidate index
+    # rank r scores its candidates with a known function of the GLOBAL candidate index; the payload of a candidate is its
+    # 7 action tokens (int64, a known function of the global index too) -- what the driver needs of the winner and of the
+    # winner's prompt group (gripper vote, run_simpler_eval_with_openpi.py:365-401)
     S = 4
     gidx = [prompts.index(p) * S + s for p in mine for s in range(S)]
     scores = torch.tensor([((g * 37) % 101) / 101.0 for g in gidx], dtype=torch.float32)
-    res = gather_scores_and_select(scores, S, rank, world, n_prompts_total=len(prompts))
+    tokens = torch.tensor([[31744 + (g * 13 + j * 7) % 256 for j in range(7)] for g in gidx], dtype=torch.int64)
+    res = gather_records_and_select(scores, S, rank, world, n_prompts_total=len(prompts), local_payload=tokens)
+    res = {k: (v.tolist() if torch.is_tensor(v) else v) for k, v in res.items()}
     q.put((rank, res))
     dist.destroy_process_group()
 
 
 def test_candidate_sharding_gloo_world2():
+    """2 ranks x 4 prompts x 4 samples: one all-gather of [score | 7 tokens] records; every rank must hold the same winner
+    index, the winner's tokens and its whole prompt group's tokens (winner exchange)."""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -140,10 +146,28 @@ def test_candidate_sharding_gloo_world2():
     all_scores = torch.tensor([((g * 37) % 101) / 101.0 for g in range(32)]).view(8, S)
     bg = int(all_scores.mean(1).argmax())
     bi = int(all_scores[bg].argmax())
+    tok = lambda g: [31744 + (g * 13 + j * 7) % 256 for j in range(7)]
     for r in range(2):
         assert outs[r]["global_idx"] == bg * S + bi and outs[r]["group"] == bg
         assert abs(outs[r]["max_score"] - float(all_scores[bg, bi])) < 1e-7
+        assert outs[r]["winner_payload"] == tok(bg * S + bi)                       # exact: token ids < 2^24 survive fp32
+        assert outs[r]["group_payload"] == [tok(bg * S + s) for s in range(S)]
+        assert outs[r]["payload"] == [tok(g) for g in range(32)]
+        assert np.allclose(outs[r]["scores"], all_scores.view(-1).numpy(), atol=0)
     assert outs[0] == outs[1]
+
+
+def test_gather_records_world1_fp32_payload():
+    from cover_vla_amd.sharding import gather_records_and_select
+    g = torch.Generator().manual_seed(0)
+    scores = torch.rand(16, generator=g)
+    chunk = torch.randn(16, 4, 7, generator=g)
+    r = gather_records_and_select(scores, 2, 0, 1, 8, local_payload=chunk)
+    gm = scores.view(8, 2).mean(1)
+    bg = int(gm.argmax()); bi = int(scores.view(8, 2)[bg].argmax())
+    assert r["global_idx"] == bg * 2 + bi
+    assert torch.equal(r["winner_payload"], chunk[bg * 2 + bi].reshape(-1))
+    assert torch.equal(r["group_payload"], chunk[bg * 2:bg * 2 + 2].reshape(2, -1))
 
 
 # ------------------------------------------------------------------------------------------------ checkpoint format

@@ -1,0 +1,68 @@
+"""N > 1 path on a GPU: two fresh rank processes (started by tests/conftest.py before this process touches the GPU) run
+bench.py --small with --share-gpu --backend gloo, in weak and in strong scaling. Checks the prompt sharding, the ONE
+all-gather of [score | tokens] records and the winner exchange: every rank must end with the same winner index, the
+winner's tokens and its prompt group's tokens; the strong-scaling run must select exactly what an unsharded run selects."""
+import json
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _collect(run):
+    outs = []
+    for p in run["procs"]:
+        try:
+            log, _ = p.communicate(timeout=900)
+        except Exception:
+            p.kill()
+            raise
+        assert p.returncode == 0, log[-3000:]
+        outs.append(log)
+    recs = []
+    for r in range(2):
+        with open(f"{run['out']}.rank{r}.json") as f:
+            recs.append(json.load(f))
+    line = [l for l in outs[0].splitlines() if l.startswith("{")][-1]
+    return recs, json.loads(line)
+
+
+def test_two_ranks_weak_scaling_winner_exchange(dev, multirank_runs):
+    assert "weak" in multirank_runs, "rank processes were not launched (no GPU at collection time?)"
+    recs, line = _collect(multirank_runs["weak"])
+    S, P = 4, 8
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["config"]["candidates_total"] == 2 * P * S
+    assert recs[0]["global_idx"] == recs[1]["global_idx"]
+    assert recs[0]["winner_tokens"] == recs[1]["winner_tokens"] and recs[0]["group_tokens"] == recs[1]["group_tokens"]
+    assert recs[0]["scores"] == recs[1]["scores"] and len(recs[0]["scores"]) == 2 * P * S
+    # the winner's tokens are those of the OWNING rank's local candidate: global prompt g = r + j * W
+    gi = recs[0]["global_idx"]
+    g, s = gi // S, gi % S
+    owner, j = g % 2, g // 2
+    assert recs[owner]["local_tokens"][j * S + s] == recs[0]["winner_tokens"]
+    assert recs[owner]["local_tokens"][j * S:(j + 1) * S] == recs[0]["group_tokens"]
+    # both ranks ran the same observation and the same 8 prompts: identical local work -> identical scores per rank slot
+    sc = torch.tensor(recs[0]["scores"]).view(P, 2, S)
+    assert torch.equal(sc[:, 0], sc[:, 1])
+
+
+def test_two_ranks_strong_scaling_equals_unsharded(dev, multirank_runs):
+    assert "strong" in multirank_runs, "rank processes were not launched (no GPU at collection time?)"
+    recs, line = _collect(multirank_runs["strong"])
+    S, P = 4, 8
+    assert line["scaling"] == "strong" and line["config"]["candidates_total"] == P * S and line["config"]["prompts_per_gpu"] == P // 2
+    assert recs[0]["prompt_ids"] == [0, 2, 4, 6] and recs[1]["prompt_ids"] == [1, 3, 5, 7]
+    assert recs[0]["global_idx"] == recs[1]["global_idx"] and recs[0]["winner_tokens"] == recs[1]["winner_tokens"]
+    import bench
+    pipe = bench.Pipeline(dev, small=True)
+    idx, tok, _ = pipe.decision()
+    tok = tok.cpu().view(P, S, 7)
+    # every rank's local tokens are the unsharded run's tokens of its prompts (candidates do not interact)
+    for r in range(2):
+        assert recs[r]["local_tokens"] == tok[r::2].reshape(-1, 7).tolist()
+    # scores: the trajectory encoder batch differs (16 vs 32 rows) but per-candidate arithmetic is row-independent
+    ref = pipe.ver.score_histories
+    assert recs[0]["global_idx"] == idx
+    assert recs[0]["winner_tokens"] == tok.view(-1, 7)[idx].tolist()
+    assert recs[0]["group_tokens"] == tok[idx // S].tolist()

@@ -16,11 +16,11 @@ sys.path.insert(0, os.path.join(ROOT, "oracle"))
 from cover_vla_amd import synth  # noqa: E402
 
 
-def _case(seed=3, P=3, Lt=9, n_samples=2):
+def _case(seed=3, P=3, Lt=9, n_samples=2, n_cams=1):
     c = dict(synth.OPENVLA_SMALL)
     sd = synth.openvla_state(c, seed=seed, std=0.08)
     g = torch.Generator().manual_seed(seed)
-    frame = torch.randint(0, 256, (1, c["image"], c["image"], 3), generator=g, dtype=torch.uint8)
+    frame = torch.randint(0, 256, (n_cams, c["image"], c["image"], 3), generator=g, dtype=torch.uint8)
     lens = torch.tensor([Lt, Lt - 3, Lt - 1][:P], dtype=torch.int32)
     toks = torch.zeros(P, Lt, dtype=torch.long)
     for p in range(P):
@@ -29,14 +29,15 @@ def _case(seed=3, P=3, Lt=9, n_samples=2):
     return c, sd, frame, toks, lens, u
 
 
-@pytest.mark.parametrize("greedy", [True, False])
-def test_openvla_small_matches_oracle(dev, greedy):
+@pytest.mark.parametrize("greedy,n_cams", [(True, 1), (False, 1), (True, 2), (False, 2)])
+def test_openvla_small_matches_oracle(dev, greedy, n_cams):
+    """n_cams = 2 is BASELINE config 4's observation (two 224^2 cameras -> 512 patch rows in the shared prefix)."""
     from cover_ref import blocks as Bk, openvla as OR
     from cover_vla_amd.openvla import OpenVLA
-    c, sd, frame, toks, lens, u = _case()
+    c, sd, frame, toks, lens, u = _case(n_cams=n_cams)
     n_samples = 1 if greedy else 2
     P = toks.shape[0]
-    model = OpenVLA(sd, c, device="cuda:0", max_prompts=4, max_candidates=8, max_text=toks.shape[1])
+    model = OpenVLA(sd, c, device="cuda:0", max_prompts=4, max_candidates=8, max_text=toks.shape[1], n_cams=n_cams)
     un = None if greedy else u[: P * n_samples]
     otr = {}
     with torch.no_grad():
@@ -117,11 +118,11 @@ def test_openvla_vision_graph_replay_equals_eager_and_cached_bos(dev):
     e2 = model.encode_image(f1).clone()            # replay on another frame: the graph reads the persistent frame buffer
     assert not torch.equal(e0.view(torch.int16), e2.view(torch.int16))
     fresh = OpenVLA(sd, c, device="cuda:0", max_prompts=4, max_candidates=8, max_text=toks.shape[1])
-    os.environ["COVER_VISION_GRAPH"] = "0"
-    try:
-        e3 = fresh.encode_image(f1).clone()        # never captured
-    finally:
-        os.environ.pop("COVER_VISION_GRAPH", None)
+    fresh.vision_graph = False
+    e3 = fresh.encode_image(f1).clone()            # never captured
+    fresh.vision_overlap = False                   # both towers on one stream (bench.py's profiled decision)
+    e4 = fresh.encode_image(f1).clone()
+    assert torch.equal(e3.view(torch.int16), e4.view(torch.int16))
     assert torch.equal(e2.view(torch.int16), e3.view(torch.int16))
     t0, _ = model.sample(f0, toks.to(dev), lens.to(dev), 2, u.to(dev), 1.0)
     t1, _ = model.sample(f0, toks.to(dev), lens.to(dev), 2, u.to(dev), 1.0)
