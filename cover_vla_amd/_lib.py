@@ -181,6 +181,7 @@ SYMBOLS = {
     "cover_softmax_rows_f32": (c_i, [c_p, c_i, c_i, c_i, c_f, c_p]),
     "cover_l2norm_rows_f32": (c_i, [c_p, c_i, c_p, c_i, c_i, c_i, c_p]),
     "cover_add_f32": (c_i, [c_p, c_i, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_p]),
+    "cover_act_f32": (c_i, [c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_p]),
     "cover_mha_f32": (c_i, [_P(MhaF32Args), c_p]),
     "cover_masked_mean_f32": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_p]),
     "cover_sincos_time_embed": (c_i, [c_p, c_i, c_i, C.c_double, C.c_double, c_p, c_i, c_p]),
@@ -189,6 +190,9 @@ SYMBOLS = {
     "cover_group_argmax": (c_i, [c_p, c_i, c_i, c_p, c_p, c_p]),
     "cover_tokens_to_histories": (c_i, [c_p, c_i, c_i, c_i, c_p, c_i, c_p, c_i, c_f, c_p, c_p, c_p]),
     "cover_actions_to_histories": (c_i, [c_p, c_ll, c_ll, c_i, c_i, c_p, c_p, c_i, c_f, c_p, c_p, c_p]),
+    "cover_resample_axis": (c_i, [c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_i, c_p]),
+    "cover_u8_hwc_to_f32_chw_norm": (c_i, [c_p, c_p, c_i, c_i, _P(c_f), _P(c_f), c_p]),
+    "cover_resize_bilinear_pad_f32": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p]),
     "cover_vit_workspace_bytes": (C.c_size_t, [_P(VitDesc), c_i, c_i]),
     "cover_vit_forward": (c_i, [_P(VitDesc), c_p, c_i, c_i, c_p, Workspace, c_i, c_p]),
     "cover_decoder_workspace_bytes": (C.c_size_t, [_P(DecDesc), c_i]),

@@ -155,6 +155,11 @@ int cover_add_f32(const float* a, int lda, const float* b, int ldb, float* y, in
     HIPCHK(launch_add_f32(a, lda, b, ldb, y, ldy, rows, cols, b_rows, ST(stream)), "add_f32");
     return COVER_OK;
 }
+int cover_act_f32(const float* x, int ldx, float* y, int ldy, int rows, int cols, int act, void* stream) {
+    if (!x || !y) return fail(COVER_EINVAL, "cover_act_f32: null pointer");
+    HIPCHK(launch_act_f32(x, ldx, y, ldy, rows, cols, act, ST(stream)), "act_f32");
+    return COVER_OK;
+}
 int cover_mha_f32(const cover_mha_f32_args* a, void* stream) {
     if (!a) return fail(COVER_EINVAL, "cover_mha_f32: null args");
     HIPCHK(launch_mha_f32(a, ST(stream)), "mha_f32 (Tq*Tk <= 8192)");
@@ -197,6 +202,26 @@ int cover_actions_to_histories(const float* actions, long long n_stride, long lo
 }
 int cover_group_argmax(const float* scores, int N, int group_size, int* result_out, float* best_out, void* stream) {
     HIPCHK(launch_group_argmax(scores, N, group_size, result_out, best_out, ST(stream)), "group_argmax");
+    return COVER_OK;
+}
+
+int cover_resample_axis(const void* in, int in_is_f32, void* out, int out_is_f32, int Hin, int Win, int C, int Hout, int Wout,
+                        int axis, const int* bounds, const void* coefs, int ksize, int fixed_point, void* stream) {
+    if (!in || !out || !bounds || !coefs || ksize <= 0 || (axis != 0 && axis != 1)) return fail(COVER_EINVAL, "cover_resample_axis: bad arguments");
+    if ((axis == 0 && Win != Wout) || (axis == 1 && Hin != Hout)) return fail(COVER_EINVAL, "cover_resample_axis: the other axis must keep its size");
+    HIPCHK(launch_resample_axis(in, in_is_f32 ? 1 : 0, out, out_is_f32 ? 1 : 0, Hin, Win, C, Hout, Wout, axis, bounds, coefs, ksize, fixed_point, ST(stream)),
+           "resample_axis (fixed point: uint8 -> uint8 only)");
+    return COVER_OK;
+}
+int cover_u8_hwc_to_f32_chw_norm(const uint8_t* in, float* out, int H, int W, const float* mean3, const float* std3, void* stream) {
+    if (!in || !out || !mean3 || !std3) return fail(COVER_EINVAL, "cover_u8_hwc_to_f32_chw_norm: null pointer");
+    HIPCHK(launch_u8_to_chw_norm(in, out, H, W, 3, mean3, std3, ST(stream)), "u8_hwc_to_f32_chw_norm");
+    return COVER_OK;
+}
+int cover_resize_bilinear_pad_f32(const float* in, float* out, int NC, int Hin, int Win, int Hr, int Wr, int Hout, int Wout, int pad_top,
+                                  int pad_left, float pad_value, void* stream) {
+    if (!in || !out) return fail(COVER_EINVAL, "cover_resize_bilinear_pad_f32: null pointer");
+    HIPCHK(launch_bilinear_pad(in, out, NC, Hin, Win, Hr, Wr, Hout, Wout, pad_top, pad_left, pad_value, ST(stream)), "resize_bilinear_pad_f32");
     return COVER_OK;
 }
 

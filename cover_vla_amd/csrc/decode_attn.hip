@@ -134,8 +134,15 @@ __global__ __launch_bounds__(1024) void decode_attn_fused_k(DecAttnDev a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     DAT(5);
     // ---------------- tile iterator: every role describes its tile by per-lane K-row / V^T-row pointers and a mask ----------------
-    const int prev_slot1 = __shfl(my_slot1, (lane & 48) | ((r + 15) & 15));
-    const bool leader = q_ok && (r == 0 || my_slot1 != prev_slot1);
+    // a run leader = the FIRST candidate of the tile that carries its prompt slot (compared against every earlier row, not only
+    // the previous one: slots may recur non-contiguously, e.g. 0,1,0,1 -- with a previous-row test each recurrence would open
+    // a second run of the same slot and its keys would enter the softmax twice; invalid rows carry slot -1 and never match)
+    bool leader = q_ok;
+#pragma unroll
+    for (int j = 0; j < 15; ++j) {
+        const int other = __shfl(my_slot1, (lane & 48) | j);
+        leader = leader && !(j < r && other == my_slot1);
+    }
     const unsigned leaders = (unsigned)(__ballot(leader && g == 0) & 0xffffull);
     const int role = w < a.WA ? 0 : (w < a.WA + WB ? 1 : 2);
     const int wl = role == 0 ? w : (role == 1 ? w - a.WA : w - a.WA - WB);

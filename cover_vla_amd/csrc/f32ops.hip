@@ -295,6 +295,16 @@ hipError_t launch_add_f32(const float* a, int lda, const float* b, int ldb, floa
     return hipGetLastError();
 }
 
+__global__ void act_f32_k(const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy, int cols, int act) {
+    const int r = blockIdx.x;
+    for (int c = threadIdx.x; c < cols; c += blockDim.x) y[(size_t)r * ldy + c] = act_apply(x[(size_t)r * ldx + c], act);
+}
+hipError_t launch_act_f32(const float* x, int ldx, float* y, int ldy, int rows, int cols, int act, hipStream_t st) {
+    if (rows <= 0) return hipSuccess;
+    hipLaunchKernelGGL(act_f32_k, dim3(rows), dim3(256), 0, st, x, ldx, y, ldy, cols, act);
+    return hipGetLastError();
+}
+
 // ---------------------------------------------------------------------------------------------------
 // small multi-head attention: one block per (batch, head); Tq*Tk <= 4096, Dh <= 128
 // ---------------------------------------------------------------------------------------------------

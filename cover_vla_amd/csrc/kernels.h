@@ -48,6 +48,7 @@ hipError_t launch_softmax_rows_f32(float* x, int ldx, int rows, int cols, float 
 hipError_t launch_l2norm_rows_f32(const float* x, int ldx, float* y, int ldy, int rows, int cols, hipStream_t st);
 hipError_t launch_add_f32(const float* a, int lda, const float* b, int ldb, float* y, int ldy, int rows, int cols,
                           int b_rows, hipStream_t st);
+hipError_t launch_act_f32(const float* x, int ldx, float* y, int ldy, int rows, int cols, int act, hipStream_t st);
 hipError_t launch_mha_f32(const cover_mha_f32_args* a, hipStream_t st);
 hipError_t launch_masked_mean_f32(const float* x, const uint8_t* pad, float* y, int B, int T, int D, hipStream_t st);
 hipError_t launch_sincos_time_embed(const float* time, int B, int dim, double min_period, double max_period, bf16_t* out,
@@ -64,6 +65,13 @@ hipError_t launch_actions_to_histories(const float* actions, long long n_stride,
                                        uint8_t* pad, hipStream_t st);
 hipError_t launch_group_argmax(const float* scores, int N, int gs, int* result, float* best, hipStream_t st);
 size_t gemm_workspace_bytes(int M, int N, int K);
+
+// ---- image.hip -----------------------------------------------------------------------------------
+hipError_t launch_resample_axis(const void* in, int in_kind, void* out, int out_kind, int Hin, int Win, int C, int Hout, int Wout,
+                                int axis, const int* bounds, const void* coefs, int ksize, int fixed, hipStream_t st);
+hipError_t launch_u8_to_chw_norm(const uint8_t* in, float* out, int H, int W, int C, const float* mean, const float* stdv, hipStream_t st);
+hipError_t launch_bilinear_pad(const float* in, float* out, int NC, int Hin, int Win, int Hr, int Wr, int Hout, int Wout, int pad_top,
+                               int pad_left, float pad_value, hipStream_t st);
 
 // ---- prof.hip: optional per-launch hipEvent timing (classes: 0 skinny GEMM, 1 tiled GEMM, 2 attention) ----------
 bool prof_enabled();

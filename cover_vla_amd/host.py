@@ -92,7 +92,8 @@ def process_inputs(action_queue: Sequence[np.ndarray], verifier_action: bool, ac
 
 
 def verify_and_select(verifier, raw_image, task_description: str, task_list: Sequence[str], action_queue, action_history,
-                      samples_per_prompt: int, n_action_steps: int = 4, threshold: float = 0.1, stats=None):
+                      samples_per_prompt: int, n_action_steps: int = 4, threshold: float = 0.1, stats=None,
+                      process_image: bool = True):
     """run_simpler_eval_with_openpi.py:329-401: stage 1 scores candidate 0 under the current instruction; if its score
     is < threshold, stage 2 scores all candidates grouped per prompt; then the gripper majority vote inside the winner's
     prompt group and extraction of the winner's remaining steps.
@@ -101,6 +102,9 @@ def verify_and_select(verifier, raw_image, task_description: str, task_list: Seq
     B = len(task_list)
     num_past = min(len(action_history), 6)
     hist_v = process_inputs(action_queue, True, action_history, n_action_steps, stats)
+    if process_image:      # images_list = [process_raw_image_to_jpg(raw_img)] * B  (run_simpler_eval_with_openpi.py:342)
+        from .imaging import process_raw_image_to_jpg
+        raw_image = process_raw_image_to_jpg(raw_image)
     images = [raw_image] * B
     max_score, max_instruction, max_hist, gidx = verifier.compute_max_similarity_scores_batch(
         images=images[0:1], instructions=[task_description], all_action_histories=hist_v[0:1],

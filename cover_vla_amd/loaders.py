@@ -107,12 +107,47 @@ def infer_pi0_sizes(n: Dict[str, torch.Tensor], chunk: int) -> dict:
                 image=int(round(n_pos ** 0.5)) * patch, chunk=chunk, _kD=kD, _qD=qD)
 
 
+_NORM_KEY = re.compile(r"^(?:model\.)?(normalize_inputs|normalize_targets|unnormalize_outputs)\.buffer_(\w+)\.(mean|std|min|max)$")
+
+
+def pi0_normalization(sd: Dict[str, torch.Tensor], cfg: dict) -> dict:
+    """The checkpoint's Normalize / Unnormalize buffers (normalize.py:44-107: `normalize_inputs.buffer_observation_state.mean`
+    ..., `unnormalize_outputs.buffer_action.std` ...) and the mode of each feature type from config.json's
+    `normalization_mapping` (configs/policies.py; INT-ACT checkpoints: all IDENTITY, pi0_finetune_bridge.json:6-10).
+    Returns {"state": (mode, a, b), "action": (mode, a, b)} with (a, b) = (mean, std) or (min, max) fp32, None for IDENTITY.
+    Raises when a non-IDENTITY mode has no finite buffers in the checkpoint (the reference asserts the same,
+    normalize.py:167-168)."""
+    nm = {str(k).upper(): str(v).upper().split(".")[-1] for k, v in (cfg.get("normalization_mapping") or {}).items()}
+    bufs = {}
+    for k, v in sd.items():
+        m = _NORM_KEY.match(k)
+        if m:
+            bufs[(m.group(1), m.group(2), m.group(3))] = v.to(torch.float32)
+    out = {}
+    for name, ftype, module, feat in (("state", "STATE", "normalize_inputs", "observation_state"),
+                                      ("action", "ACTION", "unnormalize_outputs", "action")):
+        mode = nm.get(ftype, "IDENTITY")
+        if mode == "IDENTITY":
+            out[name] = ("IDENTITY", None, None)
+            continue
+        ka, kb = ("mean", "std") if mode == "MEAN_STD" else ("min", "max")
+        a, b = bufs.get((module, feat, ka)), bufs.get((module, feat, kb))
+        if a is None or b is None or torch.isinf(a).any() or torch.isinf(b).any():
+            raise ValueError(f"checkpoint uses {mode} normalisation for {ftype} but carries no finite "
+                             f"{module}.buffer_{feat}.{ka}/{kb} (normalize.py:167-168 asserts the same)")
+        out[name] = (mode, a, b)
+    return out
+
+
 def load_pi0_pretrained(path: str, head_dim: int = 256, vit_heads: int = 16) -> Tuple[Dict[str, torch.Tensor], dict, dict]:
-    """Directory with config.json + model.safetensors -> (neutral state dict, size dict, raw config)."""
+    """Directory with config.json + model.safetensors -> (neutral state dict, size dict, raw config). The raw config gains
+    `_normalization` = pi0_normalization(...) (the Normalize / Unnormalize buffers of the checkpoint)."""
     from safetensors.torch import load_file
     with open(os.path.join(path, "config.json")) as f:
         cfg = json.load(f)
-    n = pi0_reference_to_neutral(load_file(os.path.join(path, "model.safetensors")))
+    raw = load_file(os.path.join(path, "model.safetensors"))
+    cfg["_normalization"] = pi0_normalization(raw, cfg)
+    n = pi0_reference_to_neutral(raw)
     c = infer_pi0_sizes(n, int(cfg.get("chunk_size", 50)))
     c["D"] = head_dim
     c["Hkv"] = c.pop("_kD") // head_dim

@@ -366,6 +366,14 @@ def add_f32(a, b, out=None):
     return out
 
 
+def act_f32(x, act, out=None):
+    _chk_dev(x)
+    out = torch.empty_like(x) if out is None else out
+    L.check(L.lib().cover_act_f32(x.data_ptr(), x.stride(0), out.data_ptr(), out.stride(0), x.shape[0], x.shape[1], ACT[act], _stream()),
+            "act_f32")
+    return out
+
+
 def mha_f32(q, k, v, B, Tq, Tk, H, Dh, q_strides, k_strides, v_strides, key_pad=None, out=None, o_strides=None):
     """strides = (batch, token) in elements; heads are contiguous blocks of Dh inside a token row."""
     _chk_dev(q, k, v)

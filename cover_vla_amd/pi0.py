@@ -7,8 +7,8 @@
       CoVer_VLA/inference/experiments/robot/simpler/run_simpler_eval_with_openpi.py:322-326)
 
 What changes underneath (results are unchanged): the reference runs vision + prefix B times on identical inputs
-(run_simpler_eval_with_openpi.py:305-313); here the SigLIP tower runs once per distinct camera frame and the
-PaliGemma prefix once per DISTINCT prompt, the KV cache is a static allocation the 10 denoise steps append to
+(run_simpler_eval_with_openpi.py:305-313); here the SigLIP tower runs once per distinct set of camera frames and the
+PaliGemma prefix once per DISTINCT (frames, prompt) pair, the KV cache is a static allocation the 10 denoise steps append to
 instead of torch.cat (paligemma_with_expert.py:305-308), masks are lengths, and every layer loop is one C call.
 All arithmetic is libcover_hip; torch here allocates buffers and does index bookkeeping only.
 """
@@ -72,37 +72,86 @@ class PI0FlowMatching:
         ops.scale_bf16(y, D ** 0.5, float(torch.tensor(D ** 0.5, dtype=BF)))
         return y.view(n, T, D)
 
+    @staticmethod
+    def _image_classes(cams: List[torch.Tensor], B: int) -> np.ndarray:
+        """Equality classes of the rows' camera frames (all cameras together): int64 [B], class ids in order of first
+        occurrence. Rows are grouped by a float64 fingerprint (two fixed projections per camera) and every group is then
+        VERIFIED element-wise against its first row, so a collision can only split work, never merge different frames."""
+        if B == 1:
+            return np.zeros(1, dtype=np.int64)
+        if all(bool(torch.equal(im[:1].expand_as(im), im)) for im in cams):
+            return np.zeros(B, dtype=np.int64)                                   # the evaluation driver's case: one frame
+        fps = []
+        for im in cams:
+            flat = im.reshape(B, -1).to(torch.float64)
+            n = flat.shape[1]
+            w1 = torch.cos(torch.arange(n, device=im.device, dtype=torch.float64) * 0.7548776662466927)
+            w2 = torch.sin(torch.arange(n, device=im.device, dtype=torch.float64) * 0.5698402909980532)
+            fps += [flat @ w1, flat @ w2]
+        fp = torch.stack(fps, 1).cpu().numpy()
+        cls = np.full(B, -1, dtype=np.int64)
+        reps: List[int] = []
+        for r in range(B):
+            for k, rr in enumerate(reps):
+                if np.array_equal(fp[r], fp[rr]) and all(bool(torch.equal(im[r], im[rr])) for im in cams):
+                    cls[r] = k
+                    break
+            if cls[r] < 0:
+                cls[r] = len(reps)
+                reps.append(r)
+        return cls
+
     def sample_actions(self, images: List[torch.Tensor], img_masks: List[torch.Tensor], lang_tokens: torch.Tensor,
                        lang_masks: torch.Tensor, state: torch.Tensor, noise: Optional[torch.Tensor] = None,
                        noise_std: float = 1.0, trace: Optional[dict] = None) -> torch.Tensor:
         dev, c = self.dev, self.c
         B = state.shape[0]
         Lg = lang_tokens.shape[1]
-        if B > self.max_batch or Lg > self.max_lang or len(images) != self.n_cams:
+        if B > self.max_batch or Lg > self.max_lang or len(images) != len(img_masks):
             raise ValueError(f"batch {B}/lang {Lg}/cams {len(images)} exceed the sizes this model was built for")
         if noise is None:
             noise = torch.normal(mean=0.0, std=noise_std, size=(B, self.chunk, self.max_action_dim), dtype=torch.float32,
                                  device=dev)
-        # ---- dedup (index bookkeeping): distinct prompts and distinct camera frames
+        # ---- cameras: the reference marks an absent camera with an all-False mask over an all -1 image
+        # (modeling_pi0.py:372-385); its tokens are padding -- never attended by a valid query, positions do not advance
+        # over them (cumsum of the pad mask, :685), their own rows are never read back -- so dropping that camera from the
+        # prefix leaves every used output unchanged. Per-row mixed masks do not occur on this path.
+        cams = []
+        for ci, (im, mk) in enumerate(zip(images, img_masks)):
+            mk = mk.to(torch.bool)
+            if bool(mk.all()):
+                cams.append(im)
+            elif bool(mk.any()):
+                raise NotImplementedError("img_masks that differ across the rows of one camera are not supported "
+                                          "(prepare_images only produces all-True / all-False masks, modeling_pi0.py:372-385)")
+        if not cams:
+            raise ValueError("every camera is masked out")
+        if len(cams) > self.n_cams:
+            raise ValueError(f"{len(cams)} cameras > n_cams={self.n_cams} this model was built for")
+        # ---- dedup (index bookkeeping): a prefix is computed once per distinct (camera frames, prompt) pair, the SigLIP
+        # tower once per distinct set of camera frames
         # (on the host: the count U is needed there anyway, and a device row-sort of B x 2Lg integers costs ~0.6 ms of
         # rocprim kernels against ~50 us for the round trip of a few tens of KB)
+        img_class = self._image_classes(cams, B)                                   # host int64 [B], 0 for a shared frame
         key = torch.cat([lang_tokens, lang_masks.to(lang_tokens.dtype)], dim=1).cpu().numpy()
+        key = np.concatenate([img_class[:, None].astype(key.dtype), key], axis=1)
         _, first_h, inv_h = np.unique(key, axis=0, return_index=True, return_inverse=True)
         U = int(first_h.shape[0])
         if U > self.max_prompts:
-            raise ValueError(f"{U} distinct prompts > max_prompts={self.max_prompts}")
+            raise ValueError(f"{U} distinct (frames, prompt) pairs > max_prompts={self.max_prompts}")
         prompt_of_row = torch.from_numpy(np.ascontiguousarray(inv_h.reshape(-1)).astype(np.int64)).to(dev)
         first_row = torch.from_numpy(np.ascontiguousarray(first_h).astype(np.int64)).to(dev)
-        shared_img = all(bool(torch.equal(im[:1].expand_as(im), im)) for im in images) if B > 1 else True
-        n_img_all = self.n_img * self.n_cams
+        n_ic = int(img_class.max()) + 1
+        ic_first = torch.from_numpy(np.array([int(np.nonzero(img_class == k)[0][0]) for k in range(n_ic)], dtype=np.int64)).to(dev)
+        ic_of_group = torch.from_numpy(img_class[first_h].astype(np.int64)).to(dev)
+        n_img_all = self.n_img * len(cams)
         Tp = n_img_all + Lg
         D = c["lm_dim"]
         prefix = torch.empty(U, Tp, D, dtype=BF, device=dev)
-        for ci, im in enumerate(images):
-            src = im[:1] if shared_img else im[first_row]
-            tok = self._image_tokens(src)  # [1 or U, n_img, D]
+        for ci, im in enumerate(cams):
+            tok = self._image_tokens(im[ic_first])  # [n_ic, n_img, D]
             rows = torch.arange(self.n_img, device=dev)
-            sidx = (rows[None] + (0 if shared_img else 1) * torch.arange(U, device=dev)[:, None] * self.n_img).reshape(-1)
+            sidx = (rows[None] + ic_of_group[:, None] * self.n_img).reshape(-1)
             didx = (torch.arange(U, device=dev)[:, None] * Tp + ci * self.n_img + rows[None]).reshape(-1)
             ops.copy_rows(tok.view(-1, D), prefix.view(-1, D), U * self.n_img, D, sidx.to(torch.int32), didx.to(torch.int32))
         utok = lang_tokens[first_row].contiguous()
@@ -218,13 +267,14 @@ class PI0Config:
 
     def __init__(self, *, image_keys=("observation.images.top",), n_action_steps=4, chunk_size=4, max_state_dim=32,
                  max_action_dim=32, tokenizer_max_length=72, num_steps=10, action_dim=7, device="cuda:0",
-                 resize_imgs_with_padding=(224, 224)):
+                 resize_imgs_with_padding=(224, 224), empty_cameras=0):
         self.image_features = list(image_keys)
         self.n_action_steps, self.chunk_size = n_action_steps, chunk_size
         self.max_state_dim, self.max_action_dim = max_state_dim, max_action_dim
         self.tokenizer_max_length, self.num_steps = tokenizer_max_length, num_steps
         self.action_dim, self.device = action_dim, device
         self.resize_imgs_with_padding = resize_imgs_with_padding
+        self.empty_cameras = empty_cameras          # configuration_pi0.py:45
 
 
 class PI0Policy:
@@ -232,12 +282,38 @@ class PI0Policy:
 
     def __init__(self, config: PI0Config, model: PI0FlowMatching, tokenizer: Callable,
                  action_mean: Optional[torch.Tensor] = None, action_std: Optional[torch.Tensor] = None,
-                 state_mean: Optional[torch.Tensor] = None, state_std: Optional[torch.Tensor] = None):
+                 state_mean: Optional[torch.Tensor] = None, state_std: Optional[torch.Tensor] = None,
+                 normalization: Optional[dict] = None):
+        """normalization: {"state": (mode, a, b), "action": (mode, a, b)} with mode IDENTITY / MEAN_STD (a, b = mean, std) /
+        MIN_MAX (a, b = min, max) -- loaders.pi0_normalization reads it from a checkpoint's Normalize / Unnormalize buffers
+        (normalize.py:152-183, 226-254). INT-ACT checkpoints use IDENTITY (pi0_finetune_bridge.json:6-10)."""
         self.config, self.model, self.tokenizer = config, model, tokenizer
-        # INT-ACT checkpoints use IDENTITY normalisation (pi0_finetune_bridge.json:6-10); mean/std optional
-        self.action_mean, self.action_std, self.state_mean, self.state_std = action_mean, action_std, state_mean, state_std
+        norm = dict(normalization or {})
+        if state_mean is not None:
+            norm["state"] = ("MEAN_STD", state_mean, state_std)
+        if action_mean is not None:
+            norm["action"] = ("MEAN_STD", action_mean, action_std)
+        dev = model.dev
+        mv = lambda t: None if t is None else torch.as_tensor(t, dtype=torch.float32).to(dev)
+        self._norm = {k: (m, mv(a), mv(b)) for k, (m, a, b) in norm.items()}
         self._preprocess_adapter = None
         self.reset()
+
+    def _normalize_state(self, x):
+        mode, a, b = self._norm.get("state", ("IDENTITY", None, None))
+        if mode == "MEAN_STD":
+            return (x - a) / (b + 1e-8)                       # normalize.py:169
+        if mode == "MIN_MAX":
+            return (x - a) / (b - a + 1e-8) * 2 - 1           # :177-179
+        return x
+
+    def _unnormalize_action(self, x):
+        mode, a, b = self._norm.get("action", ("IDENTITY", None, None))
+        if mode == "MEAN_STD":
+            return x * b + a                                  # :243
+        if mode == "MIN_MAX":
+            return (x + 1) / 2 * (b - a) + a                  # :250-251
+        return x
 
     @classmethod
     def from_pretrained(cls, pretrained_name_or_path: str, *, tokenizer: Callable, device="cuda:0", max_batch=64,
@@ -248,12 +324,15 @@ class PI0Policy:
         sd, c, cfg = load_pi0_pretrained(pretrained_name_or_path)
         max_lang = int(cfg.get("tokenizer_max_length", 48))
         model = PI0FlowMatching(sd, c, device=device, max_batch=max_batch, max_prompts=max_prompts, max_lang=max_lang,
+                                n_cams=len(image_keys),
                                 num_steps=int(cfg.get("num_steps", 10)), max_state_dim=int(cfg.get("max_state_dim", 32)),
                                 max_action_dim=int(cfg.get("max_action_dim", 32)))
         pc = PI0Config(image_keys=image_keys, n_action_steps=int(cfg.get("n_action_steps", c["chunk"])), chunk_size=c["chunk"],
                        max_state_dim=int(cfg.get("max_state_dim", 32)), max_action_dim=int(cfg.get("max_action_dim", 32)),
                        tokenizer_max_length=max_lang, num_steps=int(cfg.get("num_steps", 10)), device=device,
-                       resize_imgs_with_padding=tuple(cfg.get("resize_imgs_with_padding", (c["image"], c["image"]))))
+                       resize_imgs_with_padding=tuple(cfg.get("resize_imgs_with_padding", (c["image"], c["image"]))),
+                       empty_cameras=int(cfg.get("empty_cameras", 0)))
+        kwargs.setdefault("normalization", cfg.get("_normalization"))
         return cls(pc, model, tokenizer, **kwargs)
 
     def to(self, device):
@@ -267,19 +346,31 @@ class PI0Policy:
         self._action_queue = collections.deque([], maxlen=self.config.n_action_steps)
 
     def prepare_images(self, batch):
-        """modeling_pi0.py:344-387 at the evaluated size: resize_with_pad is the identity at 224x224 and the adapter
-        already scaled to [-1,1] (INT-ACT .../simpler.py:48-65)."""
+        """modeling_pi0.py:344-387: every configured camera present in the batch is resized with padding to
+        `resize_imgs_with_padding` (a no-op at the evaluated 224 x 224; otherwise the bilinear + left/top pad of
+        resize_with_pad :131-150, on the device) and carries an all-True mask; up to `empty_cameras` missing cameras are
+        appended as all -1 images with all-False masks."""
+        from .imaging import resize_with_pad
         present = [k for k in self.config.image_features if k in batch]
+        missing = [k for k in self.config.image_features if k not in batch]
         if not present:
             raise ValueError(f"All image features are missing from the batch. At least one expected. "
                              f"(batch: {batch.keys()}) (image_features:{self.config.image_features})")
         images, masks = [], []
         for k in present:
             img = batch[k]
-            if tuple(img.shape[2:]) != tuple(self.config.resize_imgs_with_padding):
-                raise ValueError(f"(b,c,{self.config.resize_imgs_with_padding}) expected, but {tuple(img.shape)}")
+            if self.config.resize_imgs_with_padding is not None:
+                img = resize_with_pad(img, *self.config.resize_imgs_with_padding, pad_value=0)
+            mask = torch.ones(img.shape[0], dtype=torch.bool, device=img.device)
             images.append(img)
-            masks.append(torch.ones(img.shape[0], dtype=torch.bool, device=img.device))
+            masks.append(mask)
+        for num_empty in range(len(missing)):
+            if num_empty >= self.config.empty_cameras:
+                break
+            img = torch.ones_like(img) * -1
+            mask = torch.zeros_like(mask)
+            images.append(img)
+            masks.append(mask)
         return images, masks
 
     def prepare_language(self, batch):
@@ -294,16 +385,13 @@ class PI0Policy:
     def select_action(self, batch: dict, noise: Optional[torch.Tensor] = None, noise_std: float = 1.0) -> collections.deque:
         """Returns the deque itself (the local modification of modeling_pi0.py:303-307); the caller copies and clears it."""
         if len(self._action_queue) == 0:
-            state = batch["observation.state"]
-            if self.state_mean is not None:
-                state = (state - self.state_mean) / (self.state_std + 1e-8)
+            state = self._normalize_state(batch["observation.state"])
             images, img_masks = self.prepare_images(batch)
             state = pad_vector(state, self.config.max_state_dim)
             lang_tokens, lang_masks = self.prepare_language(batch)
             actions = self.model.sample_actions(images, img_masks, lang_tokens, lang_masks, state, noise=noise,
                                                 noise_std=noise_std)
             actions = actions[:, : self.config.n_action_steps, : self.config.action_dim]
-            if self.action_mean is not None:
-                actions = actions * self.action_std + self.action_mean
+            actions = self._unnormalize_action(actions)
             self._action_queue.extend(actions.transpose(0, 1))
         return self._action_queue

@@ -98,11 +98,29 @@ def _traj_sd(g: _G, d: int, ff: int, layers: int, std: float) -> Dict[str, Tenso
 
 def verifier_checkpoint(n_members: int = 3, seed: int = 1234, num_patches: int = 576, vision_dim: int = 1024,
                         text_dim: int = 1024, dim: int = 512, action_dim: int = 7, pooling_layers: int = 4,
-                        traj_layers: int = 4, nontrivial: bool = True, std: float = 0.05) -> dict:
-    """Merged verifier checkpoint (weights-only flavour: only `ensemble_components`)."""
+                        traj_layers: int = 4, nontrivial: bool = True, std: float = 0.05, use_transformer: bool = True,
+                        history_length: int = 10) -> dict:
+    """Merged verifier checkpoint (weights-only flavour: only `ensemble_components`). use_transformer=False gives the MLP
+    action-encoder variant (`complex_action_encoder` = Sequential(Linear, LayerNorm, ReLU, Dropout, Linear) -> keys 0.*, 1.*,
+    4.*; efficient_ensemble_merged.py:148-184) together with the top-level metadata keys of the full-format checkpoint
+    (:41-47), which is the only way the reference learns `use_transformer`."""
     comps = []
     for m in range(n_members):
         g = _G(seed + 1000 * m, nontrivial)
+        if not use_transformer:
+            comps.append({
+                "text_aware_visual_extraction": {"temperature": torch.tensor(0.07),
+                                                 "pos_emb": sincos_position_embedding(num_patches, vision_dim)},
+                "vision_poolings": _pooling_sd(g, vision_dim, dim, pooling_layers, std),
+                "text_pooling": _pooling_sd(g, text_dim, dim, pooling_layers, std),
+                "input_projection": {"weight": g.w(dim, 2 * dim, std=std), "bias": g.b(dim)},
+                "single_step_action_encoder": None, "trajectory_encoder": None,
+                "complex_action_encoder": {"0.weight": g.w(dim, history_length * action_dim, std=0.2), "0.bias": g.b(dim),
+                                           "1.weight": g.ln_w(dim), "1.bias": g.b(dim),
+                                           "4.weight": g.w(dim, dim, std=std), "4.bias": g.b(dim)},
+                "action_padding_value": -5.0,
+            })
+            continue
         comps.append({
             "text_aware_visual_extraction": {"temperature": torch.tensor(0.07),
                                              "pos_emb": sincos_position_embedding(num_patches, vision_dim)},
@@ -113,6 +131,9 @@ def verifier_checkpoint(n_members: int = 3, seed: int = 1234, num_patches: int =
             "trajectory_encoder": _traj_sd(g, dim, 2 * dim, traj_layers, std),
             "action_padding_value": -5.0,
         })
+    if not use_transformer:
+        return {"ensemble_components": comps, "backbone": "hf-hub:timm/ViT-L-16-SigLIP2-384", "use_transformer": False,
+                "history_length": history_length, "action_dim": action_dim, "num_models": n_members}
     return {"ensemble_components": comps}
 
 

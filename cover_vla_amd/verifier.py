@@ -78,9 +78,16 @@ class _Member:
         self.vision = _Pooling(comp["vision_poolings"], dev)
         self.text = _Pooling(comp["text_pooling"], dev)
         self.ip = _dev_sd(comp["input_projection"], dev)
-        self.se = _dev_sd(comp["single_step_action_encoder"], dev)
-        self.traj = _dev_sd(comp["trajectory_encoder"], dev)
-        self.traj_layers = 1 + max(int(k.split(".")[1]) for k in comp["trajectory_encoder"])
+        self.mlp = None
+        if comp.get("trajectory_encoder") is not None:
+            self.se = _dev_sd(comp["single_step_action_encoder"], dev)
+            self.traj = _dev_sd(comp["trajectory_encoder"], dev)
+            self.traj_layers = 1 + max(int(k.split(".")[1]) for k in comp["trajectory_encoder"])
+        else:
+            # MLP action encoder (use_transformer = False): Sequential(Linear(h*a, 512), LayerNorm, ReLU, Dropout, Linear)
+            # -> state-dict keys 0.*, 1.*, 4.* (efficient_ensemble_merged.py:148-184)
+            self.mlp = _dev_sd(comp["complex_action_encoder"], dev)
+            self.se, self.traj, self.traj_layers = None, None, 0
         self.pad_value = float(comp["action_padding_value"])
 
     def image_text(self, pf: torch.Tensor, tf: torch.Tensor) -> torch.Tensor:
@@ -100,6 +107,11 @@ class _Member:
     def trajectory(self, hist: torch.Tensor, pad: torch.Tensor) -> torch.Tensor:
         """hist fp32 [N, 10, 7], pad uint8 [N, 10] -> unit [N, 512] (efficient_ensemble_merged.py:226-245)."""
         N, T, A = hist.shape
+        if self.mlp is not None:   # flat_actions -> complex_action_encoder -> L2 norm (:241-245); padding rows are plain inputs
+            m = self.mlp
+            h = ops.gemm_f32(hist.reshape(N, T * A), m["0.weight"], bias=m["0.bias"])
+            h = ops.act_f32(ops.layernorm_f32(h, m["1.weight"], m["1.bias"]), "relu")
+            return ops.l2norm_rows_f32(ops.gemm_f32(h, m["4.weight"], bias=m["4.bias"]))
         sd, E, H = self.traj, self.se["weight"].shape[0], 8
         x = ops.gemm_f32(hist.view(N * T, A), self.se["weight"], bias=self.se["bias"])
         for i in range(self.traj_layers):
@@ -204,7 +216,7 @@ class _TrajectoryStack:
     def __init__(self, members: List["_Member"]):
         m0 = members[0]
         self.n, self.layers, self.dev = len(members), m0.traj_layers, m0.dev
-        self.ok = all(mm.traj_layers == m0.traj_layers and mm.se["weight"].shape == m0.se["weight"].shape and
+        self.ok = all(mm.mlp is None for mm in members) and all(mm.traj_layers == m0.traj_layers and mm.se["weight"].shape == m0.se["weight"].shape and
                       all(mm.traj[k].shape == m0.traj[k].shape for k in m0.traj) for mm in members)
         if not self.ok:
             return
@@ -299,11 +311,14 @@ class EfficientEnsembleMerged:
         else:
             self.backbone, self.use_transformer = ck["backbone"], ck["use_transformer"]
             self.history_length, self.action_dim, self.num_models = ck["history_length"], ck["action_dim"], ck["num_models"]
-        if not self.use_transformer:
-            raise NotImplementedError("MLP action encoder variant (complex_action_encoder) is not on the evaluated path")
         self.trainable_models = [_Member(c, dev) for c in ck["ensemble_components"]]
         self._traj_stack = _TrajectoryStack(self.trainable_models) if self.num_models > 1 else None
         self._it_stack = _ImageTextStack(self.trainable_models) if self.num_models > 1 else None
+        if preprocess is None:
+            # open_clip's transform for the SigLIP2 checkpoints (:69) restated: Resize(BICUBIC, squash) + ToTensor + Normalize(.5)
+            from .imaging import siglip_preprocess
+            size = encoder.image_size if encoder is not None else 384
+            preprocess = lambda im: siglip_preprocess(im, size)
         self.encoder, self.preprocess, self.tokenizer = encoder, preprocess, tokenizer
         self._dev = dev
 
@@ -372,9 +387,12 @@ class EfficientEnsembleMerged:
         return self.score_histories(self.image_text_embeddings(patch_features, text_features), all_action_histories, group_size)
 
     def fuse_embeddings(self, image, instruction, action_histories):
+        """efficient_ensemble_merged.py:249-293 -> (fused_image_text [N,512] (the one pair's embedding, a row per history),
+        fused_action [N,512]). The reference stacks the histories with np.array (equal lengths, :267); shorter histories are
+        front-padded here, which gives the same valid rows."""
         pf, tf = self._encode_pair(image, instruction)
         r = self.score_features(pf, tf, action_histories, 1)
-        return r["fused_it"].view(1, -1), r["fused_act"]
+        return r["fused_it"].view(1, -1).expand(r["fused_act"].shape[0], -1), r["fused_act"]
 
     def predict(self, image, instruction, possible_action_histories):
         """efficient_ensemble_merged.py:295-307."""
@@ -384,10 +402,15 @@ class EfficientEnsembleMerged:
         return possible_action_histories[idx], {str(i): float(scores[i]) for i in range(len(scores))}
 
     def _encode_pair(self, image, instruction):
-        if self.encoder is None or self.preprocess is None or self.tokenizer is None:
-            raise L.CoverError("EfficientEnsembleMerged needs encoder/preprocess/tokenizer for image/text inputs")
+        if self.encoder is None:
+            raise L.CoverError("EfficientEnsembleMerged needs the SigLIP2 encoder for image/text inputs")
+        if isinstance(image, np.ndarray):                      # efficient_ensemble_merged.py:252-253, 334-337
+            from PIL import Image
+            image = Image.fromarray(image.astype("uint8"))
         img_tensor = self.preprocess(image).unsqueeze(0)
         if isinstance(instruction, str):
+            if self.tokenizer is None:
+                raise L.CoverError("EfficientEnsembleMerged needs a tokenizer for string instructions (open_clip's is un-vendored)")
             toks = self.tokenizer([instruction], context_length=self.encoder.context_length)
         else:
             toks = instruction if instruction.ndim > 1 else instruction.unsqueeze(0)

@@ -257,6 +257,9 @@ typedef struct cover_mha_f32_args {
     int B, Tq, Tk, H, Dh;
     float scale;
 } cover_mha_f32_args;
+/* y = act(x) elementwise (COVER_ACT_*): the ReLU between LayerNorm and the second Linear of the verifier's MLP action encoder
+ * (`complex_action_encoder`, bridge_verifier/ensemble_eval/efficient_ensemble_merged.py:148-184, 241-243). */
+int cover_act_f32(const float* x, int ldx, float* y, int ldy, int rows, int cols, int act, void* stream);
 int cover_mha_f32(const cover_mha_f32_args* args, void* stream);
 /* masked mean over T (efficient_ensemble_merged.py:236-240): y[b] = sum_t x[b,t]*(1-pad) / max(sum(1-pad), 1e-9) */
 int cover_masked_mean_f32(const float* x, const uint8_t* pad, float* y, int B, int T, int D, void* stream);
@@ -404,6 +407,26 @@ int cover_timer_start(void* timer, void* stream);
 int cover_timer_stop(void* timer, void* stream, float* ms_out);
 int cover_timer_destroy(void* timer);
 int cover_stream_sync(void* stream);
+
+/* ---- image resampling on the device (the pre-processing either side of the hot path; cover_vla_amd/imaging.py builds the
+ * span tables with the restated filter-bank code) --------------------------------------------------------------------------
+ * cover_resample_axis: one separable pass along H (axis 0) or W (axis 1) of an HWC image:
+ *   out[o] = sum_{j < bounds[2o+1]} coefs[o*ksize + j] * in[bounds[2o] + j].
+ *   fixed_point = 1: Pillow's 8-bit path (int32 coefficients with 22 fractional bits, accumulator seeded with 1 << 21,
+ *   clip8(ss >> 22); uint8 -> uint8) = torchvision Resize on a PIL image = open_clip's SigLIP2 preprocess, replaces the
+ *   `self.preprocess(image)` call of bridge_verifier/ensemble_eval/efficient_ensemble_merged.py:338.
+ *   fixed_point = 0: TensorFlow ScaleAndTranslate float path (fp32 coefficients, sequential accumulation; a uint8 output is
+ *   the truncating cast) = tf.image.resize(bilinear, antialias=True) of process_raw_image_to_jpg,
+ *   CoVer_VLA/inference/experiments/robot/simpler/eval_utils.py:273-283.
+ * cover_u8_hwc_to_f32_chw_norm: ToTensor + Normalize, ((x / 255) - mean) / std, HWC uint8 -> CHW fp32.
+ * cover_resize_bilinear_pad_f32: F.interpolate(bilinear, align_corners=False) of an fp32 [NC, Hin, Win] stack to Hr x Wr,
+ *   placed at (pad_top, pad_left) of an Hout x Wout canvas filled with pad_value = resize_with_pad,
+ *   lerobot_custom/lerobot/common/policies/pi0/modeling_pi0.py:131-150. */
+int cover_resample_axis(const void* in, int in_is_f32, void* out, int out_is_f32, int Hin, int Win, int C, int Hout, int Wout,
+                        int axis, const int* bounds, const void* coefs, int ksize, int fixed_point, void* stream);
+int cover_u8_hwc_to_f32_chw_norm(const uint8_t* in, float* out, int H, int W, const float* mean3, const float* std3, void* stream);
+int cover_resize_bilinear_pad_f32(const float* in, float* out, int NC, int Hin, int Win, int Hr, int Wr, int Hout, int Wout,
+                                  int pad_top, int pad_left, float pad_value, void* stream);
 
 /* Per-launch kernel timing for bench.py's roofline objects: between begin/end every GEMM / attention launch issued by
  * this library carries a hipEvent pair stamped with the kernel's own start / stop on its stream. Classes:

@@ -95,6 +95,13 @@ def image_text_embedding(member, pf, tf):
 def trajectory_embedding(member, histories):
     """efficient_ensemble_merged.py:226-245. histories fp32 [N,10,7] (front padded with -5) -> [N,512] unit rows."""
     a = histories.float()
+    if member.get("trajectory_encoder") is None:
+        # MLP variant (:148-184, 241-243): flat actions -> Linear -> LayerNorm -> ReLU -> (Dropout) -> Linear; no padding mask
+        m = member["complex_action_encoder"]
+        h = a.reshape(a.shape[0], -1) @ m["0.weight"].T + m["0.bias"]
+        h = torch.relu(_ln(h, m["1.weight"], m["1.bias"]))
+        traj = h @ m["4.weight"].T + m["4.bias"]
+        return traj / traj.norm(dim=-1, keepdim=True)
     pad = a[:, :, 0] == member["action_padding_value"]
     x = a @ member["single_step_action_encoder"]["weight"].T + member["single_step_action_encoder"]["bias"]
     sd = member["trajectory_encoder"]

@@ -89,7 +89,7 @@ def build_reference_ensemble(model, eem, ckpt, pf, tf):
     boundary (extract_features returns the supplied pf/tf)."""
     ens = eem.EfficientEnsembleMerged.__new__(eem.EfficientEnsembleMerged)
     ens.device = "cpu"
-    ens.use_transformer = True
+    ens.use_transformer = bool(ckpt.get("use_transformer", True))
     ens.history_length = 10
     ens.action_dim = 7
     ens.num_models = len(ckpt["ensemble_components"])
@@ -104,16 +104,23 @@ def build_reference_ensemble(model, eem, ckpt, pf, tf):
         tp.load_state_dict(cs["text_pooling"])
         ip = torch.nn.Linear(1024, 512)
         ip.load_state_dict(cs["input_projection"])
-        se = torch.nn.Linear(7, 512)
-        se.load_state_dict(cs["single_step_action_encoder"])
-        layer = torch.nn.TransformerEncoderLayer(d_model=512, nhead=8, dim_feedforward=1024, batch_first=False, dropout=0.1)
-        te = torch.nn.TransformerEncoder(layer, num_layers=4)
-        te.load_state_dict(cs["trajectory_encoder"])
-        for m in (ta, vp, tp, ip, se, te):
-            m.eval()
+        se = te = ce = None
+        if ens.use_transformer:
+            se = torch.nn.Linear(7, 512)
+            se.load_state_dict(cs["single_step_action_encoder"])
+            layer = torch.nn.TransformerEncoderLayer(d_model=512, nhead=8, dim_feedforward=1024, batch_first=False, dropout=0.1)
+            te = torch.nn.TransformerEncoder(layer, num_layers=4)
+            te.load_state_dict(cs["trajectory_encoder"])
+        else:   # the module stack of efficient_ensemble_merged.py:150-157
+            ce = torch.nn.Sequential(torch.nn.Linear(10 * 7, 512), torch.nn.LayerNorm(512), torch.nn.ReLU(), torch.nn.Dropout(0.1),
+                                     torch.nn.Linear(512, 512))
+            ce.load_state_dict(cs["complex_action_encoder"])
+        for m in (ta, vp, tp, ip, se, te, ce):
+            if m is not None:
+                m.eval()
         ens.trainable_models.append({
             "text_aware_visual_extraction": ta, "vision_poolings": vp, "text_pooling": tp, "input_projection": ip,
-            "single_step_action_encoder": se, "trajectory_encoder": te, "complex_action_encoder": None,
+            "single_step_action_encoder": se, "trajectory_encoder": te, "complex_action_encoder": ce,
             "action_padding_value": cs["action_padding_value"]})
 
     class _Feat:
@@ -156,6 +163,35 @@ def gen_verifier():
         save(f"verifier_m{members}_n{N}_g{group}", members=members, N=N, group=group, ckpt_seed=1234 + seed, input_seed=seed,
              its=its, acts=acts, scores=scores, max_score=np.float32(score), global_idx=np.int64(int(gidx)),
              hist_lens=np.array([len(h) for h in hists]))
+    # MLP action-encoder variant (use_transformer = False): the same public call through the reference's complex_action_encoder
+    ckpt = synth.verifier_checkpoint(2, seed=1234 + 21, use_transformer=False)
+    pf, tf, hists = synth.verifier_inputs(8, seed=21)
+    ens = build_reference_ensemble(model, eem, ckpt, pf, tf)
+    with torch.no_grad():
+        score, instr, hist, gidx = ens.compute_max_similarity_scores_batch([img] * 8, ["x"] * 8, hists, cfg_repeat_language_instructions=2)
+        hb = torch.tensor(np.array([np.vstack([np.ones((10 - len(h), 7)) * -5, h]) if len(h) < 10 else h for h in hists]), dtype=torch.float32)
+        acts = torch.stack([ens.get_embeddings_from_model_batch(mi, pf, tf, hb)[1] for mi in range(2)])
+    save("verifier_cae_m2_n8_g2", members=2, N=8, group=2, ckpt_seed=1234 + 21, input_seed=21, acts=acts, max_score=np.float32(score),
+         global_idx=np.int64(int(gidx)))
+    # PUBLIC API of the class (boundary row b): the 4-tuple of compute_max_similarity_scores_batch with DISTINCT instructions
+    # per group (max_instruction rule :441-445), predict (:295-307) and fuse_embeddings (:249-293), stub encoders at the
+    # feature boundary, ndarray image input
+    ckpt = synth.verifier_checkpoint(2, seed=1234 + 31)
+    pf, tf, hists = synth.verifier_inputs(12, seed=31)
+    ens = build_reference_ensemble(model, eem, ckpt, pf, tf)
+    instrs = [f"instruction {i // 3}" for i in range(12)]
+    with torch.no_grad():
+        score, instr, hist, gidx = ens.compute_max_similarity_scores_batch([img] * 12, instrs, hists, cfg_repeat_language_instructions=3)
+        assert isinstance(score, float) and isinstance(instr, str) and isinstance(hist, np.ndarray)
+        # predict / fuse_embeddings stack the histories with np.array (:267): equal lengths only, no padding
+        _, _, h10 = synth.verifier_inputs(6, seed=32, min_hist=10)
+        p_hist, p_scores = ens.predict(img, "instruction 0", h10)
+        f_it, f_act = ens.fuse_embeddings(img, "instruction 0", h10)
+        s1, i1, h1, g1 = ens.compute_max_similarity_scores_batch([img], ["only"], hists[4:5], cfg_repeat_language_instructions=1)
+    save("verifier_api_m2_n12_g3", ckpt_seed=1234 + 31, input_seed=31, max_score=np.float32(score), instr_index=np.int64(instrs.index(instr)),
+         global_idx=np.int64(int(gidx)), hist=hist, predict_index=np.int64([i for i, h in enumerate(h10) if h is p_hist][0]),
+         predict_scores=np.array([p_scores[str(i)] for i in range(6)], dtype=np.float64), fused_it=f_it, fused_act=f_act,
+         stage1_score=np.float32(s1), stage1_idx=np.int64(int(g1)))
     # selection edge cases (G4): exact ties and the grouped rule, through the reference's own selection code path
     # by feeding features that make every candidate identical (all scores tie -> index 0 must win)
     ckpt = synth.verifier_checkpoint(2, seed=99)

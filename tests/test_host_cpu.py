@@ -74,14 +74,14 @@ def test_two_stage_verification_and_gripper_vote():
     hist = [rng.normal(size=7) for _ in range(3)]
     # stage 1 confident -> candidate 0, one verifier call
     fv = _FakeVerifier(0.5, np.zeros(B))
-    r = host.verify_and_select(fv, None, "a", tasks, q, hist, S)
+    r = host.verify_and_select(fv, None, "a", tasks, q, hist, S, process_image=False)
     assert fv.calls == [(1, 1)] and r["global_action_idx"] == 0 and r["max_instruction"] == "a"
     # group 0 grippers (+1, -1, -1): majority open (-1) overrides the winner's own +1
     assert r["execute_action"][-1] == -1.0
     assert len(r["remaining"]) == 3 and r["remaining"][0].shape == (1, 7)
     # stage 1 below 0.1 -> stage 2 over all candidates, grouped; winner in group 1
     fv = _FakeVerifier(0.05, [0.1, 0.1, 0.1, 0.2, 0.9, 0.3])
-    r = host.verify_and_select(fv, None, "a", tasks, q, hist, S)
+    r = host.verify_and_select(fv, None, "a", tasks, q, hist, S, process_image=False)
     assert fv.calls == [(1, 1), (B, S)] and r["global_action_idx"] == 4 and r["max_instruction"] == "b"
     assert r["execute_action"][-1] == 1.0                  # group 1 grippers (+1, +1, -1)
     assert np.array_equal(r["remaining"][1], q[2][4:5])
@@ -201,3 +201,18 @@ def test_pi0_checkpoint_key_layout_round_trip(tmp_path):
         assert torch.equal(n[k], sd[k]), k
     for k in ("lm_dim", "lm_mlp", "ex_dim", "ex_mlp", "layers", "Hq", "Hkv", "D", "vocab", "vit_dim", "vit_mlp", "vit_layers", "patch", "image", "chunk"):
         assert c[k] == tiny[k], (k, c[k], tiny[k])
+
+
+def test_pi0_normalization_buffers_from_checkpoint_keys():
+    """normalize.py:44-107 buffer names; IDENTITY needs no buffers, MEAN_STD / MIN_MAX need finite ones."""
+    from cover_vla_amd import loaders
+    sd = {"normalize_inputs.buffer_observation_state.mean": torch.zeros(7), "normalize_inputs.buffer_observation_state.std": torch.ones(7),
+          "model.unnormalize_outputs.buffer_action.mean": torch.ones(7), "model.unnormalize_outputs.buffer_action.std": torch.full((7,), 2.0)}
+    n = loaders.pi0_normalization(sd, {"normalization_mapping": {"STATE": "MEAN_STD", "ACTION": "NormalizationMode.MEAN_STD", "VISUAL": "IDENTITY"}})
+    assert n["state"][0] == "MEAN_STD" and n["action"][0] == "MEAN_STD" and float(n["action"][2][0]) == 2.0
+    assert loaders.pi0_normalization({}, {})["state"][0] == "IDENTITY"
+    with pytest.raises(ValueError):
+        loaders.pi0_normalization({}, {"normalization_mapping": {"STATE": "MIN_MAX"}})
+    sd["normalize_inputs.buffer_observation_state.std"] = torch.full((7,), float("inf"))
+    with pytest.raises(ValueError):
+        loaders.pi0_normalization(sd, {"normalization_mapping": {"STATE": "MEAN_STD"}})

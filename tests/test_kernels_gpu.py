@@ -604,7 +604,14 @@ def test_decode_attention_fused_with_an_explicit_own_slot_table(dev):
     _decode_attention_case(dev, 128, 8, 29, 3, 2, True, permute_slots=True)
 
 
-def _decode_attention_case(dev, D, H, N, write_t, mode, from_partials, permute_slots):
+@pytest.mark.parametrize("N,pattern", [(32, "interleaved"), (29, "interleaved"), (40, "scattered"), (144, "interleaved")])
+def test_decode_attention_fused_with_recurring_prompt_slots(dev, N, pattern):
+    """a prompt slot that recurs NON-contiguously inside a 16-candidate tile (0,1,0,1,... / a random assignment) must
+    enter every candidate's softmax once. Checked against the three-launch path AND directly against fp32 torch."""
+    _decode_attention_case(dev, 128, 8, N, 3, 2, True, permute_slots=False, slot_pattern=pattern, check_fp32=True)
+
+
+def _decode_attention_case(dev, D, H, N, write_t, mode, from_partials, permute_slots, slot_pattern="grouped", check_fp32=False):
     # one launch (RoPE + KV append + [shared | per-prompt | own] attention) == rope_kv_write + attention over 3 segments
     # (N = 144: more than 128 (candidate tile, head) units for H = 8, i.e. the unsplit VS = 1 variant; fewer: VS = 2)
     T0, T1, cap2, npos = 257, 24, 32, 320
@@ -624,7 +631,12 @@ def _decode_attention_case(dev, D, H, N, write_t, mode, from_partials, permute_s
     k0, v0 = bf(torch.randn(1, T0, H, D, generator=g)), bf(torch.randn(1, T0, H, D, generator=g))
     k1, v1 = bf(torch.randn(8, T1, H, D, generator=g)), bf(torch.randn(8, T1, H, D, generator=g))
     k2, v2 = bf(torch.randn(N, cap2, H, D, generator=g)), bf(torch.randn(N, cap2, H, D, generator=g))
-    slot1 = (torch.arange(N) // 3 % 8).to(torch.int32)     # prompt groups straddle the 16-candidate tiles
+    if slot_pattern == "grouped":
+        slot1 = (torch.arange(N) // 3 % 8).to(torch.int32)     # prompt groups straddle the 16-candidate tiles
+    elif slot_pattern == "interleaved":
+        slot1 = (torch.arange(N) % 3).to(torch.int32)          # 0,1,2,0,1,2,...: every slot recurs inside every tile
+    else:
+        slot1 = torch.randint(0, 8, (N,), generator=g, dtype=torch.int32)
     len1 = (9 + (slot1 * 5) % 16).to(torch.int32)
     zero = torch.zeros(N, dtype=torch.int32)
     c0, c1 = make_cache(k0, v0, dev), make_cache(k1, v1, dev)
@@ -650,3 +662,18 @@ def _decode_attention_case(dev, D, H, N, write_t, mode, from_partials, permute_s
     o, r = out.float().cpu(), ref.float().cpu()
     assert torch.isfinite(o).all()
     assert rel_l2(o, r) < 6e-3 and (o - r).abs().max() < 3e-2
+    if check_fp32:
+        # direct fp32 restatement from the caches the fused launch left behind: softmax(q . [K0 | K1[slot] | K2[own]]) V
+        kc2 = cb[0].float().cpu().view(N, cap2, H, D)
+        vt2 = cb[1].float().cpu().view(N, H, D, cap2)
+        q = qa[:, :H * D].float().cpu().view(N, H, D)          # rotated in place by the reference path's rope_kv_write
+        exp = torch.empty(N, H, D)
+        for n in range(N):
+            sl, ln = int(slot1[n]), int(len1[n])
+            own = int(slot2[n]) if slot2 is not None else n
+            kk = torch.cat([k0[0].float(), k1[sl, :ln].float(), kc2[own, :L2]], 0)                       # [T, H, D]
+            vv = torch.cat([v0[0].float(), v1[sl, :ln].float(), vt2[own, :, :, :L2].permute(2, 0, 1)], 0)
+            sc = torch.einsum("hd,thd->ht", q[n], kk) * D ** -0.5
+            exp[n] = torch.einsum("ht,thd->hd", torch.softmax(sc, -1), vv)
+        e = exp.view(N, H * D)
+        assert rel_l2(o, e) < 8e-3 and (o - e).abs().max() < 4e-2   # bf16 probabilities and output rounding

@@ -33,6 +33,35 @@ def test_verifier_oracle_matches_reference(path):
     assert abs(r["max_score"] - float(z["max_score"])) < 1e-5
 
 
+def test_verifier_oracle_mlp_action_encoder_matches_reference():
+    """use_transformer = False variant (complex_action_encoder, efficient_ensemble_merged.py:148-184, 241-243)."""
+    from cover_ref import verifier as V
+    z = np.load(os.path.join(GOLD, "verifier_cae_m2_n8_g2.npz"))
+    ckpt = synth.verifier_checkpoint(2, seed=int(z["ckpt_seed"]), use_transformer=False)
+    pf, tf, hists = synth.verifier_inputs(8, seed=int(z["input_seed"]))
+    with torch.no_grad():
+        o = V.compute_max_similarity_scores(ckpt["ensemble_components"], pf, tf, hists, 2)
+    assert np.allclose(o["acts"].numpy(), z["acts"], atol=1e-5)
+    assert o["global_idx"] == int(z["global_idx"]) and abs(o["max_score"] - float(z["max_score"])) < 1e-5
+
+
+def test_verifier_oracle_public_api_golden():
+    """The reference's public 4-tuple (distinct instructions per group), restated at the feature level."""
+    from cover_ref import verifier as V
+    z = np.load(os.path.join(GOLD, "verifier_api_m2_n12_g3.npz"))
+    ckpt = synth.verifier_checkpoint(2, seed=int(z["ckpt_seed"]))
+    pf, tf, hists = synth.verifier_inputs(12, seed=int(z["input_seed"]))
+    with torch.no_grad():
+        o = V.compute_max_similarity_scores(ckpt["ensemble_components"], pf, tf, hists, 3)
+        _, _, h10 = synth.verifier_inputs(6, seed=32, min_hist=10)
+        p = V.compute_max_similarity_scores(ckpt["ensemble_components"], pf, tf, h10, 1)
+    assert o["global_idx"] == int(z["global_idx"]) and o["group"] == int(z["instr_index"]) // 3
+    assert abs(o["max_score"] - float(z["max_score"])) < 1e-5
+    assert np.allclose(p["scores"].numpy(), z["predict_scores"], atol=1e-5) and int(p["scores"].argmax()) == int(z["predict_index"])
+    assert np.allclose(p["fused_act"].numpy(), z["fused_act"], atol=1e-5)
+    assert np.allclose(p["fused_it"].numpy().repeat(6, 0), z["fused_it"], atol=1e-5)
+
+
 def test_verifier_ties_first_index_wins():
     z = np.load(os.path.join(GOLD, "verifier_ties.npz"))
     ckpt = synth.verifier_checkpoint(2, seed=99)
