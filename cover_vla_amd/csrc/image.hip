@@ -40,9 +40,15 @@ __global__ __launch_bounds__(256) void resample_axis_k(const TIn* __restrict__ i
         v = v < 0 ? 0 : (v > 255 ? 255 : v);
         out[idx] = (TOut)v;
     } else {
+        // separate IEEE multiply and add, as the host form (numpy) evaluates them: HIP's __fmul_rn / __fadd_rn are plain
+        // operators that hipcc contracts into v_fma_f32 (-ffp-contract=fast), which differs in the last bit
+#pragma clang fp contract(off)
         const float* k = (const float*)coefs + (size_t)o * ksize;
         float acc = 0.0f;
-        for (int j = 0; j < cnt; ++j) acc = __fadd_rn(acc, __fmul_rn((float)p[j * step], k[j]));   // no FMA contraction
+        for (int j = 0; j < cnt; ++j) {
+            const float prod = (float)p[j * step] * k[j];
+            acc = acc + prod;
+        }
         if (trunc_u8) {
             acc = acc < 0.f ? 0.f : (acc > 255.f ? 255.f : acc);
             out[idx] = (TOut)(int)acc;                      // static_cast<uint8>(float): truncation
@@ -79,6 +85,7 @@ hipError_t launch_resample_axis(const void* in, int in_kind, void* out, int out_
 
 __global__ __launch_bounds__(256) void u8_to_chw_norm_k(const uint8_t* __restrict__ in, float* __restrict__ out, int H, int W, int C,
                                                         float m0, float m1, float m2, float s0, float s1, float s2) {
+#pragma clang fp contract(off)
     const long long total = (long long)H * W * C;
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // CHW index: writes coalesced
     if (idx >= total) return;
@@ -101,6 +108,7 @@ hipError_t launch_u8_to_chw_norm(const uint8_t* in, float* out, int H, int W, in
 __global__ __launch_bounds__(256) void bilinear_pad_k(const float* __restrict__ in, float* __restrict__ out, int NC, int Hin, int Win,
                                                       int Hr, int Wr, int Hout, int Wout, int pad_top, int pad_left, float rh, float rw,
                                                       float pad_value) {
+#pragma clang fp contract(off)
     const long long total = (long long)NC * Hout * Wout;
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= total) return;

@@ -32,6 +32,13 @@ def _f32(t, dev):
     return t.detach().to(torch.float32).contiguous().to(dev)
 
 
+def _bf_f32(t, dev):
+    """A parameter the reference holds in bf16 (norm weights / biases / layer scales of a model cast with .to(bfloat16):
+    paligemma_with_expert.py:216-227, HF bf16 checkpoints), kept as fp32 storage of the bf16-ROUNDED value: the kernels read
+    fp32 vectors, the arithmetic sees exactly the reference's parameter."""
+    return t.detach().to(BF).to(torch.float32).contiguous().to(dev)
+
+
 # ------------------------------------------------------------------------------------------------ ViT tower
 class VitTower:
     """Pre-LN ViT (SigLIP / SigLIP2 / DINOv2) from a neutral state dict (cover_vla_amd.synth.vit_state key layout).
@@ -57,7 +64,7 @@ class VitTower:
         self.patch_lin = ops.pack_linear(sd["patch.weight"].to(dev), sd["patch.bias"])
         self.pos = sd["pos"].to(BF).contiguous().to(dev)
         self.prefix = sd["prefix"].to(BF).contiguous().to(dev) if prefix_tokens else None
-        self.post_ln = (_f32(sd["post_ln.weight"], dev), _f32(sd["post_ln.bias"], dev)) if "post_ln.weight" in sd else None
+        self.post_ln = (_bf_f32(sd["post_ln.weight"], dev), _bf_f32(sd["post_ln.bias"], dev)) if "post_ln.weight" in sd else None
         H, Dh, Dp = heads, self.dh, self.dp
         self._keep = []
         arr = (L.VitLayer * nl)()
@@ -81,8 +88,8 @@ class VitTower:
             w2 = torch.zeros(dim, self.mlp_p)
             w2[:, :mlp] = sd[p + "fc2.weight"].float()
             fc2 = ops.pack_linear(w2.to(dev), sd[p + "fc2.bias"])
-            ln = [_f32(sd[p + k], dev) for k in ("ln1.weight", "ln1.bias", "ln2.weight", "ln2.bias")]
-            ls = [_f32(sd[p + k], dev) for k in ("ls1", "ls2")] if layerscale else [None, None]
+            ln = [_bf_f32(sd[p + k], dev) for k in ("ln1.weight", "ln1.bias", "ln2.weight", "ln2.bias")]
+            ls = [_bf_f32(sd[p + k], dev) for k in ("ls1", "ls2")] if layerscale else [None, None]
             self._keep += [qkv, proj, fc1, fc2, ln, ls]
             a = arr[i]
             a.ln1_w, a.ln1_b, a.ln2_w, a.ln2_b = (t.data_ptr() for t in ln)
@@ -195,7 +202,10 @@ class Decoder:
     Replaces the layer loop of paligemma_with_expert.py:258-360 (and HF LlamaModel for the OpenVLA profile)."""
 
     def __init__(self, sd, *, dim, layers, Hq, Hkv, D, mlp, act, norm, eps, rope, n_pos=1024, device="cuda:0",
-                 cache: Optional[KvGeometry] = None, share_cache_with: Optional["Decoder"] = None, weight_dtype_f32_norm=True):
+                 cache: Optional[KvGeometry] = None, share_cache_with: Optional["Decoder"] = None, final_norm_bf16=True):
+        """final_norm_bf16: the stack's final norm weight is a bf16 parameter in the reference (PaliGemma's language model, HF
+        bf16 Llama) -- False for the pi0 action expert, whose final norm is outside the name filter of
+        to_bfloat16_like_physical_intelligence (paligemma_with_expert.py:219-227) and stays fp32. Layer norms are bf16 in all."""
         dev = torch.device(device)
         self.dev, self.dim, self.n_layers, self.Hq, self.Hkv, self.D, self.mlp = dev, dim, layers, Hq, Hkv, D, mlp
         self.act, self.norm, self.eps = act, norm, eps
@@ -216,8 +226,8 @@ class Decoder:
             o = ops.pack_linear(sd[p + "self_attn.o_proj.weight"].to(dev))
             gu = ops.pack_linear(torch.cat([sd[p + "mlp.gate_proj.weight"], sd[p + "mlp.up_proj.weight"]], 0).to(dev), glu=True)
             down = ops.pack_linear(sd[p + "mlp.down_proj.weight"].to(dev))
-            n1 = _f32(sd[p + "input_layernorm.weight"], dev)
-            n2 = _f32(sd[p + "post_attention_layernorm.weight"], dev)
+            n1 = _bf_f32(sd[p + "input_layernorm.weight"], dev)
+            n2 = _bf_f32(sd[p + "post_attention_layernorm.weight"], dev)
             self._keep += [qkv, o, gu, down, n1, n2]
             a = arr[i]
             a.in_norm_w, a.post_norm_w = n1.data_ptr(), n2.data_ptr()
@@ -225,7 +235,7 @@ class Decoder:
             a.o_w, a.gate_up_w, a.down_w = o.wp.data_ptr(), gu.wp.data_ptr(), down.wp.data_ptr()
             a.k_cache, a.vt_cache = self.k_cache[i].data_ptr(), self.vt_cache[i].data_ptr()
         self._arr = arr
-        self.final_norm = _f32(sd["norm.weight"], dev)
+        self.final_norm = (_bf_f32 if final_norm_bf16 else _f32)(sd["norm.weight"], dev)
         cos, sin = rope_tables(rope, n_pos, D)
         self.cos, self.sin = cos.contiguous().to(dev), sin.contiguous().to(dev)
         d = L.DecDesc()

@@ -59,7 +59,9 @@ def pack_linear(weight: torch.Tensor, bias: Optional[torch.Tensor] = None, glu: 
     nbytes = h.cover_packed_weight_bytes(N, K)
     wp = torch.empty(nbytes // 2, dtype=torch.bfloat16, device=w.device)
     L.check(h.cover_pack_weight_bf16(w.data_ptr(), K, N, K, wp.data_ptr(), 1 if glu else 0, _stream()), "pack_weight")
-    b = None if bias is None else bias.detach().to(torch.float32).contiguous().to(w.device)
+    # the bias of a bf16 nn.Linear is a bf16 parameter in the reference (paligemma.to(bf16), HF bf16 checkpoints): round it
+    # ONCE at load; the epilogue then adds exactly that value in fp32
+    b = None if bias is None else bias.detach().to(torch.bfloat16).to(torch.float32).contiguous().to(w.device)
     return PackedLinear(wp, N, K, b, glu)
 
 

@@ -262,7 +262,7 @@ def test_pi0_rows_with_different_frames_share_no_prefix(dev):
     tk, mk = toks.clone(), masks.clone()
     tk[1], mk[1], tk[2], mk[2] = tk[0], mk[0], tk[0], mk[0]
     cls = PI0FlowMatching._image_classes([im.to(dev)], B)
-    assert cls[0] == cls[2] and cls[1] != cls[0] and len(set(cls.tolist())) == len({0, 1, 3, 4, 5})
+    assert cls[0] == cls[2] and cls[1] != cls[0] and cls.tolist() == [0, 1, 0, 0, 2, 0]
     ones = [torch.ones(B, dtype=torch.bool, device=dev)]
     x = model.sample_actions([im.to(dev)], ones, tk.to(dev), mk.to(dev), state.to(dev), noise=noise.to(dev)).cpu()
     for b in range(B):
@@ -364,3 +364,53 @@ def test_pi0_policy_prepare_images_and_normalisation(dev, tmp_path):
     ref.pop("unnormalize_outputs.buffer_action.min")
     with pytest.raises(ValueError):
         loaders.pi0_normalization(ref, cfg)
+
+
+def test_full_width_gemma_layers_match_reference_g2(dev):
+    """cover_decoder_forward at the reference's REAL layer shapes -- Gemma-2B layer (2048 wide, 8 q heads / 1 kv
+    head x 256, MLP 16384) on a T = 328 prefix with two prompt lengths, then the action-expert layer (1024 wide, MLP 4096) on
+    the 5 suffix tokens over the cached prefix (KV geometry, MQA sharing, VISLEN suffix mask, fp32 suffix input) -- against
+    golden vectors from the reference's own PaliGemmaWithExpertModel.forward (oracle/gen_golden_g2.py).
+    Tolerance: per-layer hidden-state rel-L2 <= 1.2e-2 (SURVEY 8c allows 2e-2; measured 0.7e-2), K / V cache rows <= 2e-3
+    (measured: K bit-exact, V 1e-4)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_oracle_golden import _g2_case
+    from cover_vla_amd import ops
+    from cover_vla_amd.models import BF, Decoder, KvGeometry
+    g2, seed, (prefix, pad, att, suffix, s_pad, s_att), gold = _g2_case()
+    sd = synth.pi0_state(g2, seed=seed)
+    sub = lambda p: {k[len(p):]: v for k, v in sd.items() if k.startswith(p)}
+    B, T, D = prefix.shape
+    S, W = suffix.shape[1], suffix.shape[2]
+    geom = KvGeometry(g2["Hkv"], g2["D"], [B, B], [T, S])
+    n_pos = T + S + 8
+    lm = Decoder(sub("lm."), dim=g2["lm_dim"], layers=1, Hq=g2["Hq"], Hkv=g2["Hkv"], D=g2["D"], mlp=g2["lm_mlp"], act="gelu_tanh",
+                 norm="gemma", eps=1e-6, rope="pi0", n_pos=n_pos, device="cuda:0", cache=geom)
+    ex = Decoder(sub("expert."), dim=g2["ex_dim"], layers=1, Hq=g2["Hq"], Hkv=g2["Hkv"], D=g2["D"], mlp=g2["ex_mlp"], act="gelu_tanh",
+                 norm="gemma", eps=1e-6, rope="pi0", n_pos=n_pos, device="cuda:0", share_cache_with=lm, final_norm_bf16=False)
+    plen = pad.sum(1).to(torch.int32).to(dev)
+    ppos = (torch.cumsum(pad, dim=1) - 1).clamp(min=0).to(torch.int32).contiguous().to(dev)
+    x = prefix.clone().to(dev).view(B * T, D)
+    g0 = lm.group(B, T, ppos.view(-1), [dict(region=0, length=T, len_of_batch=plen)], 0)
+    lm.forward(x, [g0], final_norm=True)
+    pre = x.view(B, T, D).float().cpu()
+    n0, n1 = int(pad[0].sum()), int(pad[1].sum())
+    rel = lambda a, b: ((a.float() - b).norm() / b.norm()).item()
+    r0, r1 = rel(pre[0, :n0], gold["pre_b0"][:n0]), rel(pre[1, ::4][: (n1 + 3) // 4], gold["pre_b1"][: (n1 + 3) // 4])
+    # the layer's post-RoPE K / V as the cache holds them: K [slot][t][h][d], V^T [slot][h][d][cap]
+    cap = geom.caps[0]
+    kc = lm.k_cache[0][: B * cap * g2["D"]].view(B, cap, g2["D"]).float().cpu()
+    vt = lm.vt_cache[0][: B * g2["D"] * cap].view(B, g2["D"], cap).float().cpu()
+    rk, rv = rel(kc[0, :n0], gold["k_b0"][:n0]), rel(vt[0, :, :n0].T, gold["v_b0"][:n0])
+    # suffix: the expert layer over [its row's prefix | the suffix itself], state token sees 1 suffix key, actions all 5
+    vis_len = torch.tensor([1] + [S] * (S - 1), dtype=torch.int32, device=dev)
+    row = torch.arange(B, dtype=torch.int32, device=dev)
+    spos = (plen[:, None] + torch.arange(S, device=dev, dtype=torch.int32)[None]).contiguous()
+    g1 = ex.group(B, S, spos.view(-1), [dict(region=0, length=T, len_of_batch=plen, slot_of_batch=row),
+                                         dict(region=1, length=S, mask=ops.MASK_VISLEN, vis_len=vis_len)], 1)
+    xb = torch.empty(B * S, W, dtype=BF, device=dev)
+    ex.forward(xb, [g1], final_norm=True, x_f32=suffix.to(dev).view(B * S, W).contiguous())
+    rs = rel(xb.view(B, S, W).float().cpu(), gold["suffix"])
+    print(f"G2 rel-L2: prefix {r0:.4f} / {r1:.4f}, K {rk:.4f}, V {rv:.4f}, suffix {rs:.4f}")
+    assert r0 < 1.2e-2 and r1 < 1.2e-2 and rs < 1.2e-2
+    assert rk < 2e-3 and rv < 2e-3

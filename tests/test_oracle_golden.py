@@ -160,3 +160,38 @@ def test_blocks_match_hf_dinov2_with_registers():
         h2 = Bk.vit_encode(cfg, sd, x, n_blocks=2)
     assert np.allclose(h1.numpy(), z["hidden_1"], atol=2e-4, rtol=1e-4)
     assert np.allclose(h2.numpy(), z["hidden_2"], atol=2e-4, rtol=1e-4)
+
+
+def _g2_case():
+    from gen_golden_g2 import G2, SEED, g2_inputs
+    z = np.load(os.path.join(GOLD, "pi0_g2_fullwidth.npz"))
+    assert int(z["seed"]) == SEED and all(int(z["g2_" + k]) == v for k, v in G2.items())
+    unbits = lambda a: torch.from_numpy(a.view(np.int16).copy()).view(torch.bfloat16).float()
+    gold = dict(pre_b0=unbits(z["prefix_out_b0"]), pre_b1=unbits(z["prefix_out_b1_every4"]), k_b0=unbits(z["k_b0"]), v_b0=unbits(z["v_b0"]),
+                suffix=torch.from_numpy(z["suffix_out"]))
+    return dict(G2), SEED, g2_inputs(), gold
+
+
+def test_oracle_full_width_gemma_layers_match_reference_g2():
+    """one full-width Gemma-2B layer (T = 328, head_dim 256, MQA 8:1, MLP 16384) and one expert layer (5 suffix
+    tokens over the cached prefix) through the reference's PaliGemmaWithExpertModel.forward vs the oracle's decoder_forward."""
+    from cover_ref import blocks as Bk, pi0 as P
+    g2, seed, (prefix, pad, att, suffix, s_pad, s_att), gold = _g2_case()
+    sd = P.cast_like_reference(synth.pi0_state(g2, seed=seed))
+    lm = Bk.DecoderCfg(g2["lm_dim"], 1, g2["Hq"], g2["Hkv"], g2["D"], g2["lm_mlp"], "gelu_tanh", "gemma", 1e-6, "pi0")
+    ex = Bk.DecoderCfg(g2["ex_dim"], 1, g2["Hq"], g2["Hkv"], g2["D"], g2["ex_mlp"], "gelu_tanh", "gemma", 1e-6, "pi0")
+    B = prefix.shape[0]
+    with torch.no_grad():
+        pmask = P.make_att_2d_masks(pad, att)
+        ppos = torch.cumsum(pad, dim=1) - 1
+        pre, kv = Bk.decoder_forward(lm, P.sub(sd, "lm."), prefix, ppos.clamp(min=0), pmask, past=None, keep_kv=True, final_norm=True)
+        S, T = s_pad.shape[1], pad.shape[1]
+        full = torch.cat([pad[:, None, :].expand(B, S, T), P.make_att_2d_masks(s_pad, s_att)], dim=2)
+        spos = torch.sum(pad, dim=-1)[:, None] + torch.cumsum(s_pad, dim=1) - 1
+        suf, _ = Bk.decoder_forward(ex, P.sub(sd, "expert."), suffix, spos, full, past=kv, keep_kv=False, final_norm=True)
+    n0, n1 = int(pad[0].sum()), int(pad[1].sum())
+    rel = lambda a, b: ((a.float() - b).norm() / b.norm()).item()
+    assert rel(pre[0, :n0], gold["pre_b0"][:n0]) < 2e-3                       # two eager bf16 evaluations of the same graph
+    assert rel(pre[1, ::4][: (n1 + 3) // 4], gold["pre_b1"][: (n1 + 3) // 4]) < 2e-3
+    assert rel(kv[0][0][0, :n0, 0], gold["k_b0"][:n0]) < 2e-3 and rel(kv[0][1][0, :n0, 0], gold["v_b0"][:n0]) < 2e-3
+    assert rel(suf, gold["suffix"]) < 2e-3
