@@ -162,7 +162,7 @@ def vit_embed(cfg: VitCfg, sd, pixels):
     """pixels fp32 [B,3,H,W] (already normalised) -> bf16 tokens [B, prefix+P, dim] (conv patch embed + bias + pos)."""
     B = pixels.shape[0]
     w = sd["patch.weight"].view(cfg.dim, 3, cfg.patch, cfg.patch)
-    x = F.conv2d(pixels.to(BF), w, sd["patch.bias"], stride=cfg.patch)
+    x = F.conv2d(pixels.to(w.dtype), w, sd["patch.bias"], stride=cfg.patch)   # bf16 towers: pixels cast to bf16 (eager semantics)
     x = x.flatten(2).transpose(1, 2)
     if cfg.prefix_tokens:
         x = torch.cat([sd["prefix"][None].expand(B, -1, -1), x], 1)

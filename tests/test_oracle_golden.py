@@ -195,3 +195,65 @@ def test_oracle_full_width_gemma_layers_match_reference_g2():
     assert rel(pre[1, ::4][: (n1 + 3) // 4], gold["pre_b1"][: (n1 + 3) // 4]) < 2e-3
     assert rel(kv[0][0][0, :n0, 0], gold["k_b0"][:n0]) < 2e-3 and rel(kv[0][1][0, :n0, 0], gold["v_b0"][:n0]) < 2e-3
     assert rel(suf, gold["suffix"]) < 2e-3
+
+
+def _rel(a, b):
+    return ((a.float() - b.float()).norm() / b.float().norm()).item()
+
+
+def test_oracle_siglip2_bridge_matches_hf_text_and_image_towers():
+    """the verifier backbone restatement (cover_ref.openvla.siglip2_features) against HF SiglipVisionModel +
+    SiglipTextModel with the bridge's hook semantics: patch features = the LAST block's attention-module output, text
+    features = transformer -> final_layer_norm -> head on every position (fixture: oracle/gen_golden_hf.py)."""
+    from cover_ref import openvla as OR
+    from gen_golden_hf import siglip2_bridge_weights
+    z = np.load(os.path.join(GOLD, "hf_siglip2_bridge_tiny.npz"))
+    c, sd = siglip2_bridge_weights(int(z["weight_seed"]))
+    with torch.no_grad():
+        pf, tf = OR.siglip2_features(c, sd, torch.from_numpy(z["pixels"]), torch.from_numpy(z["ids"]))      # fp32 weights: fp32 math
+    assert torch.allclose(pf, torch.from_numpy(z["patch_features"]), atol=2e-5)
+    assert torch.allclose(tf, torch.from_numpy(z["text_features"]), atol=2e-5)
+    # HF's own pooled output = head(last position): the same projection the restatement applies to every position
+    pooled = torch.from_numpy(z["text_pooled"])
+    assert torch.allclose(tf[:, -1], pooled / pooled.norm(dim=-1, keepdim=True), atol=2e-5)
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_oracle_openvla_end_to_end_matches_hf_composition(prec):
+    """END-TO-END P2 pin: the oracle's sampler (vision towers -> projector -> [BOS | patches | prompt] -> Llama -> 7 greedy
+    tokens) against the same pipeline composed from HF modules (Dinov2WithRegisters + SiglipVision + LlamaForCausalLM), per-step
+    logits and token ids. fp32: logits atol 2e-3, tokens exact. bf16 (two different eager bf16 evaluations: HF rounds scores to
+    bf16 before the softmax, the reference repo's convention keeps them fp32): logits rel-L2 <= 3e-2, tokens exact wherever the
+    HF top-1 / top-2 margin exceeds twice the logit error."""
+    from cover_ref import blocks as Bk, openvla as OR
+    from gen_golden_hf import openvla_e2e_weights
+    z = np.load(os.path.join(GOLD, "hf_openvla_e2e_tiny.npz"))
+    c, sd = openvla_e2e_weights(int(z["weight_seed"]))
+    frame, toks, lens = torch.from_numpy(z["frame"]), torch.from_numpy(z["toks"]), torch.from_numpy(z["lens"])
+    ref_l, ref_t = torch.from_numpy(z["logits_" + prec]), torch.from_numpy(z["tokens_" + prec])
+    tr = {}
+    if prec == "bf16":
+        with torch.no_grad():
+            tok = OR.sample(c, Bk.to_bf16(sd), frame, toks, lens, 1, None, trace=tr)
+    else:
+        with _fp32_blocks(), torch.no_grad():          # the same graph evaluated in fp32 (structure pin)
+            tok = OR.sample(c, sd, frame, toks, lens, 1, None, trace=tr)
+    lg = tr["logits"]
+    if prec == "fp32":
+        assert torch.allclose(lg, ref_l, atol=2e-3), (lg - ref_l).abs().max()
+        assert torch.equal(tok, ref_t)
+        return
+    n_dec = 0
+    for n in range(tok.shape[0]):
+        agree_so_far = True
+        for i in range(7):
+            if not agree_so_far:
+                break                                # free-running: after the first differing pick the contexts differ
+            err = (lg[n, i] - ref_l[n, i]).abs().max().item()
+            assert _rel(lg[n, i], ref_l[n, i]) < 3e-2, (n, i, _rel(lg[n, i], ref_l[n, i]))
+            top2 = torch.topk(ref_l[n, i, : c["tok_vocab"]], 2).values
+            if (top2[0] - top2[1]).item() > 2 * err:
+                n_dec += 1
+                assert tok[n, i] == ref_t[n, i], (n, i)
+            agree_so_far = bool(tok[n, i] == ref_t[n, i])
+    assert n_dec >= 10
