@@ -19,6 +19,13 @@
 #include "common.h"
 #include "kernels.h"
 
+#ifdef COVER_PC_DEBUG
+__device__ unsigned long long g_pc_tl[1024 * 8];   // per block (thread 0): start, loop start, loop end, end, epilogue stamps (100 MHz wall clock)
+#define PCTL(slot) do { if (threadIdx.x == 0) g_pc_tl[((blockIdx.y * gridDim.x + blockIdx.x) & 1023) * 8 + (slot)] = wall_clock64(); } while (0)
+#else
+#define PCTL(slot) do { } while (0)
+#endif
+
 struct EpiDev {
     const float* bias;
     const void* residual;
@@ -102,6 +109,9 @@ __device__ __forceinline__ void epi_value4(const EpiDev& e, int m, int n0, int N
 #pragma unroll
         for (int i = 0; i < 4; ++i) v[i] *= e.out_scale;
     }
+}
+__device__ __forceinline__ bool epi_is_plain(const EpiDev& e) {
+    return !e.bias && !e.residual && !e.lscale && e.act == ACT_NONE && e.out_scale == 1.0f;
 }
 // the store half of epi_store4 (values already through epi_value4)
 __device__ __forceinline__ void epi_put4(const EpiDev& e, void* C, int ldc, int m, int n0, int N, const float v[4]) {
@@ -239,6 +249,108 @@ template <int WM, int WN>
 __device__ __forceinline__ void tiled_epilogue(f32x4 (&acc)[WN][WM], const EpiDev& epi, void* C, int ldc, int M, int N, int mw,
                                                int nw, int r, int g, float* __restrict__ partial) {
     tiled_epilogue_row<WM, WN, 0>(acc, epi, C, ldc, M, N, mw, nw, r, g, partial);
+}
+
+// ---- LDS-staged epilogue --------------------------------------------------------------------------------------------
+// The direct epilogue stores 8 bytes per lane: one wave instruction = 16 rows x 32 contiguous bytes, a partial line per
+// row, and with a power-of-two row pitch (N = 12288, 4096: 24 / 8 KiB) all 16 rows of an instruction sit in the SAME L2
+// channel. Per-block timelines of the 224 x 128 kernel at M = 448 (tools/dbg/pc_timeline.py): main loop 46.6 us, epilogue 21.6 us
+// -- a third of the kernel waiting for its own stores. Here the finished values (bias / activation / GLU / scale applied in
+// registers, as before) go to the block's LDS tile -- the pipeline stages are dead by now -- and leave as 16-byte
+// stores, a row of the tile contiguous: BN = 128 bf16 columns = 256 B = 16 lanes, four full rows per wave instruction.
+// Raw fp32 split-K partials take the same path when the tile fits. Falls back to the direct form for ragged tiles.
+// mode 0: raw fp32 accumulators (split-K partials, or the generic epilogue whose arithmetic runs in the store loop);
+// mode 1: plain / GLU -- the accumulators rounded to bf16 (the nn.Linear output rounding point), nothing else.
+template <int WM, int WN, int F>
+__device__ __forceinline__ void staged_fill_row(f32x4 (&acc)[WN][WM], char* st, int pitch, int m0, int n0, int mw, int nw, int r, int g,
+                                                int mode) {
+    char* row = st + (size_t)(mw + F * 16 + r - m0) * pitch;
+    if (mode == 0) {
+#pragma unroll
+        for (int b = 0; b < WN; ++b)
+            *(float4*)(row + (nw - n0 + b * 16 + 4 * g) * 4) = make_float4(acc[b][F][0], acc[b][F][1], acc[b][F][2], acc[b][F][3]);
+    } else {
+#pragma unroll
+        for (int b = 0; b < WN; ++b) {
+            uint2 p;
+            p.x = pack_bf2(acc[b][F][0], acc[b][F][1]);
+            p.y = pack_bf2(acc[b][F][2], acc[b][F][3]);
+            *(uint2*)(row + (nw - n0 + b * 16 + 4 * g) * 2) = p;
+        }
+    }
+    if constexpr (F + 1 < WM) staged_fill_row<WM, WN, F + 1>(acc, st, pitch, m0, n0, mw, nw, r, g, mode);
+}
+
+// BM x BN tile of the block at (m0, n0); the calling threads are `nthr` consecutive threads with index `t` (every one of them
+// owns accumulators). `st` = the block's dynamic LDS (at least st_bytes large), free to overwrite.
+template <int WM, int WN, int BM, int BN>
+__device__ __forceinline__ void tiled_epilogue_staged(f32x4 (&acc)[WN][WM], const EpiDev& epi, void* C, int ldc, int M, int N, int m0,
+                                                      int n0, int mw, int nw, int r, int g, float* __restrict__ partial, char* st,
+                                                      int st_bytes, int t, int nthr) {
+    const bool raw = partial != nullptr;
+    const bool glu = !raw && epi.glu;
+    const bool plain = !raw && !glu && epi_is_plain(epi);
+    const bool generic = !raw && !glu && !plain;
+    const int mode = (raw || generic) ? 0 : 1;                        // what the LDS tile holds: fp32 accumulators / bf16 values
+    const int esz_out = (raw || epi.out_f32) ? 4 : 2;
+    const int ocols = glu ? BN / 2 : BN;                               // output columns of the tile
+    const int Nout = glu ? (N >> 1) : N;
+    const int oc0 = glu ? (n0 >> 1) : n0;
+    const int row_bytes = ocols * esz_out;                             // of the OUTPUT tile
+    const int pitch = BN * (mode == 0 ? 4 : 2) + 16;                   // LDS row; +16 B: consecutive rows start 4 banks apart
+    char* base = raw ? (char*)(partial + (size_t)blockIdx.y * M * N) : (char*)C;
+    const size_t ld_bytes = (size_t)(raw ? N : ldc) * esz_out;
+    const int cvalid = min(ocols, Nout - oc0);                         // ragged last column tile: whole 16-byte chunks only
+    const bool ok = (size_t)BM * pitch <= (size_t)st_bytes && cvalid > 0 && ((cvalid * esz_out) & 15) == 0 && (ld_bytes & 15) == 0 &&
+                    ((((uintptr_t)base) + (size_t)oc0 * esz_out) & 15) == 0 && !((glu || plain) && epi.out_f32);
+    if (!ok) {   // uniform over the block
+        tiled_epilogue<WM, WN>(acc, epi, C, ldc, M, N, mw, nw, r, g, partial);
+        return;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");       // every wave is done reading the pipeline stages
+    PCTL(4);
+    staged_fill_row<WM, WN, 0>(acc, st, pitch, m0, n0, mw, nw, r, g, mode);
+    PCTL(5);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    PCTL(6);
+    const int cpr = (cvalid * esz_out) >> 4;                           // 16-byte chunks per output row
+    const int total = BM * cpr;
+    for (int c = t; c < total; c += nthr) {
+        const int row = c / cpr, ch = c - row * cpr;
+        const int m = m0 + row;
+        if (m >= M) continue;
+        const char* lrow = st + (size_t)row * pitch;
+        char* dst = base + (size_t)m * ld_bytes + (size_t)oc0 * esz_out + ch * 16;
+        if (raw || plain) {
+            *(uint4*)dst = *(const uint4*)(lrow + ch * 16);
+        } else if (glu) {   // output columns 8 ch .. 8 ch + 7 = pair ch / 2, half ch % 2: gate at tile column 32 (ch / 2) + 8 (ch % 2), up 16 further
+            const char* gp = lrow + ((ch >> 1) * 32 + (ch & 1) * 8) * 2;
+            const uint4 gq = *(const uint4*)gp, uq = *(const uint4*)(gp + 32);
+            const uint32_t gw[4] = {gq.x, gq.y, gq.z, gq.w}, uw[4] = {uq.x, uq.y, uq.z, uq.w};
+            uint32_t ow[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {   // epi_store4_glu's arithmetic on the already bf16-rounded gate / up values
+                const float g0 = bfround(act_apply(bf2f((bf16_t)(gw[i] & 0xffffu)), epi.act)), g1 = bfround(act_apply(bf2f((bf16_t)(gw[i] >> 16)), epi.act));
+                ow[i] = pack_bf2(g0 * bf2f((bf16_t)(uw[i] & 0xffffu)), g1 * bf2f((bf16_t)(uw[i] >> 16)));
+            }
+            *(uint4*)dst = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+        } else {            // generic epilogue on the staged fp32 sums, ONE copy of the arithmetic (a loop, not 14-28 inlined copies:
+                            // inlined per fragment it made the epilogue 65 000 lines of ISA and a block spent 18 us fetching it); the
+                            // bias / layer-scale / residual operands are read row-contiguous here
+            if (epi.out_f32) {       // 4 fp32 outputs per chunk
+                const float4 a4 = *(const float4*)(lrow + ch * 16);
+                float v[4] = {a4.x, a4.y, a4.z, a4.w};
+                epi_value4(epi, m, n0 + ch * 4, N, v);
+                *(float4*)dst = make_float4(v[0], v[1], v[2], v[3]);
+            } else {                 // 8 bf16 outputs per chunk
+                const float4 a4 = *(const float4*)(lrow + ch * 32), b4 = *(const float4*)(lrow + ch * 32 + 16);
+                float v[4] = {a4.x, a4.y, a4.z, a4.w}, w[4] = {b4.x, b4.y, b4.z, b4.w};
+                epi_value4(epi, m, n0 + ch * 8, N, v);
+                epi_value4(epi, m, n0 + ch * 8 + 4, N, w);
+                *(uint4*)dst = make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(w[0], w[1]), pack_bf2(w[2], w[3]));
+            }
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -401,7 +513,8 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_tiled(const bf16_t* __res
     }
 
     // ---- epilogue ----
-    tiled_epilogue<WM, WN>(acc, epi, C, ldc, M, N, m0 + wm * (WM * 16), n0 + wn * (WN * 16), r, g, partial);
+    tiled_epilogue_staged<WM, WN, BM_, BN_>(acc, epi, C, ldc, M, N, m0, n0, m0 + wm * (WM * 16), n0 + wn * (WN * 16), r, g, partial, smem,
+                                            NST * (A_BYTES + B_BYTES), tid, 64 * NW);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -424,16 +537,18 @@ extern "C" int cover_pc_debug(unsigned long long* out, int reset) {
     return 0;
 }
 #define PCT() __builtin_readcyclecounter()
+extern "C" int cover_pc_timeline(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pc_tl), sizeof(g_pc_tl)); }
 #endif
 template <int WM, int WN, int NST, int NL = 1, int CGM = 2, int CGN = 2>
 __global__ __launch_bounds__(64 * (CGM * CGN + NL)) void gemm_tiled_pc(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ Wp,
                                                      void* C, int ldc, int M, int N, int Kp, EpiDev epi, int tiles_m,
                                                      int tiles_n, int kt_per, float* __restrict__ partial) {
+    PCTL(0);
     constexpr int NCW = CGM * CGN;                            // MFMA waves: a CGM x CGN grid of (WM*16) x (WN*16) wave tiles
     constexpr int BM_ = CGM * WM * 16, BN_ = CGN * WN * 16;
     constexpr int A_BYTES = BM_ * BK * 2, B_BYTES = BN_ * BK * 2;
     constexpr int AT = A_BYTES / 1024, BT = B_BYTES / 1024;   // 1-KiB LDS-DMA instructions per k-tile (all by the loaders)
-    static_assert((NST - 2) * (AT + BT) <= 63, "counted vmcnt must fit its 6-bit field");
+    static_assert((NST - 2) * ((AT + BT) / NL) <= 63, "counted vmcnt must fit its 6-bit field");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* As = smem;                   // [NST][A_BYTES]
     char* Bs = smem + NST * A_BYTES;   // [NST][B_BYTES]
@@ -574,9 +689,11 @@ __global__ __launch_bounds__(64 * (CGM * CGN + NL)) void gemm_tiled_pc(const bf1
     u32x4 xa[WM], wa[WN], xb[WM], wb[WN];
     int cur = 0;
     __builtin_amdgcn_s_barrier();
+    PCTL(1);
 #ifdef COVER_PC_DEBUG
     unsigned long long dbg_bar = 0;
     const unsigned long long dbg_t0 = PCT();
+    const unsigned long long dbg_w0 = wall_clock64();
 #endif
     read_frags(0, 0, xa, wa);
     for (int kt = 0; kt < nk; ++kt) {
@@ -604,9 +721,12 @@ __global__ __launch_bounds__(64 * (CGM * CGN + NL)) void gemm_tiled_pc(const bf1
         __builtin_amdgcn_sched_barrier(0);
     }
 #ifdef COVER_PC_DEBUG
-    if (lane == 0 && w == 0) { atomicAdd(&g_pc_dbg[3], dbg_bar); atomicAdd(&g_pc_dbg[4], PCT() - dbg_t0); }
+    if (lane == 0 && w == 0) { atomicAdd(&g_pc_dbg[3], dbg_bar); atomicAdd(&g_pc_dbg[4], PCT() - dbg_t0); atomicAdd(&g_pc_dbg[6], wall_clock64() - dbg_w0); }
 #endif
-    tiled_epilogue<WM, WN>(acc, epi, C, ldc, M, N, m0 + wm * (WM * 16), n0 + wn * (WN * 16), r, g, partial);
+    PCTL(2);
+    tiled_epilogue_staged<WM, WN, BM_, BN_>(acc, epi, C, ldc, M, N, m0, n0, m0 + wm * (WM * 16), n0 + wn * (WN * 16), r, g, partial, smem,
+                                            NST * (A_BYTES + B_BYTES), tid, 64 * NCW);
+    PCTL(3);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1505,7 +1625,8 @@ size_t gemm_workspace_bytes(int M, int N, int K) {
     if (M > 64) {
         // tiled kernel: split-K (up to 8 slices of fp32 partials) is only used when the output tile grid is small
         const long long blocks64 = (long long)((M + 63) / 64) * ((N + 63) / 64);
-        return blocks64 < 192 ? (size_t)8 * M * N * sizeof(float) : 0;
+        const long long blocks224 = (long long)((M + 223) / 224) * ((N + 127) / 128);   // 224 x 128 tiles of narrow outputs split K too
+        return (blocks64 < 192 || blocks224 < 192) ? (size_t)8 * M * N * sizeof(float) : 0;
     }
     const size_t a = plan_skinny(M, N, Kp).ws_bytes, b = plan_skinny2(M, N, Kp).ws_bytes;
     size_t c = plan_skinny3(M, N, Kp).ws_bytes;
@@ -1639,7 +1760,7 @@ hipError_t launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* Wp, void* C,
     // ---- tile / split-K selection: fill >= ~1 block per CU when the problem allows it
     // tile configurations: {wave tile (WM, WN) in 16-row units, wave grid, stages}
     struct Cand { int wm, wn, wgm, wgn, nst; };
-    const Cand cands[14] = {
+    const Cand cands[18] = {
         {4, 4, 2, 2, 2},   // 0: 128x128, 4 waves of 64x64, 2 stages (64 KiB)
         {2, 4, 2, 2, 2},   // 1:  64x128, 4 waves of 32x64, 2 stages (48 KiB)
         {2, 2, 2, 2, 3},   // 2:  64x64,  4 waves of 32x32, 3 stages (48 KiB)
@@ -1654,6 +1775,12 @@ hipError_t launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* Wp, void* C,
         {4, 4, 2, 2, 3},   // b: 128x128, loader wave + 4 MFMA waves, 3 stages (96 KiB)
         {4, 4, 4, 2, 3},   // c: 256x128, 4 loader waves + 8 MFMA waves of 64x64, 3 stages (144 KiB)
         {4, 4, 2, 4, 3},   // d: 128x256, 4 loader waves + 8 MFMA waves of 64x64, 3 stages (144 KiB)
+        // 224-row tiles (M = 448 = 2 x 224: no row padding, and the column width is chosen per GEMM so that the whole tile
+        // grid is ONE round of <= 256 blocks): 4 loader waves + MFMA waves of 112 x 48 / 112 x 32
+        {7, 3, 2, 2, 4},   // e: 224x96,  4 MFMA waves of 112x48 + 4 loaders, 4 stages (160 KiB)
+        {7, 2, 2, 4, 3},   // f: 224x128, 8 MFMA waves of 112x32 + 4 loaders, 3 stages (132 KiB)
+        {7, 3, 2, 4, 3},   // g: 224x192, 8 MFMA waves of 112x48 + 4 loaders, 3 stages (156 KiB)
+        {7, 2, 2, 3, 4},   // h: 224x96,  6 MFMA waves of 112x32 + 4 loaders, 4 stages (160 KiB)
     };
     // Measured on MI355X (tools/bench_kernels.py, M = 441): this single-barrier-per-k-tile structure is latency-bound per
     // block, so residency beats tile size until the tile grid oversubscribes the chip several times over, while 64x64
@@ -1681,10 +1808,38 @@ hipError_t launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* Wp, void* C,
         if (N > 4096 && nblocks(13) >= 176) pick = N >= 16384 ? 12 : 13;
         else if (N <= 4096 && Kp >= 8192 && nblocks(12) >= 256) pick = 12;
     }
+    // 224-row tiles (picks 15-17): M = 448 -- the OpenVLA prefill pass: 256 patch rows + 8 prompts x 24 text rows -- is exactly two
+    // of them, where 128-row tiles pad 12.5 % and 64 x 128 tiles need 1.3-2.7 rounds of blocks. The column width and the number of
+    // K slices are chosen per GEMM so that the grid is ONE round of <= 256 blocks, with a cost model fitted to per-block timelines
+    // (tools/dbg/pc_timeline.py; us per 64-deep k-tile: 224x96 0.67, 224x128 0.70, 224x192 1.05; ~5 us of prologue + epilogue
+    // per block; split-K reduction ~4 us + slab bytes at 3 TB/s). Cold weights, M = 448, kernel timestamps, before -> after:
+    // qkv 81.5 -> 52 us (224x96/128), gate_up 138 -> 78.5 us (224x192, 1.03 PFLOP/s), down 72.6 + norm -> 43 + 10 us (224x128, 4 slices).
+    int S_forced = 0;
+    {
+        static const char* no224 = getenv("COVER_TILES_224");   // experiment knob: 0 disables
+        const int t224 = (M + 223) / 224, waste224 = t224 * 224 - M;
+        if (variant != 2 && Kp >= 2048 && M >= 400 && waste224 * 10 <= M && !(no224 && no224[0] == '0')) {
+            const int bns[3] = {96, 128, 192}, idx[3] = {17, 15, 16};
+            const double ktile_us[3] = {0.67, 0.70, 1.05};
+            double best = 1e30;
+            for (int c = 0; c < 3; ++c) {
+                if (epi.glu && (bns[c] % 32)) continue;
+                for (int S = 1; S <= 8; S *= 2) {
+                    if (S > 1 && (ws == nullptr || (size_t)S * M * N * sizeof(float) > ws_bytes || epi.glu || (Kp / BK) / S < 8)) break;
+                    const long long blocks = (long long)t224 * ((N + bns[c] - 1) / bns[c]) * S;
+                    const long long rounds = (blocks + 255) / 256;
+                    double us = rounds * (ktile_us[c] * ((Kp / BK + S - 1) / S) + 5.0);
+                    if (S > 1) us += 4.0 + (double)S * M * N * 4.0 / 3.0e6;
+                    else if (epi.norm_w != nullptr && epi.norm_out != nullptr) us += 6.0;   // the norm is its own launch without a reduction to ride on
+                    if (us < best) { best = us; pick = idx[c]; S_forced = S; }
+                }
+            }
+        }
+    }
     {
         static const char* force = getenv("COVER_TILE_PICK");  // experiment knob: index into cands
         if (force && force[0] >= '0' && force[0] <= '9') pick = force[0] - '0';
-        if (force && force[0] >= 'a' && force[0] <= 'd') pick = 10 + (force[0] - 'a');
+        if (force && force[0] >= 'a' && force[0] <= 'h') pick = 10 + (force[0] - 'a');
     }
     if (variant == 2 && pick > 2) pick = 0;
     const Cand cd = cands[pick];
@@ -1692,10 +1847,15 @@ hipError_t launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* Wp, void* C,
     const int tiles_m = (M + bm - 1) / bm, tiles_n = (N + bn - 1) / bn;
     const int nk_total = Kp / BK;
     int S = 1;
-    if (ws != nullptr) {
+    static const char* force_pick = getenv("COVER_TILE_PICK");
+    if (S_forced > 0 && !force_pick) {
+        S = S_forced;
+    } else if (ws != nullptr) {
         while ((long long)tiles_m * tiles_n * S < 192 && S < 8 && nk_total / (S * 2) >= 8 &&
                (size_t)(S * 2) * M * N * sizeof(float) <= ws_bytes)
             S *= 2;
+        static const char* split_env = getenv("COVER_TILE_SPLIT");   // experiment knob: force the number of K slices
+        if (split_env && atoi(split_env) >= 1 && (size_t)atoi(split_env) * M * N * sizeof(float) <= ws_bytes) S = atoi(split_env);
     }
     const int kt_per = (nk_total + S - 1) / S;
     S = (nk_total + kt_per - 1) / kt_per;
@@ -1741,7 +1901,11 @@ hipError_t launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* Wp, void* C,
         else if (pick == 10) { if (nl == 4) LAUNCH_PC(2, 4, 4, 4); else if (nl == 2) LAUNCH_PC(2, 4, 4, 2); else LAUNCH_PC(2, 4, 4, 1); }
         else if (pick == 11) { if (nl == 4) LAUNCH_PC(4, 4, 3, 4); else LAUNCH_PC(4, 4, 3, 1); }
         else if (pick == 12) LAUNCH_PC(4, 4, 3, 4, 4, 2);
-        else LAUNCH_PC(4, 4, 3, 4, 2, 4);
+        else if (pick == 13) LAUNCH_PC(4, 4, 3, 4, 2, 4);
+        else if (pick == 14) LAUNCH_PC(7, 3, 4, 4, 2, 2);
+        else if (pick == 15) LAUNCH_PC(7, 2, 3, 4, 2, 4);
+        else if (pick == 16) LAUNCH_PC(7, 3, 3, 4, 2, 4);
+        else LAUNCH_PC(7, 2, 4, 4, 2, 3);
     } else if (variant == 2) {
         if (pick == 0) LAUNCH_T(4, 4, false, 2, 2, 2);
         else if (pick == 1) LAUNCH_T(2, 4, false, 2, 2, 2);

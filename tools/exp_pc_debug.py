@@ -21,4 +21,4 @@ for K, N in [(4096, 12288), (4096, 22016), (11008, 4096)]:
     torch.cuda.synchronize()
     fn(buf.ctypes.data, 1)
     b = buf.astype(np.float64); kt = b[5]
-    print(f"N={N} K={K} M={M}: per k-tile cycles  loader: wait-data {b[0]/kt:.0f} barrier {b[1]/kt:.0f} issue {b[2]/kt:.0f} | consumer: barrier {b[3]/kt:.0f} total {b[4]/kt:.0f}")
+    print(f"N={N} K={K} M={M}: per k-tile cycles  loader: wait-data {b[0]/kt:.0f} barrier {b[1]/kt:.0f} issue {b[2]/kt:.0f} | consumer: barrier {b[3]/kt:.0f} total {b[4]/kt:.0f} | clock {b[4]/max(b[6],1)*100:.0f} MHz (s_memtime per 100 MHz wall tick)")
