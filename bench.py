@@ -64,7 +64,8 @@ def build_inputs(dev, cfg, n_prompts, n_samples, n_cams=1, seed=0, n_gen=7):
 
 
 class Pipeline:
-    def __init__(self, dev, small=False, n_prompts=N_PROMPTS, n_samples=N_SAMPLES, n_cams=1, members=3, prompt_ids=None):
+    def __init__(self, dev, small=False, n_prompts=N_PROMPTS, n_samples=N_SAMPLES, n_cams=1, members=3, prompt_ids=None,
+                 weight_dtype="bf16", horizon=1):
         """prompt_ids: the global prompt indices this rank owns (strong scaling); None = all n_prompts."""
         from cover_vla_amd import synth
         from cover_vla_amd.openvla import OpenVLA
@@ -78,7 +79,9 @@ class Pipeline:
         P = len(self.prompt_ids)
         wd = torch.bfloat16
         sd = synth.openvla_state(c, seed=1234, nontrivial=False, device=dev, wdtype=wd)
-        self.policy = OpenVLA(sd, c, device=str(dev), max_prompts=P, max_candidates=P * n_samples, max_text=LT, n_cams=n_cams)
+        self.horizon, self.weight_dtype = horizon, weight_dtype
+        self.policy = OpenVLA(sd, c, device=str(dev), max_prompts=P, max_candidates=P * n_samples, max_text=LT, n_cams=n_cams,
+                              horizon=horizon, weight_dtype=weight_dtype)
         del sd
         ssd = synth.siglip2_state(sc, seed=4321, nontrivial=False, device=dev, wdtype=wd)
         if small:
@@ -90,7 +93,7 @@ class Pipeline:
         torch.cuda.empty_cache()
         ck = synth.verifier_checkpoint(members, seed=1234, num_patches=self.enc.num_patches, vision_dim=sc["dim"], text_dim=sc["dim"])
         self.ver = EfficientEnsembleMerged(ck, device=str(dev), encoder=self.enc)
-        g = build_inputs(dev, c, n_prompts, n_samples, n_cams)
+        g = build_inputs(dev, c, n_prompts, n_samples, n_cams, n_gen=7 * horizon)
         ids = torch.tensor(self.prompt_ids, device=dev)
         cand = (ids[:, None] * n_samples + torch.arange(n_samples, device=dev)[None]).reshape(-1)
         self.inp = dict(g, toks=g["toks"][ids].contiguous(), lens=g["lens"][ids].contiguous(), u=g["u"][cand].contiguous())
@@ -161,10 +164,11 @@ class Pipeline:
             its = out["its"]
         # de-tokenise + assemble the verifier histories on the device: no host sync between sampler and verifier
         from cover_vla_amd import ops
-        hb, pad = ops.tokens_to_histories(tokens, self.c["tok_vocab"], self.centers, self.past_dev)
+        hb, pad = ops.tokens_to_histories(tokens, self.c["tok_vocab"], self.centers, self.past_dev, n_use=min(self.horizon, 4))
         if not serial:
             main.wait_stream(self.side)
         r = self.ver.score_histories(its, hb, S, pad=pad)
+        self.last_scores = r["scores"]
         if world > 1:
             # ONE collective: all-gather of [score | 7 tokens] records (RCCL over xGMI; gloo only in plumbing tests), then the
             # same deterministic grouped arg-max on every rank, which thereby also holds the winner's tokens and its prompt
@@ -323,6 +327,9 @@ def main():
     ap.add_argument("--samples", type=int, default=N_SAMPLES, help="samples per prompt (4 = headline N=32; 2 = config 2, N=16)")
     ap.add_argument("--cams", type=int, default=1, help="cameras (2 = config 4)")
     ap.add_argument("--members", type=int, default=3, help="verifier ensemble members (2 = config 4)")
+    ap.add_argument("--no-agreement", action="store_true", help="fp8: skip the comparison run through a bf16 pipeline")
+    ap.add_argument("--dtype", choices=["bf16", "fp8"], default="bf16", help="fp8 = e4m3 decoder + lm_head weights (config 5)")
+    ap.add_argument("--horizon", type=int, default=1, help="action-chunk horizon: 7 x horizon action tokens per candidate (config 5: 8)")
     ap.add_argument("--check-out", default=None, help="write this rank's selection (winner index / tokens) as JSON (plumbing tests)")
     a = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -347,7 +354,8 @@ def main():
     if strong and N_PROMPTS % world:
         raise SystemExit(f"--scaling strong shards the {N_PROMPTS} prompt groups: world size must divide {N_PROMPTS}")
     prompt_ids = list(range(rank, N_PROMPTS, world)) if strong else None
-    pipe = Pipeline(dev, small=a.small, n_samples=a.samples, n_cams=a.cams, members=a.members, prompt_ids=prompt_ids)
+    pipe = Pipeline(dev, small=a.small, n_samples=a.samples, n_cams=a.cams, members=a.members, prompt_ids=prompt_ids,
+                    weight_dtype=a.dtype, horizon=a.horizon)
 
     def sync():
         torch.cuda.synchronize()
@@ -379,20 +387,22 @@ def main():
     n_local = len(pipe.prompt_ids) * a.samples
     n_total = N_PROMPTS * a.samples if (strong or world == 1) else world * n_local
     ms_per_step = 1000.0 * dt / a.steps
-    headline = (a.samples == N_SAMPLES and a.cams == 1 and a.members == 3 and not a.small)
+    headline = (a.samples == N_SAMPLES and a.cams == 1 and a.members == 3 and not a.small and a.dtype == "bf16" and a.horizon == 1)
     metric = BASE_METRIC
     if world > 1 and not strong:
         metric += f" [weak scaling: N=32 per GPU, N={n_total} in total at {world} GPUs]"
     if not headline:
-        metric = f"candidate actions scored/sec (whole node), OpenVLA-7B N={n_total}, 224^2 RGB x {a.cams} camera(s), verifier ensemble={a.members}"
+        metric = (f"candidate actions scored/sec (whole node), OpenVLA-7B N={n_total}, 224^2 RGB x {a.cams} camera(s), verifier ensemble={a.members}, "
+                  f"{a.dtype} weights, action-chunk horizon {a.horizon}")
     out = {
         "metric": metric,
         "value": round(n_total * a.steps / dt, 3), "unit": "candidates/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
-        "dtype": "bf16", "data": "synthetic",
+        "dtype": "bf16" if a.dtype == "bf16" else "fp8 (e4m3 decoder + lm_head weights, per-channel 2^e scales; bf16 activations, KV cache, vision towers)",
+        "data": "synthetic",
         "config": {"workload": ("SMALL-PLUMBING-CONFIG (invalid as a bench line)" if a.small else
                                 f"OpenVLA-7B (DINOv2-L+SigLIP-So400m+Llama-2-7B) N={n_local} = {len(pipe.prompt_ids)} prompts x {a.samples} samples per GPU, "
-                                f"7 action tokens, {a.cams} 224x224 RGB frame(s); CoVer verifier SigLIP2-L/16-384 + {a.members}-member ensemble; "
+                                f"{7 * a.horizon} action tokens, {a.cams} 224x224 RGB frame(s); CoVer verifier SigLIP2-L/16-384 + {a.members}-member ensemble; "
                                 "random-init weights"),
                    "candidates_total": n_total, "candidates_per_gpu": n_local, "prompts_per_gpu": len(pipe.prompt_ids),
                    "parallelism": f"candidate-sharded x{world} ({'strong' if strong else 'weak'})", "lib_sha16": lib_hash()},
@@ -401,6 +411,24 @@ def main():
         # ---- rooflines: kernel start/stop stamps of every GEMM / attention launch of one extra (serialised) decision
         ms, cnt, work = profile_decision(pipe, world, rank, cpu_gather)
         out.update(roofline_objects(ms, cnt, work, ms_per_step, out["config"]["lib_sha16"]))
+    if a.dtype == "fp8" and world == 1 and not a.no_agreement:
+        # what quantisation changes ("report arg-max agreement rate and score RMSE"): the same decision through a bf16
+        # pipeline of the same synthetic checkpoint, same frame / prompts / uniforms
+        gi8, tok8, _ = pipe.decision()
+        sc8 = pipe.last_scores.clone()
+        ref = Pipeline(dev, small=a.small, n_samples=a.samples, n_cams=a.cams, members=a.members, prompt_ids=prompt_ids, weight_dtype="bf16",
+                       horizon=a.horizon)
+        gi16, tok16, _ = ref.decision()
+        sc16 = ref.last_scores
+        dbin = (tok8 - tok16).abs().float()
+        out["fp8_vs_bf16"] = {"token_agreement": round(float((tok8 == tok16).float().mean()), 4), "mean_bin_distance": round(float(dbin.mean()), 3),
+                              "first_token_agreement": round(float((tok8[:, 0] == tok16[:, 0]).float().mean()), 4),
+                              "score_rmse": round(float((sc8 - sc16).pow(2).mean().sqrt()), 5), "winner_same": bool(gi8 == gi16),
+                              "note": "random-init weights: logits are near-flat over the 256 action bins, so sampled picks are maximally "
+                                      "sensitive to quantisation; the e4m3 stream itself is bit-identical to bf16 on the de-quantised weights "
+                                      "(tests/test_fp8_gpu.py)"}
+        del ref
+        torch.cuda.empty_cache()
     if rank == 0 and world == 1 and not a.no_cpu_baseline and not a.small:
         out["cpu_baseline"] = cpu_baseline(pipe)
     if rank == 0:

@@ -31,7 +31,7 @@ class GemmEpi(C.Structure):
     _fields_ = [("bias", c_p), ("residual", c_p), ("layer_scale", c_p), ("ld_residual", c_i), ("residual_f32", c_i),
                 ("act", c_i), ("glu", c_i), ("out_f32", c_i), ("out_scale", c_f),
                 ("norm_w", c_p), ("norm_out", c_p), ("ld_norm_out", c_i), ("norm_style", c_i), ("norm_w_offset", c_f),
-                ("norm_eps", c_f), ("norm_b", c_p)]
+                ("norm_eps", c_f), ("norm_b", c_p), ("w8", c_p), ("w8_scale", c_p)]
 
 
 class KvSegment(C.Structure):
@@ -121,7 +121,9 @@ class VitDesc(C.Structure):
 
 class DecLayer(C.Structure):
     _fields_ = [("in_norm_w", c_p), ("post_norm_w", c_p), ("qkv_w", c_p), ("qkv_b", c_p), ("o_w", c_p),
-                ("gate_up_w", c_p), ("down_w", c_p), ("k_cache", c_p), ("vt_cache", c_p)]
+                ("gate_up_w", c_p), ("down_w", c_p), ("k_cache", c_p), ("vt_cache", c_p),
+                ("qkv_w8", c_p), ("qkv_s", c_p), ("o_w8", c_p), ("o_s", c_p), ("gate_up_w8", c_p), ("gate_up_s", c_p),
+                ("down_w8", c_p), ("down_s", c_p)]
 
 
 class DecDesc(C.Structure):
@@ -161,6 +163,9 @@ SYMBOLS = {
     "cover_packed_weight_bytes": (C.c_size_t, [c_i, c_i]),
     "cover_packed_k": (c_i, [c_i]),
     "cover_pack_weight_bf16": (c_i, [c_p, c_i, c_i, c_i, c_p, c_i, c_p]),
+    "cover_packed_weight_fp8_bytes": (C.c_size_t, [c_i, c_i]),
+    "cover_quantize_rows_fp8": (c_i, [c_p, c_i, c_i, c_i, c_p, c_p, c_p]),
+    "cover_pack_weight_fp8": (c_i, [c_p, c_i, c_p, c_i, c_i, c_p, c_p, c_i, c_p]),
     "cover_gemm_workspace_bytes": (C.c_size_t, [c_i, c_i, c_i]),
     "cover_gemm_bf16": (c_i, [c_p, c_i, c_p, c_p, c_i, c_i, c_i, c_i, _P(GemmEpi), c_p, C.c_size_t, c_i, c_p]),
     "cover_attention_bf16": (c_i, [_P(AttnArgs), c_p]),
@@ -189,6 +194,7 @@ SYMBOLS = {
     "cover_score_select": (c_i, [_P(ScoreSelectArgs), c_p]),
     "cover_group_argmax": (c_i, [c_p, c_i, c_i, c_p, c_p, c_p]),
     "cover_tokens_to_histories": (c_i, [c_p, c_i, c_i, c_i, c_p, c_i, c_p, c_i, c_f, c_p, c_p, c_p]),
+    "cover_tokens_to_histories_steps": (c_i, [c_p, c_i, c_i, c_i, c_p, c_i, c_p, c_i, c_i, c_f, c_p, c_p, c_p]),
     "cover_actions_to_histories": (c_i, [c_p, c_ll, c_ll, c_i, c_i, c_p, c_p, c_i, c_f, c_p, c_p, c_p]),
     "cover_resample_axis": (c_i, [c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_i, c_p]),
     "cover_u8_hwc_to_f32_chw_norm": (c_i, [c_p, c_p, c_i, c_i, _P(c_f), _P(c_f), c_p]),

@@ -49,6 +49,20 @@ int cover_pack_weight_bf16(const void* W, int ldw, int N, int K, void* Wp, int g
            "pack_weight");
     return COVER_OK;
 }
+size_t cover_packed_weight_fp8_bytes(int N, int K) { return (size_t)((N + 15) / 16) * 16 * (size_t)cover_packed_k(K); }
+int cover_quantize_rows_fp8(const void* W, int ldw, int N, int K, float* scales, void* Wdq, void* stream) {
+    if (!W || !scales || !Wdq || N <= 0 || K <= 0) return fail(COVER_EINVAL, "cover_quantize_rows_fp8: bad arguments");
+    HIPCHK(launch_quantize_rows_fp8((const bf16_t*)W, ldw, N, K, scales, (bf16_t*)Wdq, ST(stream)), "quantize_rows_fp8");
+    return COVER_OK;
+}
+int cover_pack_weight_fp8(const void* Wdq, int ldw, const float* scales, int N, int K, void* Wq, float* scales_packed, int glu,
+                          void* stream) {
+    if (!Wdq || !scales || !Wq || !scales_packed || N <= 0 || K <= 0) return fail(COVER_EINVAL, "cover_pack_weight_fp8: bad arguments");
+    if (glu && ((N / 2) % 16 != 0 || (N & 1))) return fail(COVER_EINVAL, "cover_pack_weight_fp8: glu needs N/2 % 16 == 0");
+    HIPCHK(launch_pack_weight_fp8((const bf16_t*)Wdq, ldw, scales, N, K, (uint8_t*)Wq, scales_packed, cover_packed_k(K), glu, ST(stream)),
+           "pack_weight_fp8");
+    return COVER_OK;
+}
 size_t cover_gemm_workspace_bytes(int M, int N, int K) { return gemm_workspace_bytes(M, N, K); }
 int cover_gemm_bf16(const void* A, int lda, const void* Wp, void* C, int ldc, int M, int N, int K,
                     const cover_gemm_epi* epi, void* ws, size_t ws_bytes, int variant, void* stream) {
@@ -191,6 +205,13 @@ int cover_tokens_to_histories(const int64_t* tokens, int ld_tokens, int N, int t
     if (!tokens || !centers || !hist_out || !pad_out || (n_past > 0 && !past)) return fail(COVER_EINVAL, "cover_tokens_to_histories: null pointer");
     HIPCHK(launch_tokens_to_histories(tokens, ld_tokens, N, tok_vocab, centers, n_centers, past, n_past, pad_value, hist_out, pad_out, ST(stream)),
            "tokens_to_histories (0 <= n_past <= 9)");
+    return COVER_OK;
+}
+int cover_tokens_to_histories_steps(const int64_t* tokens, int ld_tokens, int N, int tok_vocab, const float* centers, int n_centers,
+                                    const float* past, int n_past, int n_use, float pad_value, float* hist_out, uint8_t* pad_out, void* stream) {
+    if (!tokens || !centers || !hist_out || !pad_out || (n_past > 0 && !past)) return fail(COVER_EINVAL, "cover_tokens_to_histories_steps: null pointer");
+    HIPCHK(launch_tokens_to_histories(tokens, ld_tokens, N, tok_vocab, centers, n_centers, past, n_past, pad_value, hist_out, pad_out, ST(stream), n_use),
+           "tokens_to_histories_steps (n_use >= 1, n_past + n_use <= 10, ld_tokens >= 7 n_use)");
     return COVER_OK;
 }
 int cover_actions_to_histories(const float* actions, long long n_stride, long long t_stride, int N, int n_use, const float* lo_hi,
@@ -399,10 +420,12 @@ int cover_decoder_forward(const cover_dec_desc* d, const cover_dec_pass* p, void
         memset(&e, 0, sizeof e);
         e.out_scale = 1.0f;
         e.bias = L.qkv_b;
+        e.w8 = L.qkv_w8; e.w8_scale = L.qkv_s;
         // weight-streaming path: leave the split-K partials for rope_kv_write to fold (one launch and one pass less)
         int qkv_splits = 0;
         if (rows <= 64 && p->n_groups == 1 && (variant == 0 || variant == 3))
-            HIPCHK(launch_gemm_skinny_partial((const bf16_t*)h, dim, (const bf16_t*)L.qkv_w, (float*)sk, skb, rows, nqkv, dim, &qkv_splits, st), "dec qkv (partials)");
+            HIPCHK(launch_gemm_skinny_partial((const bf16_t*)h, dim, (const bf16_t*)L.qkv_w, (float*)sk, skb, rows, nqkv, dim, &qkv_splits, st,
+                                              L.qkv_w8, L.qkv_s), "dec qkv (partials)");
         else
             HIPCHK(launch_gemm_bf16((const bf16_t*)h, dim, (const bf16_t*)L.qkv_w, qkv, nqkv, rows, nqkv, dim, &e, (float*)sk, skb, variant, st), "dec qkv");
         cover_rope_args ras[2];
@@ -498,10 +521,12 @@ int cover_decoder_forward(const cover_dec_desc* d, const cover_dec_pass* p, void
         e.residual = first_f32 ? (const void*)p->x_f32 : (const void*)x; e.residual_f32 = first_f32 ? 1 : 0; e.ld_residual = dim;
         e.norm_w = L.post_norm_w; e.norm_out = h; e.ld_norm_out = dim; e.norm_style = d->norm_style;
         e.norm_w_offset = d->norm_w_offset; e.norm_eps = d->norm_eps;
+        e.w8 = L.o_w8; e.w8_scale = L.o_s;
         HIPCHK(launch_gemm_bf16((const bf16_t*)attn, HD, (const bf16_t*)L.o_w, x, dim, rows, dim, HD, &e, (float*)sk, skb, variant, st), "dec o_proj (+post_norm)");
         memset(&e, 0, sizeof e);
         e.out_scale = 1.0f;
         e.act = d->act; e.glu = 1;
+        e.w8 = L.gate_up_w8; e.w8_scale = L.gate_up_s;
         HIPCHK(launch_gemm_bf16((const bf16_t*)h, dim, (const bf16_t*)L.gate_up_w, mlp, d->mlp, rows, 2 * d->mlp, dim, &e, (float*)sk, skb, variant, st), "dec gate_up");
         memset(&e, 0, sizeof e);
         e.out_scale = 1.0f;
@@ -510,6 +535,7 @@ int cover_decoder_forward(const cover_dec_desc* d, const cover_dec_pass* p, void
             e.norm_w = d->layers_host[l + 1].in_norm_w; e.norm_out = h; e.ld_norm_out = dim; e.norm_style = d->norm_style;
             e.norm_w_offset = d->norm_w_offset; e.norm_eps = d->norm_eps;
         }
+        e.w8 = L.down_w8; e.w8_scale = L.down_s;
         HIPCHK(launch_gemm_bf16((const bf16_t*)mlp, d->mlp, (const bf16_t*)L.down_w, x, dim, rows, dim, d->mlp, &e, (float*)sk, skb, variant, st), "dec down (+next in_norm)");
     }
     if (p->final_norm)

@@ -37,6 +37,8 @@ struct EpiDev {
     bf16_t* norm_out;
     int ld_norm_out, norm_style;
     float norm_w_offset, norm_eps;
+    const uint8_t* w8;      // optional e4m3 twin of the weight (cover_pack_weight_fp8) + its packed-order per-channel scales:
+    const float* w8s;       // read by the weight-streaming kernels (M <= 32) instead of the bf16 image, same results
 };
 
 // val[4] are 4 consecutive columns n0..n0+3 of row m: bias / activation / layer-scale / residual / scale, in place.
@@ -729,6 +731,25 @@ __global__ __launch_bounds__(64 * (CGM * CGN + NL)) void gemm_tiled_pc(const bf1
     PCTL(3);
 }
 
+// MFMA weight fragment of 32-deep step u of a 256-deep item: bf16 items hold it as loaded; e4m3 items (16 bytes per lane = the
+// 8-wide k runs of steps 2j and 2j + 1) are converted with v_cvt_scalef32_pk_bf16_fp8 (scale 1: exact, every e4m3 value is a
+// bf16 value)
+template <bool W8, int NLD>
+__device__ __forceinline__ bf16x8 wfrag(const u32x4 (&v)[NLD], int u) {
+    if constexpr (!W8) {
+        return __builtin_bit_cast(bf16x8, v[u]);
+    } else {
+        const u32x4 q = v[u >> 1];
+        const uint32_t lo = (u & 1) ? q.z : q.x, hi = (u & 1) ? q.w : q.y;
+        uint32_t o[4];
+        o[0] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(lo, 1.0f, false));
+        o[1] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(lo, 1.0f, true));
+        o[2] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(hi, 1.0f, false));
+        o[3] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(hi, 1.0f, true));
+        return __builtin_bit_cast(bf16x8, (u32x4){o[0], o[1], o[2], o[3]});
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // Weight-streaming kernel (M <= 64)
 // ---------------------------------------------------------------------------------------------------
@@ -835,9 +856,9 @@ __global__ __launch_bounds__(512) void gemm_skinny(const bf16_t* __restrict__ A,
 // accumulator set per n-block, and the KS slices are summed through LDS at the end. Same parallelism as the first
 // generation with KS-times fewer grid-level K splits => KS-times less fp32 partial traffic for the reduce kernel.
 // ---------------------------------------------------------------------------------------------------
-template <int MF, int KS, int NBW>
+template <int MF, int KS, int NBW, bool W8 = false>
 __global__ __launch_bounds__(512) void gemm_skinny2(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ Wp,
-                                                    float* __restrict__ partial, int M, int N, int Kp) {
+                                                    float* __restrict__ partial, int M, int N, int Kp, const float* __restrict__ wscale) {
     constexpr int NG = 8 / KS, KC = 256 * KS, NBPB = NG * NBW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -856,18 +877,23 @@ __global__ __launch_bounds__(512) void gemm_skinny2(const bf16_t* __restrict__ A
     for (int i = 0; i < NBW; ++i)
 #pragma unroll
         for (int f = 0; f < MF; ++f) acc[i][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    u32x4 buf[2][8];
-    auto load8 = [&](u32x4(&dst)[8], int i) {
+    constexpr int NLD = W8 ? 4 : 8;               // 16-byte loads per lane per 256-deep item (see gemm_skinny3)
+    auto wsrc = [&](int nb, int k) -> const u32x4* {
+        if constexpr (W8) return (const u32x4*)((const uint8_t*)Wp + ((size_t)nb * (Kp >> 6) + (k >> 6)) * 1024) + lane;
+        else return (const u32x4*)(Wp + ((size_t)nb * K32 + (k >> 5)) * 512) + lane;
+    };
+    u32x4 buf[2][NLD];
+    auto load8 = [&](u32x4(&dst)[NLD], int i) {
         int nb = nb_begin + ng + NG * i;
         nb = nb < N16 ? nb : N16 - 1;
-        const u32x4* src = (const u32x4*)(Wp + ((size_t)nb * K32 + ((k0 + kw0) >> 5)) * 512) + lane;
+        const u32x4* src = wsrc(nb, k0 + kw0);
         if (nsteps == 8) {   // whole k-slice: straight-line issue (per-load branches cost ~20 % of the stream rate)
 #pragma unroll
-            for (int u = 0; u < 8; ++u) dst[u] = __builtin_nontemporal_load(src + u * 64);
+            for (int u = 0; u < NLD; ++u) dst[u] = __builtin_nontemporal_load(src + u * 64);
         } else {
 #pragma unroll
-            for (int u = 0; u < 8; ++u)
-                if (u < nsteps) dst[u] = __builtin_nontemporal_load(src + u * 64);
+            for (int u = 0; u < NLD; ++u)
+                if (u * (8 / NLD) < nsteps) dst[u] = __builtin_nontemporal_load(src + u * 64);
         }
     };
     constexpr int NFR = (KC / 32) * MF;
@@ -890,9 +916,9 @@ __global__ __launch_bounds__(512) void gemm_skinny2(const bf16_t* __restrict__ A
         for (int i = 0; i < 2; ++i) {
             int nb = nb_begin + ng + NG * i;
             nb = nb < N16 ? nb : N16 - 1;
-            const u32x4* src = (const u32x4*)(Wp + ((size_t)nb * K32 + ((k0 + kw0) >> 5)) * 512) + lane;
+            const u32x4* src = wsrc(nb, k0 + kw0);
 #pragma unroll
-            for (int u = 0; u < 8; ++u) buf[i][u] = __builtin_nontemporal_load(src + u * 64);
+            for (int u = 0; u < NLD; ++u) buf[i][u] = __builtin_nontemporal_load(src + u * 64);
         }
 #pragma unroll
         for (int j = 0; j < XL; ++j) *(uint4*)(smem + (j * 8 + w) * 1024 + lane * 16) = xr[j];
@@ -903,7 +929,7 @@ __global__ __launch_bounds__(512) void gemm_skinny2(const bf16_t* __restrict__ A
         for (int i = 0; i < NBW; ++i) {
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const bf16x8 wf = __builtin_bit_cast(bf16x8, buf[i & 1][u]);
+                const bf16x8 wf = wfrag<W8>(buf[i & 1], u);
                 const int kst = (kw0 >> 5) + u;
 #pragma unroll
                 for (int f = 0; f < MF; ++f) {
@@ -915,9 +941,9 @@ __global__ __launch_bounds__(512) void gemm_skinny2(const bf16_t* __restrict__ A
             if (i + 2 < NBW) {
                 int nb = nb_begin + ng + NG * (i + 2);
                 nb = nb < N16 ? nb : N16 - 1;
-                const u32x4* src = (const u32x4*)(Wp + ((size_t)nb * K32 + ((k0 + kw0) >> 5)) * 512) + lane;
+                const u32x4* src = wsrc(nb, k0 + kw0);
 #pragma unroll
-                for (int u = 0; u < 8; ++u) buf[i & 1][u] = __builtin_nontemporal_load(src + u * 64);
+                for (int u = 0; u < NLD; ++u) buf[i & 1][u] = __builtin_nontemporal_load(src + u * 64);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -939,9 +965,9 @@ __global__ __launch_bounds__(512) void gemm_skinny2(const bf16_t* __restrict__ A
         }
         __syncthreads();
     }
-    auto comp8 = [&](u32x4(&src)[8], f32x4(&a)[MF]) {
+    auto comp8 = [&](u32x4(&src)[NLD], f32x4(&a)[MF]) {
         auto step = [&](int u) {
-            const bf16x8 wf = __builtin_bit_cast(bf16x8, src[u]);
+            const bf16x8 wf = wfrag<W8>(src, u);
             const int kst = (kw0 >> 5) + u;
 #pragma unroll
             for (int f = 0; f < MF; ++f) {
@@ -994,6 +1020,10 @@ __global__ __launch_bounds__(512) void gemm_skinny2(const bf16_t* __restrict__ A
                 for (int e = 0; e < 4; ++e) v[e] += red[(((ww * RB + ii) * MF + f) * 4 + e) * 64 + lane];
             }
             const int m = f * 16 + r, n = nb * 16 + 4 * g;
+            if constexpr (W8) {   // per-channel power-of-two scale (packed channel order): exact in fp32, commutes with the slab sum
+                const float4 sc = *(const float4*)(wscale + (size_t)(nb < N16 ? nb : N16 - 1) * 16 + 4 * g);
+                v[0] *= sc.x; v[1] *= sc.y; v[2] *= sc.z; v[3] *= sc.w;
+            }
             if (nb < N16 && m < M && n < N) {
                 float* o = partial + ((size_t)s * M + m) * N + n;
                 if (n + 3 < N && ((((uintptr_t)o) & 15) == 0)) {
@@ -1026,10 +1056,10 @@ extern "C" int cover_sk_debug(unsigned long long* out) {
 #else
 #define SKT(slot) do { } while (0)
 #endif
-template <int MF, int KS, int NBW, int NBUF>
+template <int MF, int KS, int NBW, int NBUF, bool W8 = false>
 __global__ __launch_bounds__(512) void gemm_skinny3(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ Wp,
                                                     void* C, int ldc, int M, int N, int Kp, EpiDev epi,
-                                                    float* __restrict__ partial, int kper) {
+                                                    float* __restrict__ partial, int kper, const float* __restrict__ wscale) {
     SKT(0);
     constexpr int NG = 8 / KS, KC = 256 * KS, NBPB = NG * NBW;
     constexpr int XB = MF * 16 * KC * 2;          // bytes of one activation chunk (fragment-major)
@@ -1056,20 +1086,28 @@ __global__ __launch_bounds__(512) void gemm_skinny3(const bf16_t* __restrict__ A
     // weight stream: item t = (chunk c = t / NBW, n-block i = t % NBW) -> 8 x 1 KiB (this wave's 256 k of that chunk)
     const int items = nchunks * NBW;
     auto steps_of = [&](int c) { return max(0, min(8, (min(KC, ke - kb - c * KC) - kw0) >> 5)); };
-    u32x4 buf[NBUF][8];
-    auto load8 = [&](u32x4(&dst)[8], int t) {
+    // W8: e4m3 weights (cover_pack_weight_fp8: 1 KiB per 16 n x 64 k block, a lane's 16 bytes = its 8-wide k runs of two
+    // consecutive 32-deep steps): half the bytes per item, de-quantised to bf16 fragments in registers (exact), the
+    // power-of-two per-channel scale applied to the fp32 sums after the k-slice reduction (exact)
+    constexpr int NLD = W8 ? 4 : 8;               // 16-byte loads per lane per 256-deep item
+    auto wsrc = [&](int nb, int k) -> const u32x4* {
+        if constexpr (W8) return (const u32x4*)((const uint8_t*)Wp + ((size_t)nb * (Kp >> 6) + (k >> 6)) * 1024) + lane;
+        else return (const u32x4*)(Wp + ((size_t)nb * K32 + (k >> 5)) * 512) + lane;
+    };
+    u32x4 buf[NBUF][NLD];
+    auto load8 = [&](u32x4(&dst)[NLD], int t) {
         const int c = t / NBW, i = t - c * NBW;
         int nb = nb_begin + ng + NG * i;
         nb = nb < N16 ? nb : N16 - 1;
         const int nst = steps_of(c);
-        const u32x4* src = (const u32x4*)(Wp + ((size_t)nb * K32 + ((kb + c * KC + kw0) >> 5)) * 512) + lane;
+        const u32x4* src = wsrc(nb, kb + c * KC + kw0);
         if (nst == 8) {   // whole k-slice (every chunk but a ragged last one): straight-line issue
 #pragma unroll
-            for (int u = 0; u < 8; ++u) dst[u] = __builtin_nontemporal_load(src + u * 64);
+            for (int u = 0; u < NLD; ++u) dst[u] = __builtin_nontemporal_load(src + u * 64);
         } else {
 #pragma unroll
-            for (int u = 0; u < 8; ++u)
-                if (u < nst) dst[u] = __builtin_nontemporal_load(src + u * 64);
+            for (int u = 0; u < NLD; ++u)
+                if (u * (8 / NLD) < nst) dst[u] = __builtin_nontemporal_load(src + u * 64);
         }
     };
     // activation chunk staging through registers: wave w moves fragments fi = j*8 + w (fi = kst*MF + f); lane
@@ -1093,11 +1131,11 @@ __global__ __launch_bounds__(512) void gemm_skinny3(const bf16_t* __restrict__ A
 #pragma unroll
         for (int j = 0; j < XL; ++j) *(uint4*)(smem + b * XB + (j * 8 + w) * 1024 + lane * 16) = xr[j];
     };
-    auto comp8 = [&](u32x4(&src)[8], f32x4(&a)[MF], int c) {
+    auto comp8 = [&](u32x4(&src)[NLD], f32x4(&a)[MF], int c) {
         const int nst = steps_of(c);
         const char* xb = smem + (c & 1) * XB;
         auto step = [&](int u) {
-            const bf16x8 wf = __builtin_bit_cast(bf16x8, src[u]);
+            const bf16x8 wf = wfrag<W8>(src, u);
             const int kst = (kw0 >> 5) + u;
 #pragma unroll
             for (int f = 0; f < MF; ++f) {
@@ -1132,9 +1170,9 @@ __global__ __launch_bounds__(512) void gemm_skinny3(const bf16_t* __restrict__ A
         for (int b = 0; b < NBUF; ++b) {
             int nb = nb_begin + ng + NG * b;
             nb = nb < N16 ? nb : N16 - 1;
-            const u32x4* src = (const u32x4*)(Wp + ((size_t)nb * K32 + ((kb + kw0) >> 5)) * 512) + lane;
+            const u32x4* src = wsrc(nb, kb + kw0);
 #pragma unroll
-            for (int u = 0; u < 8; ++u) buf[b][u] = __builtin_nontemporal_load(src + u * 64);
+            for (int u = 0; u < NLD; ++u) buf[b][u] = __builtin_nontemporal_load(src + u * 64);
         }
         x_write(0);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // LDS-only: the weight items stay in flight
@@ -1170,7 +1208,7 @@ __global__ __launch_bounds__(512) void gemm_skinny3(const bf16_t* __restrict__ A
             for (int i = 0; i < NBW; ++i) {
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
-                    const bf16x8 wf = __builtin_bit_cast(bf16x8, buf[i % NBUF][u]);
+                    const bf16x8 wf = wfrag<W8>(buf[i % NBUF], u);
                     const int kst = (kw0 >> 5) + u;
 #pragma unroll
                     for (int f = 0; f < MF; ++f) {
@@ -1180,10 +1218,10 @@ __global__ __launch_bounds__(512) void gemm_skinny3(const bf16_t* __restrict__ A
                 }
                 int nb = nb_begin + ng + NG * i;
                 nb = nb < N16 ? nb : N16 - 1;
-                const u32x4* src = (const u32x4*)(Wp + ((size_t)nb * K32 + ((k1 + kw0) >> 5)) * 512) + lane;
+                const u32x4* src = wsrc(nb, k1 + kw0);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int u = 0; u < 8; ++u) buf[i % NBUF][u] = __builtin_nontemporal_load(src + u * 64);
+                for (int u = 0; u < NLD; ++u) buf[i % NBUF][u] = __builtin_nontemporal_load(src + u * 64);
                 __builtin_amdgcn_sched_barrier(0);
             }
             x_write((c0 + 1) & 1);
@@ -1195,7 +1233,7 @@ __global__ __launch_bounds__(512) void gemm_skinny3(const bf16_t* __restrict__ A
             for (int i = 0; i < NBW; ++i) {
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
-                    const bf16x8 wf = __builtin_bit_cast(bf16x8, buf[i % NBUF][u]);
+                    const bf16x8 wf = wfrag<W8>(buf[i % NBUF], u);
                     const int kst = (kw0 >> 5) + u;
 #pragma unroll
                     for (int f = 0; f < MF; ++f) {
@@ -1251,6 +1289,11 @@ __global__ __launch_bounds__(512) void gemm_skinny3(const bf16_t* __restrict__ A
                 const int ww = gsel * KS + kk;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] += red[(((ww * RB + ii) * MF + f) * 4 + e) * 64 + lane];
+            }
+            if constexpr (W8) {   // per-channel power-of-two scale (packed channel order): exact in fp32
+                const int nbs = nb_begin + gsel + NG * (i0 + ii);
+                const float4 sc = *(const float4*)(wscale + (size_t)(nbs < N16 ? nbs : N16 - 1) * 16 + 4 * g);
+                v[0] *= sc.x; v[1] *= sc.y; v[2] *= sc.z; v[3] *= sc.w;
             }
         };
         if (partial) {   // split-K slice: raw sums, the epilogue belongs to whoever folds the slabs
@@ -1503,6 +1546,9 @@ static EpiDev make_epi(const cover_gemm_epi* e) {
     d.norm_style = e ? e->norm_style : 0;
     d.norm_w_offset = e ? e->norm_w_offset : 0.f;
     d.norm_eps = e ? e->norm_eps : 0.f;
+    d.w8 = e ? (const uint8_t*)e->w8 : nullptr;
+    d.w8s = e ? e->w8_scale : nullptr;
+    if (!d.w8 || !d.w8s) { d.w8 = nullptr; d.w8s = nullptr; }
     return d;
 }
 
@@ -1636,22 +1682,45 @@ size_t gemm_workspace_bytes(int M, int N, int K) {
     return ab > c ? ab : c;
 }
 
+// second-generation weight streaming; e4m3 weights for M <= 32 when a twin is given
+static void launch_skinny2(const Skinny2Plan& p, const bf16_t* A, int lda, const bf16_t* Wp, float* ws, int M, int N, int K, int Kp,
+                           const uint8_t* w8, const float* w8s, hipStream_t st) {
+    dim3 grid(p.gx, p.S), block(512);
+#define SK2(MF_, KS_, NBW_, W8_) launch_streaming(sk_class(N, K), (W8_ ? 1.0 : 2.0) * (double)N * (double)K, gemm_skinny2<MF_, KS_, NBW_, W8_>, grid, block, p.lds, st, A, lda, W8_ ? (const bf16_t*)w8 : Wp, ws, M, N, Kp, w8s)
+    if (w8 && w8s && p.MF <= 2) {
+        if (p.MF == 1) { if (p.NBW == 6) SK2(1, 4, 6, true); else if (p.NBW == 4) SK2(1, 4, 4, true); else if (p.NBW == 3) SK2(1, 4, 3, true); else SK2(1, 4, 2, true); }
+        else { if (p.NBW == 6) SK2(2, 4, 6, true); else if (p.NBW == 4) SK2(2, 4, 4, true); else if (p.NBW == 3) SK2(2, 4, 3, true); else SK2(2, 4, 2, true); }
+    } else {
+        if (p.MF == 1) { if (p.NBW == 6) SK2(1, 4, 6, false); else if (p.NBW == 4) SK2(1, 4, 4, false); else if (p.NBW == 3) SK2(1, 4, 3, false); else SK2(1, 4, 2, false); }
+        else if (p.MF == 2) { if (p.NBW == 6) SK2(2, 4, 6, false); else if (p.NBW == 4) SK2(2, 4, 4, false); else if (p.NBW == 3) SK2(2, 4, 3, false); else SK2(2, 4, 2, false); }
+        else if (p.MF == 3) SK2(3, 2, 2, false);
+        else SK2(4, 2, 2, false);
+    }
+#undef SK2
+}
+
 static hipError_t launch_skinny3(const Skinny3Plan& p, const bf16_t* A, int lda, const bf16_t* Wp, void* C, int ldc, int M, int N,
                                  int Kp, const EpiDev& epi, float* partial, hipStream_t st) {
     hipError_t e = hipSuccess;
     dim3 grid(p.gx, p.S), block(512);
-#define SK3(MF_, NBW_)                                                                                                       \
+#define SK3(MF_, NBW_, W8_)                                                                                                  \
     do {                                                                                                                    \
-        auto kfn = gemm_skinny3<MF_, 4, NBW_, NBW_>;                                                                        \
+        auto kfn = gemm_skinny3<MF_, 4, NBW_, NBW_, W8_>;                                                                   \
         if (p.lds > 64 * 1024) {                                                                                            \
             static hipError_t attr = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
             e = attr;                                                                                                       \
         }                                                                                                                   \
         if (e == hipSuccess)                                                                                                \
-            launch_streaming(sk_class(N, Kp), 2.0 * (double)N * (double)Kp, kfn, grid, block, p.lds, st, A, lda, Wp, C, ldc, M, N, Kp, epi, partial, p.kper); \
+            launch_streaming(sk_class(N, Kp), (W8_ ? 1.0 : 2.0) * (double)N * (double)Kp, kfn, grid, block, p.lds, st, A, lda,  \
+                             W8_ ? (const bf16_t*)epi.w8 : Wp, C, ldc, M, N, Kp, epi, partial, p.kper, epi.w8s);             \
     } while (0)
-    if (p.MF == 1) { if (p.NBW == 4) SK3(1, 4); else if (p.NBW == 3) SK3(1, 3); else SK3(1, 2); }
-    else { if (p.NBW == 4) SK3(2, 4); else if (p.NBW == 3) SK3(2, 3); else SK3(2, 2); }
+    if (epi.w8) {   // e4m3 weight stream
+        if (p.MF == 1) { if (p.NBW == 4) SK3(1, 4, true); else if (p.NBW == 3) SK3(1, 3, true); else SK3(1, 2, true); }
+        else { if (p.NBW == 4) SK3(2, 4, true); else if (p.NBW == 3) SK3(2, 3, true); else SK3(2, 2, true); }
+    } else {
+        if (p.MF == 1) { if (p.NBW == 4) SK3(1, 4, false); else if (p.NBW == 3) SK3(1, 3, false); else SK3(1, 2, false); }
+        else { if (p.NBW == 4) SK3(2, 4, false); else if (p.NBW == 3) SK3(2, 3, false); else SK3(2, 2, false); }
+    }
 #undef SK3
     if (e == hipSuccess) e = hipGetLastError();
     return e;
@@ -1703,12 +1772,7 @@ hipError_t launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* Wp, void* C,
             Skinny2Plan p = plan_skinny2(M, N, Kp);
             if (ws == nullptr || ws_bytes < p.ws_bytes) return hipErrorInvalidValue;
             dim3 grid(p.gx, p.S), block(512);
-#define SK2(MF_, KS_, NBW_) launch_streaming(sk_class(N, K), 2.0 * (double)N * (double)K, gemm_skinny2<MF_, KS_, NBW_>, grid, block, p.lds, st, A, lda, Wp, ws, M, N, Kp)
-            if (p.MF == 1) { if (p.NBW == 6) SK2(1, 4, 6); else if (p.NBW == 4) SK2(1, 4, 4); else if (p.NBW == 3) SK2(1, 4, 3); else SK2(1, 4, 2); }
-            else if (p.MF == 2) { if (p.NBW == 6) SK2(2, 4, 6); else if (p.NBW == 4) SK2(2, 4, 4); else if (p.NBW == 3) SK2(2, 4, 3); else SK2(2, 4, 2); }
-            else if (p.MF == 3) SK2(3, 2, 2);
-            else SK2(4, 2, 2);
-#undef SK2
+            launch_skinny2(p, A, lda, Wp, ws, M, N, K, Kp, epi.w8, epi.w8s, st);
             S = p.S;
         }
         hipError_t e = hipGetLastError();
@@ -1948,7 +2012,7 @@ hipError_t launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* Wp, void* C,
 // Weight-streaming GEMM WITHOUT its reduction: leaves fp32 partials [S][M][N] in ws for a consumer that folds them
 // (the decoder fuses the QKV reduction into rope_kv_write). Returns the number of K slices through *S_out.
 hipError_t launch_gemm_skinny_partial(const bf16_t* A, int lda, const bf16_t* Wp, float* ws, size_t ws_bytes, int M, int N,
-                                      int K, int* S_out, hipStream_t st) {
+                                      int K, int* S_out, hipStream_t st, const void* w8, const float* w8s) {
     if (M <= 0 || M > 64 || N <= 0) return hipErrorInvalidValue;
     const int Kp = (K + 127) / 128 * 128;
     {
@@ -1957,6 +2021,7 @@ hipError_t launch_gemm_skinny_partial(const bf16_t* A, int lda, const bf16_t* Wp
         const size_t need = (size_t)p3.S * M * N * sizeof(float);
         if (p3.ok && !(g3 && g3[0] == '0') && ws != nullptr && ws_bytes >= need) {
             EpiDev none = make_epi(nullptr);
+            if (w8 && w8s) { none.w8 = (const uint8_t*)w8; none.w8s = w8s; }
             hipError_t e = launch_skinny3(p3, A, lda, Wp, nullptr, 0, M, N, Kp, none, ws, st);
             *S_out = p3.S;
             return e;
@@ -1965,13 +2030,93 @@ hipError_t launch_gemm_skinny_partial(const bf16_t* A, int lda, const bf16_t* Wp
     Skinny2Plan p = plan_skinny2(M, N, Kp);
     if (ws == nullptr || ws_bytes < p.ws_bytes) return hipErrorInvalidValue;
     dim3 grid(p.gx, p.S), block(512);
-#define SK2(MF_, KS_, NBW_) launch_streaming(sk_class(N, K), 2.0 * (double)N * (double)K, gemm_skinny2<MF_, KS_, NBW_>, grid, block, p.lds, st, A, lda, Wp, ws, M, N, Kp)
-    if (p.MF == 1) { if (p.NBW == 6) SK2(1, 4, 6); else if (p.NBW == 4) SK2(1, 4, 4); else if (p.NBW == 3) SK2(1, 4, 3); else SK2(1, 4, 2); }
-    else if (p.MF == 2) { if (p.NBW == 6) SK2(2, 4, 6); else if (p.NBW == 4) SK2(2, 4, 4); else if (p.NBW == 3) SK2(2, 4, 3); else SK2(2, 4, 2); }
-    else if (p.MF == 3) SK2(3, 2, 2);
-    else SK2(4, 2, 2);
-#undef SK2
+    launch_skinny2(p, A, lda, Wp, ws, M, N, K, Kp, (const uint8_t*)w8, w8s, st);
     *S_out = p.S;
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// e4m3 weights (BASELINE config 5). Per OUTPUT CHANNEL scale s_n = the smallest power of two with max_k |W[n,k]| / s_n <= 448
+// (the e4m3 maximum); q = RNE_e4m3(W / s_n). A power-of-two scale makes (a) the division exact, (b) s_n * q exactly
+// representable in bf16 (3 mantissa bits of e4m3 inside bf16's 7) -- so the SAME quantised weight exists as an e4m3 image for
+// the HBM-bound weight-streaming kernels (half the bytes) and as a bf16 image for the MFMA-bound tiled kernels, and both
+// give bit-identical GEMM results (products and sums just scale by 2^e).
+//   quantize_rows_fp8_k : W bf16 [N, ldw] -> scales[N] fp32, Wdq bf16 [N, ldw] (= s_n * q, the de-quantised twin)
+//   pack_weight_fp8_k   : Wdq + scales -> packed e4m3 image [n/16][k/64][lane = n%16 + 16*((k%32)/8)][16 B = the lane's 8-wide k run
+//                         of the two 32-deep steps of the 64-block] and the scales in PACKED channel order
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void quantize_rows_fp8_k(const bf16_t* __restrict__ W, int ldw, int K, float* __restrict__ scales,
+                                                           bf16_t* __restrict__ Wdq) {
+    __shared__ float red[16];
+    const int n = blockIdx.x;
+    const bf16_t* w = W + (size_t)n * ldw;
+    float mx = 0.f;
+    for (int k = threadIdx.x; k < K; k += blockDim.x) mx = fmaxf(mx, fabsf(bf2f(w[k])));
+    mx = block_max(mx, red);
+    // smallest power of two s with mx / s <= 448: s = 2^ceil(log2(mx / 448)); frexp gives mx / 448 = f * 2^e with f in [0.5, 1)
+    float s = 1.0f;
+    if (mx > 0.f) {
+        int e;
+        const float f = frexpf(mx / 448.0f, &e);
+        s = ldexpf(1.0f, f == 0.5f ? e - 1 : e);
+    }
+    if (threadIdx.x == 0) scales[n] = s;
+    const float inv = 1.0f / s;   // exact (power of two)
+    for (int k = threadIdx.x; k < K; k += blockDim.x) {
+        const float x = bf2f(w[k]) * inv;
+        const int pk = __builtin_amdgcn_cvt_pk_fp8_f32(x, 0.0f, 0, false);      // RNE to OCP e4m3 (gfx950)
+        const f32x2_t back = __builtin_amdgcn_cvt_pk_f32_fp8((uint32_t)pk, false);
+        Wdq[(size_t)n * ldw + k] = f2bf(back[0] * s);                           // exact: e4m3 value times a power of two
+    }
+}
+
+__global__ void pack_weight_fp8_k(const bf16_t* __restrict__ Wdq, int ldw, const float* __restrict__ scales, int N, int K,
+                                  uint8_t* __restrict__ Wq, float* __restrict__ scales_packed, int Kp, int glu) {
+    const int K64 = Kp >> 6;
+    const int N16 = (N + 15) >> 4;
+    const long long total = (long long)N16 * K64 * 64;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const int lane = (int)(idx & 63);
+        const long long blk = idx >> 6;
+        const int kb = (int)(blk % K64);
+        const int nb = (int)(blk / K64);
+        int n = nb * 16 + (lane & 15);
+        if (glu) {  // packed block 2i = gate rows [16i,16i+16), block 2i+1 = up rows N/2 + [16i,16i+16)  (as pack_weight)
+            const int half = N >> 1, i = nb >> 1;
+            n = ((nb & 1) ? half : 0) + i * 16 + (lane & 15);
+            if (i * 16 + (lane & 15) >= half) n = N;
+        }
+        const float s = n < N ? scales[n] : 1.0f, inv = 1.0f / s;
+        if (kb == 0 && (lane >> 4) == 0) scales_packed[nb * 16 + (lane & 15)] = s;
+        uint32_t o[4];
+#pragma unroll
+        for (int half_ = 0; half_ < 2; ++half_) {      // k32 step 0 / 1 of the 64-block
+            const int k = kb * 64 + half_ * 32 + (lane >> 4) * 8;
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (n < N && k + e < K) ? bf2f(Wdq[(size_t)n * ldw + k + e]) * inv : 0.f;
+            int lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], 0, false);
+            lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], lo, true);
+            int hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[4], v[5], 0, false);
+            hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[6], v[7], hi, true);
+            o[2 * half_] = (uint32_t)lo;
+            o[2 * half_ + 1] = (uint32_t)hi;
+        }
+        *(uint4*)(Wq + idx * 16) = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+hipError_t launch_quantize_rows_fp8(const bf16_t* W, int ldw, int N, int K, float* scales, bf16_t* Wdq, hipStream_t st) {
+    if (N <= 0) return hipSuccess;
+    hipLaunchKernelGGL(quantize_rows_fp8_k, dim3(N), dim3(256), 0, st, W, ldw, K, scales, Wdq);
+    return hipGetLastError();
+}
+hipError_t launch_pack_weight_fp8(const bf16_t* Wdq, int ldw, const float* scales, int N, int K, uint8_t* Wq, float* scales_packed,
+                                  int Kpad, int glu, hipStream_t st) {
+    const long long total = (long long)((N + 15) / 16) * (Kpad / 64) * 64;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 65535) blocks = 65535;
+    hipLaunchKernelGGL(pack_weight_fp8_k, dim3(blocks), dim3(256), 0, st, Wdq, ldw, scales, N, K, Wq, scales_packed, Kpad, glu);
     return hipGetLastError();
 }
 

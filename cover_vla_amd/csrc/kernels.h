@@ -13,7 +13,10 @@ hipError_t launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* Wp, void* C,
                             const cover_gemm_epi* epi, float* splitk_ws, size_t splitk_ws_bytes, int variant,
                             hipStream_t st);
 hipError_t launch_gemm_skinny_partial(const bf16_t* A, int lda, const bf16_t* Wp, float* ws, size_t ws_bytes, int M, int N,
-                                      int K, int* S_out, hipStream_t st);
+                                      int K, int* S_out, hipStream_t st, const void* w8 = nullptr, const float* w8s = nullptr);
+hipError_t launch_quantize_rows_fp8(const bf16_t* W, int ldw, int N, int K, float* scales, bf16_t* Wdq, hipStream_t st);
+hipError_t launch_pack_weight_fp8(const bf16_t* Wdq, int ldw, const float* scales, int N, int K, uint8_t* Wq, float* scales_packed,
+                                  int Kpad, int glu, hipStream_t st);
 hipError_t launch_pack_weight_bf16(const bf16_t* W, int ldw, int N, int K, bf16_t* Wp, int Kpad, int glu_interleave,
                                    hipStream_t st);
 
@@ -59,7 +62,7 @@ hipError_t launch_token_select(const cover_token_select_args* a, hipStream_t st)
 hipError_t launch_score_select(const cover_score_select_args* a, hipStream_t st);
 hipError_t launch_tokens_to_histories(const int64_t* tokens, int ld_tokens, int N, int tok_vocab, const float* centers,
                                       int n_centers, const float* past, int n_past, float pad_value, float* hist, uint8_t* pad,
-                                      hipStream_t st);
+                                      hipStream_t st, int n_use = 1);
 hipError_t launch_actions_to_histories(const float* actions, long long n_stride, long long t_stride, int N, int n_use,
                                        const float* lo_hi, const float* past, int n_past, float pad_value, float* hist,
                                        uint8_t* pad, hipStream_t st);

@@ -194,22 +194,23 @@ hipError_t launch_group_argmax(const float* scores, int N, int gs, int* result, 
 // ---------------------------------------------------------------------------------------------------
 __global__ void tokens_to_histories_k(const int64_t* __restrict__ tokens, int ld_tokens, int N, int tok_vocab,
                                       const float* __restrict__ centers, int n_centers, const float* __restrict__ past,
-                                      int n_past, float pad_value, float* __restrict__ hist, uint8_t* __restrict__ pad) {
+                                      int n_past, int n_use, float pad_value, float* __restrict__ hist, uint8_t* __restrict__ pad) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= N * 10) return;
     const int n = idx / 10, t = idx - n * 10;
-    const int n_pad = 10 - n_past - 1;
+    const int n_pad = 10 - n_past - n_use;
     float* o = hist + (size_t)idx * 7;
     if (t < n_pad) {
         for (int d = 0; d < 7; ++d) o[d] = pad_value;
         pad[idx] = 1;
-    } else if (t < 9) {
+    } else if (t < n_pad + n_past) {
         const float* p = past + (size_t)(t - n_pad) * 7;
         for (int d = 0; d < 7; ++d) o[d] = p[d];
         pad[idx] = 0;
     } else {
+        const int step = t - n_pad - n_past;          // the step-th 7-token action of the candidate's chunk (action-chunk horizon > 1)
         for (int d = 0; d < 7; ++d) {
-            long long b = (long long)tok_vocab - tokens[(size_t)n * ld_tokens + d] - 1;
+            long long b = (long long)tok_vocab - tokens[(size_t)n * ld_tokens + step * 7 + d] - 1;
             b = b < 0 ? 0 : (b > n_centers - 1 ? n_centers - 1 : b);
             float a = centers[b];
             if (d == 6) a = a < 0.5f ? 0.f : 1.f;
@@ -220,11 +221,11 @@ __global__ void tokens_to_histories_k(const int64_t* __restrict__ tokens, int ld
 }
 hipError_t launch_tokens_to_histories(const int64_t* tokens, int ld_tokens, int N, int tok_vocab, const float* centers,
                                       int n_centers, const float* past, int n_past, float pad_value, float* hist, uint8_t* pad,
-                                      hipStream_t st) {
+                                      hipStream_t st, int n_use) {
     if (N <= 0) return hipSuccess;
-    if (n_past < 0 || n_past > 9) return hipErrorInvalidValue;
+    if (n_past < 0 || n_use < 1 || n_past + n_use > 10 || ld_tokens < 7 * n_use) return hipErrorInvalidValue;
     hipLaunchKernelGGL(tokens_to_histories_k, dim3((N * 10 + 255) / 256), dim3(256), 0, st, tokens, ld_tokens, N, tok_vocab,
-                       centers, n_centers, past, n_past, pad_value, hist, pad);
+                       centers, n_centers, past, n_past, n_use, pad_value, hist, pad);
     return hipGetLastError();
 }
 

@@ -202,7 +202,8 @@ class Decoder:
     Replaces the layer loop of paligemma_with_expert.py:258-360 (and HF LlamaModel for the OpenVLA profile)."""
 
     def __init__(self, sd, *, dim, layers, Hq, Hkv, D, mlp, act, norm, eps, rope, n_pos=1024, device="cuda:0",
-                 cache: Optional[KvGeometry] = None, share_cache_with: Optional["Decoder"] = None, final_norm_bf16=True):
+                 cache: Optional[KvGeometry] = None, share_cache_with: Optional["Decoder"] = None, final_norm_bf16=True,
+                 fp8_weights=False):
         """final_norm_bf16: the stack's final norm weight is a bf16 parameter in the reference (PaliGemma's language model, HF
         bf16 Llama) -- False for the pi0 action expert, whose final norm is outside the name filter of
         to_bfloat16_like_physical_intelligence (paligemma_with_expert.py:219-227) and stays fp32. Layer norms are bf16 in all."""
@@ -222,10 +223,11 @@ class Decoder:
         for i in range(layers):
             p = f"layers.{i}."
             wqkv = torch.cat([sd[p + f"self_attn.{n}_proj.weight"] for n in ("q", "k", "v")], 0)
-            qkv = ops.pack_linear(wqkv.to(dev))
-            o = ops.pack_linear(sd[p + "self_attn.o_proj.weight"].to(dev))
-            gu = ops.pack_linear(torch.cat([sd[p + "mlp.gate_proj.weight"], sd[p + "mlp.up_proj.weight"]], 0).to(dev), glu=True)
-            down = ops.pack_linear(sd[p + "mlp.down_proj.weight"].to(dev))
+            qkv = ops.pack_linear(wqkv.to(dev), fp8=fp8_weights)
+            o = ops.pack_linear(sd[p + "self_attn.o_proj.weight"].to(dev), fp8=fp8_weights)
+            gu = ops.pack_linear(torch.cat([sd[p + "mlp.gate_proj.weight"], sd[p + "mlp.up_proj.weight"]], 0).to(dev), glu=True,
+                                 fp8=fp8_weights)
+            down = ops.pack_linear(sd[p + "mlp.down_proj.weight"].to(dev), fp8=fp8_weights)
             n1 = _bf_f32(sd[p + "input_layernorm.weight"], dev)
             n2 = _bf_f32(sd[p + "post_attention_layernorm.weight"], dev)
             self._keep += [qkv, o, gu, down, n1, n2]
@@ -234,7 +236,12 @@ class Decoder:
             a.qkv_w, a.qkv_b = qkv.wp.data_ptr(), None
             a.o_w, a.gate_up_w, a.down_w = o.wp.data_ptr(), gu.wp.data_ptr(), down.wp.data_ptr()
             a.k_cache, a.vt_cache = self.k_cache[i].data_ptr(), self.vt_cache[i].data_ptr()
+            if fp8_weights:
+                a.qkv_w8, a.qkv_s, a.o_w8, a.o_s = qkv.w8.data_ptr(), qkv.w8s.data_ptr(), o.w8.data_ptr(), o.w8s.data_ptr()
+                a.gate_up_w8, a.gate_up_s = gu.w8.data_ptr(), gu.w8s.data_ptr()
+                a.down_w8, a.down_s = down.w8.data_ptr(), down.w8s.data_ptr()
         self._arr = arr
+        self.fp8_weights = fp8_weights
         self.final_norm = (_bf_f32 if final_norm_bf16 else _f32)(sd["norm.weight"], dev)
         cos, sin = rope_tables(rope, n_pos, D)
         self.cos, self.sin = cos.contiguous().to(dev), sin.contiguous().to(dev)

@@ -32,7 +32,10 @@ IMAGENET_MEAN, IMAGENET_STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
 
 class OpenVLA:
     def __init__(self, sd: Dict[str, torch.Tensor], c: dict, *, device="cuda:0", max_prompts=8, max_candidates=32,
-                 max_text=32, horizon=1, n_cams=1):
+                 max_text=32, horizon=1, n_cams=1, weight_dtype="bf16"):
+        """weight_dtype "fp8" (BASELINE config 5): the Llama projections and the lm_head are quantised to e4m3 with per-channel
+        power-of-two scales; the HBM-bound decode passes stream the e4m3 image, the MFMA-bound prefill the bf16 image of the same
+        quantised values (cover_vla_amd.ops.pack_linear). The vision towers and the projector stay bf16 (MFMA-bound)."""
         self.c, self.dev = dict(c), torch.device(device)
         dev = self.dev
         sub = lambda p: {k[len(p):]: v for k, v in sd.items() if k.startswith(p)}
@@ -47,13 +50,17 @@ class OpenVLA:
         self.fused = c["dino_dim"] + c["sig_dim"]
         self.proj = [ops.pack_linear(sd[f"projector.fc{i}.weight"].to(dev), sd[f"projector.fc{i}.bias"]) for i in (1, 2, 3)]
         self.embed = sd["llm.embed_tokens.weight"].to(BF).contiguous().to(dev)
-        self.lm_head = ops.pack_linear(sd["lm_head.weight"].to(dev))
+        fp8 = weight_dtype == "fp8"
+        if weight_dtype not in ("bf16", "fp8"):
+            raise ValueError("weight_dtype must be 'bf16' or 'fp8'")
+        self.weight_dtype = weight_dtype
+        self.lm_head = ops.pack_linear(sd["lm_head.weight"].to(dev), fp8=fp8)
         self.n_gen = 7 * horizon
         self.T0 = 1 + self.n_patches * n_cams          # [BOS] + patches
         geom = KvGeometry(c["Hkv"], c["D"], [1, max_prompts, max_candidates], [self.T0, max_text, self.n_gen])
         self.llm = Decoder(sub("llm."), dim=c["llm_dim"], layers=c["llm_layers"], Hq=c["Hq"], Hkv=c["Hkv"], D=c["D"],
                            mlp=c["llm_mlp"], act="silu", norm="llama", eps=1e-5, rope="hf", n_pos=self.T0 + max_text + self.n_gen + 8,
-                           device=device, cache=geom)
+                           device=device, cache=geom, fp8_weights=fp8)
         self.max_prompts, self.max_candidates, self.max_text = max_prompts, max_candidates, max_text
         D = c["llm_dim"]
         self.action_lo = c["tok_vocab"] - c["n_bins"]

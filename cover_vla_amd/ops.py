@@ -40,6 +40,9 @@ class PackedLinear:
     K: int
     bias: Optional[torch.Tensor] = None   # fp32 [N]
     glu: bool = False
+    w8: Optional[torch.Tensor] = None     # e4m3 twin of the same quantised weight (uint8 storage), cover_pack_weight_fp8
+    w8s: Optional[torch.Tensor] = None    # fp32 per-channel power-of-two scales in packed channel order
+    use_w8: bool = True                   # tests: False reads the bf16 image in the weight-streaming kernels too
 
     @property
     def n_out(self) -> int:
@@ -50,19 +53,32 @@ class PackedLinear:
         return (self.K + 127) // 128 * 128
 
 
-def pack_linear(weight: torch.Tensor, bias: Optional[torch.Tensor] = None, glu: bool = False) -> PackedLinear:
-    """weight: [N, K] (nn.Linear layout) on the device; for glu=True weight = cat([gate, up], 0)."""
+def pack_linear(weight: torch.Tensor, bias: Optional[torch.Tensor] = None, glu: bool = False, fp8: bool = False) -> PackedLinear:
+    """weight: [N, K] (nn.Linear layout) on the device; for glu=True weight = cat([gate, up], 0).
+    fp8=True: the weight is QUANTISED to e4m3 with per-output-channel power-of-two scales (cover_quantize_rows_fp8) and kept
+    twice -- as the e4m3 image the HBM-bound weight-streaming kernels read (half the bytes) and as the bf16 image of the same
+    de-quantised values for the MFMA-bound tiled kernels; both give bit-identical results."""
     _chk_dev(weight)
     w = weight.to(torch.bfloat16).contiguous()
     N, K = w.shape
     h = L.lib()
+    w8 = w8s = None
+    if fp8:
+        scales = torch.empty(N, dtype=torch.float32, device=w.device)
+        wdq = torch.empty_like(w)
+        L.check(h.cover_quantize_rows_fp8(w.data_ptr(), K, N, K, scales.data_ptr(), wdq.data_ptr(), _stream()), "quantize_rows_fp8")
+        w8 = torch.empty(h.cover_packed_weight_fp8_bytes(N, K), dtype=torch.uint8, device=w.device)
+        w8s = torch.empty((N + 15) // 16 * 16, dtype=torch.float32, device=w.device)
+        L.check(h.cover_pack_weight_fp8(wdq.data_ptr(), K, scales.data_ptr(), N, K, w8.data_ptr(), w8s.data_ptr(), 1 if glu else 0,
+                                        _stream()), "pack_weight_fp8")
+        w = wdq
     nbytes = h.cover_packed_weight_bytes(N, K)
     wp = torch.empty(nbytes // 2, dtype=torch.bfloat16, device=w.device)
     L.check(h.cover_pack_weight_bf16(w.data_ptr(), K, N, K, wp.data_ptr(), 1 if glu else 0, _stream()), "pack_weight")
     # the bias of a bf16 nn.Linear is a bf16 parameter in the reference (paligemma.to(bf16), HF bf16 checkpoints): round it
     # ONCE at load; the epilogue then adds exactly that value in fp32
     b = None if bias is None else bias.detach().to(torch.bfloat16).to(torch.float32).contiguous().to(w.device)
-    return PackedLinear(wp, N, K, b, glu)
+    return PackedLinear(wp, N, K, b, glu, w8, w8s)
 
 
 def gemm_workspace(M: int, N: int, K: int, device) -> Optional[torch.Tensor]:
@@ -93,6 +109,8 @@ def gemm(a: torch.Tensor, lin: PackedLinear, *, act: str = "none", residual: Opt
     e.glu = 1 if lin.glu else 0
     e.out_f32 = 1 if out.dtype == torch.float32 else 0
     e.out_scale = out_scale
+    if lin.w8 is not None and lin.use_w8:
+        e.w8, e.w8_scale = lin.w8.data_ptr(), lin.w8s.data_ptr()
     if norm_w is not None:
         e.norm_w, e.norm_out, e.ld_norm_out = norm_w.data_ptr(), norm_out.data_ptr(), norm_out.stride(0)
         e.norm_style, e.norm_w_offset, e.norm_eps = norm_style, norm_w_offset, norm_eps
@@ -443,16 +461,17 @@ def score_select(it, act, group_size):
     return scores, result, best, fit, fact
 
 
-def tokens_to_histories(tokens, tok_vocab, centers, past, pad_value=-5.0):
-    """tokens int64 [N, >=7] (device), centers fp32 [n_centers], past fp32 [n_past, 7] -> (hist fp32 [N,10,7], pad uint8 [N,10])."""
+def tokens_to_histories(tokens, tok_vocab, centers, past, pad_value=-5.0, n_use=1):
+    """tokens int64 [N, >= 7 n_use] (device), centers fp32 [n_centers], past fp32 [n_past, 7] -> (hist fp32 [N,10,7], pad uint8
+    [N,10]); n_use = how many 7-token actions of a candidate's chunk become history rows (action-chunk horizon > 1)."""
     _chk_dev(tokens, centers)
     N = tokens.shape[0]
     hist = torch.empty(N, 10, 7, dtype=torch.float32, device=tokens.device)
     pad = torch.empty(N, 10, dtype=torch.uint8, device=tokens.device)
     n_past = 0 if past is None else past.shape[0]
-    L.check(L.lib().cover_tokens_to_histories(tokens.data_ptr(), tokens.stride(0), N, tok_vocab, centers.data_ptr(),
-                                              centers.numel(), _ptr(past), n_past, pad_value, hist.data_ptr(), pad.data_ptr(),
-                                              _stream()), "tokens_to_histories")
+    L.check(L.lib().cover_tokens_to_histories_steps(tokens.data_ptr(), tokens.stride(0), N, tok_vocab, centers.data_ptr(),
+                                                    centers.numel(), _ptr(past), n_past, n_use, pad_value, hist.data_ptr(),
+                                                    pad.data_ptr(), _stream()), "tokens_to_histories")
     return hist, pad
 
 

@@ -70,6 +70,11 @@ typedef struct cover_gemm_epi {
     float norm_w_offset;
     float norm_eps;
     const float* norm_b;      /* [N] LayerNorm bias (norm_style 2) or NULL */
+    /* Optional e4m3 twin of the SAME (quantised) weight, cover_pack_weight_fp8, with its packed-order per-channel scales: the
+     * weight-streaming kernels (M <= 32, HBM-bound) read it instead of the bf16 image -- half the bytes, bit-identical results
+     * (power-of-two scales). NULL = bf16 only. */
+    const void* w8;
+    const float* w8_scale;
 } cover_gemm_epi;
 
 /* bytes needed for the packed form of an [N, K] weight (K padded to a multiple of 128, N to 16) */
@@ -78,6 +83,17 @@ int cover_packed_k(int K);
 /* W: bf16 [N, ldw] row-major (PyTorch nn.Linear layout) -> Wp. glu_interleave=1 expects W = [gate(N/2 rows); up(N/2 rows)]
  * and emits 16-row blocks gate0,up0,gate1,up1,... */
 int cover_pack_weight_bf16(const void* W, int ldw, int N, int K, void* Wp, int glu_interleave, void* stream);
+
+/* e4m3 weights (BASELINE.json config 5; the reference has no fp8 path -- SURVEY.md 7 step 9). Per-output-channel
+ * POWER-OF-TWO scales: s_n = smallest 2^e with max_k |W[n,k]| / s_n <= 448, q = RNE_e4m3(W / s_n).
+ * cover_quantize_rows_fp8: W bf16 [N, ldw] -> scales[N] fp32 and Wdq bf16 [N, ldw] = s_n * q (exactly representable: pack it with
+ *   cover_pack_weight_bf16 for the MFMA-bound kernels).
+ * cover_pack_weight_fp8: Wdq + scales -> the e4m3 image (cover_packed_weight_fp8_bytes) for the HBM-bound weight-streaming
+ *   kernels and the scales in packed channel order [ceil(N/16)*16] (glu_interleave as cover_pack_weight_bf16). */
+size_t cover_packed_weight_fp8_bytes(int N, int K);
+int cover_quantize_rows_fp8(const void* W, int ldw, int N, int K, float* scales, void* Wdq, void* stream);
+int cover_pack_weight_fp8(const void* Wdq, int ldw, const float* scales, int N, int K, void* Wq, float* scales_packed,
+                          int glu_interleave, void* stream);
 
 /* variant: 0 = auto, 1 = LDS-tiled with async global->LDS (global_load_lds), 2 = LDS-tiled register-staged,
  *          3 = weight-streaming (requires M <= 64; the library picks the second-generation split-K kernel or, for
@@ -310,6 +326,11 @@ int cover_tokens_to_histories(const int64_t* tokens, int ld_tokens, int N, int t
  * p01 / p99 (lo_hi = fp32 [12] = lo[6] | hi[6], NULL = pass through), gripper 0 if a < 0.5 else 1.
  * hist[n] = [pad rows | past[0..n_past) | n_use chunk rows], n_past + n_use <= 10. fp32 arithmetic (the reference does this
  * in float64 on the host and converts: results agree to fp32 rounding). */
+/* the same for an action-chunk horizon > 1: the first n_use 7-token actions of every candidate become its n_use newest history rows
+ * (the driver scores n_action_steps future steps, run_simpler_eval_with_openpi.py:338-341) */
+int cover_tokens_to_histories_steps(const int64_t* tokens, int ld_tokens, int N, int tok_vocab, const float* centers, int n_centers,
+                                    const float* past, int n_past, int n_use, float pad_value, float* hist_out, uint8_t* pad_out,
+                                    void* stream);
 int cover_actions_to_histories(const float* actions, long long n_stride, long long t_stride, int N, int n_use, const float* lo_hi,
                                const float* past, int n_past, float pad_value, float* hist_out, uint8_t* pad_out, void* stream);
 
@@ -354,6 +375,9 @@ typedef struct cover_dec_layer {
     const void* gate_up_w;                    /* packed, glu-interleaved [2*mlp, dim] */
     const void* down_w;                       /* packed [dim, mlp] */
     void* k_cache; void* vt_cache;            /* this layer's cache bases (bf16) */
+    /* optional e4m3 twins (cover_pack_weight_fp8) + packed-order scales of the four projections; NULL = bf16 only */
+    const void* qkv_w8; const float* qkv_s; const void* o_w8; const float* o_s;
+    const void* gate_up_w8; const float* gate_up_s; const void* down_w8; const float* down_s;
 } cover_dec_layer;
 typedef struct cover_dec_desc {
     int dim, Hq, Hkv, D, mlp, n_layers, act;  /* act: COVER_ACT_GELU_TANH (Gemma) / COVER_ACT_SILU (Llama) */
