@@ -130,3 +130,41 @@ def verify_and_select(verifier, raw_image, task_description: str, task_list: Seq
     remaining = deque(np.asarray(action_queue[t])[gidx:gidx + 1] for t in range(1, n_action_steps))
     return dict(execute_action=execute_action, max_score=max_score, max_instruction=max_instruction,
                 global_action_idx=gidx, remaining=remaining, history_row=max_hist[num_past].copy())
+
+
+class EpisodeLog:
+    """The per-episode record the driver pickles (run_simpler_eval_with_openpi.py:238-247 schema; filled at :404-407 on a
+    verified decision, :419-422 on a queued step, closed at :454-455) -- the e2e parity artefact analyze_success_rate.py reads.
+    Same field names and per-step value types, so records written next to this path load in the reference's analysis."""
+
+    FIELDS = ("verifier_scores", "selected_instructions", "execute_actions", "step_timestamps", "original_task_description",
+              "used_task_description", "success", "episode_length")
+
+    def __init__(self, original_task_description: str, task_description: str):
+        self.data = {"verifier_scores": [], "selected_instructions": [], "execute_actions": [], "step_timestamps": [],
+                     "original_task_description": original_task_description, "used_task_description": task_description,
+                     "success": False, "episode_length": 0}
+
+    def record_decision(self, max_score: float, max_instruction: str, execute_action, t: int) -> None:
+        d = self.data
+        d["verifier_scores"].append(max_score)
+        d["selected_instructions"].append(max_instruction)
+        d["execute_actions"].append(np.asarray(execute_action).copy())
+        d["step_timestamps"].append(t)
+
+    def record_queued(self, task_description: str, execute_action, t: int) -> None:
+        d = self.data
+        d["verifier_scores"].append(None)
+        d["selected_instructions"].append(task_description)
+        d["execute_actions"].append(np.asarray(execute_action).copy())
+        d["step_timestamps"].append(t)
+
+    def finish(self, success: bool, t: int) -> dict:
+        self.data["success"] = success
+        self.data["episode_length"] = t
+        return self.data
+
+    def save(self, path: str) -> None:
+        import pickle
+        with open(path, "wb") as f:
+            pickle.dump(self.data, f)

@@ -11,8 +11,8 @@ Reference behaviour restated here (not its code):
     {"reset": True} -> policy.reset(), reply {"status": "reset"}; anything else is an observation ->
     policy.select_action(obs), reply = the packed action. On an exception the traceback TEXT is sent and the connection is
     closed with the websocket INTERNAL_ERROR code (1011) and the reason string below.
-The transport is not part of this package's scope (the image has no `websockets`): `PolicySession` turns one received message
-into one reply and says whether to close; `serve_websocket` wires it to the `websockets` package when that is installed.
+`PolicySession` turns one received message into one reply and says whether to close (transport-agnostic); `serve_websocket`
+runs it over the `websockets` package when installed, else over the RFC 6455 transport of cover_vla_amd.wsproto.
 """
 import traceback
 from typing import Any, Callable, Optional, Tuple, Union
@@ -104,32 +104,83 @@ class VerifiedPolicy:
         self._switch(path)
 
 
-def serve_websocket(policy: Any, host: str = "0.0.0.0", port: int = 8000, metadata: Optional[dict] = None) -> None:
-    """Blocking websocket server with the reference's framing (no compression, no size limit). Needs the `websockets`
-    package, which this image does not have: the call fails loudly instead of falling back to another transport."""
+async def _serve(conn_recv_send_close, session: PolicySession) -> None:
+    """The per-connection loop of websocket_policy_server.py:54-91 over any connection object with send / recv / close."""
+    ws = conn_recv_send_close
+    await ws.send(session.greeting())
+    while True:
+        msg = await ws.recv()                       # raises the transport's ConnectionClosed when the client leaves
+        reply, close = session.handle(msg)
+        await ws.send(reply)
+        if close:
+            await ws.close(code=CLOSE_INTERNAL_ERROR, reason=CLOSE_REASON)
+            return
+
+
+def serve_websocket(policy: Any, host: str = "0.0.0.0", port: int = 8000, metadata: Optional[dict] = None,
+                    ready: Optional[Callable[[int], None]] = None) -> None:
+    """Blocking websocket server with the reference's framing (binary msgpack frames, no compression, no size limit; traceback
+    as a text frame + close code 1011 on error). Runs on the `websockets` package when it is installed (the reference's
+    transport), else on the RFC 6455 transport in cover_vla_amd.wsproto (standard library only). `ready(port)` is called once the
+    socket listens (port 0 = pick a free one)."""
+    import asyncio
     try:
-        import asyncio
         import websockets
         import websockets.asyncio.server
-    except ImportError as e:   # pragma: no cover - depends on the deployment image
-        raise ImportError("serve_websocket needs the 'websockets' package; PolicySession works with any transport") from e
+    except ImportError:
+        websockets = None
 
-    async def handler(ws):   # pragma: no cover - needs the package
-        session = PolicySession(policy, metadata)
-        await ws.send(session.greeting())
-        while True:
+    if websockets is not None:   # pragma: no cover - depends on the deployment image
+        async def handler(ws):
             try:
-                msg = await ws.recv()
+                await _serve(ws, PolicySession(policy, metadata))
             except websockets.ConnectionClosed:
                 return
-            reply, close = session.handle(msg)
-            await ws.send(reply)
-            if close:
-                await ws.close(code=CLOSE_INTERNAL_ERROR, reason=CLOSE_REASON)
+
+        async def run():
+            async with websockets.asyncio.server.serve(handler, host, port, compression=None, max_size=None) as server:
+                if ready is not None:
+                    ready(port)
+                await server.serve_forever()
+    else:
+        from . import wsproto
+
+        async def handler(ws):
+            try:
+                await _serve(ws, PolicySession(policy, metadata))
+            except wsproto.ConnectionClosed:
                 return
 
-    async def run():   # pragma: no cover
-        async with websockets.asyncio.server.serve(handler, host, port, compression=None, max_size=None) as server:
-            await server.serve_forever()
+        async def run():
+            await wsproto.serve(handler, host, port, ready=ready)
 
-    asyncio.run(run())   # pragma: no cover
+    asyncio.run(run())
+
+
+class WebsocketClientPolicy:
+    """Client side of the same protocol (the simulator's wrapper, websocket_client_policy.py in the reference's package):
+    connect, read the metadata greeting, then select_action(obs) / reset() / switch_model(path) as request-reply pairs."""
+
+    def __init__(self, host: str = "127.0.0.1", port: int = 8000, timeout: float = 60.0):
+        from . import wsproto
+        self._ws = wsproto.ClientConnection(host, port, timeout)
+        self.metadata = unpack(self._ws.recv())
+
+    def _call(self, obj):
+        self._ws.send(pack(obj))
+        reply = self._ws.recv()
+        if isinstance(reply, str):
+            raise RuntimeError(f"Error in policy server:\n{reply}")
+        return unpack(reply)
+
+    def select_action(self, obs: dict):
+        return self._call(obs)
+
+    def reset(self):
+        return self._call({"reset": True})
+
+    def switch_model(self, path: str):
+        return self._call({"new_model_path": path})
+
+    def close(self):
+        self._ws.close()

@@ -216,3 +216,57 @@ def test_pi0_normalization_buffers_from_checkpoint_keys():
     sd["normalize_inputs.buffer_observation_state.std"] = torch.full((7,), float("inf"))
     with pytest.raises(ValueError):
         loaders.pi0_normalization(sd, {"normalization_mapping": {"STATE": "MEAN_STD"}})
+
+
+def test_checkpoint_key_names_match_the_reference_converter():
+    """the names loaders.neutral_to_pi0_reference writes / pi0_reference_to_neutral reads are exactly the names the
+    reference's converter assigns (fixture: oracle/gen_golden_keys.py from convert_pi0_to_hf_lerobot.py:67-245,384-386), at the
+    real layer counts (27 SigLIP blocks, 18 + 18 decoder layers)."""
+    import json
+    from cover_vla_amd import loaders
+    with open(os.path.join(GOLD, "pi0_checkpoint_keys.json")) as f:
+        fx = json.load(f)
+    ref_keys = set(fx["keys"])
+    # a structural state dict at the real layer counts with 1-element tensors (names only)
+    n = {}
+    for i in range(27):
+        for nm in ("ln1", "ln2", "q", "k", "v", "o", "fc1", "fc2"):
+            for wb in ("weight", "bias"):
+                n[f"vision.blocks.{i}.{nm}.{wb}"] = torch.zeros(1)
+    n.update({"vision.patch.weight": torch.zeros(1, 3 * 14 * 14), "vision.patch.bias": torch.zeros(1), "vision.pos": torch.zeros(1, 1),
+              "vision.post_ln.weight": torch.zeros(1), "vision.post_ln.bias": torch.zeros(1), "projector.weight": torch.zeros(1),
+              "projector.bias": torch.zeros(1), "lm.embed_tokens.weight": torch.zeros(1), "lm.norm.weight": torch.zeros(1),
+              "expert.norm.weight": torch.zeros(1)})
+    for pre in ("lm", "expert"):
+        for i in range(18):
+            for nm in ("input_layernorm", "post_attention_layernorm", "self_attn.q_proj", "self_attn.k_proj", "self_attn.v_proj",
+                       "self_attn.o_proj", "mlp.gate_proj", "mlp.up_proj", "mlp.down_proj"):
+                n[f"{pre}.layers.{i}.{nm}.weight"] = torch.zeros(1)
+    for nm in ("state_proj", "action_in_proj", "action_out_proj", "action_time_mlp_in", "action_time_mlp_out"):
+        n[nm + ".weight"], n[nm + ".bias"] = torch.zeros(1), torch.zeros(1)
+    ours = set(loaders.neutral_to_pi0_reference(n, 14).keys())
+    # the converter also writes tied / dummy tensors our neutral layout does not carry: lm_head (tied to embed_tokens), the expert's
+    # zero embedding and zero lm_head
+    extras = {"model.paligemma_with_expert.paligemma.language_model.lm_head.weight",
+              "model.paligemma_with_expert.gemma_expert.model.embed_tokens.weight", "model.paligemma_with_expert.gemma_expert.lm_head.weight"}
+    assert ours <= ref_keys, sorted(ours - ref_keys)[:5]
+    assert ref_keys - ours == extras, sorted(ref_keys - ours - extras)[:5]
+    # and reading a dict with exactly the reference's names (extras included) gives back the neutral names
+    back = loaders.pi0_reference_to_neutral({k: torch.zeros(1, 3, 14, 14) if k.endswith("patch_embedding.weight") else torch.zeros(1) for k in ref_keys})
+    assert set(back.keys()) == set(n.keys())
+
+
+def test_episode_log_schema_matches_the_driver(tmp_path):
+    import json
+    import pickle
+    with open(os.path.join(GOLD, "pi0_checkpoint_keys.json")) as f:
+        fields = json.load(f)["episode_fields"]
+    log = host.EpisodeLog("put the spoon on the towel", "place spoon on towel")
+    assert list(log.data.keys()) == fields == list(host.EpisodeLog.FIELDS)
+    log.record_decision(0.31, "place spoon on towel", np.arange(7.0), 0)
+    log.record_queued("place spoon on towel", np.arange(7.0) + 1, 1)
+    d = log.finish(True, 2)
+    assert d["verifier_scores"] == [0.31, None] and d["step_timestamps"] == [0, 1] and d["success"] is True and d["episode_length"] == 2
+    log.save(str(tmp_path / "ep.pkl"))
+    with open(tmp_path / "ep.pkl", "rb") as f:
+        assert list(pickle.load(f).keys()) == fields

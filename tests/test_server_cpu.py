@@ -106,7 +106,73 @@ def test_verified_policy_composes_sampler_and_verifier():
     assert np.array_equal(out, np.arange(21, 28, dtype=np.float32)) and seen["ctx"] == {"groups": 4}
     r, close = s.handle(server.pack({"new_model_path": "x"}))           # one checkpoint: refused loudly, connection closed
     assert close and "NotImplementedError" in r
-    import importlib.util
-    if importlib.util.find_spec("websockets") is None:
-        with pytest.raises(ImportError):
-            server.serve_websocket(pol)                                  # no silent fallback transport in this image
+
+
+# ------------------------------------------------------------------------------------------------ websocket transport
+class _EchoPolicy:
+    def __init__(self):
+        self.resets, self.paths = 0, []
+
+    def select_action(self, obs):
+        if "boom" in obs:
+            raise ValueError("scripted failure")
+        img = obs["image"]
+        return {"actions": (img.astype(np.float32).mean(axis=(0, 1)) + obs["offset"]).astype(np.float32), "n": np.int64(img.size)}
+
+    def reset(self):
+        self.resets += 1
+
+    def switch_model(self, path):
+        self.paths.append(path)
+
+
+def test_websocket_round_trip_on_localhost():
+    """serve_websocket end to end over a real TCP socket (RFC 6455 transport of cover_vla_amd.wsproto): greeting, an observation
+    with a 0.9 MB frame (64-bit length header, masked client frame), reset, model switch, and the error path -- traceback as a TEXT
+    frame, then close code 1011 with the reference's reason (websocket_policy_server.py:54-91)."""
+    import threading
+    from cover_vla_amd import server, wsproto
+    pol = _EchoPolicy()
+    port_box, ev = [], threading.Event()
+
+    def ready(port):
+        port_box.append(port)
+        ev.set()
+
+    th = threading.Thread(target=lambda: server.serve_websocket(pol, "127.0.0.1", 0, {"policy": "echo", "horizon": 4}, ready=ready), daemon=True)
+    th.start()
+    assert ev.wait(20)
+    cl = server.WebsocketClientPolicy("127.0.0.1", port_box[0])
+    assert cl.metadata == {"policy": "echo", "horizon": 4}
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 256, size=(480, 640, 3), dtype=np.uint8)
+    out = cl.select_action({"image": img, "offset": np.float32(0.5), "task": "put the spoon on the towel"})
+    assert np.allclose(out["actions"], img.astype(np.float32).mean(axis=(0, 1)) + 0.5) and int(out["n"]) == img.size
+    assert cl.reset() == {"status": "reset"} and pol.resets == 1
+    assert cl.switch_model("/ckpt/a") == {"status": "model switched"} and pol.paths == ["/ckpt/a"]
+    small = cl.select_action({"image": img[:4, :4], "offset": np.float32(0.0)})       # 7-bit length frames
+    assert small["actions"].shape == (3,)
+    with pytest.raises(RuntimeError) as ei:
+        cl.select_action({"boom": True})
+    assert "scripted failure" in str(ei.value) and "Traceback" in str(ei.value)
+    with pytest.raises(wsproto.ConnectionClosed) as ce:                                  # the server closes with INTERNAL_ERROR
+        cl._ws.recv()
+    assert ce.value.code == server.CLOSE_INTERNAL_ERROR and ce.value.reason == server.CLOSE_REASON
+    # a second client on the same server (one session per connection)
+    cl2 = server.WebsocketClientPolicy("127.0.0.1", port_box[0])
+    assert cl2.reset() == {"status": "reset"} and pol.resets == 2
+    cl2.close()
+
+
+def test_websocket_frame_codec_known_answers():
+    from cover_vla_amd import wsproto
+    # RFC 6455 section 1.3 handshake example
+    assert wsproto.accept_key("dGhlIHNhbXBsZSBub25jZQ==") == "s3pPLMBiTxaQ9kYGzzhZRbK+xOo="
+    # RFC 6455 section 5.7: unmasked text "Hello", and the 256-byte binary header 0x82 0x7E 0x0100
+    assert wsproto.encode_frame(wsproto.OP_TEXT, b"Hello", False) == bytes([0x81, 0x05, 0x48, 0x65, 0x6C, 0x6C, 0x6F])
+    f = wsproto.encode_frame(wsproto.OP_BINARY, bytes(256), False)
+    assert f[:4] == bytes([0x82, 0x7E, 0x01, 0x00]) and len(f) == 260
+    f = wsproto.encode_frame(wsproto.OP_BINARY, bytes(65536), False)
+    assert f[:2] == bytes([0x82, 0x7F]) and f[2:10] == (65536).to_bytes(8, "big")
+    m = wsproto.encode_frame(wsproto.OP_TEXT, b"Hello", True)                            # masked: key at [2:6]
+    assert m[1] == 0x85 and bytes(b ^ m[2 + (i & 3)] for i, b in enumerate(m[6:])) == b"Hello"

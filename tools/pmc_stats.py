@@ -1,6 +1,7 @@
 """FETCH_SIZE (rocprofv3 --pmc FETCH_SIZE --kernel-trace) per kernel, with the gfx950 correction from
 /opt/skills/guides/MI355X_MICROARCH.md §HBM: FETCH_SIZE reports half the bytes of a wide coalesced stream -> x2.
-Usage: python tools/pmc_stats.py <db> [out.json]"""
+Usage: python tools/pmc_stats.py <db> [out.json [lib_sha16]]   (lib_sha16 = sha256(libcover_hip.so)[:16] of the build that ran: bench.py quotes
+the traffic figure only when it matches the library it is running)"""
 import collections, json, re, sqlite3, sys
 
 db = sqlite3.connect(sys.argv[1]); cur = db.cursor()
@@ -24,5 +25,5 @@ for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
 if len(sys.argv) > 2 and sk_n:
     json.dump({"kernel": "gemm_skinny2 + gemm_skinny3", "launches": sk_n, "hbm_fetch_bytes_per_launch": sk_bytes / sk_n,
                "correction": "FETCH_SIZE x2 (gfx950 wide coalesced loads, MI355X_MICROARCH.md HBM section)",
-               "source": sys.argv[1]}, open(sys.argv[2], "w"), indent=1)
+               "source": sys.argv[1], "lib_sha16": sys.argv[3] if len(sys.argv) > 3 else None}, open(sys.argv[2], "w"), indent=1)
     print(f"# gemm_skinny2 + gemm_skinny3: {sk_n} launches, corrected HBM fetch {sk_bytes/sk_n/1e6:.1f} MB per launch")
