@@ -414,3 +414,49 @@ def test_full_width_gemma_layers_match_reference_g2(dev):
     print(f"G2 rel-L2: prefix {r0:.4f} / {r1:.4f}, K {rk:.4f}, V {rv:.4f}, suffix {rs:.4f}")
     assert r0 < 1.2e-2 and r1 < 1.2e-2 and rs < 1.2e-2
     assert rk < 2e-3 and rv < 2e-3
+
+
+# ------------------------------------------------------------------------------------------------ serving boundary on the device
+def test_policy_server_composes_real_sampler_and_verifier(dev):
+    """one served request end to end -- packed observation -> PolicySession -> VerifiedPolicy(sample = the OpenVLA
+    candidate sampler on the device, choose = device de-tokenisation + CoVer verifier + grouped arg-max) -> packed action --
+    equals running the same pieces directly."""
+    from cover_vla_amd import ops, server
+    from cover_vla_amd.openvla import OpenVLA
+    from cover_vla_amd.verifier import EfficientEnsembleMerged
+    from tests.test_openvla_gpu import _case
+    c, sd, frame, toks, lens, u = _case(seed=9)
+    P, S = toks.shape[0], 2
+    policy = OpenVLA(sd, c, device="cuda:0", max_prompts=4, max_candidates=8, max_text=toks.shape[1])
+    ck = synth.verifier_checkpoint(2, seed=9)
+    pf, tf, _ = synth.verifier_inputs(P * S, seed=9)
+    ver = EfficientEnsembleMerged(ck, device="cuda:0")
+    its = ver.image_text_embeddings(pf.to(dev), tf.to(dev))
+    bins = np.linspace(-1, 1, c["n_bins"])
+    centers = torch.tensor((bins[:-1] + bins[1:]) / 2.0, dtype=torch.float32, device=dev)
+
+    def sample(obs):
+        fr = torch.from_numpy(np.array(obs["frame"])).to(dev)
+        tokens, _ = policy.sample(fr, toks.to(dev), lens.to(dev), S, torch.from_numpy(np.array(obs["uniforms"])).to(dev), 1.0)
+        return tokens, {"past": torch.from_numpy(np.array(obs["past"])).float().to(dev)}
+
+    def choose(tokens, ctx, obs):
+        hb, pad = ops.tokens_to_histories(tokens, c["tok_vocab"], centers, ctx["past"])
+        r = ver.score_histories(its, hb, S, pad=pad)
+        gi = int(r["result"][0])
+        return {"action": policy.tokens_to_actions(tokens[gi].cpu().numpy()).astype(np.float32), "index": np.int64(gi),
+                "score": np.float32(float(r["best"][0]))}
+
+    session = server.PolicySession(server.VerifiedPolicy(sample, choose, reset=lambda: None), {"policy": "openvla-small+cover"})
+    assert server.unpack(session.greeting()) == {"policy": "openvla-small+cover"}
+    past = (np.random.default_rng(0).normal(size=(6, 7)) * 0.02).astype(np.float32)
+    obs = {"frame": frame.numpy(), "uniforms": u[: P * S].numpy(), "past": past}
+    reply, close = session.handle(server.pack(obs))
+    assert not close
+    out = server.unpack(reply)
+    # the same pieces called directly
+    tokens, ctx = sample(obs)
+    ref = choose(tokens, ctx, obs)
+    assert int(out["index"]) == int(ref["index"]) and np.array_equal(out["action"], ref["action"]) and out["action"].shape == (7,)
+    assert abs(float(out["score"]) - float(ref["score"])) < 1e-7
+    assert server.unpack(session.handle(server.pack({"reset": True}))[0]) == {"status": "reset"}
