@@ -186,6 +186,7 @@ SYMBOLS = {
     "cover_softmax_rows_f32": (c_i, [c_p, c_i, c_i, c_i, c_f, c_p]),
     "cover_l2norm_rows_f32": (c_i, [c_p, c_i, c_p, c_i, c_i, c_i, c_p]),
     "cover_add_f32": (c_i, [c_p, c_i, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_p]),
+    "cover_xent_diag_f32": (c_i, [c_p, c_i, c_i, c_i, c_p, c_p, c_p]),
     "cover_act_f32": (c_i, [c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_p]),
     "cover_mha_f32": (c_i, [_P(MhaF32Args), c_p]),
     "cover_masked_mean_f32": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_p]),

@@ -169,6 +169,12 @@ int cover_add_f32(const float* a, int lda, const float* b, int ldb, float* y, in
     HIPCHK(launch_add_f32(a, lda, b, ldb, y, ldy, rows, cols, b_rows, ST(stream)), "add_f32");
     return COVER_OK;
 }
+int cover_xent_diag_f32(const float* logits, int ld, int rows, int cols, float* loss, int* rank, void* stream) {
+    if (!logits || !loss || !rank) return fail(COVER_EINVAL, "cover_xent_diag_f32: null pointer");
+    if (rows > cols) return fail(COVER_EINVAL, "cover_xent_diag_f32: row r is labelled r, so rows <= cols");
+    HIPCHK(launch_xent_diag_f32(logits, ld, rows, cols, loss, rank, ST(stream)), "xent_diag_f32");
+    return COVER_OK;
+}
 int cover_act_f32(const float* x, int ldx, float* y, int ldy, int rows, int cols, int act, void* stream) {
     if (!x || !y) return fail(COVER_EINVAL, "cover_act_f32: null pointer");
     HIPCHK(launch_act_f32(x, ldx, y, ldy, rows, cols, act, ST(stream)), "act_f32");

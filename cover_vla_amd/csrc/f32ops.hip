@@ -282,6 +282,37 @@ hipError_t launch_l2norm_rows_f32(const float* x, int ldx, float* y, int ldy, in
     return hipGetLastError();
 }
 
+// Cross entropy of each row against the label on its diagonal (label of row r = r), and the rank of that label's logit in its
+// row (number of strictly larger logits, plus equal logits at a lower column): the retrieval statistics of the verifier's
+// contrastive evaluation (finetune_trajectory_bridge_ddp.py:446-469, :1081-1090).
+__global__ __launch_bounds__(256) void xent_diag_f32_k(const float* __restrict__ x, int ldx, int cols, float* __restrict__ loss,
+                                                       int* __restrict__ rank) {
+    __shared__ float red[16];
+    const int r = blockIdx.x;
+    const float* xr = x + (size_t)r * ldx;
+    const float d = xr[r];
+    float m = -INFINITY;
+    for (int c = threadIdx.x; c < cols; c += 256) m = fmaxf(m, xr[c]);
+    m = block_max(m, red);
+    float s = 0.f, above = 0.f;
+    for (int c = threadIdx.x; c < cols; c += 256) {
+        const float v = xr[c];
+        s += expf(v - m);
+        above += (v > d || (v == d && c < r)) ? 1.f : 0.f;
+    }
+    s = block_sum(s, red);
+    above = block_sum(above, red);
+    if (threadIdx.x == 0) {
+        loss[r] = (m + logf(s)) - d;
+        rank[r] = (int)above;
+    }
+}
+hipError_t launch_xent_diag_f32(const float* x, int ldx, int rows, int cols, float* loss, int* rank, hipStream_t st) {
+    if (rows <= 0) return hipSuccess;
+    hipLaunchKernelGGL(xent_diag_f32_k, dim3(rows), dim3(256), 0, st, x, ldx, cols, loss, rank);
+    return hipGetLastError();
+}
+
 __global__ void add_f32_k(const float* __restrict__ a, int lda, const float* __restrict__ b, int ldb,
                           float* __restrict__ y, int ldy, int cols, int b_rows) {
     const int r = blockIdx.x;

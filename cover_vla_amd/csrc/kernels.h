@@ -51,6 +51,7 @@ hipError_t launch_softmax_rows_f32(float* x, int ldx, int rows, int cols, float 
 hipError_t launch_l2norm_rows_f32(const float* x, int ldx, float* y, int ldy, int rows, int cols, hipStream_t st);
 hipError_t launch_add_f32(const float* a, int lda, const float* b, int ldb, float* y, int ldy, int rows, int cols,
                           int b_rows, hipStream_t st);
+hipError_t launch_xent_diag_f32(const float* x, int ldx, int rows, int cols, float* loss, int* rank, hipStream_t st);
 hipError_t launch_act_f32(const float* x, int ldx, float* y, int ldy, int rows, int cols, int act, hipStream_t st);
 hipError_t launch_mha_f32(const cover_mha_f32_args* a, hipStream_t st);
 hipError_t launch_masked_mean_f32(const float* x, const uint8_t* pad, float* y, int B, int T, int D, hipStream_t st);

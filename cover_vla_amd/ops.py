@@ -386,6 +386,17 @@ def add_f32(a, b, out=None):
     return out
 
 
+def xent_diag_f32(logits):
+    """logits fp32 [B, C] (B <= C) -> (loss fp32 [B] = logsumexp(row) - row[r], rank int32 [B] = entries ranked ahead of row[r])."""
+    _chk_dev(logits)
+    B, Cn = logits.shape
+    loss = torch.empty(B, dtype=torch.float32, device=logits.device)
+    rank = torch.empty(B, dtype=torch.int32, device=logits.device)
+    L.check(L.lib().cover_xent_diag_f32(logits.data_ptr(), logits.stride(0), B, Cn, loss.data_ptr(), rank.data_ptr(), _stream()),
+            "xent_diag_f32")
+    return loss, rank
+
+
 def act_f32(x, act, out=None):
     _chk_dev(x)
     out = torch.empty_like(x) if out is None else out

@@ -153,6 +153,20 @@ def verifier_inputs(n_candidates: int, seed: int = 7, num_patches: int = 576, nu
     return pf, tf, hists
 
 
+def verifier_batch_inputs(batch: int, seed: int = 7, num_patches: int = 576, num_tokens: int = 64, dim: int = 1024, hist_len: int = 10,
+                          pad_value: float = -5.0):
+    """A validation batch of `batch` DISTINCT (image, text, history) triples at the feature boundary: unit-norm patch / text
+    features [B, P, D] / [B, T, D] and histories [B, H, 7], short ones left-padded with the padding value (BridgeDataset)."""
+    g = torch.Generator().manual_seed(seed)
+    pf = torch.nn.functional.normalize(torch.randn(batch, num_patches, dim, generator=g), dim=-1)
+    tf = torch.nn.functional.normalize(torch.randn(batch, num_tokens, dim, generator=g), dim=-1)
+    hist = torch.randn(batch, hist_len, 7, generator=g) * 0.02
+    hist[:, :, 6] = (torch.rand(batch, hist_len, generator=g) > 0.5).float()
+    for b in range(batch):
+        hist[b, : (b * 2) % 5] = pad_value
+    return pf, tf, hist
+
+
 # ------------------------------------------------------------------------------------------------ transformers
 def vit_state(g: _G, *, dim: int, layers: int, heads: int, mlp: int, patch: int, n_pos: int, layerscale: bool = False,
               prefix_tokens: int = 0, post_ln: bool = True) -> Dict[str, Tensor]:

@@ -254,6 +254,68 @@ class _TrajectoryStack:
         return ops.l2norm_rows_f32(m, out=out.view(G * N, E))
 
 
+class VLASigLIP2Bridge:
+    """One verifier model as it is trained and validated (bridge_verifier/ensemble_eval/finetune_trajectory_bridge_ddp.py:182-421):
+    forward(image, text, action_histories) -> (image_logits, action_logits), both [B, B], for B DISTINCT (image, text, history)
+    triples, and the symmetric InfoNCE loss + retrieval accuracies of its validation loop (:446-469, :1081-1090). Inference
+    (eval) mode only: dropout is the identity, no gradients -- the optimiser side of training is outside the hot path.
+
+    `component` is one entry of the merged checkpoint's `ensemble_components` (the trainable heads, merge_ensemble_checkpoints
+    layout); `logit_scale` is the model's learned log-temperature (init 2.6592, :210)."""
+
+    def __init__(self, component: dict, logit_scale: float = 2.6592, device="cuda:0", encoder: Optional["SigLIP2Encoder"] = None):
+        L.lib()
+        self.device = torch.device(device)
+        self.member = _Member(component, self.device)
+        self.logit_scale = float(logit_scale)
+        self.encoder = encoder
+        self.history_length, self.action_dim = 10, 7
+
+    def forward_features(self, patch_features, text_features, action_histories):
+        """patch_features [B, P, D], text_features [B, T, D] (unit rows, what extract_features returns :297-355),
+        action_histories [B, H, A] padded with the member's padding value -> (image_logits, action_logits) fp32 [B, B]."""
+        pf = _f32(patch_features, self.device)
+        tf = _f32(text_features, self.device)
+        hist = _f32(torch.as_tensor(np.asarray(action_histories.cpu() if torch.is_tensor(action_histories) else action_histories)), self.device)
+        B = pf.shape[0]
+        if tf.shape[0] != B or hist.shape[0] != B:
+            raise ValueError(f"batch sizes differ: images {B}, texts {tf.shape[0]}, histories {hist.shape[0]}")
+        it = torch.empty(B, 512, dtype=torch.float32, device=self.device)
+        for b in range(B):                                   # per-sample text-aware heads (:368-377)
+            it[b:b + 1].copy_(self.member.image_text(pf[b], tf[b]))
+        pad = (hist[:, :, 0] == self.member.pad_value).to(torch.uint8).contiguous()   # :384 (a comparison, no arithmetic)
+        act = self.member.trajectory(hist.contiguous(), pad)                           # :380-412
+        scale = float(np.exp(np.float32(self.logit_scale)))                            # :414
+        image_logits = ops.gemm_f32(it, act, alpha=scale)                              # :416
+        action_logits = ops.gemm_f32(act, it, alpha=scale)                             # :417
+        return image_logits, action_logits
+
+    def forward(self, image, text, action_histories):
+        if self.encoder is None:
+            raise RuntimeError("VLASigLIP2Bridge.forward needs a SigLIP2Encoder; call forward_features with extracted features instead")
+        pf, tf = self.encoder.extract_features(image, text)
+        return self.forward_features(pf, tf, action_histories)
+
+    __call__ = forward
+
+    @staticmethod
+    def contrastive_metrics(image_logits, action_logits, k_values=(1, 5)) -> Dict[str, float]:
+        """loss = (CE(image_logits, arange) + CE(action_logits, arange)) / 2 (:895-899) and the top-k retrieval accuracies of
+        calculate_accuracy_metrics (:446-469). Row statistics come from one kernel per direction; only the B-element means run on
+        the host. Ties at the k-th place are broken towards the lower column (torch.topk leaves the order of equal values open)."""
+        B = image_logits.shape[0]
+        li, ri = ops.xent_diag_f32(image_logits)
+        la, ra = ops.xent_diag_f32(action_logits)
+        li, ri, la, ra = (t.cpu().numpy() for t in (li, ri, la, ra))
+        out = {"image_loss": float(li.astype(np.float64).mean()), "action_loss": float(la.astype(np.float64).mean())}
+        out["loss"] = 0.5 * (out["image_loss"] + out["action_loss"])
+        for k in k_values:
+            if k <= B:
+                out[f"img2act_top{k}_acc"] = float((ri < k).mean())
+                out[f"act2img_top{k}_acc"] = float((ra < k).mean())
+        return out
+
+
 class SigLIP2Encoder:
     """The frozen shared encoder: SigLIP2 ViT-L/16-384 image tower (patch features = the LAST block's attention-module
     output, forward hook at finetune_trajectory_bridge_ddp.py:272-274) and text tower (transformer output -> ln_final

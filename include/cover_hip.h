@@ -275,6 +275,11 @@ typedef struct cover_mha_f32_args {
 } cover_mha_f32_args;
 /* y = act(x) elementwise (COVER_ACT_*): the ReLU between LayerNorm and the second Linear of the verifier's MLP action encoder
  * (`complex_action_encoder`, bridge_verifier/ensemble_eval/efficient_ensemble_merged.py:148-184, 241-243). */
+/* Contrastive evaluation statistics: loss[r] = logsumexp(logits[r, :]) - logits[r, r] (F.cross_entropy against labels arange(B),
+ * reduction left to the caller) and rank[r] = how many entries of row r rank ahead of its diagonal (top-k hit <=> rank < k).
+ * Replaces the per-batch F.cross_entropy + torch.topk of bridge_verifier/ensemble_eval/finetune_trajectory_bridge_ddp.py:446-469,
+ * :1081-1090 (validation forward). rows <= cols. */
+int cover_xent_diag_f32(const float* logits, int ld, int rows, int cols, float* loss, int* rank, void* stream);
 int cover_act_f32(const float* x, int ldx, float* y, int ldy, int rows, int cols, int act, void* stream);
 int cover_mha_f32(const cover_mha_f32_args* args, void* stream);
 /* masked mean over T (efficient_ensemble_merged.py:236-240): y[b] = sum_t x[b,t]*(1-pad) / max(sum(1-pad), 1e-9) */

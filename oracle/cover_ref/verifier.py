@@ -155,3 +155,30 @@ def compute_max_similarity_scores(members, pf, tf, histories, group_size=1):
     gidx, g, i, mx, gm = select(scores, group_size)
     return {"scores": scores, "global_idx": gidx, "group": g, "in_group": i, "max_score": mx, "group_mean": gm,
             "fused_it": f_it, "fused_act": f_act, "its": its, "acts": acts}
+
+
+def contrastive_forward(member, logit_scale, pf, tf, histories):
+    """finetune_trajectory_bridge_ddp.py:357-421 in eval mode for a batch of B DISTINCT triples: pf [B,P,D], tf [B,T,D],
+    histories [B,10,7] -> (image_logits, action_logits) [B,B]."""
+    it = torch.cat([image_text_embedding(member, pf[b:b + 1], tf[b:b + 1]) for b in range(pf.shape[0])], dim=0)
+    act = trajectory_embedding(member, histories)
+    scale = torch.tensor(float(logit_scale), dtype=torch.float32).exp()
+    return scale * (it @ act.T), scale * (act @ it.T)
+
+
+def contrastive_metrics(image_logits, action_logits, k_values=(1, 5)):
+    """Loss of the training / validation loops (:895-899) and calculate_accuracy_metrics (:446-469)."""
+    B = image_logits.shape[0]
+    labels = torch.arange(B)
+
+    def ce(x):
+        return float((torch.logsumexp(x, dim=1) - x[labels, labels]).mean())
+
+    out = {"image_loss": ce(image_logits), "action_loss": ce(action_logits)}
+    out["loss"] = 0.5 * (out["image_loss"] + out["action_loss"])
+    for name, x in (("img2act", image_logits), ("act2img", action_logits)):
+        for k in k_values:
+            if k <= B:
+                top = torch.topk(x, k, dim=1).indices
+                out[f"{name}_top{k}_acc"] = float((top == labels.view(-1, 1)).any(dim=1).float().mean())
+    return out

@@ -203,6 +203,65 @@ def gen_verifier():
     save("verifier_ties", global_idx=np.int64(int(gidx)), max_score=np.float32(score), hist=same[0])
 
 
+def gen_verifier_training():
+    """Validation forward of ONE verifier model through the reference's own training module
+    (finetune_trajectory_bridge_ddp.py): VLA_SigLIP2_Bridge.__init__ + forward + the loss / accuracy code of the loops.
+    The frozen SigLIP2 model is a shape-only stand-in object (attributes __init__ reads: dims, patch size, the two hooked
+    modules); extract_features is replaced at the feature boundary by the supplied batch of B distinct (pf, tf)."""
+    import importlib
+    import warnings
+    warnings.filterwarnings("ignore")
+    model, _ = import_reference_verifier()
+    ft = importlib.import_module("bridge_verifier.ensemble_eval.finetune_trajectory_bridge_ddp")
+    nn = torch.nn
+
+    class _Trunk(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.num_features = 1024
+            self.patch_embed = nn.Module()
+            self.patch_embed.proj = nn.Conv2d(3, 4, 16, 16)
+            blk = nn.Module()
+            blk.attn = nn.Identity()
+            self.blocks = nn.ModuleList([blk])
+
+    class _Clip(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.visual = nn.Module()
+            self.visual.trunk = _Trunk()
+            self.visual.image_size = (384, 384)
+            self.text = nn.Module()
+            self.text.output_dim = 1024
+            self.text.transformer = nn.Identity()
+
+    for use_tr, B, seed in [(True, 12, 41), (False, 6, 43)]:
+        ckpt = synth.verifier_checkpoint(1, seed=1234 + seed, use_transformer=use_tr)
+        cs = ckpt["ensemble_components"][0]
+        cfg = model.ModelConfig(clip_model=_Clip(), history_length=10, action_dim=7)
+        net = ft.VLA_SigLIP2_Bridge(cfg, use_transformer=use_tr).set_trainable_dtype(torch.float32)
+        for name in ("text_aware_visual_extraction", "vision_poolings", "text_pooling", "input_projection",
+                     "single_step_action_encoder", "trajectory_encoder", "complex_action_encoder"):
+            if cs.get(name) is not None:
+                getattr(net, name).load_state_dict(cs[name])
+        logit_scale = 2.6592 + 0.01 * seed          # a trained value, not the init
+        with torch.no_grad():
+            net.logit_scale.fill_(logit_scale)
+        net.eval()
+        pf, tf, hist = synth.verifier_batch_inputs(B, seed=seed)
+        net.extract_features = lambda images, text: (pf, tf)
+        with torch.no_grad():
+            li, la = net(torch.zeros(B, 3, 8, 8), torch.zeros(B, 64, dtype=torch.long), hist)
+            labels = torch.arange(B)
+            il = torch.nn.functional.cross_entropy(li, labels)
+            al = torch.nn.functional.cross_entropy(la, labels)
+            acc = ft.calculate_accuracy_metrics(li, la, B, "cpu")
+        save(f"verifier_train_fwd_{'tr' if use_tr else 'mlp'}_b{B}", ckpt_seed=1234 + seed, input_seed=seed, use_transformer=use_tr,
+             logit_scale=np.float32(logit_scale), B=B, hist=hist, image_logits=li, action_logits=la,
+             image_loss=np.float32(il), action_loss=np.float32(al), loss=np.float32((il + al) / 2),
+             acc_names=np.array(sorted(acc)), acc_values=np.array([acc[k] for k in sorted(acc)], dtype=np.float64))
+
+
 # ======================================================================================== adapter math (P1 host glue)
 def gen_adapter():
     """BridgeSimplerAdapter.postprocess / postprocess_verifier + geometry helpers on 64 random normalised action rows."""
@@ -243,6 +302,8 @@ if __name__ == "__main__":
     torch.manual_seed(0)
     if "verifier" in which:
         gen_verifier()
+    if "verifier_train" in which or "verifier" in which:
+        gen_verifier_training()
     if "adapter" in which:
         gen_adapter()
     if "pi0" in which:

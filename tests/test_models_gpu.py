@@ -127,6 +127,39 @@ def test_verifier_mlp_action_encoder_matches_reference_golden(dev):
     assert int(r["result"][0]) == int(z["global_idx"]) and abs(float(r["best"][0]) - float(z["max_score"])) < 1e-5
 
 
+@pytest.mark.parametrize("name", ["verifier_train_fwd_tr_b12", "verifier_train_fwd_mlp_b6"])
+def test_verifier_contrastive_forward_matches_reference_golden(dev, name):
+    """SURVEY 8(f)4, verifier half: the forward the verifier is trained / validated with (one model, B distinct triples ->
+    [B, B] logits both ways, symmetric InfoNCE loss, top-k retrieval accuracy) against the reference's own
+    VLA_SigLIP2_Bridge.forward + calculate_accuracy_metrics (finetune_trajectory_bridge_ddp.py:357-421, :446-469, :895-899).
+    fp32 heads: tolerance 5e-5 on logits of magnitude ~15 * cos."""
+    from cover_vla_amd import ops
+    from cover_vla_amd.verifier import VLASigLIP2Bridge
+    z = np.load(os.path.join(GOLD, name + ".npz"))
+    ckpt = synth.verifier_checkpoint(1, seed=int(z["ckpt_seed"]), use_transformer=bool(z["use_transformer"]))
+    pf, tf, hist = synth.verifier_batch_inputs(int(z["B"]), seed=int(z["input_seed"]))
+    assert np.array_equal(hist.numpy(), z["hist"])
+    net = VLASigLIP2Bridge(ckpt["ensemble_components"][0], logit_scale=float(z["logit_scale"]), device="cuda:0")
+    li, la = net.forward_features(pf, tf, hist)
+    assert np.allclose(li.cpu().numpy(), z["image_logits"], atol=5e-5) and np.allclose(la.cpu().numpy(), z["action_logits"], atol=5e-5)
+    assert torch.equal(li, la.T.contiguous()) or np.allclose(li.cpu().numpy(), la.cpu().numpy().T, atol=1e-6)
+    m = net.contrastive_metrics(li, la)
+    assert abs(m["loss"] - float(z["loss"])) < 2e-5 and abs(m["image_loss"] - float(z["image_loss"])) < 2e-5
+    assert abs(m["action_loss"] - float(z["action_loss"])) < 2e-5
+    for k, v in zip(z["acc_names"], z["acc_values"]):
+        assert abs(m[str(k)] - float(v)) < 1e-7, k
+    # the row statistics kernel against torch on the device logits (exact ranks; loss to fp32 rounding)
+    loss, rank = ops.xent_diag_f32(li)
+    ref = torch.logsumexp(li.double(), 1) - li.double().diagonal()
+    assert torch.allclose(loss.double(), ref, atol=1e-5)
+    d = li.diagonal().view(-1, 1)
+    cols = torch.arange(li.shape[1], device=li.device).view(1, -1)
+    rows = torch.arange(li.shape[0], device=li.device).view(-1, 1)
+    assert torch.equal(rank.long(), ((li > d) | ((li == d) & (cols < rows))).sum(1))
+    with pytest.raises(RuntimeError):
+        net(None, None, hist)                      # no encoder attached: refuses instead of guessing features
+
+
 def test_verifier_members_batched_equals_member_loop(dev):
     """All members' trajectory encoders as batched launches (member = batch index) == the per-member loop, bit for bit."""
     from cover_vla_amd.verifier import EfficientEnsembleMerged

@@ -45,6 +45,24 @@ def test_verifier_oracle_mlp_action_encoder_matches_reference():
     assert o["global_idx"] == int(z["global_idx"]) and abs(o["max_score"] - float(z["max_score"])) < 1e-5
 
 
+@pytest.mark.parametrize("name", ["verifier_train_fwd_tr_b12", "verifier_train_fwd_mlp_b6"])
+def test_verifier_oracle_contrastive_forward_matches_reference(name):
+    """Validation forward of one verifier model + InfoNCE loss + top-k accuracies (finetune_trajectory_bridge_ddp.py:357-421,
+    :446-469, :895-899), against the reference's own VLA_SigLIP2_Bridge.forward (oracle/gen_golden.py gen_verifier_training)."""
+    from cover_ref import verifier as V
+    z = np.load(os.path.join(GOLD, name + ".npz"))
+    ckpt = synth.verifier_checkpoint(1, seed=int(z["ckpt_seed"]), use_transformer=bool(z["use_transformer"]))
+    pf, tf, hist = synth.verifier_batch_inputs(int(z["B"]), seed=int(z["input_seed"]))
+    assert np.array_equal(hist.numpy(), z["hist"])          # the seeded batch is the generator's batch
+    with torch.no_grad():
+        li, la = V.contrastive_forward(ckpt["ensemble_components"][0], float(z["logit_scale"]), pf, tf, hist)
+    assert np.allclose(li.numpy(), z["image_logits"], atol=2e-5) and np.allclose(la.numpy(), z["action_logits"], atol=2e-5)
+    m = V.contrastive_metrics(li, la)
+    assert abs(m["loss"] - float(z["loss"])) < 1e-5 and abs(m["image_loss"] - float(z["image_loss"])) < 1e-5
+    for k, v in zip(z["acc_names"], z["acc_values"]):
+        assert abs(m[str(k)] - float(v)) < 1e-7, k
+
+
 def test_verifier_oracle_public_api_golden():
     """The reference's public 4-tuple (distinct instructions per group), restated at the feature level."""
     from cover_ref import verifier as V
