@@ -1,0 +1,207 @@
+"""pi0-FAST token path goldens: the REFERENCE's PI0FAST pieces -- embed_inputs (modeling_pi0fast.py:888-946),
+block_causal_update_causal_mask (:236-330) and the PaliGemma forward call of PI0FAST.forward / generate_actions (:686-716,
+:861-884) -- imported from /root/reference in THIS container only, on a tiny seeded PaliGemma. See gen_golden.py /
+gen_golden_pi0.py for the rules. What is emulated and why:
+  * `generate_actions` runs HF `generate` through a monkey-patched `prepare_inputs_for_generation` written against
+    transformers 4.48 internals (HybridCache, _update_causal_mask) that 5.x no longer has. Greedy generation is therefore
+    restated here as the loop it is: forward the left-padded sequence with the block-causal mask and 1-indexed positions
+    (prepare_inputs_for_generation :352-354), take the arg-max of the last position, append it as a suffix token
+    (token type 1, pad mask 1), repeat; a finished row (EOS) keeps emitting the pad token as `generate` does.
+    Every forward is the reference's own embed_inputs + mask function + `pi0_paligemma.forward`.
+  * HF 4.48.3 -> 5.x behaviour changes are neutralised as in gen_golden_pi0.py so the goldens carry 4.48.3 semantics:
+    get_image_features / sqrt(hidden), un-scaled embed_tokens, and GemmaModel's `inputs_embeds * sqrt(hidden)` (5.x moved the
+    factor into the embedding module, so with `inputs_embeds` given it would be lost): applied here in the tensor dtype.
+  * The FAST action tokenizer (`physical-intelligence/fast`) and the PaliGemma tokenizer are not vendored: inputs are token
+    ids, outputs are token ids. The DCT half of `decode_actions_with_fast` (:735-792) is pinned separately with a stand-in
+    BPE decoder (chr / ord round trip), the arithmetic after it being the reference's own.
+"""
+from __future__ import annotations
+
+import importlib
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import gen_golden_pi0 as G  # noqa: E402
+
+TINY = dict(G.TINY)
+
+
+def import_reference_pi0fast():
+    G.import_reference_pi0()
+    G._shell("lerobot.common.policies.pi0fast", os.path.join(G.LR, "common", "policies", "pi0fast"))
+    import transformers.cache_utils as cu
+    for n in ("HybridCache", "StaticCache"):      # isinstance() targets of the generation-time mask code only
+        if not hasattr(cu, n):
+            setattr(cu, n, type(n, (), {}))
+    return importlib.import_module("lerobot.common.policies.pi0fast.modeling_pi0fast")
+
+
+def build_reference_model(m, tiny, dtype):
+    from transformers import PaliGemmaForConditionalGeneration
+    from transformers.models.auto import CONFIG_MAPPING
+    n_img = (tiny["image"] // tiny["patch"]) ** 2
+    cfg = CONFIG_MAPPING["paligemma"](
+        transformers_version="4.48.1", _vocab_size=tiny["vocab"], bos_token_id=2, eos_token_id=1, hidden_size=tiny["lm_dim"],
+        image_token_index=tiny["vocab"] - 1, model_type="paligemma", pad_token_id=0, projection_dim=tiny["lm_dim"],
+        text_config={"hidden_activation": "gelu_pytorch_tanh", "hidden_size": tiny["lm_dim"], "intermediate_size": tiny["lm_mlp"],
+                     "model_type": "gemma", "num_attention_heads": tiny["Hq"], "num_hidden_layers": tiny["layers"],
+                     "num_image_tokens": n_img, "num_key_value_heads": tiny["Hkv"], "head_dim": tiny["D"], "torch_dtype": "float32",
+                     "vocab_size": tiny["vocab"], "_attn_implementation": "eager"},
+        vision_config={"hidden_size": tiny["vit_dim"], "intermediate_size": tiny["vit_mlp"], "model_type": "siglip_vision_model",
+                       "num_attention_heads": tiny["vit_heads"], "num_hidden_layers": tiny["vit_layers"], "num_image_tokens": n_img,
+                       "patch_size": tiny["patch"], "image_size": tiny["image"], "projection_dim": tiny["lm_dim"],
+                       "projector_hidden_act": "gelu_pytorch_tanh", "torch_dtype": "float32", "vision_use_head": False})
+    pg = PaliGemmaForConditionalGeneration(config=cfg).eval()
+    net = m.PI0FAST.__new__(m.PI0FAST)
+    torch.nn.Module.__init__(net)
+    net.pi0_paligemma = pg
+    net.pad_token_id, net.ignore_index = 0, -100
+    hidden = tiny["lm_dim"]
+
+    def embed_image_4483(image):
+        feats = pg.model.get_image_features(image).pooler_output
+        return feats / (hidden ** 0.5)
+
+    def embed_tokens_4483(tokens):
+        return torch.nn.functional.embedding(tokens, pg.model.language_model.embed_tokens.weight)
+
+    net.embed_image = embed_image_4483
+    net.embed_tokens = embed_tokens_4483
+    return net, pg
+
+
+def load_weights(pg, sd, dtype):
+    """neutral (synth.pi0_state) vision / projector / lm weights into the HF module (the tied lm_head follows embed_tokens)."""
+    shim = types.SimpleNamespace(paligemma_with_expert=types.SimpleNamespace(paligemma=pg))
+    vt = pg.model.vision_tower
+    vt = getattr(vt, "vision_model", vt)
+    lm = pg.model.language_model
+    with torch.no_grad():
+        def put(p, t):
+            assert p.shape == t.shape, (p.shape, t.shape)
+            p.copy_(t.to(p.dtype))
+        ps = vt.embeddings.patch_embedding
+        put(ps.weight, sd["vision.patch.weight"].view(ps.weight.shape)); put(ps.bias, sd["vision.patch.bias"])
+        put(vt.embeddings.position_embedding.weight, sd["vision.pos"])
+        for i, L in enumerate(vt.encoder.layers):
+            p = f"vision.blocks.{i}."
+            put(L.layer_norm1.weight, sd[p + "ln1.weight"]); put(L.layer_norm1.bias, sd[p + "ln1.bias"])
+            put(L.layer_norm2.weight, sd[p + "ln2.weight"]); put(L.layer_norm2.bias, sd[p + "ln2.bias"])
+            for a, b in (("q_proj", "q"), ("k_proj", "k"), ("v_proj", "v"), ("out_proj", "o")):
+                put(getattr(L.self_attn, a).weight, sd[p + b + ".weight"]); put(getattr(L.self_attn, a).bias, sd[p + b + ".bias"])
+            put(L.mlp.fc1.weight, sd[p + "fc1.weight"]); put(L.mlp.fc1.bias, sd[p + "fc1.bias"])
+            put(L.mlp.fc2.weight, sd[p + "fc2.weight"]); put(L.mlp.fc2.bias, sd[p + "fc2.bias"])
+        put(vt.post_layernorm.weight, sd["vision.post_ln.weight"]); put(vt.post_layernorm.bias, sd["vision.post_ln.bias"])
+        mmp = pg.model.multi_modal_projector.linear
+        put(mmp.weight, sd["projector.weight"]); put(mmp.bias, sd["projector.bias"])
+        put(lm.embed_tokens.weight, sd["lm.embed_tokens.weight"])
+        for i, L in enumerate(lm.layers):
+            p = f"lm.layers.{i}."
+            put(L.input_layernorm.weight, sd[p + "input_layernorm.weight"])
+            put(L.post_attention_layernorm.weight, sd[p + "post_attention_layernorm.weight"])
+            for n in ("q_proj", "k_proj", "v_proj", "o_proj"):
+                put(getattr(L.self_attn, n).weight, sd[p + f"self_attn.{n}.weight"])
+            for n in ("gate_proj", "up_proj", "down_proj"):
+                put(getattr(L.mlp, n).weight, sd[p + f"mlp.{n}.weight"])
+        put(lm.norm.weight, sd["lm.norm.weight"])
+    if dtype == torch.bfloat16:   # PI0FAST.__init__ :466-473: language_model / vision_tower / multi_modal params -> bf16
+        for name, param in pg.named_parameters():
+            if any(s in name for s in ("language_model", "vision_tower", "multi_modal")):
+                param.data = param.data.to(torch.bfloat16)
+    assert pg.lm_head.weight.data_ptr() == lm.embed_tokens.weight.data_ptr() or torch.equal(pg.lm_head.weight, lm.embed_tokens.weight)
+
+
+def fast_inputs(tiny, B, Lp, seed):
+    """B rows = B // 2 prompts x 2 candidates (identical rows -> identical tokens), one camera frame, right-padded prefix ids."""
+    g = torch.Generator().manual_seed(seed)
+    img = (torch.rand(1, 3, tiny["image"], tiny["image"], generator=g) * 2 - 1).repeat(B, 1, 1, 1)
+    n_prompts = max(1, B // 2)
+    lens = [3 + (i * 4) % (Lp - 2) for i in range(n_prompts)]
+    toks = torch.zeros(B, Lp, dtype=torch.long)
+    pad = torch.zeros(B, Lp, dtype=torch.long)
+    for b in range(B):
+        pi = b % n_prompts
+        gg = torch.Generator().manual_seed(seed * 100 + pi)
+        toks[b, :lens[pi]] = torch.randint(2, tiny["vocab"] - 1, (lens[pi],), generator=gg)
+        pad[b, :lens[pi]] = 1
+    return img, toks, pad
+
+
+def reference_generate(m, net, pg, img, toks, pad, n_new, eos, dtype, force=None):
+    """force int64 [B, n_new]: teacher-force the fed-back tokens (the logits of every step then belong to a known, varied prefix)."""
+    B = toks.shape[0]
+    hidden = pg.config.text_config.hidden_size
+    img = img.to(dtype)
+    gen = torch.zeros(B, 0, dtype=torch.long)
+    done = torch.zeros(B, dtype=torch.bool)
+    logits_all, first = [], None
+    for step in range(n_new):
+        ids = torch.cat([toks, gen], dim=1)
+        pm = torch.cat([pad, torch.ones(B, gen.shape[1], dtype=torch.long)], dim=1)
+        ar = torch.cat([torch.zeros_like(pad), torch.ones(B, gen.shape[1], dtype=torch.long)], dim=1)   # prefix bidirectional, generated causal
+        embs, pad_masks, _, _, _, tti = net.embed_inputs([img], [torch.ones(B, dtype=torch.bool)], ids, pm, ar, ar.clone(), ar.clone(),
+                                                         padding_side="left")
+        if first is None:
+            first = (embs.float().clone(), pad_masks.clone())
+        position_ids = torch.cumsum(pad_masks, dim=1)              # (cumsum - 1) + 1: PaliGemma positions are 1-indexed (:352-354)
+        cache_position = torch.arange(0, embs.shape[1])
+        mask4 = m.block_causal_update_causal_mask(attention_mask=pad_masks, past_key_values=None, cache_position=cache_position,
+                                                  input_tensor=embs, token_type_ids=tti.to(torch.int64), dtype=pg.dtype,
+                                                  attn_implementation="eager")
+        x = embs * torch.tensor(hidden ** 0.5, dtype=embs.dtype)  # GemmaModel.forward of 4.48.3: hidden_states * normalizer
+        out = pg.forward(input_ids=None, token_type_ids=None, attention_mask=mask4, position_ids=position_ids, past_key_values=None,
+                         inputs_embeds=x, use_cache=False, labels=None)
+        lg = out.logits[:, -1].float()
+        nxt = lg.argmax(-1) if force is None else force[:, step]
+        nxt = torch.where(done, torch.zeros_like(nxt), nxt)        # finished rows emit the pad token
+        logits_all.append(lg)
+        gen = torch.cat([gen, nxt[:, None]], dim=1)
+        done = done | (nxt == eos)
+    return gen, torch.stack(logits_all), first
+
+
+def gen_pi0fast(save):
+    import warnings
+    warnings.filterwarnings("ignore")
+    from cover_vla_amd import synth
+    m = import_reference_pi0fast()
+    for name, B, Lp, n_new, seed, dtype in [("pi0fast_tiny_b6_f32", 6, 12, 8, 31, torch.float32), ("pi0fast_tiny_b6_bf16", 6, 12, 8, 31, torch.bfloat16),
+                                             ("pi0fast_tiny_b1_f32", 1, 7, 5, 32, torch.float32)]:
+        tiny = dict(TINY)
+        net, pg = build_reference_model(m, tiny, dtype)
+        sd = synth.pi0_state(tiny, seed=seed)
+        load_weights(pg, sd, dtype)
+        img, toks, pad = fast_inputs(tiny, B, Lp, seed)
+        with torch.no_grad():
+            gen, logits, (embs0, pm0) = reference_generate(m, net, pg, img, toks, pad, n_new, eos=1, dtype=dtype)
+            # teacher-forced continuation (varied tokens, none of them EOS): logits of every step
+            gf = torch.Generator().manual_seed(seed + 7)
+            force = torch.randint(2, tiny["vocab"] - 1, (B, n_new), generator=gf)
+            _, logits_f, _ = reference_generate(m, net, pg, img, toks, pad, n_new, eos=1, dtype=dtype, force=force)
+            # the EOS rule: declare row 0's first pick the EOS token -> that row (and its twin) emits pad tokens from then on
+            eos2 = int(gen[0, 0])
+            gen_e, logits_e, _ = reference_generate(m, net, pg, img, toks, pad, n_new, eos=eos2, dtype=dtype)
+        save(name, B=B, Lp=Lp, n_new=n_new, seed=seed, tokens=gen, logits=logits, prefix_embs_leftpad=embs0, pad_masks_leftpad=pm0,
+             force=force, logits_forced=logits_f, eos2=eos2, tokens_eos2=gen_e, logits_eos2=logits_e,
+             **{"tiny_" + k: v for k, v in tiny.items()})
+    # ---- the DCT half of decode_actions_with_fast, with a chr/ord stand-in for the BPE decoder
+    net = m.PI0FAST.__new__(m.PI0FAST)
+    torch.nn.Module.__init__(net)
+    bpe = types.SimpleNamespace(decode=lambda toks: "".join(chr(t) for t in toks))
+    net.fast_tokenizer = types.SimpleNamespace(bpe_tokenizer=bpe, min_token=-20, scale=10.0, time_horizon=None, action_dim=None,
+                                               called_time_horizon=None, called_action_dim=None)
+    rng = np.random.default_rng(3)
+    seqs = [list(rng.integers(0, 60, size=n)) for n in (28, 20, 35)]      # exact, short (padded) and long (truncated) for 4 x 7
+    acts = net.decode_actions_with_fast(seqs, time_horizon=4, action_dim=7, relaxed_decoding=True)
+    save("pi0fast_dct_decode", seq0=np.array(seqs[0]), seq1=np.array(seqs[1]), seq2=np.array(seqs[2]), actions=acts, min_token=-20, scale=10.0)
+
+
+if __name__ == "__main__":
+    from gen_golden import save
+    gen_pi0fast(save)

@@ -275,3 +275,64 @@ def test_oracle_openvla_end_to_end_matches_hf_composition(prec):
                 assert tok[n, i] == ref_t[n, i], (n, i)
             agree_so_far = bool(tok[n, i] == ref_t[n, i])
     assert n_dec >= 10
+
+
+# ------------------------------------------------------------------------------------------------ pi0-FAST token path
+def _fast_case(name):
+    from gen_golden_pi0fast import fast_inputs
+    z = np.load(os.path.join(GOLD, name + ".npz"))
+    tiny = {k[5:]: int(z[k]) for k in z.files if k.startswith("tiny_")}
+    sd = synth.pi0_state(tiny, seed=int(z["seed"]))
+    return z, tiny, sd, fast_inputs(tiny, int(z["B"]), int(z["Lp"]), int(z["seed"]))
+
+
+@pytest.mark.parametrize("name", ["pi0fast_tiny_b6_f32", "pi0fast_tiny_b1_f32"])
+def test_oracle_pi0fast_tokens_match_reference(name):
+    """Greedy pi0-FAST token generation (embed_inputs + block-causal mask + PaliGemma forward of the REFERENCE, imported by
+    oracle/gen_golden_pi0fast.py) vs the restatement, fp32: logits of every step, the picked tokens, the teacher-forced
+    continuation and the pad-after-EOS rule."""
+    from cover_ref import pi0fast as PF
+    z, tiny, sd, (img, toks, pad) = _fast_case(name)
+    n_new = int(z["n_new"])
+    with _fp32_blocks() as Bk, torch.no_grad():
+        vit = Bk.VitCfg(tiny["vit_dim"], tiny["vit_layers"], tiny["vit_heads"], tiny["vit_mlp"], tiny["patch"], "gelu_tanh", 1e-6)
+        lm = Bk.DecoderCfg(tiny["lm_dim"], tiny["layers"], tiny["Hq"], tiny["Hkv"], tiny["D"], tiny["lm_mlp"], "gelu_tanh", "gemma", 1e-6, "hf")
+        gen, lg = PF.generate(vit, lm, sd, img, toks, pad, n_new)
+        _, lgf = PF.generate(vit, lm, sd, img, toks, pad, n_new, force=torch.from_numpy(z["force"]))
+        gen_e, lge = PF.generate(vit, lm, sd, img, toks, pad, n_new, eos=int(z["eos2"]))
+    assert np.allclose(lg.numpy(), z["logits"], atol=3e-4), np.abs(lg.numpy() - z["logits"]).max()
+    assert np.array_equal(gen.numpy(), z["tokens"])
+    assert np.allclose(lgf.numpy(), z["logits_forced"], atol=3e-4), np.abs(lgf.numpy() - z["logits_forced"]).max()
+    assert np.array_equal(gen_e.numpy(), z["tokens_eos2"]) and (z["tokens_eos2"][0, 1:] == 0).all()
+    # the embedded prefix of the reference (left padded) holds the same rows as the restatement's (right padded)
+    with _fp32_blocks() as Bk, torch.no_grad():
+        pe, pm = PF.embed_inputs(vit, lm, sd, img, toks, pad)
+    ref_e, ref_m = z["prefix_embs_leftpad"], z["pad_masks_leftpad"]
+    for b in range(pe.shape[0]):
+        assert np.allclose(pe[b][pm[b].bool()].numpy(), ref_e[b][ref_m[b].astype(bool)], atol=2e-5)
+
+
+def test_oracle_pi0fast_bf16_matches_reference():
+    """The same path with the language model / tower / projector in bf16 (PI0FAST.__init__ :466-473), teacher-forced: logits
+    within bf16 noise of the reference's bf16 run, arg-max equal wherever the reference's margin exceeds the error."""
+    from cover_ref import blocks as Bk, pi0fast as PF
+    z, tiny, sd, (img, toks, pad) = _fast_case("pi0fast_tiny_b6_bf16")
+    sdb = {k: (v.to(torch.bfloat16) if k.startswith(("lm.", "vision.", "projector.")) else v) for k, v in sd.items()}
+    vit = Bk.VitCfg(tiny["vit_dim"], tiny["vit_layers"], tiny["vit_heads"], tiny["vit_mlp"], tiny["patch"], "gelu_tanh", 1e-6)
+    lm = Bk.DecoderCfg(tiny["lm_dim"], tiny["layers"], tiny["Hq"], tiny["Hkv"], tiny["D"], tiny["lm_mlp"], "gelu_tanh", "gemma", 1e-6, "hf")
+    with torch.no_grad():
+        _, lgf = PF.generate(vit, lm, sdb, img, toks, pad, int(z["n_new"]), force=torch.from_numpy(z["force"]))
+    ref = torch.from_numpy(z["logits_forced"])
+    assert _rel(lgf, ref) < 2e-2, _rel(lgf, ref)
+    err = (lgf - ref).abs().amax(-1)
+    top2 = torch.topk(ref, 2, dim=-1).values
+    decided = (top2[..., 0] - top2[..., 1]) > 2 * err
+    assert decided.sum() >= 30 and torch.equal(lgf.argmax(-1)[decided], ref.argmax(-1)[decided])
+
+
+def test_oracle_pi0fast_dct_decode_matches_reference():
+    from cover_ref import pi0fast as PF
+    z = np.load(os.path.join(GOLD, "pi0fast_dct_decode.npz"))
+    seqs = [z["seq0"].tolist(), z["seq1"].tolist(), z["seq2"].tolist()]
+    out = PF.decode_actions_with_fast(seqs, lambda t: "".join(chr(i) for i in t), int(z["min_token"]), float(z["scale"]), 4, 7)
+    assert np.allclose(out, z["actions"], atol=1e-12)
