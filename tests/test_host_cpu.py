@@ -270,3 +270,18 @@ def test_episode_log_schema_matches_the_driver(tmp_path):
     log.save(str(tmp_path / "ep.pkl"))
     with open(tmp_path / "ep.pkl", "rb") as f:
         assert list(pickle.load(f).keys()) == fields
+
+
+def test_pi0fast_dct_decode_matches_reference_golden():
+    from cover_vla_amd.pi0fast import fast_coefficients_to_actions, fast_tokens_to_paligemma_tokens
+    z = np.load(os.path.join(GOLD, "pi0fast_dct_decode.npz"))
+    seqs = [z["seq0"].tolist(), z["seq1"].tolist(), z["seq2"].tolist()]
+    out = fast_coefficients_to_actions(seqs, lambda t: "".join(chr(i) for i in t), min_token=int(z["min_token"]), scale=float(z["scale"]),
+                                       time_horizon=4, action_dim=7)
+    assert np.allclose(out, z["actions"], atol=1e-12)
+    bad = fast_coefficients_to_actions([[1, 2, 3]], lambda t: (_ for _ in ()).throw(ValueError("no tokenizer")), min_token=0, scale=10.0,
+                                       time_horizon=4, action_dim=7)
+    assert bad.shape == (1, 4, 7) and not bad.any()                                  # undecodable sequence -> zeros, as the reference
+    t = np.array([0, 5, 1000])
+    assert np.array_equal(fast_tokens_to_paligemma_tokens(fast_tokens_to_paligemma_tokens(t, 257152), 257152), t)
+    assert fast_tokens_to_paligemma_tokens(np.array([0]), 257152)[0] == 257152 - 1 - 128

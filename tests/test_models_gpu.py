@@ -493,3 +493,125 @@ def test_policy_server_composes_real_sampler_and_verifier(dev):
     assert int(out["index"]) == int(ref["index"]) and np.array_equal(out["action"], ref["action"]) and out["action"].shape == (7,)
     assert abs(float(out["score"]) - float(ref["score"])) < 1e-7
     assert server.unpack(session.handle(server.pack({"reset": True}))[0]) == {"status": "reset"}
+
+
+# ------------------------------------------------------------------------------------------------ pi0-FAST token path
+def _fast_case(name):
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    z = np.load(os.path.join(GOLD, name + ".npz"))
+    tiny = {k[5:]: int(z[k]) for k in z.files if k.startswith("tiny_")}
+    B, Lp, seed = int(z["B"]), int(z["Lp"]), int(z["seed"])
+    sd = synth.pi0_state(tiny, seed=seed)
+    # the generator's inputs (oracle/gen_golden_pi0fast.py fast_inputs), restated: the reference tree is not on the GPU box
+    g = torch.Generator().manual_seed(seed)
+    img = (torch.rand(1, 3, tiny["image"], tiny["image"], generator=g) * 2 - 1).repeat(B, 1, 1, 1)
+    n_prompts = max(1, B // 2)
+    lens = [3 + (i * 4) % (Lp - 2) for i in range(n_prompts)]
+    toks = torch.zeros(B, Lp, dtype=torch.long)
+    pad = torch.zeros(B, Lp, dtype=torch.long)
+    for b in range(B):
+        pi = b % n_prompts
+        gg = torch.Generator().manual_seed(seed * 100 + pi)
+        toks[b, :lens[pi]] = torch.randint(2, tiny["vocab"] - 1, (lens[pi],), generator=gg)
+        pad[b, :lens[pi]] = 1
+    return z, tiny, sd, img, toks, pad
+
+
+def test_pi0fast_tokens_match_reference_golden(dev):
+    """SURVEY 8(f)4, pi0-FAST half: greedy action-token generation (prefix-LM prefill + cached decode + tied lm_head + arg-max on
+    the device) against the REFERENCE's embed_inputs / block-causal mask / PaliGemma forward run in bf16 (golden:
+    oracle/gen_golden_pi0fast.py). Teacher-forced logits of every step: rel-L2 <= 2e-2 (bf16 model); the arg-max agrees wherever
+    the reference's top-2 margin exceeds twice the observed error; free-running tokens equal the reference's while that holds;
+    the pad-after-EOS rule of `generate`."""
+    from cover_vla_amd.pi0fast import PI0FASTTokens
+    z, tiny, sd, img, toks, pad = _fast_case("pi0fast_tiny_b6_bf16")
+    B, n_new = int(z["B"]), int(z["n_new"])
+    model = PI0FASTTokens(sd, tiny, device="cuda:0", max_batch=8, max_prompt=toks.shape[1], max_new_tokens=16)
+    args = ([img.to(dev)], [torch.ones(B, dtype=torch.bool, device=dev)], toks.to(dev), pad.to(dev), n_new)
+    # (a) teacher-forced continuation
+    tr = {}
+    model.generate_tokens(*args, force_tokens=torch.from_numpy(z["force"]), trace=tr)
+    lg = torch.stack([t.float().cpu() for t in tr["logits"]])                        # [n_new, B, V]
+    ref = torch.from_numpy(z["logits_forced"])
+    rel = ((lg - ref).norm() / ref.norm()).item()
+    assert rel < 2e-2, rel
+    err = (lg - ref).abs().amax(-1)
+    top2 = torch.topk(ref, 2, dim=-1).values
+    decided = (top2[..., 0] - top2[..., 1]) > 2 * err
+    assert decided.sum() >= 30 and torch.equal(lg.argmax(-1)[decided], ref.argmax(-1)[decided])
+    # prompt token embeddings (gather x sqrt(dim)) are exact, image tokens agree at bf16 level with the reference's HF tower
+    # (the golden holds embed_inputs' output, i.e. BEFORE GemmaModel's * sqrt(dim) = 16 here, an exact power of two)
+    pe = tr["prefix_embs"].float().cpu().numpy() / 16.0
+    ref_e, ref_m = z["prefix_embs_leftpad"], z["pad_masks_leftpad"].astype(bool)
+    n_img = model.n_img
+    for b in range(B):
+        mine = np.concatenate([pe[b, :n_img], pe[b, n_img:][pad[b].numpy().astype(bool)]], 0)
+        theirs = ref_e[b][ref_m[b]]
+        assert np.array_equal(mine[n_img:], theirs[n_img:])
+        assert np.linalg.norm(mine[:n_img] - theirs[:n_img]) / np.linalg.norm(theirs[:n_img]) < 1.5e-2
+    # (b) free running: every row's tokens equal the reference's up to (excluding) the first step whose pick was not decided
+    tr2 = {}
+    out = model.generate_tokens(*args, trace=tr2).cpu()
+    ref_t = torch.from_numpy(z["tokens"])
+    lg2 = torch.stack([t.float().cpu() for t in tr2["logits"]])
+    assert lg2.shape[1] == 3                                   # rows 3..5 repeat (frame, prompt) of rows 0..2: generated once
+    lg2 = torch.cat([lg2, lg2], dim=1)
+    ref2 = torch.from_numpy(z["logits"])
+    n_checked = 0
+    for b in range(B):
+        for i in range(n_new):
+            e = (lg2[i, b] - ref2[i, b]).abs().max().item()
+            t2 = torch.topk(ref2[i, b], 2).values
+            if (t2[0] - t2[1]).item() <= 2 * e:
+                break
+            assert out[b, i] == ref_t[b, i], (b, i)
+            n_checked += 1
+    assert n_checked >= 12
+    assert torch.equal(out[:3], out[3:])                                               # identical rows -> identical tokens (row independence)
+    # (c) EOS: declare row 0's first token the EOS id -> pad tokens afterwards, other rows unaffected
+    eos2 = int(out[0, 0])
+    out_e = model.generate_tokens(*args, eos_token_id=eos2).cpu()
+    assert (out_e[out[:, 0] == eos2][:, 1:] == 0).all() and (out_e[out[:, 0] == eos2][:, 0] == eos2).all()
+    keep = out[:, 0] != eos2
+    first_eos = [(out[b] == eos2).nonzero() for b in range(B)]
+    for b in range(B):
+        if keep[b] and first_eos[b].numel() == 0:
+            assert torch.equal(out_e[b], out[b])
+    # deterministic
+    assert torch.equal(model.generate_tokens(*args).cpu(), out)
+
+
+def test_pi0fast_tokens_match_oracle_with_ragged_prompts_and_two_cameras(dev):
+    """HIP vs the CPU oracle (itself pinned to the reference goldens in tests/test_oracle_golden.py) on a case the goldens do
+    not hold: distinct frames per row, B = 5 rows with ragged prompts, 10 new tokens, teacher-forced; bf16 tolerance."""
+    from cover_vla_amd.pi0fast import PI0FASTTokens
+    from cover_ref import blocks as Bk, pi0fast as PF
+    tiny = dict(lm_dim=256, lm_mlp=512, ex_dim=128, ex_mlp=256, layers=2, Hq=4, Hkv=1, D=64, vocab=96, vit_dim=128, vit_mlp=200,
+                vit_layers=2, vit_heads=4, patch=14, image=56, chunk=4)
+    sd = synth.pi0_state(tiny, seed=77)
+    g = torch.Generator().manual_seed(5)
+    B, L, n_new = 5, 9, 10
+    img = torch.rand(B, 3, 56, 56, generator=g) * 2 - 1
+    lens = [9, 2, 5, 7, 1]
+    toks = torch.zeros(B, L, dtype=torch.long)
+    pad = torch.zeros(B, L, dtype=torch.long)
+    for b in range(B):
+        toks[b, :lens[b]] = torch.randint(2, 95, (lens[b],), generator=g)
+        pad[b, :lens[b]] = 1
+    force = torch.randint(2, 95, (B, n_new), generator=g)
+    sdb = {k: (v.to(torch.bfloat16) if k.startswith(("lm.", "vision.", "projector.")) else v) for k, v in sd.items()}
+    vit = Bk.VitCfg(tiny["vit_dim"], tiny["vit_layers"], tiny["vit_heads"], tiny["vit_mlp"], tiny["patch"], "gelu_tanh", 1e-6)
+    lm = Bk.DecoderCfg(tiny["lm_dim"], tiny["layers"], tiny["Hq"], tiny["Hkv"], tiny["D"], tiny["lm_mlp"], "gelu_tanh", "gemma", 1e-6, "hf")
+    with torch.no_grad():
+        _, ref = PF.generate(vit, lm, sdb, img, toks, pad, n_new, force=force)
+    model = PI0FASTTokens(sd, tiny, device="cuda:0", max_batch=8, max_prompt=L, max_new_tokens=16)
+    tr = {}
+    model.generate_tokens([img.to(dev)], [torch.ones(B, dtype=torch.bool, device=dev)], toks.to(dev), pad.to(dev), n_new,
+                          force_tokens=force, trace=tr)
+    lg = torch.stack([t.float().cpu() for t in tr["logits"]])
+    rel = ((lg - ref).norm() / ref.norm()).item()
+    assert rel < 2e-2, rel
+    err = (lg - ref).abs().amax(-1)
+    top2 = torch.topk(ref, 2, dim=-1).values
+    decided = (top2[..., 0] - top2[..., 1]) > 2 * err
+    assert decided.sum() >= 25 and torch.equal(lg.argmax(-1)[decided], ref.argmax(-1)[decided])
