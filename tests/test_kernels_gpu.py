@@ -430,6 +430,17 @@ def test_token_select(dev):
         cs = np.cumsum(p, dtype=np.float32)
         pick = int(np.argmax(cs > np.float32(u[r].item()) * cs[-1]))
         assert abs(tok[r].item() - (31744 + pick)) <= 0  # same arithmetic -> same index
+    # wide greedy ranges (pi0-FAST: 257 152 logits): the 1024-thread vector path, ragged tail, ties, and the scalar path for an
+    # unaligned lower bound -- first maximum wins everywhere
+    wide = torch.randn(3, 257152, generator=g)
+    wide[1, 7] = wide[1, 200003] = wide[1, 257149] = 60.0
+    wide[2, 257149] = 70.0                                       # in the scalar tail of [4, 257150)
+    for lo, hi in [(0, 257152), (4, 257150), (3, 257150)]:
+        tok, lgv = ops.token_select(wide.to(dev), lo, hi)
+        ref = wide[:, lo:hi].argmax(-1) + lo
+        assert torch.equal(tok.cpu(), ref), (lo, hi)
+        assert torch.equal(lgv.cpu(), wide[torch.arange(3), ref])
+    assert ops.token_select(wide.to(dev), 0, 257152)[0][1].item() == 7
 
 
 def test_score_select(dev):
