@@ -445,7 +445,15 @@ int cover_decoder_forward(const cover_dec_desc* d, const cover_dec_pass* p, void
             if (G.B * G.T == 0) continue;
             bf16_t* gq = (bf16_t*)qkv + (size_t)row0[g] * nqkv;
             const cover_kv_segment& W = G.segs[G.write_seg];
-            if (G.T == 1 && G.seg0_shared && G.n_seg == 3 && G.write_seg == 2 && Hq == Hkv && (D == 64 || D == 128) &&
+            // The fused launch is one block per (16 candidates, head) and re-reads the shared segment per block; with many units
+            // AND long own-token segments (config 5: N = 512, up to 56 own keys, several serial tiles per pool-C wave) the
+            // three-launch path -- shared segment as ONE flash pass over all candidates, then the per-candidate segments seeded
+            // with its state -- is faster (N = 512: fused 109 / 163 / 362 us per layer at 1 / 16 / 56 own keys, crossover ~20;
+            // decision 1045 -> 950 ms). At <= 8 own keys the fused launch wins at every N measured (N = 128 / 256 / 512).
+            static const char* da_max_env = getenv("COVER_DA_FUSED_MAX_N");   // experiment knob: force the three-launch path above N
+            const int da_max = da_max_env ? atoi(da_max_env) : (1 << 30);
+            const bool da_long = ((G.B + 15) / 16) * Hq >= 768 && G.segs[2].len > 16;
+            if (G.T == 1 && G.seg0_shared && G.n_seg == 3 && G.write_seg == 2 && Hq == Hkv && (D == 64 || D == 128) && G.B <= da_max && !da_long &&
                 G.segs[0].mask_mode == COVER_MASK_LEN && G.segs[1].mask_mode == COVER_MASK_LEN && G.segs[2].mask_mode == COVER_MASK_LEN &&
                 G.write_t_offset_of_batch == nullptr && G.segs[2].len_of_batch == nullptr && G.segs[0].len_of_batch == nullptr) {
                 // single-token candidate decode: RoPE + KV append + 3-segment attention in ONE launch

@@ -1868,9 +1868,11 @@ hipError_t launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* Wp, void* C,
     // 75.1 us, gate_up 125.8 -> 119.1 us). Narrow outputs keep the smaller tiles (o_proj: 664 vs 701 TF at M = 2624).
     static const char* big_env = getenv("COVER_BIG_TILES");   // experiment knob: 0 disables the 12-wave tiles
     // (at M = 448 the micro-benchmark gain does not survive inside the decision -- 41.22 vs 40.98 ms -- so: long panels only)
-    if (variant != 2 && Kp >= 2048 && M >= 1024 && !(big_env && big_env[0] == '0')) {
+    // M = 512 (decode rows of BASELINE config 5: N = 512 candidates) is two 256-row tiles: qkv 75.4 -> 60.2 us, gate_up 135.9 -> 116.9,
+    // down 73.1 -> 48.4 + 13.5 (four K slices + reduction); o_proj stays on the 64 x 128 tiles (29.0 vs 25.4 + 13.5).
+    if (variant != 2 && Kp >= 2048 && M >= 512 && !(big_env && big_env[0] == '0')) {
         if (N > 4096 && nblocks(13) >= 176) pick = N >= 16384 ? 12 : 13;
-        else if (N <= 4096 && Kp >= 8192 && nblocks(12) >= 256) pick = 12;
+        else if (N <= 4096 && Kp >= 8192 && (nblocks(12) >= 256 || (M < 1024 && ws != nullptr))) pick = 12;
     }
     // 224-row tiles (picks 15-17): M = 448 -- the OpenVLA prefill pass: 256 patch rows + 8 prompts x 24 text rows -- is exactly two
     // of them, where 128-row tiles pad 12.5 % and 64 x 128 tiles need 1.3-2.7 rounds of blocks. The column width and the number of
