@@ -610,6 +610,12 @@ def test_decode_attention_fused_matches_three_launch_path(dev, D, H, N, write_t,
     _decode_attention_case(dev, D, H, N, write_t, mode, from_partials, permute_slots=False)
 
 
+def test_decode_attention_fused_at_many_units_with_long_own_segments(dev):
+    """The regime where cover_decoder_forward switches from the fused launch to the three-launch path (>= 768 (tile, head) units and
+    > 16 own keys, BASELINE config 5): both paths must agree there too. N = 400 candidates x 32 heads, 20 own keys."""
+    _decode_attention_case(dev, 128, 32, 400, 19, 2, False, permute_slots=False)
+
+
 def test_decode_attention_fused_with_an_explicit_own_slot_table(dev):
     # candidates' own-token segments live in permuted cache slots (write_slot_of_batch / seg[2].slot_of_batch)
     _decode_attention_case(dev, 128, 8, 29, 3, 2, True, permute_slots=True)
