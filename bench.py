@@ -332,7 +332,20 @@ def main():
     ap.add_argument("--horizon", type=int, default=1, help="action-chunk horizon: 7 x horizon action tokens per candidate (config 5: 8)")
     ap.add_argument("--check-out", default=None, help="write this rank's selection (winner index / tokens) as JSON (plumbing tests)")
     a = ap.parse_args()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start one rank per GPU as CHILD processes (torch.distributed.run) before
+        # anything here touches the GPU, and leave with their exit code (never exec from a process that may have initialised HIP)
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if a.gpus != world and "WORLD_SIZE" in os.environ and a.gpus != 1:
+        raise SystemExit(f"--gpus {a.gpus} but the launcher started {world} rank(s)")
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
