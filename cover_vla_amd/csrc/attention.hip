@@ -42,14 +42,23 @@ struct AttnDev {
     float* so_o; float* so_ml;
 };
 
-template <int D, bool KSPLIT>
+#ifdef COVER_AT_DEBUG
+__device__ unsigned long long g_at_dbg[512 * 8];   // per block (thread 0): start, Q loaded, first tile's K landed, tiles done, merged, end (100 MHz)
+extern "C" int cover_at_debug(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_at_dbg), sizeof(g_at_dbg)); }
+#define ATT(slot) do { if (threadIdx.x == 0) g_at_dbg[(((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) & 511) * 8 + (slot)] = wall_clock64(); } while (0)
+#else
+#define ATT(slot) do { } while (0)
+#endif
+// NWS: waves per block in key-split mode (4 or 8), a compile-time constant there so that the merge below is straight-line code
+template <int D, bool KSPLIT, int NWS = 4>
 __device__ __forceinline__ void attn_body(const AttnDev& a, int bx, int kvh, int b) {
+    ATT(0);
     constexpr int KS = D / 32;  // k-steps of QK^T
     constexpr int DB = D / 16;  // 16-row d blocks of O^T
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int nw = blockDim.x >> 6;
+    const int nw = KSPLIT ? NWS : (int)(blockDim.x >> 6);
     const int tile = KSPLIT ? bx : bx * nw + w;
     const int r = lane & 15, g = lane >> 4;
 
@@ -68,6 +77,10 @@ __device__ __forceinline__ void attn_body(const AttnDev& a, int bx, int kvh, int
         for (int ks = 0; ks < KS; ++ks) qf[ks] = as_bf16x8(*(const uint4*)(qp + ks * 32));
     }
 
+#ifdef COVER_AT_DEBUG
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ATT(1);
+#endif
     float m_run = -INFINITY, l_run = 0.f;
     f32x4 oacc[DB];
 #pragma unroll
@@ -124,6 +137,9 @@ __device__ __forceinline__ void attn_body(const AttnDev& a, int bx, int kvh, int
 #pragma unroll
                 for (int db = 0; db < DB; ++db) vr[db] = *(const uint4*)(vp + (long long)(db * 16) * sg.vt_d);
             }
+#ifdef COVER_AT_DEBUG
+            if (tile_counter == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); ATT(2); }
+#endif
             // ---- S^T = K . Q^T for two 16-key blocks ----
             f32x4 s0 = (f32x4){0.f, 0.f, 0.f, 0.f}, s1 = s0;
 #pragma unroll
@@ -178,12 +194,17 @@ __device__ __forceinline__ void attn_body(const AttnDev& a, int bx, int kvh, int
         }
     }
 
+    ATT(3);
+    // In key-split mode every wave merges and stores ITS share of the d blocks (db = w, w + NWS, ...). The merge used to run on
+    // wave 0 alone behind `i < nw` tests on a run-time nw: the compiler kept it as a chain of dependent LDS reads, 11.8 us of a
+    // 23.5 us launch at D = 256 (3.8 of 7.7 at D = 64; per-block timelines, tools/dbg/at_timeline.py). Same sums in the same order.
+    int db_first = 0, db_step = 1;
     if (KSPLIT) {
-        // merge the nw partial states: LDS layout per wave: [DB*4 floats per lane][64 lanes] + m[16] + l[16]
+        // LDS layout per wave: [DB*4 floats per lane][64 lanes] + m[16] + l[16]
         float* so = (float*)smem;
         constexpr int OW = DB * 4 * 64;
-        float* sm = so + nw * OW;
-        float* sl = sm + nw * 16;
+        float* sm = so + NWS * OW;
+        float* sl = sm + NWS * 16;
 #pragma unroll
         for (int db = 0; db < DB; ++db)
 #pragma unroll
@@ -193,60 +214,78 @@ __device__ __forceinline__ void attn_body(const AttnDev& a, int bx, int kvh, int
             sl[w * 16 + r] = l_run;
         }
         __syncthreads();
-        if (w != 0) return;
+        float mi[NWS], li[NWS], f[NWS];
+#pragma unroll
+        for (int i = 0; i < NWS; ++i) {
+            mi[i] = sm[i * 16 + r];
+            li[i] = sl[i * 16 + r];
+        }
         float mx = -INFINITY;
-        for (int i = 0; i < nw; ++i) mx = fmaxf(mx, sm[i * 16 + r]);
+#pragma unroll
+        for (int i = 0; i < NWS; ++i) mx = fmaxf(mx, mi[i]);
         float lt = 0.f;
-        float f[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) f[i] = 0.f;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            if (i >= nw) break;
-            const float mi = sm[i * 16 + r];
-            f[i] = (mi == -INFINITY) ? 0.f : exp2f(mi - mx);
-            lt += sl[i * 16 + r] * f[i];
+        for (int i = 0; i < NWS; ++i) {
+            f[i] = (mi[i] == -INFINITY) ? 0.f : exp2f(mi[i] - mx);
+            lt += li[i] * f[i];
         }
 #pragma unroll
-        for (int db = 0; db < DB; ++db)
+        for (int dbi = 0; dbi < (DB + NWS - 1) / NWS; ++dbi) {
+            const int db = w + dbi * NWS;
+            if (db < DB) {
+                float x[NWS][4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float acc = 0.f;
+                for (int i = 0; i < NWS; ++i)
 #pragma unroll
-                for (int i = 0; i < 8; ++i)
-                    if (i < nw) acc += so[i * OW + (db * 4 + e) * 64 + lane] * f[i];
-                oacc[db][e] = acc;
+                    for (int e = 0; e < 4; ++e) x[i][e] = so[i * OW + (db * 4 + e) * 64 + lane];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float acc = 0.f;
+#pragma unroll
+                    for (int i = 0; i < NWS; ++i) acc += x[i][e] * f[i];
+                    oacc[dbi][e] = acc;              // this wave's dbi-th block (db = w + dbi * NWS) now lives in slot dbi
+                }
             }
+        }
         l_run = lt;
         m_run = mx;
+        db_first = w;
+        db_step = NWS;
     }
+    ATT(4);
 
     if (!q_ok) return;
     const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
     if (a.so_o) {  // hand the state to the next call instead of writing the final output
-        if (g == 0) {
+        if (g == 0 && (!KSPLIT || w == 0)) {
             a.so_ml[srow * 2] = m_run;
             a.so_ml[srow * 2 + 1] = l_run;
         }
         float* so = a.so_o + srow * D + 4 * g;
 #pragma unroll
-        for (int db = 0; db < DB; ++db)
-            *(float4*)(so + db * 16) = make_float4(oacc[db][0] * inv, oacc[db][1] * inv, oacc[db][2] * inv, oacc[db][3] * inv);
+        for (int k = 0; k < DB; ++k) {
+            const int db = db_first + k * db_step;
+            if (db < DB) *(float4*)(so + db * 16) = make_float4(oacc[k][0] * inv, oacc[k][1] * inv, oacc[k][2] * inv, oacc[k][3] * inv);
+        }
         return;
     }
     bf16_t* op = a.out + (long long)b * a.o_b + (long long)t * a.o_t + (long long)h * a.o_h + 4 * g;
 #pragma unroll
-    for (int db = 0; db < DB; ++db) {
-        uint2 v;
-        v.x = pack_bf2(oacc[db][0] * inv, oacc[db][1] * inv);
-        v.y = pack_bf2(oacc[db][2] * inv, oacc[db][3] * inv);
-        *(uint2*)(op + db * 16) = v;
+    for (int k = 0; k < DB; ++k) {
+        const int db = db_first + k * db_step;
+        if (db < DB) {
+            uint2 v;
+            v.x = pack_bf2(oacc[k][0] * inv, oacc[k][1] * inv);
+            v.y = pack_bf2(oacc[k][2] * inv, oacc[k][3] * inv);
+            *(uint2*)(op + db * 16) = v;
+        }
     }
+    ATT(5);
 }
 
-template <int D, bool KSPLIT>
+template <int D, bool KSPLIT, int NWS = 4>
 __global__ __launch_bounds__(512) void attn_kernel(AttnDev a) {
-    attn_body<D, KSPLIT>(a, blockIdx.x, blockIdx.y, blockIdx.z);
+    attn_body<D, KSPLIT, NWS>(a, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
 // Two independent attention problems (the two row groups of a prefill pass: shared-prefix rows and the prompts' text rows)
@@ -285,7 +324,11 @@ static hipError_t launch_d(const AttnDev& a, hipStream_t st) {
         const int nw = (qtiles <= nw8_max && D <= 128) ? 8 : 4;
         const size_t lds = (size_t)(nw * (D / 16) * 4 * 64 + 2 * nw * 16) * sizeof(float);
         dim3 grid(tiles, a.Hkv, a.B), block(64 * nw);
-        hipLaunchKernelGGL((attn_kernel<D, true>), grid, block, lds, st, a);
+        if (nw == 8) {
+            if constexpr (D <= 128) hipLaunchKernelGGL((attn_kernel<D, true, 8>), grid, block, lds, st, a);
+        } else {
+            hipLaunchKernelGGL((attn_kernel<D, true, 4>), grid, block, lds, st, a);
+        }
     } else {
         const int nw = tiles >= 4 ? 4 : tiles;
         dim3 grid((tiles + nw - 1) / nw, a.Hkv, a.B), block(64 * nw);
