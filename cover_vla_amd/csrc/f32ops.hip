@@ -347,12 +347,25 @@ __global__ __launch_bounds__(256) void mha_f32_k(cover_mha_f32_args a) {
     const float* v = a.v + (size_t)b * a.v_b_stride + (size_t)h * a.Dh;
     const uint8_t* pad = a.key_pad ? a.key_pad + (size_t)b * a.Tk : nullptr;
     const int n = a.Tq * a.Tk;
+    const bool vec4 = (a.Dh & 3) == 0 && ((a.q_t_stride | a.k_t_stride | a.q_b_stride | a.k_b_stride) & 3) == 0 &&
+                      (((uintptr_t)a.q | (uintptr_t)a.k) & 15) == 0;
     for (int idx = threadIdx.x; idx < n; idx += 256) {
         const int i = idx / a.Tk, j = idx - i * a.Tk;
         const float* qi = q + (size_t)i * a.q_t_stride;
         const float* kj = k + (size_t)j * a.k_t_stride;
         float s = 0.f;
-        for (int d = 0; d < a.Dh; ++d) s += (qi[d] * a.scale) * kj[d];
+        if (vec4) {   // 16-byte loads, eight of them in flight; the sum runs in the same d order as the scalar loop
+#pragma unroll 4
+            for (int d = 0; d < a.Dh; d += 4) {
+                const float4 qv = *(const float4*)(qi + d), kv = *(const float4*)(kj + d);
+                s += (qv.x * a.scale) * kv.x;
+                s += (qv.y * a.scale) * kv.y;
+                s += (qv.z * a.scale) * kv.z;
+                s += (qv.w * a.scale) * kv.w;
+            }
+        } else {
+            for (int d = 0; d < a.Dh; ++d) s += (qi[d] * a.scale) * kj[d];
+        }
         sc[idx] = (pad && pad[j]) ? -INFINITY : s;
     }
     __syncthreads();
@@ -377,7 +390,15 @@ __global__ __launch_bounds__(256) void mha_f32_k(cover_mha_f32_args a) {
     for (int idx = threadIdx.x; idx < a.Tq * a.Dh; idx += 256) {
         const int i = idx / a.Dh, d = idx - i * a.Dh;
         float acc = 0.f;
-        for (int j = 0; j < a.Tk; ++j) acc += sc[i * a.Tk + j] * v[(size_t)j * a.v_t_stride + d];
+        int j = 0;
+        for (; j + 8 <= a.Tk; j += 8) {   // eight value loads in flight (a rolled loop waits for each one), summed in key order
+            float vv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) vv[u] = v[(size_t)(j + u) * a.v_t_stride + d];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += sc[i * a.Tk + j + u] * vv[u];
+        }
+        for (; j < a.Tk; ++j) acc += sc[i * a.Tk + j] * v[(size_t)j * a.v_t_stride + d];
         o[(size_t)i * a.o_t_stride + d] = acc;
     }
 }

@@ -1372,11 +1372,30 @@ __global__ __launch_bounds__(256) void splitk_reduce(const float* __restrict__ p
             epi_store4_glu(epi, C, ldc, m, j0, Nout, gv, uv);
         } else {
             float v[4] = {0, 0, 0, 0};
-            for (int s = 0; s < S; ++s) {
-                const float* p = partial + ((size_t)s * M + m) * N + j0;
+            const float* p0 = partial + (size_t)m * N + j0;
+            const size_t sstride = (size_t)M * N;
+            if (j0 + 3 < N && ((((uintptr_t)p0) | (sstride * sizeof(float))) & 15) == 0) {
+                // whole group of four columns: 16-byte loads, four slabs in flight (a rolled loop with guarded scalar loads is a
+                // chain of S dependent round trips), summed in slab order
+                int s = 0;
+                for (; s + 4 <= S; s += 4) {
+                    float4 a[4];
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    if (j0 + i < N) v[i] += p[i];
+                    for (int j = 0; j < 4; ++j) a[j] = *(const float4*)(p0 + (s + j) * sstride);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { v[0] += a[j].x; v[1] += a[j].y; v[2] += a[j].z; v[3] += a[j].w; }
+                }
+                for (; s < S; ++s) {
+                    const float4 a = *(const float4*)(p0 + s * sstride);
+                    v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w;
+                }
+            } else {
+                for (int s = 0; s < S; ++s) {
+                    const float* p = partial + ((size_t)s * M + m) * N + j0;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (j0 + i < N) v[i] += p[i];
+                }
             }
             epi_store4(epi, C, ldc, m, j0, N, v);
         }
