@@ -1419,9 +1419,17 @@ __device__ __forceinline__ float block_sum_lds(float v, float* red) {
     return t;
 }
 
+#ifdef COVER_RN_DEBUG
+__device__ unsigned long long g_rn_dbg[512 * 8];   // per block (thread 0): start, slabs landed, epilogue done, before / after the block sum, end
+extern "C" int cover_rn_debug(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_rn_dbg), sizeof(g_rn_dbg)); }
+#define RNT(slot) do { if (threadIdx.x == 0) g_rn_dbg[(blockIdx.x & 511) * 8 + (slot)] = wall_clock64(); } while (0)
+#else
+#define RNT(slot) do { } while (0)
+#endif
 __global__ __launch_bounds__(512) void splitk_reduce_norm(const float* __restrict__ partial, int S, bf16_t* C, int ldc, int M,
                                                           int N, EpiDev epi) {
     __shared__ float red[16];
+    RNT(0);
     const int m = blockIdx.x;
     float vals[2][8];
     float q = 0.f;
@@ -1461,8 +1469,13 @@ __global__ __launch_bounds__(512) void splitk_reduce_norm(const float* __restric
                 const float4 a = *(const float4*)(p0 + s * sstride), b = *(const float4*)(p0 + s * sstride + 4);
                 v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w; v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
             }
+            if (c == 0) RNT(1);
+            // (the bf16 residual row is read in here, eight 2-byte loads BEHIND the slabs: 1.2 of the kernel's 3.5 us by the
+            // timeline -- yet requesting it as one 16-byte load ahead of the slabs made the decision 0.4 ms slower in a same-box
+            // A/B (35.0 vs 35.4 ms), so it stays)
             epi_value4(epi, m, n0, N, v);
             epi_value4(epi, m, n0 + 4, N, v + 4);
+            if (c == 0) RNT(2);
             uint4 u;
             u.x = pack_bf2(v[0], v[1]); u.y = pack_bf2(v[2], v[3]); u.z = pack_bf2(v[4], v[5]); u.w = pack_bf2(v[6], v[7]);
             *(uint4*)(C + (size_t)m * ldc + n0) = u;
@@ -1493,7 +1506,9 @@ __global__ __launch_bounds__(512) void splitk_reduce_norm(const float* __restric
                 }
         rstd = rsqrtf(block_sum_lds(q2, red + 8) / N + epi.norm_eps);
     } else {
+        RNT(3);
         rstd = rsqrtf(block_sum_lds(q, red) / N + epi.norm_eps);
+        RNT(4);
     }
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
@@ -1512,6 +1527,7 @@ __global__ __launch_bounds__(512) void splitk_reduce_norm(const float* __restric
             *(uint4*)(epi.norm_out + (size_t)m * epi.ld_norm_out + n0) = u;
         }
     }
+    RNT(5);
 }
 
 // ---------------------------------------------------------------------------------------------------
