@@ -373,6 +373,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_tiled(const bf16_t* __res
     constexpr int A_BYTES = BM_ * BK * 2, B_BYTES = BN_ * BK * 2;
     constexpr int AI = BM_ / (8 * NW), BI = BN_ / (8 * NW);  // 1-KiB staging instructions per wave per tile
     constexpr int NST = GLDS ? NST_ : 2;         // LDS stages (NST - 1 k-tiles stay in flight across the barrier)
+    PCTL(0);
     static_assert(BM_ % (8 * NW) == 0 && BN_ % (8 * NW) == 0, "tile rows must split evenly over the waves");
     static_assert((NST - 2) * (AI + BI) <= 63, "counted vmcnt must fit its 6-bit field");
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -472,6 +473,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_tiled(const bf16_t* __res
         }
     };
 
+    PCTL(1);
     if (GLDS) {
         // 3-stage ring, two k-tiles in flight: tile kt is waited for with a COUNTED vmcnt (the AI+BI loads of tile kt+1
         // stay outstanding across the barrier), a raw s_barrier publishes it, then tile kt+2 is issued into the stage
@@ -515,8 +517,10 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_tiled(const bf16_t* __res
     }
 
     // ---- epilogue ----
+    PCTL(2);
     tiled_epilogue_staged<WM, WN, BM_, BN_>(acc, epi, C, ldc, M, N, m0, n0, m0 + wm * (WM * 16), n0 + wn * (WN * 16), r, g, partial, smem,
                                             NST * (A_BYTES + B_BYTES), tid, 64 * NW);
+    PCTL(3);
 }
 
 // ---------------------------------------------------------------------------------------------------
