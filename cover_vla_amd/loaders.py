@@ -154,3 +154,51 @@ def load_pi0_pretrained(path: str, head_dim: int = 256, vit_heads: int = 16) -> 
     c["Hq"] = c.pop("_qD") // head_dim
     c["vit_heads"] = vit_heads
     return n, c, cfg
+
+
+# ------------------------------------------------------------------------------------------------ pi0-FAST
+# `PI0FASTPolicy.save_pretrained` writes the policy's state dict: `model.pi0_paligemma.<PaliGemmaForConditionalGeneration keys>`
+# (modeling_pi0fast.py:462) -- the same HF module (transformers 4.48.3 layout: vision_tower.vision_model.*, multi_modal_projector.
+# linear.*, language_model.model.*, language_model.lm_head.weight tied to embed_tokens) that pi0 keeps under
+# `model.paligemma_with_expert.paligemma.` (key list pinned in tests/golden/pi0_checkpoint_keys.json), plus the Normalize buffers.
+_FAST = "model.pi0_paligemma."
+
+
+def pi0fast_reference_to_neutral(sd: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    """-> neutral vision.* / projector.* / lm.* (what cover_vla_amd.pi0fast.PI0FASTTokens consumes)."""
+    moved = {}
+    for k, v in sd.items():
+        kk = k if k.startswith("model.") else "model." + k
+        if kk.startswith(_FAST):
+            moved[_PWE + "paligemma." + kk[len(_FAST):]] = v
+    return pi0_reference_to_neutral(moved)
+
+
+def neutral_to_pi0fast_reference(sd: Dict[str, torch.Tensor], patch: int) -> Dict[str, torch.Tensor]:
+    keep = {k: v for k, v in sd.items() if k.startswith(("vision.", "projector.", "lm."))}
+    out = {}
+    for k, v in neutral_to_pi0_reference(keep, patch).items():
+        out[_FAST + k[len(_PWE + "paligemma."):]] = v
+    out[_FAST + "language_model.lm_head.weight"] = sd["lm.embed_tokens.weight"]      # tied
+    return out
+
+
+def load_pi0fast_pretrained(path: str, head_dim: int = 256, vit_heads: int = 16) -> Tuple[Dict[str, torch.Tensor], dict, dict]:
+    """Directory with config.json + model.safetensors of a pi0-FAST policy -> (neutral state dict, size dict, raw config)."""
+    from safetensors.torch import load_file
+    with open(os.path.join(path, "config.json")) as f:
+        cfg = json.load(f)
+    raw = load_file(os.path.join(path, "model.safetensors"))
+    cfg["_normalization"] = pi0_normalization(raw, cfg)
+    n = pi0fast_reference_to_neutral(raw)
+    if "lm.embed_tokens.weight" not in n:
+        raise ValueError(f"{path}: no model.pi0_paligemma.* tensors -- not a pi0-FAST checkpoint")
+    vit_dim = n["vision.patch.bias"].shape[0]
+    patch = int(round((n["vision.patch.weight"].shape[1] // 3) ** 0.5))
+    kD, qD = n["lm.layers.0.self_attn.k_proj.weight"].shape[0], n["lm.layers.0.self_attn.q_proj.weight"].shape[0]
+    c = dict(lm_dim=n["lm.norm.weight"].shape[0], lm_mlp=n["lm.layers.0.mlp.gate_proj.weight"].shape[0],
+             layers=1 + max(int(k.split(".")[2]) for k in n if k.startswith("lm.layers.")), vocab=n["lm.embed_tokens.weight"].shape[0],
+             vit_dim=vit_dim, vit_mlp=n["vision.blocks.0.fc1.weight"].shape[0],
+             vit_layers=1 + max(int(k.split(".")[2]) for k in n if k.startswith("vision.blocks.")), patch=patch,
+             image=int(round(n["vision.pos"].shape[0] ** 0.5)) * patch, D=head_dim, Hkv=kD // head_dim, Hq=qD // head_dim, vit_heads=vit_heads)
+    return n, c, cfg

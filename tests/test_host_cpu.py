@@ -285,3 +285,42 @@ def test_pi0fast_dct_decode_matches_reference_golden():
     t = np.array([0, 5, 1000])
     assert np.array_equal(fast_tokens_to_paligemma_tokens(fast_tokens_to_paligemma_tokens(t, 257152), 257152), t)
     assert fast_tokens_to_paligemma_tokens(np.array([0]), 257152)[0] == 257152 - 1 - 128
+
+
+def test_pi0fast_checkpoint_key_map_round_trip(tmp_path):
+    """SURVEY 8f-3 for the pi0-FAST policy: `model.pi0_paligemma.*` = the PaliGemma module pi0 keeps under
+    `model.paligemma_with_expert.paligemma.` (names pinned by tests/golden/pi0_checkpoint_keys.json, the reference converter's
+    list); neutral -> reference names -> safetensors on disk -> loader -> the same tensors and sizes."""
+    import json
+    from safetensors.torch import save_file
+    from cover_vla_amd import loaders, synth
+    tiny = dict(lm_dim=64, lm_mlp=128, ex_dim=32, ex_mlp=64, layers=2, Hq=4, Hkv=1, D=16, vocab=40, vit_dim=32, vit_mlp=48, vit_layers=2,
+                vit_heads=2, patch=14, image=28, chunk=4)
+    sd = synth.pi0_state(tiny, seed=3)
+    ref = loaders.neutral_to_pi0fast_reference(sd, tiny["patch"])
+    with open(os.path.join(GOLD, "pi0_checkpoint_keys.json")) as f:
+        pinned = json.load(f)
+    pinned = pinned["keys"] if isinstance(pinned, dict) else pinned
+    pg = "model.paligemma_with_expert.paligemma."
+    suffixes = {k[len(pg):] for k in pinned if k.startswith(pg)}
+    # per-layer names of the pinned list are templated on the layer index: compare with the index normalised
+    norm = lambda k: re.sub(r"layers\.\d+\.", "layers.N.", k)
+    ours = {norm(k[len("model.pi0_paligemma."):]) for k in ref}
+    assert ours <= {norm(s_) for s_ in suffixes} | {"language_model.lm_head.weight"}, sorted(ours - {norm(s_) for s_ in suffixes})[:5]
+    d = tmp_path / "fast"
+    d.mkdir()
+    save_file({k: v.contiguous().clone() for k, v in ref.items()}, str(d / "model.safetensors"))   # (clone: the tied lm_head shares storage)
+    (d / "config.json").write_text(json.dumps({"type": "pi0fast", "normalization_mapping": {"VISUAL": "IDENTITY", "STATE": "IDENTITY", "ACTION": "IDENTITY"}}))
+    n, c, cfg = loaders.load_pi0fast_pretrained(str(d), head_dim=tiny["D"], vit_heads=tiny["vit_heads"])
+    for k, v in sd.items():
+        if k.startswith(("vision.", "projector.", "lm.")):
+            assert torch.equal(n[k].reshape(v.shape), v), k
+    assert all(not k.startswith("expert.") for k in n)
+    for k in ("lm_dim", "lm_mlp", "layers", "Hq", "Hkv", "D", "vocab", "vit_dim", "vit_mlp", "vit_layers", "patch", "image"):
+        assert c[k] == tiny[k], (k, c[k], tiny[k])
+    with pytest.raises(ValueError):
+        bad = tmp_path / "bad"
+        bad.mkdir()
+        save_file({"model.something_else.weight": torch.zeros(2)}, str(bad / "model.safetensors"))
+        (bad / "config.json").write_text("{}")
+        loaders.load_pi0fast_pretrained(str(bad))
