@@ -21,7 +21,9 @@ vocabulary. Work that is done once instead of per step: the prefix (image + prom
 """
 from __future__ import annotations
 
-from typing import Callable, Dict, List, Optional, Sequence
+from collections import deque
+from dataclasses import dataclass
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
 import torch
@@ -141,6 +143,110 @@ class PI0FASTTokens:
             self.lm.forward(xd, [g], final_norm=False)
             pick(xd, i)
         return out
+
+
+@dataclass
+class PI0FASTConfig:
+    """The fields of configuration_pi0fast.PI0FASTConfig the inference path reads."""
+    image_keys: Tuple[str, ...] = ("observation.images.top",)
+    state_key: str = "observation.state"
+    action_dim: int = 7                 # config.action_feature.shape[0]
+    chunk_size: int = 10                # action horizon handed to the FAST decoder
+    n_action_steps: int = 5
+    max_state_dim: int = 32
+    max_decoding_steps: int = 256
+    fast_skip_tokens: int = 128
+    relaxed_action_decoding: bool = True
+    resize_imgs_with_padding: Optional[Tuple[int, int]] = (224, 224)
+    device: str = "cuda:0"
+
+
+class PI0FASTPolicy:
+    """PI0FASTPolicy.select_action (modeling_pi0fast.py:193-233) on `PI0FASTTokens`: state discretisation + prompt text
+    (`create_input_tokens` :570-640), greedy generation on the device, `extract_actions` (:794-859) and the action queue. The two
+    tokenizers are the caller's objects (HF `AutoTokenizer("google/paligemma-3b-pt-224")` and the `physical-intelligence/fast`
+    processor in production; `cover_vla_amd.synth.CharTokenizer` in the tests): only the methods the reference calls are used."""
+
+    def __init__(self, config: PI0FASTConfig, model: PI0FASTTokens, paligemma_tokenizer, fast_processor, normalization: Optional[dict] = None):
+        self.config, self.model = config, model
+        self.paligemma_tokenizer, self.fast_tokenizer = paligemma_tokenizer, fast_processor
+        self.normalization = normalization or {"state": ("IDENTITY", None, None), "action": ("IDENTITY", None, None)}
+        self.pad_token_id = paligemma_tokenizer.pad_token_id if hasattr(paligemma_tokenizer, "pad_token_id") else paligemma_tokenizer.eos_token_id
+        self.reset()
+
+    def reset(self):
+        self._action_queue = deque([], maxlen=self.config.n_action_steps)
+
+    # ---- create_input_tokens(state, lang_text, actions=None) :570-640 (generation: the prefix only)
+    def create_input_tokens(self, state: torch.Tensor, lang_text: Sequence[str]):
+        bins = torch.linspace(-1, 1, 256 + 1, device=state.device)[:-1]
+        discretized = (torch.bucketize(state, bins) - 1)[:, :32]
+        prefix_texts = []
+        for txt, disc in zip(lang_text, discretized):
+            cleaned = txt.lower().strip().replace("_", " ")
+            state_str = " ".join(str(val.detach()) for val in disc)     # (sic: the reference joins the tensors' repr, :582-585)
+            prefix_texts.append(f"Task: {cleaned}, State: {state_str};\n")
+        out = self.paligemma_tokenizer(prefix_texts, add_special_tokens=True, return_tensors="pt", padding="longest", truncation=False)
+        ids, mask = out["input_ids"], out["attention_mask"]
+        # compact every row's valid tokens to the left (a left-padding tokenizer: the side does not enter the arithmetic)
+        B, Lp = ids.shape
+        order = torch.argsort((mask == 0).to(torch.int8), dim=1, stable=True)
+        return torch.gather(ids, 1, order), torch.gather(mask, 1, order)
+
+    def _normalize_state(self, state):
+        mode, a, b = self.normalization["state"]
+        if mode == "IDENTITY":
+            return state
+        a, b = a.to(state.device), b.to(state.device)
+        return (state - a) / (b + 1e-8) if mode == "MEAN_STD" else (state - a) / (b - a + 1e-8) * 2 - 1
+
+    def _unnormalize_action(self, act):
+        mode, a, b = self.normalization["action"]
+        if mode == "IDENTITY":
+            return act
+        a, b = a.to(act.device), b.to(act.device)
+        return act * b + a if mode == "MEAN_STD" else (act + 1) / 2 * (b - a) + a
+
+    # ---- extract_actions(tokens, action_horizon, action_dim) :794-859
+    def extract_actions(self, tokens: torch.Tensor, action_horizon: int, action_dim: int) -> torch.Tensor:
+        decoded = self.paligemma_tokenizer.batch_decode(tokens, skip_special_tokens=True)
+        cleaned = [seq.replace("Action:", "").replace(":", "").strip().split("|")[0].strip() for seq in decoded]
+        outs = []
+        for text in cleaned:
+            raw = self.paligemma_tokenizer.encode(text, return_tensors="pt", padding=False)
+            fast_ids = self.paligemma_tokenizer.vocab_size - 1 - self.config.fast_skip_tokens - raw      # _act_tokens_to_paligemma_tokens
+            ft = self.fast_tokenizer
+            acts = fast_coefficients_to_actions(fast_ids.tolist(), ft.bpe_tokenizer.decode, min_token=ft.min_token, scale=ft.scale,
+                                                time_horizon=action_horizon, action_dim=action_dim,
+                                                relaxed_decoding=self.config.relaxed_action_decoding)
+            outs.append(torch.tensor(acts, device=tokens.device).squeeze(0))
+        return torch.stack(outs, dim=0)
+
+    @torch.no_grad()
+    def select_action(self, batch: dict) -> torch.Tensor:
+        if len(self._action_queue) == 0:
+            dev = self.model.dev
+            state = self._normalize_state(batch[self.config.state_key].to(torch.float32))
+            present = [k for k in self.config.image_keys if k in batch]
+            if not present:
+                raise ValueError(f"All image features are missing from the batch. At least one expected. (batch: {batch.keys()})")
+            images = []
+            for k in present:
+                img = batch[k]
+                if self.config.resize_imgs_with_padding is not None and tuple(img.shape[-2:]) != tuple(self.config.resize_imgs_with_padding):
+                    from . import imaging
+                    img = imaging.resize_with_pad(img, *self.config.resize_imgs_with_padding, pad_value=0)
+                images.append(img.to(dev))
+            ids, mask = self.create_input_tokens(state, batch["task"])
+            B = ids.shape[0]
+            toks = self.model.generate_tokens(images, [torch.ones(B, dtype=torch.bool, device=dev) for _ in images], ids.to(dev), mask.to(dev),
+                                              self.config.max_decoding_steps, eos_token_id=self.paligemma_tokenizer.eos_token_id,
+                                              pad_token_id=self.pad_token_id)
+            actions = self.extract_actions(toks.cpu(), self.config.chunk_size, self.config.action_dim)
+            actions = actions[:, : self.config.n_action_steps, : self.config.action_dim]
+            actions = self._unnormalize_action(actions.to(torch.float32))
+            self._action_queue.extend(actions.transpose(0, 1))
+        return self._action_queue.popleft()
 
 
 def fast_coefficients_to_actions(token_lists: Sequence[Sequence[int]], bpe_decode: Callable[[Sequence[int]], str], *, min_token: int,

@@ -307,3 +307,50 @@ def siglip2_state(c: dict, seed: int = 4321, nontrivial: bool = True, std: float
     sd["text.proj.weight"] = g.w(c["dim"], c["dim"])
     sd["text.proj.bias"] = g.b(c["dim"])
     return sd
+
+
+# ------------------------------------------------------------------------------------------------ test double: tokenizer
+class CharTokenizer:
+    """Character-level stand-in for the HF tokenizers the pi0-FAST policy is built around (neither `google/paligemma-3b-pt-224` nor
+    `physical-intelligence/fast` can be downloaded here): the call surface PI0FAST.create_input_tokens / extract_actions use
+    (modeling_pi0fast.py:570-640, 794-859) -- `__call__`, `pad`, `batch_decode`, `encode`, `vocab_size`, `eos_token_id`,
+    `pad_token_id` -- over ids = 3 + ord(char). TEST INFRASTRUCTURE: the same object drives the reference's own functions in
+    oracle/gen_golden_pi0fast.py and cover_vla_amd.pi0fast.PI0FASTPolicy in the tests."""
+    pad_token_id, eos_token_id, bos_token_id = 0, 1, 2
+
+    def __init__(self, vocab_size: int = 512, padding_side: str = "right"):
+        self.vocab_size, self.padding_side = vocab_size, padding_side
+
+    def _ids(self, text, add_special_tokens):
+        ids = [3 + ord(c) for c in text]
+        return ([self.bos_token_id] + ids) if add_special_tokens else ids
+
+    def _pad(self, seqs, masks=None):
+        n = max((len(s) for s in seqs), default=0)
+        ids = torch.full((len(seqs), n), self.pad_token_id, dtype=torch.long)
+        mask = torch.zeros(len(seqs), n, dtype=torch.long)
+        for i, s in enumerate(seqs):
+            m = [1] * len(s) if masks is None else masks[i]
+            if self.padding_side == "left":
+                ids[i, n - len(s):] = torch.tensor(s, dtype=torch.long)
+                mask[i, n - len(s):] = torch.tensor(m, dtype=torch.long)
+            else:
+                ids[i, :len(s)] = torch.tensor(s, dtype=torch.long)
+                mask[i, :len(s)] = torch.tensor(m, dtype=torch.long)
+        return {"input_ids": ids, "attention_mask": mask}
+
+    def __call__(self, texts, add_special_tokens=True, return_tensors="pt", padding="longest", truncation=False):
+        single = isinstance(texts, str)
+        return self._pad([self._ids(t, add_special_tokens) for t in ([texts] if single else texts)])
+
+    def pad(self, batch, padding="longest", max_length=None, return_tensors="pt"):
+        return self._pad([list(s) for s in batch["input_ids"]], [list(m) for m in batch["attention_mask"]])
+
+    def encode(self, text, return_tensors="pt", padding=False):
+        return torch.tensor([self._ids(text, True)], dtype=torch.long)
+
+    def batch_decode(self, tokens, skip_special_tokens=True):
+        out = []
+        for row in (tokens.tolist() if torch.is_tensor(tokens) else tokens):
+            out.append("".join(chr(t - 3) for t in row if t >= 3 or not skip_special_tokens))
+        return out

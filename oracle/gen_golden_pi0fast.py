@@ -202,6 +202,45 @@ def gen_pi0fast(save):
     save("pi0fast_dct_decode", seq0=np.array(seqs[0]), seq1=np.array(seqs[1]), seq2=np.array(seqs[2]), actions=acts, min_token=-20, scale=10.0)
 
 
+def gen_pi0fast_host(save):
+    """Host glue of the pi0-FAST policy through the REFERENCE's own create_input_tokens (:570-640, generation branch) and
+    extract_actions (:794-859), driven by the character-level stand-in tokenizer (cover_vla_amd.synth.CharTokenizer) and a chr/ord
+    stand-in for the FAST BPE decoder: prompt text + state discretisation -> ids, and generated ids -> action chunk."""
+    from cover_vla_amd import synth
+    m = import_reference_pi0fast()
+    net = m.PI0FAST.__new__(m.PI0FAST)
+    torch.nn.Module.__init__(net)
+    tok = synth.CharTokenizer(vocab_size=512)
+    net.paligemma_tokenizer = tok
+    net.processor = types.SimpleNamespace(tokenizer=tok)
+    net.fast_tokenizer = types.SimpleNamespace(bpe_tokenizer=types.SimpleNamespace(decode=lambda t: "".join(chr(max(0, i)) for i in t)),
+                                               min_token=-40, scale=10.0, time_horizon=None, action_dim=None, called_time_horizon=None,
+                                               called_action_dim=None)
+    net.config = types.SimpleNamespace(max_action_dim=32, relaxed_action_decoding=True)
+    net.fast_skip_tokens, net.pad_token_id = 128, tok.pad_token_id
+    g = torch.Generator().manual_seed(9)
+    state = torch.rand(4, 8, generator=g) * 2 - 1
+    state[0, 0], state[1, 1] = -1.0, 1.0
+    tasks = ["Put the spoon on the towel", "pick_up the carrot  ", "STACK the green block", "open drawer"]
+    out = net.create_input_tokens(state=state, lang_text=tasks, actions=None)
+    H, A = 5, 7
+    payload = [[int(x) for x in torch.randint(30, 120, (n,), generator=g)] for n in (35, 20, 50, 35)]
+    # what the model would emit: "Action: <chars>|<anything>" in the policy tokenizer's ids; chars chosen so that the mirrored FAST id is >= 0
+    rows = []
+    for pl in payload:
+        text = "Action: " + "".join(chr(512 - 1 - 128 - 3 - c) for c in pl) + "|zz"
+        rows.append([3 + ord(ch) for ch in text] + [tok.eos_token_id])
+    L = max(len(r) for r in rows)
+    toks = torch.tensor([r + [0] * (L - len(r)) for r in rows], dtype=torch.long)
+    acts = net.extract_actions(toks, H, A)
+    save("pi0fast_host_glue", state=state, tasks=np.array(tasks), input_ids=out["input_ids"], padded_mask=out["padded_mask"],
+         att_mask=out["attention_mask"].to(torch.int64), gen_tokens=toks, actions=acts, horizon=H, action_dim=A)
+
+
 if __name__ == "__main__":
     from gen_golden import save
-    gen_pi0fast(save)
+    which = sys.argv[1:] or ["model", "host"]
+    if "model" in which:
+        gen_pi0fast(save)
+    if "host" in which:
+        gen_pi0fast_host(save)

@@ -324,3 +324,50 @@ def test_pi0fast_checkpoint_key_map_round_trip(tmp_path):
         save_file({"model.something_else.weight": torch.zeros(2)}, str(bad / "model.safetensors"))
         (bad / "config.json").write_text("{}")
         loaders.load_pi0fast_pretrained(str(bad))
+
+
+def test_pi0fast_policy_host_glue_matches_reference_golden():
+    """PI0FASTPolicy's host side against the reference's own create_input_tokens / extract_actions (run by
+    oracle/gen_golden_pi0fast.py with the same stand-in tokenizers): prompt text + 256-bin state discretisation -> ids and mask,
+    generated ids -> cleaned text -> FAST ids -> DCT -> action chunk; then select_action's queue on a scripted token generator."""
+    from cover_vla_amd import synth
+    from cover_vla_amd.pi0fast import PI0FASTConfig, PI0FASTPolicy
+    import types
+    z = np.load(os.path.join(GOLD, "pi0fast_host_glue.npz"))
+    tok = synth.CharTokenizer(vocab_size=512)
+    fast = types.SimpleNamespace(bpe_tokenizer=types.SimpleNamespace(decode=lambda t: "".join(chr(max(0, i)) for i in t)), min_token=-40, scale=10.0)
+    H, A = int(z["horizon"]), int(z["action_dim"])
+
+    class _Scripted:                       # stands in for PI0FASTTokens: returns the golden's generated ids
+        dev = torch.device("cpu")
+        calls = 0
+
+        def generate_tokens(self, images, img_masks, ids, mask, n_new, eos_token_id=1, pad_token_id=0):
+            _Scripted.calls += 1
+            assert ids.shape == mask.shape and images[0].shape[0] == ids.shape[0]
+            return torch.from_numpy(z["gen_tokens"])
+
+    cfg = PI0FASTConfig(action_dim=A, chunk_size=H, n_action_steps=3, resize_imgs_with_padding=None, device="cpu")
+    pol = PI0FASTPolicy(cfg, _Scripted(), tok, fast)
+    state = torch.from_numpy(z["state"])
+    ids, mask = pol.create_input_tokens(state, [str(t) for t in z["tasks"]])
+    assert torch.equal(ids, torch.from_numpy(z["input_ids"])) and torch.equal(mask, torch.from_numpy(z["padded_mask"]))
+    assert not z["att_mask"].any()                                         # generation: every prompt token is prefix (bidirectional)
+    acts = pol.extract_actions(torch.from_numpy(z["gen_tokens"]), H, A)
+    assert acts.dtype == torch.float64 and np.allclose(acts.numpy(), z["actions"], atol=1e-12)
+    # a left-padding tokenizer yields the same compacted rows
+    pol_l = PI0FASTPolicy(cfg, _Scripted(), synth.CharTokenizer(vocab_size=512, padding_side="left"), fast)
+    ids_l, mask_l = pol_l.create_input_tokens(state, [str(t) for t in z["tasks"]])
+    assert torch.equal(ids_l, ids) and torch.equal(mask_l, mask)
+    # select_action: one generation fills the queue with n_action_steps rows of [B, action_dim]
+    batch = {"observation.state": state, "observation.images.top": torch.zeros(4, 3, 8, 8), "task": [str(t) for t in z["tasks"]]}
+    a0 = pol.select_action(batch)
+    a1 = pol.select_action(batch)
+    a2 = pol.select_action(batch)
+    assert _Scripted.calls == 1 and tuple(a0.shape) == (4, A)
+    assert np.allclose(torch.stack([a0, a1, a2], 1).numpy(), z["actions"][:, :3, :A].astype(np.float32), atol=1e-6)
+    pol.select_action(batch)
+    assert _Scripted.calls == 2
+    with pytest.raises(ValueError):
+        pol.reset()
+        pol.select_action({"observation.state": state, "task": ["x"] * 4})

@@ -615,3 +615,36 @@ def test_pi0fast_tokens_match_oracle_with_ragged_prompts_and_two_cameras(dev):
     top2 = torch.topk(ref, 2, dim=-1).values
     decided = (top2[..., 0] - top2[..., 1]) > 2 * err
     assert decided.sum() >= 25 and torch.equal(lg.argmax(-1)[decided], ref.argmax(-1)[decided])
+
+
+def test_pi0fast_policy_select_action_end_to_end(dev):
+    """PI0FASTPolicy.select_action through the real token generator on the device (tiny PaliGemma, vocabulary 512 = the stand-in
+    tokenizer's): prompt text -> ids -> greedy tokens -> text -> FAST ids -> DCT -> queue. Random weights emit arbitrary text, which
+    the reference's relaxed decoding maps to SOME chunk: checked here are shapes, finiteness, determinism, row independence and
+    that the tokens handed to extract_actions are the generator's."""
+    import types
+    from cover_vla_amd.pi0fast import PI0FASTConfig, PI0FASTPolicy, PI0FASTTokens
+    tiny = dict(lm_dim=256, lm_mlp=512, ex_dim=128, ex_mlp=256, layers=2, Hq=4, Hkv=1, D=64, vocab=512, vit_dim=128, vit_mlp=200,
+                vit_layers=2, vit_heads=4, patch=14, image=56, chunk=4)
+    sd = synth.pi0_state(tiny, seed=11)
+    model = PI0FASTTokens(sd, tiny, device="cuda:0", max_batch=8, max_prompt=384, max_new_tokens=24)   # (the repr of CUDA scalars makes the prompt long)
+    tok = synth.CharTokenizer(vocab_size=512)
+    fast = types.SimpleNamespace(bpe_tokenizer=types.SimpleNamespace(decode=lambda t: "".join(chr(max(0, min(int(i), 1000))) for i in t)),
+                                 min_token=-40, scale=10.0)
+    cfg = PI0FASTConfig(action_dim=7, chunk_size=5, n_action_steps=2, max_decoding_steps=24, resize_imgs_with_padding=(56, 56))
+    pol = PI0FASTPolicy(cfg, model, tok, fast)
+    g = torch.Generator().manual_seed(2)
+    state = (torch.rand(1, 8, generator=g) * 2 - 1).repeat(4, 1)
+    img = (torch.rand(1, 3, 56, 56, generator=g) * 2 - 1).repeat(4, 1, 1, 1)
+    batch = {"observation.state": state.to(dev), "observation.images.top": img.to(dev), "task": ["put the spoon on the towel", "open drawer"] * 2}
+    a0 = pol.select_action(batch)
+    a1 = pol.select_action(batch)
+    assert tuple(a0.shape) == (4, 7) and torch.isfinite(a0).all() and torch.isfinite(a1).all()
+    assert torch.equal(a0[0], a0[2]) and torch.equal(a0[1], a0[3])             # same (frame, state, task) -> same action
+    pol.reset()
+    assert torch.equal(pol.select_action(batch), a0)                            # deterministic
+    ids, mask = pol.create_input_tokens(state.to(dev), batch["task"])         # (same device: the prompt carries the tensors' repr)
+    toks = model.generate_tokens([img.to(dev)], [torch.ones(4, dtype=torch.bool, device=dev)], ids.to(dev), mask.to(dev), 24,
+                                 eos_token_id=tok.eos_token_id, pad_token_id=tok.pad_token_id)
+    ref = pol.extract_actions(toks.cpu(), 5, 7)[:, 0, :7].to(torch.float32)
+    assert torch.allclose(a0.cpu(), ref)
