@@ -134,10 +134,44 @@ hipError_t launch_rmsnorm(const void* x, int x_f32, int ldx, const float* w, flo
 // ---------------------------------------------------------------------------------------------------
 // RoPE + KV placement: one wave per (row, head) of the fused qkv buffer
 // ---------------------------------------------------------------------------------------------------
+// V placement for multi-token groups (prefill): lanes = 64 CONSECUTIVE TOKENS of one (batch element, kv head), a wave = one
+// 8-wide d chunk of them. Each lane reads its token's 16 bytes; each of the eight stores then writes 64 consecutive tokens of
+// one V^T row = one 128-byte line, where the (row, head)-per-wave form writes one 2-byte element into each of 64 lines.
+__device__ __forceinline__ bool rope_v_tokens(const cover_rope_args& a) { return a.T >= 16 && a.n_splits <= 0 && (a.D & 7) == 0 && (a.ld_qkv & 7) == 0 && (((uintptr_t)a.qkv) & 15) == 0; }
+__device__ __forceinline__ int rope_v_waves(const cover_rope_args& a) { return a.B * a.Hkv * (a.D >> 3) * ((a.T + 63) >> 6); }
+__device__ __forceinline__ void rope_v_body(const cover_rope_args& a, int wid) {
+    const int lane = threadIdx.x & 63;
+    const int tg = (a.T + 63) >> 6, dch = a.D >> 3;
+    const int g = wid % tg, c = (wid / tg) % dch, h = (wid / (tg * dch)) % a.Hkv, b = wid / (tg * dch * a.Hkv);
+    const int t = g * 64 + lane;
+    if (b >= a.B || t >= a.T) return;
+    const int row = b * a.T + t;
+    const bf16_t* src = (const bf16_t*)a.qkv + (size_t)row * a.ld_qkv + (size_t)(a.Hq + a.Hkv + h) * a.D + 8 * c;
+    const uint4 u = *(const uint4*)src;
+    const int slot = a.slot_of_batch ? a.slot_of_batch[b] : b;
+    const int tt = a.t_offset + (a.t_offset_of_batch ? a.t_offset_of_batch[b] : 0) + t;
+    bf16_t* dst = (bf16_t*)a.vt_cache + (size_t)slot * a.vt_slot_stride + (size_t)h * a.vt_h_stride + (size_t)(8 * c) * a.vt_d_stride + tt;
+    const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        dst[(size_t)(2 * e) * a.vt_d_stride] = (bf16_t)(w[e] & 0xffffu);
+        dst[(size_t)(2 * e + 1) * a.vt_d_stride] = (bf16_t)(w[e] >> 16);
+    }
+}
+
 __device__ __forceinline__ void rope_kv_body(const cover_rope_args& a, int wid) {
     const int lane = threadIdx.x & 63;
     const int nh = a.Hq + 2 * a.Hkv;
     const int rows = a.B * a.T;
+    if (rope_v_tokens(a)) {   // q / k heads one wave per (row, head) as below; the V heads by token groups
+        const int nqk = a.Hq + a.Hkv;
+        if (wid >= rows * nqk) {
+            if (wid < rows * nqk + rope_v_waves(a)) rope_v_body(a, wid - rows * nqk);
+            return;
+        }
+        const int row = wid / nqk, hh = wid - row * nqk;
+        wid = row * nh + hh;
+    }
     if (wid >= rows * nh) return;
     const int row = wid / nh, hh = wid - row * nh;
     const int b = row / a.T, t = row - b * a.T;
@@ -206,8 +240,13 @@ __global__ __launch_bounds__(256) void rope_kv_write2_k(cover_rope_args a0, cove
 static bool rope_args_ok(const cover_rope_args* a) {
     return a->vt_cache && !(a->D & 1) && (a->rope_mode == 0 || (a->cos_table && a->sin_table));
 }
+static long long rope_waves_host(const cover_rope_args* a) {
+    const bool vt = a->T >= 16 && a->n_splits <= 0 && (a->D & 7) == 0 && (a->ld_qkv & 7) == 0 && (((uintptr_t)a->qkv) & 15) == 0;
+    if (!vt) return (long long)a->B * a->T * (a->Hq + 2 * a->Hkv);
+    return (long long)a->B * a->T * (a->Hq + a->Hkv) + (long long)a->B * a->Hkv * (a->D >> 3) * ((a->T + 63) >> 6);
+}
 hipError_t launch_rope_kv_write_pair(const cover_rope_args* a0, const cover_rope_args* a1, hipStream_t st) {
-    const long long w0 = (long long)a0->B * a0->T * (a0->Hq + 2 * a0->Hkv), w1 = (long long)a1->B * a1->T * (a1->Hq + 2 * a1->Hkv);
+    const long long w0 = rope_waves_host(a0), w1 = rope_waves_host(a1);
     if (w0 <= 0) return launch_rope_kv_write(a1, st);
     if (w1 <= 0) return launch_rope_kv_write(a0, st);
     if (!rope_args_ok(a0) || !rope_args_ok(a1)) return hipErrorInvalidValue;
@@ -216,7 +255,7 @@ hipError_t launch_rope_kv_write_pair(const cover_rope_args* a0, const cover_rope
     return hipGetLastError();
 }
 hipError_t launch_rope_kv_write(const cover_rope_args* a, hipStream_t st) {
-    const long long waves = (long long)a->B * a->T * (a->Hq + 2 * a->Hkv);
+    const long long waves = rope_waves_host(a);
     if (waves <= 0) return hipSuccess;
     if (!a->vt_cache || (a->D & 1)) return hipErrorInvalidValue;
     if (a->rope_mode != 0 && (!a->cos_table || !a->sin_table)) return hipErrorInvalidValue;
