@@ -66,3 +66,31 @@ def test_two_ranks_strong_scaling_equals_unsharded(dev, multirank_runs):
     assert recs[0]["global_idx"] == idx
     assert recs[0]["winner_tokens"] == tok.view(-1, 7)[idx].tolist()
     assert recs[0]["group_tokens"] == tok[idx // S].tolist()
+
+
+def test_rccl_backend_collectives_single_rank(dev):
+    """The collectives bench.py / sharding.py issue on the real multi-GPU path -- init_process_group("nccl" = RCCL, device_id),
+    all_gather_into_tensor of fp32 [n, 1 + 7] records on the device, barrier, all_reduce(MAX) of the step time -- run in a fresh
+    process with world_size 1 (the box has one GPU: this checks the API surface and the RCCL stack, not the transport)."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    script = (
+        "import os, torch, torch.distributed as dist\n"
+        "dev = torch.device('cuda:0'); torch.cuda.set_device(0)\n"
+        "dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)\n"
+        "rec = torch.arange(32 * 8, dtype=torch.float32, device=dev).view(32, 8).contiguous()\n"
+        "buf = torch.empty(32, 8, dtype=torch.float32, device=dev)\n"
+        "dist.all_gather_into_tensor(buf, rec)\n"
+        "assert torch.equal(buf, rec)\n"
+        "dist.barrier()\n"
+        "t = torch.tensor([1.25], device=dev); dist.all_reduce(t, op=dist.ReduceOp.MAX); assert float(t[0]) == 1.25\n"
+        "dist.barrier(); dist.destroy_process_group(); print('rccl ok')\n")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, "-c", script], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "rccl ok" in p.stdout, (p.stdout[-1500:], p.stderr[-3000:])
