@@ -45,9 +45,11 @@ def test_gemm_tiled(dev, variant, M, N, K):
     assert torch.allclose(out.float().cpu(), ref, atol=0.05, rtol=2e-2)
 
 
-@pytest.mark.parametrize("M,N,K,glu", [(1100, 6144, 2048, False), (1037, 16384, 2048, True), (2304, 4096, 8192, False), (1025, 4352, 2176, False)])
+@pytest.mark.parametrize("M,N,K,glu", [(1100, 6144, 2048, False), (1037, 16384, 2048, True), (2304, 4096, 8192, False), (1025, 4352, 2176, False),
+                                       (512, 12288, 4096, False), (512, 22016, 4096, True), (512, 4096, 11008, False), (704, 12288, 4096, False),
+                                       (530, 6144, 2048, False)])
 def test_gemm_long_panel_tiles(dev, M, N, K, glu):
-    # M >= 1024: the 12-wave kernels (8 MFMA waves on 128x256 / 256x128 tiles + 4 loader waves), ragged M and N tiles,
+    # M >= 512 (config-5 decode rows, two-camera prefill) and M >= 1024: the 12-wave kernels (8 MFMA waves on 128x256 / 256x128 tiles + 4 loader waves), ragged M and N tiles,
     # bias / activation / GLU / residual epilogues -- against fp32 matmul of the same bf16 operands (computed on the device)
     g = torch.Generator(device=dev).manual_seed(M + N)
     a = (torch.randn(M, K, device=dev, generator=g)).bfloat16()
