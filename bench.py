@@ -299,6 +299,12 @@ def roofline_objects(ms, cnt, work, ms_per_step, lib_sha):
             out["roofline_mfma"] = {"invalid": "a fraction > 1: refused"}
         else:
             out["roofline_mfma"] = obj
+    if "roofline" not in out and isinstance(out.get("roofline_mfma"), dict) and "frac" in out["roofline_mfma"]:
+        # no weight-streaming launch of >= 16 MB in this configuration (M > 64 decode rows, e.g. config 5: N = 512): the dominant
+        # kernel class is the tiled GEMM, bounded by the matrix pipes
+        m = out["roofline_mfma"]
+        out["roofline"] = {"bound": "mfma", "kernel": m["kernel"], "achieved": m["achieved"], "peak": m["peak"], "unit": m["unit"], "frac": m["frac"],
+                           "traffic": None, "launches": m["launches"], "kernel_ms_per_decision": m["kernel_ms_per_decision"]}
     if cnt[3] > 0:
         out["small_streaming_gemms"] = {"kernel": "weight-streaming launches with < 16 MB of weights (verifier text tower etc.): latency-bound",
                                         "launches": int(cnt[3]), "kernel_ms_per_decision": round(ms[3], 3)}
