@@ -53,6 +53,7 @@ class PI0FASTTokens:
                           act="gelu_tanh", norm="gemma", eps=1e-6, rope="hf", n_pos=self.Tp_cap + max_new_tokens + 8, device=device,
                           cache=geom)
         self.max_batch, self.max_prompt, self.max_new = max_batch, max_prompt, max_new_tokens
+        self.eos_check_every = 8          # decode steps between `done.all()` read-backs (0 = never stop early)
         D = c["lm_dim"]
         self.emb_scale = float(torch.tensor(D ** 0.5, dtype=BF))          # GemmaModel: normalizer in the embedding dtype
 
@@ -135,7 +136,13 @@ class PI0FASTTokens:
 
         pick(h, 0)
         xd = torch.empty(B, D, dtype=BF, device=dev)
+        # HF generate(do_sample=False) stops once every row has emitted EOS (modeling_pi0fast.py:861-946 runs it with
+        # max_new_tokens = max_decoding_steps = 256, a FAST sequence is a few dozen tokens): `done.all()` is read back every
+        # `eos_check_every` steps (one 1-byte D2H) and the rest of `out` is the pad the finished rows would have emitted anyway
+        out[:, 1:].fill_(pad_token_id)
         for i in range(1, max_new_tokens):
+            if force_tokens is None and self.eos_check_every > 0 and i % self.eos_check_every == 0 and bool(done.all()):
+                break
             ops.embed_gather(self.embed, out[:, i - 1].contiguous(), self.emb_scale, out=xd)
             pos_i = (plen + i).to(torch.int32).contiguous()                           # token i-1 sits at 1-indexed position plen + i
             g = self.lm.group(B, 1, pos_i, [dict(region=0, length=Tp, len_of_batch=plen), dict(region=1, length=i)], 1,

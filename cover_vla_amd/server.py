@@ -140,7 +140,7 @@ def serve_websocket(policy: Any, host: str = "0.0.0.0", port: int = 8000, metada
         async def run():
             async with websockets.asyncio.server.serve(handler, host, port, compression=None, max_size=None) as server:
                 if ready is not None:
-                    ready(port)
+                    ready(server.sockets[0].getsockname()[1])   # the BOUND port (port = 0 picks a free one)
                 await server.serve_forever()
     else:
         from . import wsproto

@@ -52,6 +52,7 @@ def pytest_collection_finish(session):
     base = 29700 + (os.getpid() % 1000)
     _MULTIRANK["weak"] = _launch_ranks("weak", ["--scaling", "weak"], base)
     _MULTIRANK["strong"] = _launch_ranks("strong", ["--scaling", "strong"], base + 1)
+    _MULTIRANK["config3"] = _launch_ranks("config3", ["--config", "3"], base + 2)
 
 
 @pytest.fixture(scope="session")

@@ -573,6 +573,35 @@ def test_tokens_to_histories_matches_host_path(dev):
     assert np.array_equal(pad.cpu().numpy(), (ref[:, :, 0] == -5).astype(np.uint8))
 
 
+@pytest.mark.parametrize("n_past,n_use", [(0, 2), (6, 2), (6, 4), (0, 4), (3, 3), (0, 10), (2, 8)])
+def test_tokens_to_histories_steps_matches_host_path(dev, n_past, n_use):
+    """Action-chunk horizon > 1 (BASELINE config 5): the first n_use 7-token actions of a candidate's chunk become its n_use newest
+    history rows. Reference = the de-tokeniser arithmetic (policy_wrapper.py:259-266) per step, then host.process_inputs'
+    [past | future steps] stacking (eval_utils.py:172-214) with the verifier gripper rule, then the front padding of
+    efficient_ensemble_merged.py:378-390. Bit-exact (table look-ups and copies)."""
+    import numpy as np
+    g = torch.Generator().manual_seed(31 + 16 * n_past + n_use)
+    N, vocab, nb = 11, 32000, 256
+    width = 7 * n_use + (7 if n_use % 2 else 0)              # the token row may be longer than the steps that are used
+    tok = torch.randint(vocab - nb - 3, vocab + 2, (N, width), generator=g)
+    bins = np.linspace(-1, 1, nb)
+    centers = (bins[:-1] + bins[1:]) / 2.0
+    history = [(torch.randn(7, generator=g) * 0.02).double().numpy() for _ in range(n_past)]
+    past = torch.tensor(np.stack(history), dtype=torch.float32, device=dev) if n_past else None
+    hb, pad = ops.tokens_to_histories(tok.to(dev), vocab, torch.tensor(centers, dtype=torch.float32, device=dev), past, n_use=n_use)
+    d = np.clip(vocab - tok.numpy()[:, : 7 * n_use].reshape(N, n_use, 7) - 1, 0, centers.shape[0] - 1)
+    a = centers[d]                                            # [N, n_use, 7]
+    a[..., 6] = np.where(a[..., 6] < 0.5, 0, 1)               # postprocess_gripper_verifier (simpler.py:222-226)
+    ref = np.full((N, 10, 7), -5.0, dtype=np.float32)
+    for n in range(N):
+        rows = np.vstack(history + [a[n]]) if n_past else a[n]
+        ref[n, 10 - rows.shape[0]:] = rows.astype(np.float32)
+    assert np.array_equal(hb.cpu().numpy(), ref)
+    want_pad = np.zeros((N, 10), dtype=np.uint8)
+    want_pad[:, : 10 - n_past - n_use] = 1
+    assert np.array_equal(pad.cpu().numpy(), want_pad)
+
+
 @pytest.mark.parametrize("n_past,n_use,denorm", [(6, 4, True), (0, 4, True), (2, 1, False), (6, 1, True), (0, 10, False)])
 def test_actions_to_histories_matches_host_path(dev, n_past, n_use, denorm):
     # device post-processing of flow-matching chunks == host.process_inputs(verifier_action=True) + front padding

@@ -29,22 +29,61 @@ def _collect(run):
 
 
 def test_two_ranks_weak_scaling_winner_exchange(dev, multirank_runs):
+    """Weak scaling = the headline's per-GPU work on DISTINCT candidates: 8 x W prompt groups x 4 samples of one observation, rank r
+    owns groups r, r + W, ... (run_simpler_eval_with_openpi.py:296-319 batch construction). The ranks' scores must differ, and the
+    winner must be the grouped arg-max over the UNION of both ranks' candidates."""
     assert "weak" in multirank_runs, "rank processes were not launched (no GPU at collection time?)"
     recs, line = _collect(multirank_runs["weak"])
-    S, P = 4, 8
-    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["config"]["candidates_total"] == 2 * P * S
+    S, P, W = 4, 8, 2
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["config"]["candidates_total"] == W * P * S
+    assert line["config"]["prompts_per_gpu"] == P and line["config"]["candidates_per_gpu"] == P * S
+    assert recs[0]["prompt_ids"] == list(range(0, W * P, W)) and recs[1]["prompt_ids"] == list(range(1, W * P, W))
     assert recs[0]["global_idx"] == recs[1]["global_idx"]
     assert recs[0]["winner_tokens"] == recs[1]["winner_tokens"] and recs[0]["group_tokens"] == recs[1]["group_tokens"]
-    assert recs[0]["scores"] == recs[1]["scores"] and len(recs[0]["scores"]) == 2 * P * S
+    assert recs[0]["scores"] == recs[1]["scores"] and len(recs[0]["scores"]) == W * P * S
     # the winner's tokens are those of the OWNING rank's local candidate: global prompt g = r + j * W
     gi = recs[0]["global_idx"]
     g, s = gi // S, gi % S
-    owner, j = g % 2, g // 2
+    owner, j = g % W, g // W
     assert recs[owner]["local_tokens"][j * S + s] == recs[0]["winner_tokens"]
     assert recs[owner]["local_tokens"][j * S:(j + 1) * S] == recs[0]["group_tokens"]
-    # both ranks ran the same observation and the same 8 prompts: identical local work -> identical scores per rank slot
-    sc = torch.tensor(recs[0]["scores"]).view(P, 2, S)
-    assert torch.equal(sc[:, 0], sc[:, 1])
+    # the ranks did DIFFERENT work: other prompts, other uniforms -> other tokens and other scores
+    assert recs[0]["local_tokens"] != recs[1]["local_tokens"]
+    sc = torch.tensor(recs[0]["scores"]).view(W * P, S)            # global prompt order; rank r's groups are rows r::W
+    assert not torch.equal(sc[0::W], sc[1::W])
+    # the winner is the grouped arg-max of the union (first maximum wins, efficient_ensemble_merged.py:417-448)
+    bg = int(sc.mean(1).argmax())
+    assert gi == bg * S + int(sc[bg].argmax())
+    # rank r's first prompt groups are what an unsharded headline-sized run computes for the same global prompts: prompt p and the
+    # uniforms of candidate n do not depend on how many ranks there are
+    import bench
+    pipe = bench.Pipeline(dev, small=True)                          # 8 prompts x 4 samples, global prompts 0..7
+    _, tok, _ = pipe.decision()
+    tok = tok.cpu().view(P, S, 7)
+    for r in range(W):
+        mine = torch.tensor(recs[r]["local_tokens"]).view(P, S, 7)  # local prompt j = global prompt r + j W
+        for j in range(P):
+            gp = r + j * W
+            if gp < P:
+                assert torch.equal(mine[j], tok[gp]), (r, j)
+
+
+def test_two_ranks_config3_one_prompt_group_per_rank(dev, multirank_runs):
+    """BASELINE config 3 as SURVEY 8(d) defines it (N = 256 = 8 GPUs x one prompt group of 32 samples), here at W = 2: rank r owns
+    prompt group r with 32 samples; one all-gather; the winner is the grouped arg-max over both groups."""
+    assert "config3" in multirank_runs, "rank processes were not launched (no GPU at collection time?)"
+    recs, line = _collect(multirank_runs["config3"])
+    S, W = 32, 2
+    assert line["scaling"] == "weak" and line["config"]["candidates_total"] == W * S and line["config"]["prompts_per_gpu"] == 1
+    assert recs[0]["prompt_ids"] == [0] and recs[1]["prompt_ids"] == [1]
+    assert recs[0]["global_idx"] == recs[1]["global_idx"] and recs[0]["scores"] == recs[1]["scores"]
+    sc = torch.tensor(recs[0]["scores"]).view(W, S)
+    assert not torch.equal(sc[0], sc[1])
+    bg = int(sc.mean(1).argmax())
+    gi = recs[0]["global_idx"]
+    assert gi == bg * S + int(sc[bg].argmax())
+    assert recs[bg]["local_tokens"][gi % S] == recs[0]["winner_tokens"] == recs[1]["winner_tokens"]
+    assert recs[bg]["local_tokens"] == recs[0]["group_tokens"] == recs[1]["group_tokens"]
 
 
 def test_two_ranks_strong_scaling_equals_unsharded(dev, multirank_runs):

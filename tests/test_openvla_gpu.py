@@ -19,7 +19,7 @@ sys.path.insert(0, os.path.join(ROOT, "oracle"))
 from cover_vla_amd import synth  # noqa: E402
 
 
-def _case(seed=3, P=3, Lt=9, n_samples=2, n_cams=1):
+def _case(seed=3, P=3, Lt=9, n_samples=2, n_cams=1, n_gen=7):
     c = dict(synth.OPENVLA_SMALL)
     sd = synth.openvla_state(c, seed=seed, std=0.08)
     g = torch.Generator().manual_seed(seed)
@@ -28,36 +28,48 @@ def _case(seed=3, P=3, Lt=9, n_samples=2, n_cams=1):
     toks = torch.zeros(P, Lt, dtype=torch.long)
     for p in range(P):
         toks[p, :lens[p]] = torch.randint(2, c["tok_vocab"] - c["n_bins"], (int(lens[p]),), generator=g)
-    u = torch.rand(P * n_samples, 7, generator=g)
+    u = torch.rand(P * n_samples, n_gen, generator=g)
     return c, sd, frame, toks, lens, u
 
 
-@pytest.mark.parametrize("greedy,n_cams", [(True, 1), (False, 1), (True, 2), (False, 2)])
-def test_openvla_small_matches_oracle(dev, greedy, n_cams):
-    """n_cams = 2 is BASELINE config 4's observation (two 224^2 cameras -> 512 patch rows in the shared prefix)."""
+@pytest.mark.parametrize("greedy,n_cams,horizon,wdtype", [(True, 1, 1, "bf16"), (False, 1, 1, "bf16"), (True, 2, 1, "bf16"), (False, 2, 1, "bf16"),
+                                                          (True, 1, 2, "bf16"), (False, 1, 2, "bf16"), (False, 1, 8, "bf16"),
+                                                          (False, 1, 2, "fp8"), (True, 1, 8, "fp8")])
+def test_openvla_small_matches_oracle(dev, greedy, n_cams, horizon, wdtype):
+    """n_cams = 2 is BASELINE config 4's observation (two 224^2 cameras -> 512 patch rows in the shared prefix); horizon > 1 is
+    config 5's action chunk (7 x horizon action tokens per candidate: the own-token KV segment grows to 56 keys); wdtype "fp8" =
+    config 5's e4m3 decoder / lm_head weights, compared with the oracle on the DE-QUANTISED weights."""
     from cover_ref import blocks as Bk, openvla as OR
     from cover_vla_amd.openvla import OpenVLA
-    c, sd, frame, toks, lens, u = _case(n_cams=n_cams)
+    n_gen = 7 * horizon
+    c, sd, frame, toks, lens, u = _case(n_cams=n_cams, n_gen=n_gen)
     n_samples = 1 if greedy else 2
     P = toks.shape[0]
-    model = OpenVLA(sd, c, device="cuda:0", max_prompts=4, max_candidates=8, max_text=toks.shape[1], n_cams=n_cams)
+    model = OpenVLA(sd, c, device="cuda:0", max_prompts=4, max_candidates=8, max_text=toks.shape[1], n_cams=n_cams, horizon=horizon,
+                    weight_dtype=wdtype)
     un = None if greedy else u[: P * n_samples]
     otr = {}
+    if wdtype == "fp8":
+        from tests.test_fp8_gpu import _dequant_sd
+        osd = Bk.to_bf16(_dequant_sd(sd))
+    else:
+        osd = Bk.to_bf16(sd)
     with torch.no_grad():
-        ref = OR.sample(c, Bk.to_bf16(sd), frame, toks, lens, n_samples, un, 0.9, trace=otr)
+        ref = OR.sample(c, osd, frame, toks, lens, n_samples, un, 0.9, n_gen=n_gen, trace=otr)
     # teacher-forced on the oracle's trajectory so that all 7 steps are comparable (random-weight logits have tiny
     # top-1/top-2 margins: a free-running comparison diverges at the first near-tie and says nothing afterwards)
     tr = {}
     tokens, _ = model.sample(frame.to(dev), toks.to(dev), lens.to(dev), n_samples, None if greedy else un.to(dev), 0.9, trace=tr,
                              force_tokens=ref.to(dev))
     tokens = tokens.cpu()
-    ref_logits = otr["logits"]                       # [N, 7, V]
+    assert tokens.shape == (P * n_samples, n_gen)
+    ref_logits = otr["logits"]                       # [N, n_gen, V]
     got_logits = torch.stack([l.cpu() for l in tr["logits"]], 1)
     lo, hi = (0, c["tok_vocab"]) if greedy else (c["tok_vocab"] - c["n_bins"], c["tok_vocab"])
     min_margin, n_decided = 1e9, 0
     T = 0.9
     for n in range(tokens.shape[0]):
-        for i in range(7):
+        for i in range(n_gen):
             err = (got_logits[n, i] - ref_logits[n, i]).abs().max().item()
             # bf16 stack: two independent bf16 evaluations. The oracle's OWN bf16-vs-fp32 evaluation distance on this
             # case is rel-L2 1.0-1.5e-2 / max-abs 0.05, so two bf16 paths sit ~sqrt(2) x that apart: bounds = 3.5e-2 rel-L2,
@@ -106,7 +118,7 @@ def test_openvla_small_matches_oracle(dev, greedy, n_cams):
     # free-running greedy: the first token of every candidate only depends on the prefill
     if greedy:
         free, _ = model.sample(frame.to(dev), toks.to(dev), lens.to(dev), 1)
-        assert free.shape == (P, 7)
+        assert free.shape == (P, n_gen)
 
 
 def test_siglip2_features_match_oracle(dev):
