@@ -31,7 +31,7 @@ class GemmEpi(C.Structure):
     _fields_ = [("bias", c_p), ("residual", c_p), ("layer_scale", c_p), ("ld_residual", c_i), ("residual_f32", c_i),
                 ("act", c_i), ("glu", c_i), ("out_f32", c_i), ("out_scale", c_f),
                 ("norm_w", c_p), ("norm_out", c_p), ("ld_norm_out", c_i), ("norm_style", c_i), ("norm_w_offset", c_f),
-                ("norm_eps", c_f), ("norm_b", c_p), ("w8", c_p), ("w8_scale", c_p)]
+                ("norm_eps", c_f), ("norm_b", c_p), ("w8", c_p), ("w8_scale", c_p), ("a8", c_p), ("a8_scale", c_p), ("ld_a8", c_i), ("_pad_a8", c_i)]
 
 
 class KvSegment(C.Structure):
@@ -166,6 +166,7 @@ SYMBOLS = {
     "cover_packed_weight_fp8_bytes": (C.c_size_t, [c_i, c_i]),
     "cover_quantize_rows_fp8": (c_i, [c_p, c_i, c_i, c_i, c_p, c_p, c_p]),
     "cover_pack_weight_fp8": (c_i, [c_p, c_i, c_p, c_i, c_i, c_p, c_p, c_i, c_p]),
+    "cover_quantize_act_fp8": (c_i, [c_p, c_i, c_i, c_i, c_p, c_i, c_p, c_p]),
     "cover_gemm_workspace_bytes": (C.c_size_t, [c_i, c_i, c_i]),
     "cover_gemm_bf16": (c_i, [c_p, c_i, c_p, c_p, c_i, c_i, c_i, c_i, _P(GemmEpi), c_p, C.c_size_t, c_i, c_p]),
     "cover_attention_bf16": (c_i, [_P(AttnArgs), c_p]),

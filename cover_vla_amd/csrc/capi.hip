@@ -2,6 +2,7 @@
 // Host code only; kernels live in the sibling .hip files.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <string>
 #include "kernels.h"
@@ -61,6 +62,12 @@ int cover_pack_weight_fp8(const void* Wdq, int ldw, const float* scales, int N, 
     if (glu && ((N / 2) % 16 != 0 || (N & 1))) return fail(COVER_EINVAL, "cover_pack_weight_fp8: glu needs N/2 % 16 == 0");
     HIPCHK(launch_pack_weight_fp8((const bf16_t*)Wdq, ldw, scales, N, K, (uint8_t*)Wq, scales_packed, cover_packed_k(K), glu, ST(stream)),
            "pack_weight_fp8");
+    return COVER_OK;
+}
+int cover_quantize_act_fp8(const void* X, int ldx, int M, int K, void* out8, int ld8, float* scales, void* stream) {
+    if (!X || !out8 || !scales || M < 0 || K <= 0) return fail(COVER_EINVAL, "cover_quantize_act_fp8: bad arguments");
+    HIPCHK(launch_quantize_act_fp8((const bf16_t*)X, ldx, M, K, (uint8_t*)out8, ld8, scales, ST(stream)),
+           "quantize_act_fp8 (ld8 >= padded K, ld8 % 16 == 0, ldx % 8 == 0)");
     return COVER_OK;
 }
 size_t cover_gemm_workspace_bytes(int M, int N, int K) { return gemm_workspace_bytes(M, N, K); }
@@ -365,7 +372,7 @@ int cover_vit_forward(const cover_vit_desc* d, void* x, int n_seq, int T, void* 
 }
 
 static size_t dec_ws(const cover_dec_desc* d, int rows, Carver* c, void** h, void** qkv, void** attn, void** mlp, void** sk,
-                     size_t* sk_bytes, void** st_o = nullptr, void** st_ml = nullptr) {
+                     size_t* sk_bytes, void** st_o = nullptr, void** st_ml = nullptr, void** q8 = nullptr, void** q8s = nullptr) {
     Carver tmp{nullptr, 0, 0};
     Carver& cc = c ? *c : tmp;
     const int nqkv = (d->Hq + 2 * d->Hkv) * d->D;
@@ -376,6 +383,12 @@ static size_t dec_ws(const cover_dec_desc* d, int rows, Carver* c, void** h, voi
     p = cc.take((size_t)rows * d->mlp * 2); if (mlp) *mlp = p;
     p = cc.take((size_t)rows * d->Hq * d->D * 4); if (st_o) *st_o = p;   // attention state (seg0_shared decode)
     p = cc.take((size_t)rows * d->Hq * 2 * 4); if (st_ml) *st_ml = p;
+    {   // e4m3 twin of the current GEMM input (rows > 64 with fp8 weights: the MX-scaled fp8 tiled GEMM) + its row scales
+        int kmax = d->dim > d->mlp ? d->dim : d->mlp;
+        kmax = kmax > d->Hq * d->D ? kmax : d->Hq * d->D;
+        p = cc.take((size_t)rows * ((kmax + 127) / 128 * 128)); if (q8) *q8 = p;
+        p = cc.take((size_t)rows * 4); if (q8s) *q8s = p;
+    }
     size_t skb = 0;
     {
         const int ns[4] = {nqkv, d->dim, 2 * d->mlp, d->dim};
@@ -407,9 +420,9 @@ int cover_decoder_forward(const cover_dec_desc* d, const cover_dec_pass* p, void
         rows += G.B * G.T;
     }
     Carver c{(char*)ws.ptr, ws.bytes, 0};
-    void *h, *qkv, *attn, *mlp, *sk, *st_o, *st_ml;
+    void *h, *qkv, *attn, *mlp, *sk, *st_o, *st_ml, *q8, *q8s;
     size_t skb;
-    const size_t need = dec_ws(d, rows, &c, &h, &qkv, &attn, &mlp, &sk, &skb, &st_o, &st_ml);
+    const size_t need = dec_ws(d, rows, &c, &h, &qkv, &attn, &mlp, &sk, &skb, &st_o, &st_ml, &q8, &q8s);
     if (!ws.ptr || ws.bytes < need) return fail(COVER_EWORKSPACE, "cover_decoder_forward: workspace too small");
     const int dim = d->dim, Hq = d->Hq, Hkv = d->Hkv, D = d->D, nqkv = (Hq + 2 * Hkv) * D, HD = Hq * D;
 
@@ -419,6 +432,17 @@ int cover_decoder_forward(const cover_dec_desc* d, const cover_dec_pass* p, void
         HIPCHK(launch_rmsnorm(f32in ? (const void*)p->x_f32 : (const void*)x, f32in ? 1 : 0, dim, d->layers_host[0].in_norm_w,
                               d->norm_w_offset, d->norm_style, (bf16_t*)h, dim, rows, dim, d->norm_eps, st), "dec in_norm");
     }
+    // fp8 profile with more rows than the weight-streaming kernels take (config 5: M = 512 decode rows, and its prefill): the
+    // projections run on the MX-scaled fp8 matrix instruction -- the input rows of every GEMM are quantised to e4m3 (per-row
+    // power-of-two scale) right before it, into one shared buffer
+    static const char* f8_env = getenv("COVER_FP8_MFMA");
+    const bool f8 = rows > 64 && d->layers_host[0].qkv_w8 && d->layers_host[0].o_w8 && d->layers_host[0].gate_up_w8 && d->layers_host[0].down_w8 &&
+                    !(f8_env && f8_env[0] == '0');
+    auto quant = [&](const void* src, int K, cover_gemm_epi& e) -> hipError_t {
+        const int kp = (K + 127) / 128 * 128;
+        e.a8 = q8; e.a8_scale = (const float*)q8s; e.ld_a8 = kp;
+        return launch_quantize_act_fp8((const bf16_t*)src, K, rows, K, (uint8_t*)q8, kp, (float*)q8s, st);
+    };
     for (int l = 0; l < d->n_layers; ++l) {
         const cover_dec_layer& L = d->layers_host[l];
         const bool first_f32 = (l == 0 && p->x_f32 != nullptr);
@@ -427,6 +451,7 @@ int cover_decoder_forward(const cover_dec_desc* d, const cover_dec_pass* p, void
         e.out_scale = 1.0f;
         e.bias = L.qkv_b;
         e.w8 = L.qkv_w8; e.w8_scale = L.qkv_s;
+        if (f8) HIPCHK(quant(h, dim, e), "dec quantise (qkv input)");
         // weight-streaming path: leave the split-K partials for rope_kv_write to fold (one launch and one pass less)
         int qkv_splits = 0;
         if (rows <= 64 && p->n_groups == 1 && (variant == 0 || variant == 3))
@@ -536,11 +561,13 @@ int cover_decoder_forward(const cover_dec_desc* d, const cover_dec_pass* p, void
         e.norm_w = L.post_norm_w; e.norm_out = h; e.ld_norm_out = dim; e.norm_style = d->norm_style;
         e.norm_w_offset = d->norm_w_offset; e.norm_eps = d->norm_eps;
         e.w8 = L.o_w8; e.w8_scale = L.o_s;
+        if (f8) HIPCHK(quant(attn, HD, e), "dec quantise (o_proj input)");
         HIPCHK(launch_gemm_bf16((const bf16_t*)attn, HD, (const bf16_t*)L.o_w, x, dim, rows, dim, HD, &e, (float*)sk, skb, variant, st), "dec o_proj (+post_norm)");
         memset(&e, 0, sizeof e);
         e.out_scale = 1.0f;
         e.act = d->act; e.glu = 1;
         e.w8 = L.gate_up_w8; e.w8_scale = L.gate_up_s;
+        if (f8) HIPCHK(quant(h, dim, e), "dec quantise (gate_up input)");
         HIPCHK(launch_gemm_bf16((const bf16_t*)h, dim, (const bf16_t*)L.gate_up_w, mlp, d->mlp, rows, 2 * d->mlp, dim, &e, (float*)sk, skb, variant, st), "dec gate_up");
         memset(&e, 0, sizeof e);
         e.out_scale = 1.0f;
@@ -550,6 +577,7 @@ int cover_decoder_forward(const cover_dec_desc* d, const cover_dec_pass* p, void
             e.norm_w_offset = d->norm_w_offset; e.norm_eps = d->norm_eps;
         }
         e.w8 = L.down_w8; e.w8_scale = L.down_s;
+        if (f8) HIPCHK(quant(mlp, d->mlp, e), "dec quantise (down input)");
         HIPCHK(launch_gemm_bf16((const bf16_t*)mlp, d->mlp, (const bf16_t*)L.down_w, x, dim, rows, dim, d->mlp, &e, (float*)sk, skb, variant, st), "dec down (+next in_norm)");
     }
     if (p->final_norm)

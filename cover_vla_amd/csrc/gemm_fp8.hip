@@ -1,0 +1,311 @@
+// fp8 (OCP e4m3) GEMM on the CDNA4 block-scaled matrix instruction v_mfma_scale_f32_16x16x128_f8f6f4 (BASELINE config 5:
+// "fp8 weights + fp8 KV (CDNA4 fp8 MFMA)"; the reference has no fp8 path -- SURVEY.md 7 step 9 -- so the bar is agreement rate /
+// score RMSE against the bf16 pipeline, plus kernel-level parity against an fp32 restatement on the SAME quantised operands).
+//
+//   C[M,N] = epi( a_scale[m] * w_scale[n] * sum_k A8[m,k] * W8[n,k] )        fp32 accumulate, 128 k per instruction
+//
+// Non-scaled fp8 MFMA runs at the bf16 rate on gfx950; only the MX-scaled form reaches the 2x rate (MI355X_MICROARCH.md,
+// matrix-core table). It is used here with every E8M0 block scale = 2^0: the quantisation scales are per ROW of A (dynamic,
+// cover_quantize_act_fp8) and per OUTPUT CHANNEL of W (static, cover_quantize_rows_fp8), both powers of two, and are applied to the
+// fp32 sums in the epilogue -- they are constant along k, so this is exact.
+//
+// Operand images. W8 is the e4m3 image the weight-streaming kernels already read (cover_pack_weight_fp8):
+//   Wq[n/16][k/64][lane = n%16 + 16*g][16 B] with the lane's bytes = k = 64c + {32h + 8g + e : h = 0,1; e = 0..7}  (c = k/64)
+// i.e. one 1-KiB block per (16 n, 64 k). The 32-byte MFMA operand of lane (n%16, g) for a 128-deep step is its 16 bytes of block
+// c = 0 followed by its 16 bytes of block c = 1. The contraction pairs byte j of lane (.., g) of one operand with byte j of lane
+// (.., g) of the other, so ANY k order works as long as both operands use the same one: cover_quantize_act_fp8 writes the
+// activation rows in exactly that order (inside every 64-block, position g*16 + h*8 + e holds k = 32h + 8g + e). A row of a
+// 128-deep k-tile is then 128 B = 8 chunks of 16 B, lane (m%16, g) needs chunks g (c = 0) and 4 + g (c = 1): the same LDS image,
+// XOR chunk swizzle and read pattern as the bf16 kernel (gemm_tiled_pc), with half the bytes per FLOP.
+//
+// Structure = gemm_tiled_pc: NL loader waves own every LDS-DMA piece (global_load_lds, counted vmcnt ring, NST stages), CGM x CGN
+// MFMA waves of (WM*16) x (WN*16). One barrier per k-tile; the MFMA waves read all fragments of a tile right after it and start
+// their MFMAs behind counted lgkmcnt waits (the first MFMA needs 4 of the 2(WM+WN) reads), the partner wave on the SIMD fills the gap.
+#include <stdlib.h>
+#include <hip/hip_ext.h>
+#include "gemm_common.h"
+
+typedef __attribute__((ext_vector_type(8))) int i32x8;
+
+// inline-asm LDS reads / counted waits with compile-time immediates, and the template recursions that replace loops over them
+// (an asm operand cannot name a lambda capture, and an "n" operand must be a constant expression)
+template <int OFF>
+__device__ __forceinline__ void ds_read128(u32x4& dst, uint32_t addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
+}
+template <int N>
+__device__ __forceinline__ void wait_lgkm() {   // lgkmcnt is a 4-bit field: a larger count is clamped (a stricter wait is always safe)
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N > 15 ? 15 : N));
+}
+template <int F, int WM>
+__device__ __forceinline__ void read_x_frags(u32x4 (&xlo)[WM], u32x4 (&xhi)[WM], uint32_t a0, uint32_t a1) {
+    if constexpr (F < WM) {
+        ds_read128<F * 2048>(xlo[F], a0);
+        ds_read128<F * 2048>(xhi[F], a1);
+        read_x_frags<F + 1, WM>(xlo, xhi, a0, a1);
+    }
+}
+template <int B, int WN>
+__device__ __forceinline__ void read_w_frags(u32x4 (&wlo)[WN], u32x4 (&whi)[WN], uint32_t ba) {
+    if constexpr (B < WN) {
+        ds_read128<B * 2048>(wlo[B], ba);
+        ds_read128<B * 2048 + 1024>(whi[B], ba);
+        read_w_frags<B + 1, WN>(wlo, whi, ba);
+    }
+}
+__device__ __forceinline__ f32x4 mfma_f8(const u32x4& wl, const u32x4& wh, const u32x4& xl, const u32x4& xh, f32x4 c) {
+    const i32x8 wa = {(int)wl[0], (int)wl[1], (int)wl[2], (int)wl[3], (int)wh[0], (int)wh[1], (int)wh[2], (int)wh[3]};
+    const i32x8 xa = {(int)xl[0], (int)xl[1], (int)xl[2], (int)xl[3], (int)xh[0], (int)xh[1], (int)xh[2], (int)xh[3]};
+    return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wa, xa, c, 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);   // every E8M0 block scale = 2^0
+}
+// MFMAs of one k-tile, b outer / f inner, behind counted waits. Read issue order: w[0], x[0..WM), w[1..WN) (two reads each).
+template <int B, int F, int WM, int WN>
+__device__ __forceinline__ void mfma_tile(f32x4 (&acc)[WN][WM], u32x4 (&xlo)[WM], u32x4 (&xhi)[WM], u32x4 (&wlo)[WN], u32x4 (&whi)[WN]) {
+    if constexpr (B < WN) {
+        constexpr int TOTAL = 2 * (WM + WN);
+        // reads that must have landed: b == 0: w[0] + x[0..f] = 2 + 2 (f + 1); b >= 1: everything up to w[b] = 2 + 2 WM + 2 b
+        constexpr int need = (B == 0) ? 2 + 2 * (F + 1) : 2 + 2 * WM + 2 * B;
+        if constexpr (B == 0 || F == 0) {
+            wait_lgkm<TOTAL - need>();
+            asm volatile("" : "+v"(wlo[B]), "+v"(whi[B]), "+v"(xlo[F]), "+v"(xhi[F]));   // ties the fragments to the wait
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        acc[B][F] = mfma_f8(wlo[B], whi[B], xlo[F], xhi[F], acc[B][F]);
+        if constexpr (F + 1 < WM) mfma_tile<B, F + 1, WM, WN>(acc, xlo, xhi, wlo, whi);
+        else mfma_tile<B + 1, 0, WM, WN>(acc, xlo, xhi, wlo, whi);
+    }
+}
+
+template <int WM, int WN, int NST, int NL, int CGM, int CGN>
+__global__ __launch_bounds__(64 * (CGM * CGN + NL)) void gemm_tiled_pc_f8(const uint8_t* __restrict__ A8, int lda8, const uint8_t* __restrict__ W8,
+                                                                          void* C, int ldc, int M, int N, int Kp, EpiDev epi, int tiles_m, int tiles_n,
+                                                                          int kt_per, float* __restrict__ partial, const float* __restrict__ a_scale,
+                                                                          const float* __restrict__ w_scale) {
+    constexpr int NCW = CGM * CGN;
+    constexpr int BM_ = CGM * WM * 16, BN_ = CGN * WN * 16;
+    constexpr int A_BYTES = BM_ * 128, B_BYTES = BN_ * 128;   // one 128-deep k-tile: 128 B per row, as a 64-deep bf16 tile
+    constexpr int AT = A_BYTES / 1024, BT = B_BYTES / 1024;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* As = smem;                   // [NST][A_BYTES]
+    char* Bs = smem + NST * A_BYTES;   // [NST][B_BYTES]
+    const int nwg = tiles_m * tiles_n;
+    int bid = blockIdx.x;
+    {   // XCD-aware bijective remap: the row tiles that share a weight tile run on one XCD (one L2)
+        const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+        const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+        bid = base + (bid >> 3);
+    }
+    const int tn = bid / tiles_m, tm = bid % tiles_m;
+    const int m0 = tm * BM_, n0 = tn * BN_;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int K64 = Kp >> 6;
+    const int N16 = (N + 15) >> 4;
+    const int nk_total = Kp >> 7;
+    const int kt0 = blockIdx.y * kt_per;
+    const int nk = min(kt_per, nk_total - kt0);
+
+    if (w >= NCW) {   // ---------------- loader waves ----------------
+        constexpr int PT = (AT + BT) / NL;
+        static_assert((AT + BT) % NL == 0 && AT % NL == 0, "pieces must split evenly over the loader waves");
+        static_assert((NST - 2) * PT <= 63, "counted vmcnt must fit its 6-bit field");
+        const int l = w - NCW;
+        const uint8_t* src[PT];
+        uint32_t dst[PT];
+        size_t step[PT];
+        const uint32_t as_u32 = __builtin_amdgcn_readfirstlane(lds_addr_u32(As));
+        const uint32_t bs_u32 = __builtin_amdgcn_readfirstlane(lds_addr_u32(Bs));
+#pragma unroll
+        for (int i = 0; i < PT; ++i) {
+            const int j = l + i * NL;
+            if (j < AT) {   // A: LDS chunk position p = j*64 + lane: row = p>>3, c = p&7 holds global chunk c ^ (row&7)
+                const int row = j * 8 + (lane >> 3), c = lane & 7;
+                int gr = m0 + row;
+                gr = gr < M ? gr : M - 1;
+                src[i] = A8 + (size_t)gr * lda8 + (size_t)kt0 * 128 + ((c ^ (row & 7)) << 4);
+                dst[i] = as_u32 + j * 1024;
+                step[i] = 128;
+            } else {
+                const int jb = j - AT;
+                const int nbi = jb >> 1, kbi = jb & 1;
+                int nb = (n0 >> 4) + nbi;
+                nb = nb < N16 ? nb : N16 - 1;
+                src[i] = W8 + ((size_t)nb * K64 + (size_t)kt0 * 2 + kbi) * 1024 + lane * 16;
+                dst[i] = bs_u32 + jb * 1024;
+                step[i] = 2048;
+            }
+        }
+        auto issue = [&](int buf, int kt) {
+#pragma unroll
+            for (int i = 0; i < PT; ++i)
+                glds16_asm(src[i] + kt * step[i], dst[i] + buf * ((l + i * NL) < AT ? A_BYTES : B_BYTES));
+        };
+#pragma unroll
+        for (int s = 0; s < NST - 1; ++s)
+            if (s < nk) issue(s, s);
+        int cur = 0;
+        for (int kt = 0; kt < nk; ++kt) {
+            const int younger = min(nk - 1 - kt, NST - 2);   // tiles issued after kt that may stay in flight
+            if (NST >= 4 && younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PT) : "memory");
+            else if (younger >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PT) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (kt + NST - 1 < nk) issue(cur == 0 ? NST - 1 : cur - 1, kt + NST - 1);   // stage (kt-1) % NST: every consumer is past tile kt-1
+            cur = cur == NST - 1 ? 0 : cur + 1;
+        }
+        return;
+    }
+    // ---------------- MFMA waves ----------------
+    const int wm = w / CGN, wn = w % CGN;
+    const int r = lane & 15, g = lane >> 4;
+    f32x4 acc[WN][WM];  // [n-block b][m-frag f]
+#pragma unroll
+    for (int b = 0; b < WN; ++b)
+#pragma unroll
+        for (int f = 0; f < WM; ++f) acc[b][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const uint32_t a_addr0 = lds_addr_u32(As) + ((wm * (WM * 16) + r) * 8 + ((0 * 4 + g) ^ (r & 7))) * 16;
+    const uint32_t a_addr1 = lds_addr_u32(As) + ((wm * (WM * 16) + r) * 8 + ((1 * 4 + g) ^ (r & 7))) * 16;
+    const uint32_t b_addr = lds_addr_u32(Bs) + (wn * WN * 2 * 64 + lane) * 16;
+    u32x4 xlo[WM], xhi[WM], wlo[WN], whi[WN];
+    int cur = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        asm volatile("s_barrier" ::: "memory");   // tile kt published by the loaders (their vmcnt waits precede it)
+        const uint32_t a0 = a_addr0 + cur * A_BYTES, a1 = a_addr1 + cur * A_BYTES, ba = b_addr + cur * B_BYTES;
+        // issue order = need order of the MFMA sequence (b outer, f inner): w[0], x[0..WM), w[1..WN)
+        ds_read128<0>(wlo[0], ba);
+        ds_read128<1024>(whi[0], ba);
+        read_x_frags<0, WM>(xlo, xhi, a0, a1);
+        read_w_frags<1, WN>(wlo, whi, ba);
+        mfma_tile<0, 0, WM, WN>(acc, xlo, xhi, wlo, whi);
+        __builtin_amdgcn_sched_barrier(0);
+        cur = cur == NST - 1 ? 0 : cur + 1;
+    }
+    // quantisation scales (constant along k): row scale of A x channel scale of W, on the fp32 sums
+    {
+        const int mw = m0 + wm * (WM * 16), nw = n0 + wn * (WN * 16);
+        float as[WM];
+#pragma unroll
+        for (int f = 0; f < WM; ++f) {
+            int m = mw + f * 16 + r;
+            m = m < M ? m : M - 1;
+            as[f] = a_scale[m];
+        }
+#pragma unroll
+        for (int b = 0; b < WN; ++b) {
+            int nb = (nw >> 4) + b;
+            nb = nb < N16 ? nb : N16 - 1;
+            const float4 ws = *(const float4*)(w_scale + (size_t)nb * 16 + 4 * g);
+#pragma unroll
+            for (int f = 0; f < WM; ++f) {
+                acc[b][f][0] *= as[f] * ws.x; acc[b][f][1] *= as[f] * ws.y; acc[b][f][2] *= as[f] * ws.z; acc[b][f][3] *= as[f] * ws.w;
+            }
+        }
+    }
+    tiled_epilogue_staged<WM, WN, BM_, BN_>(acc, epi, C, ldc, M, N, m0, n0, m0 + wm * (WM * 16), n0 + wn * (WN * 16), r, g, partial, smem,
+                                            NST * (A_BYTES + B_BYTES), tid, 64 * NCW);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Dynamic per-row e4m3 quantisation of activation rows, written in the k order the MFMA operands want (see the header):
+//   s_m = smallest power of two with max_k |x[m,k]| / s_m <= 448,  q = RNE_e4m3(x / s_m)   (division exact)
+//   out[m][64 c + 16 g + 8 h + e] = q[m][64 c + 32 h + 8 g + e],  zero beyond K up to Kp (multiple of 128).
+// One 256-thread block per row, 8 elements (16 B in, 8 B out) per thread per step.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void quantize_act_fp8_k(const bf16_t* __restrict__ X, int ldx, int K, int Kp, uint8_t* __restrict__ out, int ld8,
+                                                          float* __restrict__ scales) {
+    __shared__ float red[16];
+    const int m = blockIdx.x;
+    const bf16_t* x = X + (size_t)m * ldx;
+    const int nch = Kp >> 3;
+    float mx = 0.f;
+    for (int c = threadIdx.x; c < nch; c += 256) {
+        const int k = c * 8;
+        if (k + 8 <= K) {
+            const uint4 v = *(const uint4*)(x + k);
+            const uint32_t wv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) mx = fmaxf(mx, fmaxf(fabsf(bf2f((bf16_t)(wv[i] & 0xffffu))), fabsf(bf2f((bf16_t)(wv[i] >> 16)))));
+        } else {
+            for (int e = 0; e < 8; ++e)
+                if (k + e < K) mx = fmaxf(mx, fabsf(bf2f(x[k + e])));
+        }
+    }
+    mx = block_max(mx, red);
+    float s = 1.0f;
+    if (mx > 0.f) {   // smallest power of two s with mx / s <= 448 (as quantize_rows_fp8_k)
+        int e;
+        const float f = frexpf(mx / 448.0f, &e);
+        s = ldexpf(1.0f, f == 0.5f ? e - 1 : e);
+    }
+    if (threadIdx.x == 0) scales[m] = s;
+    const float inv = 1.0f / s;
+    uint8_t* o = out + (size_t)m * ld8;
+    for (int c = threadIdx.x; c < nch; c += 256) {
+        const int k = c * 8;
+        float v[8];
+        if (k + 8 <= K) {
+            const uint4 q = *(const uint4*)(x + k);
+            const uint32_t wv[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                v[2 * i] = bf2f((bf16_t)(wv[i] & 0xffffu)) * inv;
+                v[2 * i + 1] = bf2f((bf16_t)(wv[i] >> 16)) * inv;
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (k + e < K) ? bf2f(x[k + e]) * inv : 0.f;
+        }
+        int lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], 0, false);
+        lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], lo, true);
+        int hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[4], v[5], 0, false);
+        hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[6], v[7], hi, true);
+        // k = 64 cc + 32 h + 8 g  ->  position 64 cc + 16 g + 8 h
+        const int cc = k >> 6, h = (k >> 5) & 1, gq = (k >> 3) & 3;
+        *(uint2*)(o + cc * 64 + gq * 16 + h * 8) = make_uint2((uint32_t)lo, (uint32_t)hi);
+    }
+}
+
+hipError_t launch_quantize_act_fp8(const bf16_t* X, int ldx, int M, int K, uint8_t* out, int ld8, float* scales, hipStream_t st) {
+    if (M <= 0) return hipSuccess;
+    const int Kp = (K + 127) / 128 * 128;
+    if (ld8 < Kp || (ld8 & 15) || (ldx & 7)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(quantize_act_fp8_k, dim3(M), dim3(256), 0, st, X, ldx, K, Kp, out, ld8, scales);
+    return hipGetLastError();
+}
+
+// pick: the tile configuration index of launch_gemm_bf16's table (10: 64x128, 12: 256x128, 13: 128x256, 15: 224x128, 17: 224x96; the 224x192 tile needs 84 accumulator + 80 fragment registers and spills at 3 waves per SIMD)
+bool gemm_fp8_tiled_supported(int pick) { return pick == 10 || pick == 12 || pick == 13 || pick == 15 || pick == 17; }
+
+hipError_t launch_gemm_fp8_tiled(int pick, const uint8_t* A8, int lda8, const float* a_scale, const uint8_t* W8, const float* w_scale, void* C, int ldc,
+                                 int M, int N, int Kp, const EpiDev& epi, int tiles_m, int tiles_n, int kt_per, int S, float* partial, size_t lds,
+                                 int prof_cls, double prof_work, hipStream_t st) {
+    hipError_t e = hipSuccess;
+    dim3 grid(tiles_m * tiles_n, S);
+#define LAUNCH_F8(WM_, WN_, NST_, NL_, CGM_, CGN_)                                                                           \
+    do {                                                                                                                     \
+        auto kfn = gemm_tiled_pc_f8<WM_, WN_, NST_, NL_, CGM_, CGN_>;                                                        \
+        if (lds > 64 * 1024) {                                                                                               \
+            static hipError_t attr = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+            e = attr;                                                                                                        \
+        }                                                                                                                    \
+        if (e == hipSuccess) {                                                                                               \
+            dim3 block(64 * (CGM_ * CGN_ + NL_));                                                                            \
+            hipEvent_t ea, eb;                                                                                               \
+            if (prof_enabled() && prof_reserve(prof_cls, prof_work, &ea, &eb) >= 0)                                          \
+                hipExtLaunchKernelGGL(kfn, grid, block, (uint32_t)lds, st, ea, eb, 0, A8, lda8, W8, C, ldc, M, N, Kp, epi, tiles_m, tiles_n, kt_per, partial, a_scale, w_scale); \
+            else                                                                                                             \
+                hipLaunchKernelGGL(kfn, grid, block, lds, st, A8, lda8, W8, C, ldc, M, N, Kp, epi, tiles_m, tiles_n, kt_per, partial, a_scale, w_scale); \
+        }                                                                                                                    \
+    } while (0)
+    switch (pick) {
+        case 10: LAUNCH_F8(2, 4, 4, 4, 2, 2); break;
+        case 12: LAUNCH_F8(4, 4, 3, 4, 4, 2); break;
+        case 13: LAUNCH_F8(4, 4, 3, 4, 2, 4); break;
+        case 15: LAUNCH_F8(7, 2, 3, 4, 2, 4); break;
+        case 17: LAUNCH_F8(7, 2, 4, 4, 2, 3); break;
+        default: return hipErrorInvalidValue;
+    }
+#undef LAUNCH_F8
+    if (e == hipSuccess) e = hipGetLastError();
+    return e;
+}

@@ -17,6 +17,7 @@ hipError_t launch_gemm_skinny_partial(const bf16_t* A, int lda, const bf16_t* Wp
 hipError_t launch_quantize_rows_fp8(const bf16_t* W, int ldw, int N, int K, float* scales, bf16_t* Wdq, hipStream_t st);
 hipError_t launch_pack_weight_fp8(const bf16_t* Wdq, int ldw, const float* scales, int N, int K, uint8_t* Wq, float* scales_packed,
                                   int Kpad, int glu, hipStream_t st);
+hipError_t launch_quantize_act_fp8(const bf16_t* X, int ldx, int M, int K, uint8_t* out, int ld8, float* scales, hipStream_t st);
 hipError_t launch_pack_weight_bf16(const bf16_t* W, int ldw, int N, int K, bf16_t* Wp, int Kpad, int glu_interleave,
                                    hipStream_t st);
 

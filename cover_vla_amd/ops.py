@@ -81,6 +81,19 @@ def pack_linear(weight: torch.Tensor, bias: Optional[torch.Tensor] = None, glu: 
     return PackedLinear(wp, N, K, b, glu, w8, w8s)
 
 
+def quantize_act_fp8(x: torch.Tensor, K: Optional[int] = None):
+    """bf16 [M, >= K] rows -> (e4m3 rows uint8 [M, padded K] in the MX MFMA operand's k order, fp32 [M] power-of-two row scales)."""
+    _chk_dev(x)
+    assert x.dtype == torch.bfloat16 and x.dim() == 2 and x.stride(1) == 1
+    M = x.shape[0]
+    K = x.shape[1] if K is None else K
+    kp = (K + 127) // 128 * 128
+    q = torch.empty(M, kp, dtype=torch.uint8, device=x.device)
+    sc = torch.empty(M, dtype=torch.float32, device=x.device)
+    L.check(L.lib().cover_quantize_act_fp8(x.data_ptr(), x.stride(0), M, K, q.data_ptr(), kp, sc.data_ptr(), _stream()), "quantize_act_fp8")
+    return q, sc
+
+
 def gemm_workspace(M: int, N: int, K: int, device) -> Optional[torch.Tensor]:
     n = L.lib().cover_gemm_workspace_bytes(M, N, K)
     return torch.empty(max(n, 4) // 4, dtype=torch.float32, device=device) if n else None
@@ -90,9 +103,11 @@ def gemm(a: torch.Tensor, lin: PackedLinear, *, act: str = "none", residual: Opt
          layer_scale: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, out_f32: bool = False,
          out_scale: float = 1.0, variant: int = 0, ws: Optional[torch.Tensor] = None, norm_w: Optional[torch.Tensor] = None,
          norm_out: Optional[torch.Tensor] = None, norm_style: int = 0, norm_w_offset: float = 0.0, norm_eps: float = 1e-6,
-         norm_b: Optional[torch.Tensor] = None
+         norm_b: Optional[torch.Tensor] = None, a8: Optional[tuple] = None
          ) -> torch.Tensor:
-    """out[M, n_out] = epi(a[M, K] @ W^T). `a` is bf16 with row stride >= padded K (zero padded)."""
+    """out[M, n_out] = epi(a[M, K] @ W^T). `a` is bf16 with row stride >= padded K (zero padded).
+    a8 = (q uint8 [M, >= padded K], scales fp32 [M]) from quantize_act_fp8: with an fp8 weight twin and M > 64 the GEMM runs on the
+    MX-scaled fp8 matrix instruction (config 5) on those operands."""
     _chk_dev(a, residual, out)
     assert a.dtype == torch.bfloat16 and a.dim() == 2 and a.stride(1) == 1
     M = a.shape[0]
@@ -111,6 +126,11 @@ def gemm(a: torch.Tensor, lin: PackedLinear, *, act: str = "none", residual: Opt
     e.out_scale = out_scale
     if lin.w8 is not None and lin.use_w8:
         e.w8, e.w8_scale = lin.w8.data_ptr(), lin.w8s.data_ptr()
+        if a8 is not None:
+            q, qs = a8
+            _chk_dev(q, qs)
+            assert q.dtype == torch.uint8 and q.shape[0] == M and q.stride(1) == 1 and qs.dtype == torch.float32
+            e.a8, e.a8_scale, e.ld_a8 = q.data_ptr(), qs.data_ptr(), q.stride(0)
     if norm_w is not None:
         e.norm_w, e.norm_out, e.ld_norm_out = norm_w.data_ptr(), norm_out.data_ptr(), norm_out.stride(0)
         e.norm_style, e.norm_w_offset, e.norm_eps = norm_style, norm_w_offset, norm_eps

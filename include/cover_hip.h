@@ -75,6 +75,14 @@ typedef struct cover_gemm_epi {
      * (power-of-two scales). NULL = bf16 only. */
     const void* w8;
     const float* w8_scale;
+    /* Optional e4m3 twin of the ACTIVATION rows (cover_quantize_act_fp8: per-row power-of-two scales, k order of the MFMA operand)
+     * with its row scales. When BOTH twins are given and the problem runs on the LDS-tiled kernels (M > 64), the GEMM runs on the
+     * MX-scaled fp8 matrix instruction v_mfma_scale_f32_16x16x128_f8f6f4 (2x the bf16 rate): C = epi(a8_scale[m] * w8_scale[n] *
+     * sum_k a8[m,k] * w8[n,k]); A / Wp are then not read. NULL = bf16 activations. */
+    const void* a8;
+    const float* a8_scale;
+    int ld_a8;               /* row pitch of a8 in BYTES (>= cover_packed_k(K), multiple of 16) */
+    int _pad_a8;
 } cover_gemm_epi;
 
 /* bytes needed for the packed form of an [N, K] weight (K padded to a multiple of 128, N to 16) */
@@ -94,6 +102,12 @@ size_t cover_packed_weight_fp8_bytes(int N, int K);
 int cover_quantize_rows_fp8(const void* W, int ldw, int N, int K, float* scales, void* Wdq, void* stream);
 int cover_pack_weight_fp8(const void* Wdq, int ldw, const float* scales, int N, int K, void* Wq, float* scales_packed,
                           int glu_interleave, void* stream);
+
+/* Dynamic per-row e4m3 quantisation of bf16 activation rows for the fp8 tiled GEMM (config 5; no reference arithmetic -- SURVEY.md 7
+ * step 9): scales[m] = smallest 2^e with max_k |X[m,k]| / 2^e <= 448, out8[m] = RNE_e4m3(X[m] / scales[m]) in the k order of the
+ * MX MFMA operand (inside every 64-wide block, byte 16 g + 8 h + e holds k = 32 h + 8 g + e), zero padded to cover_packed_k(K).
+ * ld8 in BYTES. */
+int cover_quantize_act_fp8(const void* X, int ldx, int M, int K, void* out8, int ld8, float* scales, void* stream);
 
 /* variant: 0 = auto, 1 = LDS-tiled with async global->LDS (global_load_lds), 2 = LDS-tiled register-staged,
  *          3 = weight-streaming (requires M <= 64; the library picks the second-generation split-K kernel or, for

@@ -116,16 +116,28 @@ class DecoderCfg:
         return apply_rope_pi0(x, pos, *tabs) if self.rope == "pi0" else apply_rope_hf(x, pos, *tabs)
 
 
-def decoder_forward(cfg: DecoderCfg, sd, x, positions, mask, past=None, keep_kv=True, final_norm=True, n_pos=4096):
+def fake_quant_rows_e4m3(x):
+    """What cover_quantize_act_fp8 + the fp8 MFMA see of a bf16 activation tensor [..., K]: per-row power-of-two scale (smallest
+    2^e with amax / 2^e <= 448), RNE to OCP e4m3, de-quantised (exactly representable in bf16). Config 5 only (no reference
+    arithmetic: SURVEY.md 7 step 9)."""
+    xf = x.float()
+    amax = xf.abs().amax(dim=-1, keepdim=True)
+    s = torch.where(amax > 0, torch.pow(2.0, torch.ceil(torch.log2(amax.double() / 448.0))).float(), torch.ones_like(amax))
+    return ((xf / s).to(torch.float8_e4m3fn).float() * s).to(x.dtype)
+
+
+def decoder_forward(cfg: DecoderCfg, sd, x, positions, mask, past=None, keep_kv=True, final_norm=True, n_pos=4096, act_fp8=False):
     """x [B,T,dim] (bf16, or fp32 for the pi0 suffix at layer 0). past: list of (K,V) [B,Tp,Hkv,D] per layer (post-RoPE) or
-    None. mask bool [B,T,Tp+T]. Returns (hidden [B,T,dim], new list of (K,V) including this pass's tokens if keep_kv)."""
+    None. mask bool [B,T,Tp+T]. Returns (hidden [B,T,dim], new list of (K,V) including this pass's tokens if keep_kv).
+    act_fp8: the input rows of the four projections are e4m3-quantised per row (the fp8 MFMA profile, config 5)."""
+    fq = fake_quant_rows_e4m3 if act_fp8 else (lambda t: t)
     tabs = cfg.tables(n_pos)
     B, T, _ = x.shape
     new_kv = []
     act = act_fn(cfg.act)
     for l in range(cfg.layers):
         p = f"layers.{l}."
-        h = cfg.rms(x, sd[p + "input_layernorm.weight"]).to(BF)
+        h = fq(cfg.rms(x, sd[p + "input_layernorm.weight"]).to(BF))
         q = lin(h, sd[p + "self_attn.q_proj.weight"]).view(B, T, cfg.Hq, cfg.D)
         k = lin(h, sd[p + "self_attn.k_proj.weight"]).view(B, T, cfg.Hkv, cfg.D)
         v = lin(h, sd[p + "self_attn.v_proj.weight"]).view(B, T, cfg.Hkv, cfg.D)
@@ -138,12 +150,12 @@ def decoder_forward(cfg: DecoderCfg, sd, x, positions, mask, past=None, keep_kv=
             kk, vv = k, v
         if keep_kv:
             new_kv.append((kk, vv))
-        a = eager_attention(q, kk, vv, mask, cfg.D ** -0.5).to(BF)
+        a = fq(eager_attention(q, kk, vv, mask, cfg.D ** -0.5).to(BF))
         o = lin(a, sd[p + "self_attn.o_proj.weight"])
         o += x  # in-place add into the bf16 o_proj output (paligemma_with_expert.py:332): fp32 x is rounded here
         res = o.clone()
-        h = cfg.rms(o, sd[p + "post_attention_layernorm.weight"])
-        h = lin(act(lin(h, sd[p + "mlp.gate_proj.weight"])) * lin(h, sd[p + "mlp.up_proj.weight"]), sd[p + "mlp.down_proj.weight"])
+        h = fq(cfg.rms(o, sd[p + "post_attention_layernorm.weight"]))
+        h = lin(fq(act(lin(h, sd[p + "mlp.gate_proj.weight"])) * lin(h, sd[p + "mlp.up_proj.weight"])), sd[p + "mlp.down_proj.weight"])
         h += res
         x = h
     if final_norm:

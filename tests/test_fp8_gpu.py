@@ -76,6 +76,92 @@ def test_fp8_weight_stream_is_bit_identical_to_bf16_stream(dev, M, N, K, glu):
         assert torch.equal(z8, z16)
 
 
+def _act_perm(kp):
+    """position -> k of cover_quantize_act_fp8's row order: inside every 64-block, byte 16 g + 8 h + e holds k = 32 h + 8 g + e."""
+    p = np.arange(kp)
+    c, r = p // 64, p % 64
+    g, h, e = r // 16, (r // 8) % 2, r % 8
+    return c * 64 + 32 * h + 8 * g + e
+
+
+def _dequant_act(q, sc, K):
+    """e4m3 rows in operand order + row scales -> fp32 [M, K] in natural k order."""
+    kp = q.shape[1]
+    nat = torch.empty_like(q)
+    nat[:, torch.from_numpy(_act_perm(kp))] = q
+    return (nat.view(torch.float8_e4m3fn).float() * sc[:, None])[:, :K]
+
+
+@pytest.mark.parametrize("M,K", [(5, 4096), (64, 11008), (17, 200), (3, 128)])
+def test_activation_quantiser_matches_torch_float8_cast(dev, M, K):
+    """cover_quantize_act_fp8: per-row power-of-two scale (smallest 2^e with amax / 2^e <= 448), RNE e4m3 = torch.float8_e4m3fn of
+    x / s, operand k order, zero padding to a multiple of 128. Bit-exact."""
+    g = torch.Generator().manual_seed(K + M)
+    x = (torch.randn(M, K, generator=g) * torch.logspace(-2, 1, M)[:, None]).bfloat16()
+    if M > 2:
+        x[1] = 0                                           # an all-zero row: scale 1
+        x[2, 0] = 448.0 * 2 ** -3                          # amax exactly on a power-of-two boundary
+        x[2, 1:] = x[2, 1:].clamp(-40, 40)
+    q, sc = ops.quantize_act_fp8(x.to(dev))
+    kp = (K + 127) // 128 * 128
+    assert q.shape == (M, kp)
+    amax = x.float().abs().amax(1)
+    s_ref = torch.where(amax > 0, torch.pow(2.0, torch.ceil(torch.log2(amax.double() / 448.0))).float(), torch.ones(M))
+    assert torch.equal(sc.cpu(), s_ref)
+    want = torch.zeros(M, kp)
+    want[:, :K] = x.float() / s_ref[:, None]
+    want8 = want.to(torch.float8_e4m3fn).view(torch.uint8)
+    got_nat = torch.empty(M, kp, dtype=torch.uint8)
+    got_nat[:, torch.from_numpy(_act_perm(kp))] = q.cpu()
+    # +0 / -0 of exact zeros may differ in sign only where the input is -0: compare values, then bits away from zero
+    assert torch.equal(got_nat.view(torch.float8_e4m3fn).float(), want8.view(torch.float8_e4m3fn).float())
+
+
+@pytest.mark.parametrize("M,N,K,glu,norm", [(512, 12288, 4096, False, False), (512, 22016, 4096, True, False), (512, 4096, 11008, False, True),
+                                            (512, 4096, 4096, False, True), (448, 12288, 4096, False, False), (448, 4096, 11008, False, True),
+                                            (448, 22016, 4096, True, False), (530, 4096, 4096, False, False), (1024, 8192, 2304, False, False)])
+def test_fp8_mfma_tiled_gemm_matches_fp32_on_quantised_operands(dev, M, N, K, glu, norm):
+    """The MX-scaled fp8 matrix instruction path (both operands e4m3, M > 64) vs an fp32 matmul of the SAME de-quantised operands:
+    exact products, fp32 accumulation in another order, bf16 output rounding -> rel-L2 <= 3e-3 (bias / residual / GLU / fused RMSNorm
+    epilogues, split-K plans, ragged row tiles). Also: it must differ from the bf16-activation path (the fp8 kernel really ran)."""
+    g = torch.Generator(device=dev).manual_seed(M + N + K)
+    w = torch.randn(N, K, device=dev, generator=g) * 0.02
+    w[: N // 4] *= 6.0
+    bias = None if glu else torch.randn(N, device=dev, generator=g) * 0.1
+    lin = ops.pack_linear(w, bias, glu=glu, fp8=True)
+    a = torch.zeros(M, lin.kp, dtype=torch.bfloat16, device=dev)
+    a[:, :K] = (torch.randn(M, K, device=dev, generator=g) * torch.logspace(-1, 1, M, device=dev)[:, None]).bfloat16()
+    q, sc = ops.quantize_act_fp8(a, K)
+    res = None if (glu or not norm) else torch.randn(M, N, device=dev, generator=g).bfloat16()
+    kw = {}
+    if norm:
+        nw = (torch.rand(N, device=dev, generator=g) + 0.5).float()
+        kw = dict(norm_w=nw, norm_out=torch.empty(M, N, dtype=torch.bfloat16, device=dev), norm_style=1, norm_eps=1e-5)
+    act = "silu" if glu else "none"
+    y8 = ops.gemm(a, lin, act=act, residual=res, a8=(q, sc), **kw)
+    n8 = kw["norm_out"].clone() if norm else None
+    y16 = ops.gemm(a, lin, act=act, residual=res, **kw)
+    adq = _dequant_act(q.cpu(), sc.cpu(), K)
+    wdq, _ = dequant_reference(w.cpu())
+    y = adq.double() @ wdq.double().T
+    if glu:
+        yb = y.float().bfloat16().float()
+        ref = (torch.nn.functional.silu(yb[:, : N // 2]).bfloat16().float() * yb[:, N // 2:])
+    else:
+        ref = (y + bias.cpu().bfloat16().double()).float().bfloat16().float()
+        if res is not None:
+            ref = ref + res.float().cpu()
+    rel = ((y8.float().cpu() - ref).norm() / ref.norm()).item()
+    assert rel < 3e-3, rel
+    assert not torch.equal(y8.view(torch.int16), y16.view(torch.int16)), "the fp8-activation path was not taken"
+    rel16 = ((y16.float().cpu() - ref).norm() / ref.norm()).item()
+    print(f"M={M} N={N} K={K}: fp8 MFMA vs fp32-on-quantised rel-L2 {rel:.2e}; bf16-activation path vs the same reference {rel16:.2e} (activation quantisation error)")
+    if norm:   # fused norm of the stored bf16 rows (HF LlamaRMSNorm arithmetic), checked against the kernel's own output rows
+        yo = y8.float().cpu()
+        want = (nw.cpu() * (yo * torch.rsqrt(yo.pow(2).mean(-1, keepdim=True) + 1e-5)).bfloat16().float())
+        assert ((n8.float().cpu() - want).norm() / want.norm()).item() < 4e-3
+
+
 def _dequant_sd(sd):
     out = dict(sd)
     for k, v in sd.items():
@@ -127,3 +213,13 @@ def test_openvla_fp8_matches_oracle_on_dequantised_weights(dev, greedy):
     rmse = (otr["logits"] - utr["logits"]).pow(2).mean().sqrt().item()
     print(f"fp8 vs oracle(dequantised): token agreement {(tokens == ref).float().mean().item():.3f}, data-decided {n_dec}; "
           f"quantisation effect (oracle fp8 vs oracle bf16): token agreement {agree_q:.3f}, logit RMSE {rmse:.4f}")
+
+
+def test_openvla_fp8_mfma_decode_rows_match_oracle(dev):
+    """Model-level run of the fp8 MFMA path (more than 64 decode rows on e4m3 weights) in a child process with the tile knob that
+    gives the small config an fp8-capable tile; see tests/fp8_mfma_model_case.py."""
+    import subprocess
+    env = dict(os.environ, COVER_TILE_PICK="a")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fp8_mfma_model_case.py")], env=env, capture_output=True, text=True, timeout=900)
+    print(p.stdout[-1500:])
+    assert p.returncode == 0 and "FP8_MFMA_MODEL_OK" in p.stdout, (p.stdout[-2000:], p.stderr[-3000:])
