@@ -74,7 +74,7 @@ def build_inputs(dev, cfg, n_prompts, n_samples, n_cams=1, seed=0, n_gen=7):
 
 class Pipeline:
     def __init__(self, dev, small=False, n_prompts=N_PROMPTS, n_samples=N_SAMPLES, n_cams=1, members=3, prompt_ids=None,
-                 weight_dtype="bf16", horizon=1):
+                 weight_dtype="bf16", horizon=1, own_kv="auto"):
         """prompt_ids: the global prompt indices this rank owns (strong scaling); None = all n_prompts."""
         from cover_vla_amd import synth
         from cover_vla_amd.openvla import OpenVLA
@@ -89,8 +89,11 @@ class Pipeline:
         wd = torch.bfloat16
         sd = synth.openvla_state(c, seed=1234, nontrivial=False, device=dev, wdtype=wd)
         self.horizon, self.weight_dtype = horizon, weight_dtype
+        if own_kv == "auto":   # more decode rows than the 16-candidate fused kernel is built for (config 5): head-major own-token cache,
+            own_kv = (("fp8" if weight_dtype == "fp8" else "bf16") if P * n_samples > 64 else None)   # e4m3 in the fp8 profile (fp8 KV)
+        self.own_kv = own_kv
         self.policy = OpenVLA(sd, c, device=str(dev), max_prompts=P, max_candidates=P * n_samples, max_text=LT, n_cams=n_cams,
-                              horizon=horizon, weight_dtype=weight_dtype)
+                              horizon=horizon, weight_dtype=weight_dtype, own_kv=own_kv)
         del sd
         ssd = synth.siglip2_state(sc, seed=4321, nontrivial=False, device=dev, wdtype=wd)
         if small:
@@ -373,6 +376,8 @@ def main():
     ap.add_argument("--members", type=int, default=3, help="verifier ensemble members (2 = config 4)")
     ap.add_argument("--no-agreement", action="store_true", help="fp8: skip the comparison run through a bf16 pipeline")
     ap.add_argument("--dtype", choices=["bf16", "fp8"], default="bf16", help="fp8 = e4m3 decoder + lm_head weights (config 5)")
+    ap.add_argument("--own-kv", choices=["auto", "none", "bf16", "fp8"], default="auto",
+                    help="own-token KV cache of the decode passes: auto = head-major (e4m3 with --dtype fp8) above 64 candidates per GPU, legacy below")
     ap.add_argument("--horizon", type=int, default=1, help="action-chunk horizon: 7 x horizon action tokens per candidate (config 5: 8)")
     ap.add_argument("--check-out", default=None, help="write this rank's selection (winner index / tokens) as JSON (plumbing tests)")
     a = ap.parse_args()
@@ -417,7 +422,7 @@ def main():
         n_prompts_global = N_PROMPTS if strong else N_PROMPTS * world
     prompt_ids = list(range(rank, n_prompts_global, world))
     pipe = Pipeline(dev, small=a.small, n_prompts=n_prompts_global, n_samples=a.samples, n_cams=a.cams, members=a.members,
-                    prompt_ids=prompt_ids, weight_dtype=a.dtype, horizon=a.horizon)
+                    prompt_ids=prompt_ids, weight_dtype=a.dtype, horizon=a.horizon, own_kv=None if a.own_kv == "none" else a.own_kv)
 
     def sync():
         torch.cuda.synchronize()
@@ -460,14 +465,16 @@ def main():
         "metric": metric,
         "value": round(n_total * a.steps / dt, 3), "unit": "candidates/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
-        "dtype": "bf16" if a.dtype == "bf16" else "fp8 (e4m3 decoder + lm_head weights, per-channel 2^e scales; bf16 activations, KV cache, vision towers)",
+        "dtype": "bf16" if a.dtype == "bf16" else ("fp8 (e4m3 decoder + lm_head weights with per-channel 2^e scales; passes with more than 64 rows run on the MX-scaled fp8 "
+                                                   "matrix instruction with per-row e4m3 activations; own-token KV cache " + ("e4m3 with per-row scales" if pipe.own_kv == "fp8" else "bf16") +
+                                                   "; bf16 vision towers, shared-prefix / text KV)"),
         "data": "synthetic",
         "config": {"workload": ("SMALL-PLUMBING-CONFIG (invalid as a bench line)" if a.small else
                                 f"OpenVLA-7B (DINOv2-L+SigLIP-So400m+Llama-2-7B) N={n_local} = {len(pipe.prompt_ids)} prompts x {a.samples} samples per GPU, "
                                 f"{7 * a.horizon} action tokens, {a.cams} 224x224 RGB frame(s); CoVer verifier SigLIP2-L/16-384 + {a.members}-member ensemble; "
                                 "random-init weights"),
                    "candidates_total": n_total, "candidates_per_gpu": n_local, "prompts_per_gpu": len(pipe.prompt_ids),
-                   "parallelism": f"candidate-sharded x{world} ({'strong' if strong else 'weak'})", "lib_sha16": lib_hash()},
+                   "parallelism": f"candidate-sharded x{world} ({'strong' if strong else 'weak'})", "own_kv": pipe.own_kv or "legacy", "lib_sha16": lib_hash()},
     }
     if not a.no_profile:
         # ---- rooflines: kernel start/stop stamps of every GEMM / attention launch of one extra (serialised) decision

@@ -58,6 +58,14 @@ class DecodeAttnArgs(C.Structure):
                 ("seg", KvSegment * 3), ("write_t", c_i), ("_pad", c_i), ("out", c_p), ("out_row_stride", c_ll)]
 
 
+class OwnAttnArgs(C.Structure):
+    _fields_ = [("qkv", c_p), ("ld_qkv", c_i), ("N", c_i), ("H", c_i), ("D", c_i), ("scale", c_f),
+                ("positions", c_p), ("cos_table", c_p), ("sin_table", c_p), ("n_pos", c_i), ("rope_mode", c_i),
+                ("k", c_p), ("v", c_p), ("k_scale", c_p), ("v_scale", c_p), ("fp8", c_i), ("t_cap", c_i),
+                ("slot_stride", c_ll), ("slot_of_batch", c_p), ("write_t", c_i), ("_pad", c_i),
+                ("state_o", c_p), ("state_ml", c_p)]
+
+
 class RopeArgs(C.Structure):
     _fields_ = [("qkv", c_p), ("ld_qkv", c_i),
                 ("B", c_i), ("T", c_i), ("Hq", c_i), ("Hkv", c_i), ("D", c_i),
@@ -138,7 +146,9 @@ class DecGroup(C.Structure):
     _fields_ = [("B", c_i), ("T", c_i), ("positions", c_p), ("n_seg", c_i), ("write_seg", c_i),
                 ("segs", KvSegment * 3), ("seg_k_offset", c_ll * 3), ("seg_vt_offset", c_ll * 3),
                 ("write_slot_of_batch", c_p), ("write_t_offset_of_batch", c_p),
-                ("write_t_offset", c_i), ("seg0_shared", c_i)]
+                ("write_t_offset", c_i), ("seg0_shared", c_i),
+                ("own_kv_mode", c_i), ("seg1_group", c_i), ("seg1_slot_of_group", c_p), ("seg1_len_of_group", c_p),
+                ("own_region_elems", c_ll)]
 
 
 class DecPass(C.Structure):
@@ -151,7 +161,7 @@ _STRUCTS = {
     "cover_mha_f32_args": MhaF32Args, "cover_token_select_args": TokenSelectArgs,
     "cover_score_select_args": ScoreSelectArgs, "cover_workspace": Workspace, "cover_vit_layer": VitLayer,
     "cover_vit_desc": VitDesc, "cover_dec_layer": DecLayer, "cover_dec_desc": DecDesc, "cover_dec_group": DecGroup,
-    "cover_dec_pass": DecPass, "cover_decode_attn_args": DecodeAttnArgs,
+    "cover_dec_pass": DecPass, "cover_decode_attn_args": DecodeAttnArgs, "cover_own_attn_args": OwnAttnArgs,
 }
 
 # every symbol include/cover_hip.h declares: (restype, argtypes)
@@ -171,6 +181,7 @@ SYMBOLS = {
     "cover_gemm_bf16": (c_i, [c_p, c_i, c_p, c_p, c_i, c_i, c_i, c_i, _P(GemmEpi), c_p, C.c_size_t, c_i, c_p]),
     "cover_attention_bf16": (c_i, [_P(AttnArgs), c_p]),
     "cover_decode_attention_fused": (c_i, [_P(DecodeAttnArgs), c_p]),
+    "cover_decode_own_attention": (c_i, [_P(OwnAttnArgs), c_p]),
     "cover_layernorm_bf16": (c_i, [c_p, c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_p]),
     "cover_rmsnorm_bf16": (c_i, [c_p, c_i, c_i, c_p, c_f, c_i, c_p, c_i, c_i, c_i, c_f, c_p]),
     "cover_rope_kv_write": (c_i, [_P(RopeArgs), c_p]),

@@ -96,6 +96,12 @@ int cover_decode_attention_fused(const cover_decode_attn_args* a, void* stream) 
     return COVER_OK;
 }
 
+int cover_decode_own_attention(const cover_own_attn_args* a, void* stream) {
+    if (!a) return fail(COVER_EINVAL, "cover_decode_own_attention: null args");
+    HIPCHK(launch_decode_own_attention(a, ST(stream)), "decode_own_attention (D in {64,128}, 0 <= write_t < t_cap, at most 16 loads per lane per pass)");
+    return COVER_OK;
+}
+
 int cover_layernorm_bf16(const void* x, int ldx, const float* w, const float* b, void* y, int ldy, int rows, int dim,
                          float eps, void* stream) {
     HIPCHK(launch_layernorm_bf16((const bf16_t*)x, ldx, w, b, (bf16_t*)y, ldy, rows, dim, eps, ST(stream)), "layernorm_bf16");
@@ -454,7 +460,7 @@ int cover_decoder_forward(const cover_dec_desc* d, const cover_dec_pass* p, void
         if (f8) HIPCHK(quant(h, dim, e), "dec quantise (qkv input)");
         // weight-streaming path: leave the split-K partials for rope_kv_write to fold (one launch and one pass less)
         int qkv_splits = 0;
-        if (rows <= 64 && p->n_groups == 1 && (variant == 0 || variant == 3))
+        if (rows <= 64 && p->n_groups == 1 && (variant == 0 || variant == 3) && p->groups[0].own_kv_mode == 0)
             HIPCHK(launch_gemm_skinny_partial((const bf16_t*)h, dim, (const bf16_t*)L.qkv_w, (float*)sk, skb, rows, nqkv, dim, &qkv_splits, st,
                                               L.qkv_w8, L.qkv_s), "dec qkv (partials)");
         else
@@ -475,6 +481,44 @@ int cover_decoder_forward(const cover_dec_desc* d, const cover_dec_pass* p, void
             // three-launch path -- shared segment as ONE flash pass over all candidates, then the per-candidate segments seeded
             // with its state -- is faster (N = 512: fused 109 / 163 / 362 us per layer at 1 / 16 / 56 own keys, crossover ~20;
             // decision 1045 -> 950 ms). At <= 8 own keys the fused launch wins at every N measured (N = 128 / 256 / 512).
+            if (G.own_kv_mode > 0) {
+                // large-N candidate decode: own-token pass on the VALU (RoPE + append + attention over the candidate's own keys, state
+                // out), then ONE MFMA pass over [shared prefix | the prompt's text] with the samples of a prompt as the query rows of a
+                // batch entry, resumed from that state
+                if (!(G.T == 1 && G.n_seg == 3 && G.write_seg == 2 && G.seg0_shared && Hq == Hkv && G.seg1_group > 0 && G.B % G.seg1_group == 0 &&
+                      qkv_splits == 0 && G.write_t_offset_of_batch == nullptr && G.segs[0].mask_mode == COVER_MASK_LEN && G.segs[1].mask_mode == COVER_MASK_LEN))
+                    return fail(COVER_EINVAL, "cover_decoder_forward: own_kv_mode needs T == 1, three segments (shared | per prompt | own), MHA, a regular seg1_group");
+                const long long cap = W.k_slot_stride / ((long long)Hkv * D);
+                cover_own_attn_args oa;
+                memset(&oa, 0, sizeof oa);
+                oa.qkv = gq; oa.ld_qkv = nqkv; oa.N = G.B; oa.H = Hq; oa.D = D; oa.scale = d->attn_scale;
+                oa.positions = G.positions; oa.cos_table = d->cos_table; oa.sin_table = d->sin_table; oa.n_pos = d->n_pos; oa.rope_mode = d->rope_mode;
+                oa.fp8 = G.own_kv_mode == 2; oa.t_cap = (int)cap; oa.slot_stride = W.k_slot_stride;
+                char* kb = (char*)L.k_cache + 2 * G.seg_k_offset[2];
+                char* vb = (char*)L.vt_cache + 2 * G.seg_vt_offset[2];
+                oa.k = kb; oa.v = vb;
+                if (oa.fp8) { oa.k_scale = (float*)(kb + G.own_region_elems); oa.v_scale = (float*)(vb + G.own_region_elems); }
+                oa.slot_of_batch = G.write_slot_of_batch ? G.write_slot_of_batch : G.segs[2].slot_of_batch;
+                oa.write_t = G.write_t_offset;
+                oa.state_o = (float*)st_o + (size_t)row0[g] * Hq * D;
+                oa.state_ml = (float*)st_ml + (size_t)row0[g] * Hq * 2;
+                HIPCHK(launch_decode_own_attention(&oa, st), "dec own-token attention");
+                cover_attn_args sa;
+                memset(&sa, 0, sizeof sa);
+                const int S = G.seg1_group;
+                sa.q = gq; sa.q_b_stride = (long long)S * nqkv; sa.q_t_stride = nqkv; sa.q_h_stride = D;
+                sa.out = (bf16_t*)attn + (size_t)row0[g] * HD; sa.o_b_stride = (long long)S * HD; sa.o_t_stride = HD; sa.o_h_stride = D;
+                sa.B = G.B / S; sa.Tq = S; sa.Hq = Hq; sa.Hkv = Hkv; sa.D = D; sa.scale = d->attn_scale; sa.n_seg = 2;
+                for (int s = 0; s < 2; ++s) {
+                    sa.seg[s] = G.segs[s];
+                    sa.seg[s].k = (const bf16_t*)L.k_cache + G.seg_k_offset[s];
+                    sa.seg[s].vt = (const bf16_t*)L.vt_cache + G.seg_vt_offset[s];
+                }
+                sa.seg[1].slot_of_batch = G.seg1_slot_of_group; sa.seg[1].len_of_batch = G.seg1_len_of_group;
+                sa.state_in_o = oa.state_o; sa.state_in_ml = oa.state_ml;
+                HIPCHK(launch_attention_bf16(&sa, st), "dec attention (shared prefix + prompt text, resumed from the own-token state)");
+                continue;
+            }
             static const char* da_max_env = getenv("COVER_DA_FUSED_MAX_N");   // experiment knob: force the three-launch path above N
             const int da_max = da_max_env ? atoi(da_max_env) : (1 << 30);
             const bool da_long = ((G.B + 15) / 16) * Hq >= 768 && G.segs[2].len > 16;
@@ -648,7 +692,7 @@ size_t cover_sizeof(const char* n) {
     SZ(cover_gemm_epi); SZ(cover_kv_segment); SZ(cover_attn_args); SZ(cover_rope_args); SZ(cover_patchify_args);
     SZ(cover_gemm_f32_args); SZ(cover_mha_f32_args); SZ(cover_token_select_args); SZ(cover_score_select_args);
     SZ(cover_workspace); SZ(cover_vit_layer); SZ(cover_vit_desc); SZ(cover_dec_layer); SZ(cover_dec_desc);
-    SZ(cover_dec_group); SZ(cover_dec_pass); SZ(cover_decode_attn_args);
+    SZ(cover_dec_group); SZ(cover_dec_pass); SZ(cover_decode_attn_args); SZ(cover_own_attn_args);
 #undef SZ
     return 0;
 }

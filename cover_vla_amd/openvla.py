@@ -32,10 +32,13 @@ IMAGENET_MEAN, IMAGENET_STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
 
 class OpenVLA:
     def __init__(self, sd: Dict[str, torch.Tensor], c: dict, *, device="cuda:0", max_prompts=8, max_candidates=32,
-                 max_text=32, horizon=1, n_cams=1, weight_dtype="bf16"):
+                 max_text=32, horizon=1, n_cams=1, weight_dtype="bf16", own_kv=None):
         """weight_dtype "fp8" (BASELINE config 5): the Llama projections and the lm_head are quantised to e4m3 with per-channel
         power-of-two scales; the HBM-bound decode passes stream the e4m3 image, the MFMA-bound prefill the bf16 image of the same
-        quantised values (cover_vla_amd.ops.pack_linear). The vision towers and the projector stay bf16 (MFMA-bound)."""
+        quantised values (cover_vla_amd.ops.pack_linear). The vision towers and the projector stay bf16 (MFMA-bound).
+        own_kv "bf16" / "fp8" (large N, config 5): the candidates' own-token KV segment is kept head-major (K and V [slot][h][t][d],
+        bf16 or e4m3 with per-row scales = the "fp8 KV" of config 5) and every decode pass runs the own-token VALU pass + ONE MFMA pass
+        over [shared prefix | prompt text] instead of the fused 16-candidate kernel (cover_decode_own_attention). None = legacy layout."""
         self.c, self.dev = dict(c), torch.device(device)
         dev = self.dev
         sub = lambda p: {k[len(p):]: v for k, v in sd.items() if k.startswith(p)}
@@ -54,6 +57,9 @@ class OpenVLA:
         if weight_dtype not in ("bf16", "fp8"):
             raise ValueError("weight_dtype must be 'bf16' or 'fp8'")
         self.weight_dtype = weight_dtype
+        if own_kv not in (None, "bf16", "fp8"):
+            raise ValueError("own_kv must be None, 'bf16' or 'fp8'")
+        self.own_kv = own_kv
         self.lm_head = ops.pack_linear(sd["lm_head.weight"].to(dev), fp8=fp8)
         self.n_gen = 7 * horizon
         self.T0 = 1 + self.n_patches * n_cams          # [BOS] + patches
@@ -211,6 +217,10 @@ class OpenVLA:
         # ---- decode
         pos_base = (T0 + cand_len).contiguous()
         xd = self.x_dec[:N]
+        own = {}
+        if self.own_kv is not None:   # regular structure of the batch: the n_samples candidates of prompt p are rows [p S, (p + 1) S)
+            own = dict(own_kv=self.own_kv, seg1_group=n_samples, seg1_slot_of_group=torch.arange(P, dtype=torch.int32, device=dev),
+                       seg1_len_of_group=prompt_lens.to(torch.int32).contiguous())
         for i in range(1, self.n_gen):
             fed = tokens if force_tokens is None else force_tokens
             ops.embed_gather(self.embed, fed[:, i - 1].contiguous(), out=xd)
@@ -218,7 +228,7 @@ class OpenVLA:
             g = self.llm.group(N, 1, pos,
                                [dict(region=0, length=T0, slot_of_batch=self.zero_slots),
                                 dict(region=1, length=Lt, len_of_batch=cand_len, slot_of_batch=prompt_of_cand),
-                                dict(region=2, length=i)], 2, write_t_off=i - 1, seg0_shared=True)
+                                dict(region=2, length=i)], 2, write_t_off=i - 1, seg0_shared=True, **own)
             self.llm.forward(xd, [g], final_norm=False)
             self._head_select(xd, uniforms, i, temperature, tokens, sel, trace)
             mark(f"decode{i}")

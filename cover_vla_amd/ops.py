@@ -213,6 +213,29 @@ def decode_attention_fused(qkv, N, H, D, scale, segments, write_t, out, *, posit
     return out
 
 
+def decode_own_attention(qkv, N, H, D, scale, k_own, v_own, t_cap, write_t, state, *, positions=None, cos=None, sin=None, rope_mode=0,
+                         k_scale=None, v_scale=None, slot_of_batch=None):
+    """Large-N candidate decode, own-token pass (cover_decode_own_attention): RoPE + append into the head-major own cache
+    (k_own / v_own [slots][H][t_cap][D], bf16 or uint8 e4m3 + fp32 row scales [slots][H][t_cap]) + attention over keys 0..write_t;
+    state = (o fp32 [N,H,D], ml fp32 [N,H,2]) for ops.attention(..., state_in=state)."""
+    _chk_dev(qkv, k_own, v_own, state[0], state[1])
+    a = L.OwnAttnArgs()
+    a.qkv, a.ld_qkv = qkv.data_ptr(), qkv.stride(0)
+    a.N, a.H, a.D, a.scale = N, H, D, scale
+    a.positions, a.cos_table, a.sin_table = _ptr(positions), _ptr(cos), _ptr(sin)
+    a.n_pos = cos.shape[0] if cos is not None else 0
+    a.rope_mode = rope_mode
+    a.k, a.v = k_own.data_ptr(), v_own.data_ptr()
+    a.fp8 = 1 if k_own.dtype == torch.uint8 else 0
+    a.k_scale, a.v_scale = _ptr(k_scale), _ptr(v_scale)
+    a.t_cap, a.slot_stride = t_cap, H * t_cap * D
+    a.slot_of_batch = _ptr(slot_of_batch)
+    a.write_t = write_t
+    a.state_o, a.state_ml = state[0].data_ptr(), state[1].data_ptr()
+    L.check(L.lib().cover_decode_own_attention(C.byref(a), _stream()), "decode_own_attention")
+    return state
+
+
 # ------------------------------------------------------------------------------------------------ row kernels
 def layernorm(x, w, b, eps, out=None):
     _chk_dev(x, w)

@@ -182,6 +182,29 @@ typedef struct cover_decode_attn_args {
 } cover_decode_attn_args;
 int cover_decode_attention_fused(const cover_decode_attn_args* args, void* stream);
 
+/* Candidate decode at large N (BASELINE config 5): RoPE + KV append + attention over every candidate's OWN generated tokens, one wave
+ * per (candidate, head) on the VALU (no reuse there: pure HBM streaming), leaving the (o, m, l) softmax state that
+ * cover_attention_bf16 resumes (state_in_*) over the shared image prefix and the prompt's text keys. Own-token cache layout:
+ * K and V both [slot][h][t][d] (head-major, NOT transposed), bf16 or -- fp8 = 1, the "fp8 KV" of config 5 -- e4m3 with one
+ * power-of-two fp32 scale per (slot, h, t) row at k_scale / v_scale[(slot * H + h) * t_cap + t]. q is rotated in place in qkv.
+ * Same arithmetic as cover_rope_kv_write + cover_attention_bf16 on the de-quantised values (scores scaled after the product, fp32
+ * softmax, probabilities rounded to bf16 before PV). No reference arithmetic for the fp8 cache.
+ * Requirements: one new token per candidate, Hq == Hkv == H, D in {64, 128}, write_t < t_cap <= 64 (bf16, D = 128). */
+typedef struct cover_own_attn_args {
+    void* qkv; int ld_qkv;                  /* bf16 [N][3*H*D] */
+    int N, H, D;
+    float scale;
+    const int* positions; const float* cos_table; const float* sin_table; int n_pos; int rope_mode;
+    void* k; void* v;                       /* own-token regions */
+    float* k_scale; float* v_scale;         /* fp8 only */
+    int fp8; int t_cap;
+    long long slot_stride;                  /* ELEMENTS between two slots = H * t_cap * D */
+    const int* slot_of_batch;               /* [N] or NULL (slot = n) */
+    int write_t; int _pad;                  /* position of the appended token; keys 0..write_t are attended */
+    float* state_o; float* state_ml;        /* fp32 [N][H][D] (normalised), [N][H][2] (max in scaled-log2 units, sum) */
+} cover_own_attn_args;
+int cover_decode_own_attention(const cover_own_attn_args* args, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Row kernels (HBM-bound, wave-shuffle reductions, 16-byte vector access)
  * ------------------------------------------------------------------------------------------------ */
@@ -426,6 +449,15 @@ typedef struct cover_dec_group {
     int seg0_shared;   /* 1: segs[0] is the SAME slot and length for every batch row and T == 1 (decode): it is attended
                           with the batch rows as query rows of one tile (K/V read once per 16 candidates) and chained into
                           the per-row segments through the attention state */
+    /* Large-N candidate decode (T == 1, n_seg == 3, write_seg == 2, seg0_shared): own_kv_mode 1 / 2 keeps the write segment in the
+     * head-major layout of cover_decode_own_attention (1: bf16, 2: e4m3 + row scales stored behind the data in the region's
+     * second half: own_region_elems = slots * cap * Hkv * D of that region) and runs   own-token pass (VALU)  ->  ONE MFMA pass over
+     * [segs[0] | segs[1]] with the candidates of a prompt as the query rows of a batch entry. That needs the regular structure
+     * the sampler has: rows [i * seg1_group, (i + 1) * seg1_group) share segs[1]'s slot seg1_slot_of_group[i] (NULL: i) and length
+     * seg1_len_of_group[i] (NULL: segs[1].len). The mode is a property of the cache, not of a step: use it for every pass. */
+    int own_kv_mode; int seg1_group;
+    const int* seg1_slot_of_group; const int* seg1_len_of_group;
+    long long own_region_elems;
 } cover_dec_group;
 typedef struct cover_dec_pass {
     int n_groups; int final_norm;      /* final_norm: apply final_norm_w to x at the end */

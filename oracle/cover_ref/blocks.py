@@ -126,10 +126,13 @@ def fake_quant_rows_e4m3(x):
     return ((xf / s).to(torch.float8_e4m3fn).float() * s).to(x.dtype)
 
 
-def decoder_forward(cfg: DecoderCfg, sd, x, positions, mask, past=None, keep_kv=True, final_norm=True, n_pos=4096, act_fp8=False):
+def decoder_forward(cfg: DecoderCfg, sd, x, positions, mask, past=None, keep_kv=True, final_norm=True, n_pos=4096, act_fp8=False,
+                    kv_fp8=False):
     """x [B,T,dim] (bf16, or fp32 for the pi0 suffix at layer 0). past: list of (K,V) [B,Tp,Hkv,D] per layer (post-RoPE) or
     None. mask bool [B,T,Tp+T]. Returns (hidden [B,T,dim], new list of (K,V) including this pass's tokens if keep_kv).
-    act_fp8: the input rows of the four projections are e4m3-quantised per row (the fp8 MFMA profile, config 5)."""
+    act_fp8: the input rows of the four projections are e4m3-quantised per row (the fp8 MFMA profile, config 5).
+    kv_fp8: this pass's K (after RoPE) and V rows are e4m3-quantised per (token, head) row before they enter the cache (the fp8
+    own-token KV cache of config 5)."""
     fq = fake_quant_rows_e4m3 if act_fp8 else (lambda t: t)
     tabs = cfg.tables(n_pos)
     B, T, _ = x.shape
@@ -143,6 +146,8 @@ def decoder_forward(cfg: DecoderCfg, sd, x, positions, mask, past=None, keep_kv=
         v = lin(h, sd[p + "self_attn.v_proj.weight"]).view(B, T, cfg.Hkv, cfg.D)
         q = cfg.apply_rope(q, positions, tabs)
         k = cfg.apply_rope(k, positions, tabs)
+        if kv_fp8:
+            k, v = fake_quant_rows_e4m3(k), fake_quant_rows_e4m3(v)
         if past is not None:
             kk = torch.cat([past[l][0], k], 1)
             vv = torch.cat([past[l][1], v], 1)

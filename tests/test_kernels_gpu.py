@@ -659,6 +659,101 @@ def test_decode_attention_fused_with_recurring_prompt_slots(dev, N, pattern):
     _decode_attention_case(dev, 128, 8, N, 3, 2, True, permute_slots=False, slot_pattern=pattern, check_fp32=True)
 
 
+def _rope_ref(x, pos, cos, sin, mode):
+    """x fp32 [N, H, D] (bf16 values), the two RoPE arithmetics of rope_kv_write restated in torch (bf16 roundings where the kernel has them)."""
+    half = x.shape[-1] // 2
+    x1, x2 = x[..., :half], x[..., half:]
+    c, s = cos[pos.long()][:, None, :], sin[pos.long()][:, None, :]
+    r = lambda t: t.bfloat16().float()
+    if mode == 0:
+        return x
+    if mode == 2:
+        c, s = r(c), r(s)
+        return torch.cat([r(r(x1 * c) + r(-x2 * s)), r(r(x2 * c) + r(x1 * s))], -1)
+    return torch.cat([r(x1 * c - x2 * s), r(x2 * c + x1 * s)], -1)
+
+
+def _fq_rows_e4m3(x):
+    """per-row (last dim) power-of-two scale + RNE e4m3, de-quantised: the own-token fp8 cache's quantiser restated"""
+    amax = x.abs().amax(-1, keepdim=True)
+    s = torch.where(amax > 0, torch.pow(2.0, torch.ceil(torch.log2(amax.double() / 448.0))).float(), torch.ones_like(amax))
+    return (x / s).to(torch.float8_e4m3fn).float() * s, s
+
+
+@pytest.mark.parametrize("D,H,N,S,steps,mode,fp8", [(128, 32, 64, 16, 3, 2, False), (128, 32, 64, 16, 3, 2, True), (128, 8, 96, 24, 9, 2, True),
+                                                     (128, 8, 40, 5, 18, 1, False), (64, 4, 30, 6, 7, 2, True), (64, 4, 30, 6, 7, 0, False),
+                                                     (128, 8, 48, 12, 56, 2, True), (128, 8, 48, 12, 56, 2, False)])
+def test_decode_own_attention_chain_matches_fp32_torch(dev, D, H, N, S, steps, mode, fp8):
+    """Large-N candidate decode (BASELINE config 5): own-token VALU pass (RoPE + append into the head-major own cache, bf16 or e4m3 with
+    per-row scales, + attention over the own keys, state out) chained into ONE MFMA pass over [shared prefix | prompt text] with the S
+    samples of a prompt as the query rows of a batch entry -- run for `steps` consecutive decode steps -- against an fp32 torch
+    softmax over [K0 | K1[prompt] | own keys so far]. The reference attends the values the cache holds (bf16 rows, or the e4m3
+    quantiser restated in torch): what is checked is the attention arithmetic and the append, with the usual bf16-P tolerance.
+    The cache contents themselves are compared exactly (appended rows, scales)."""
+    T0, T1, cap, npos = 257, 24, 64, 400
+    P = N // S
+    g = torch.Generator().manual_seed(7 * N + steps + D)
+    ncol = 3 * H * D
+    inv = 1.0 / (10000.0 ** (torch.arange(0, D, 2).float() / D))
+    ang = torch.arange(npos).float()[:, None] * inv[None]
+    cos, sin = ang.cos(), ang.sin()
+    k0, v0 = bf(torch.randn(1, T0, H, D, generator=g)), bf(torch.randn(1, T0, H, D, generator=g))
+    k1, v1 = bf(torch.randn(P, T1, H, D, generator=g)), bf(torch.randn(P, T1, H, D, generator=g))
+    len1 = (9 + (torch.arange(P) * 5) % 16).to(torch.int32)
+    c0, c1 = make_cache(k0, v0, dev), make_cache(k1, v1, dev)
+    s0 = ops.Segment(c0[0], c0[1], c0[2], c0[3], length=T0, slot_of_batch=torch.zeros(N, dtype=torch.int32, device=dev))
+    s1 = ops.Segment(c1[0], c1[1], c1[2], c1[3], length=T1, len_of_batch=len1.to(dev))         # slot = batch entry = prompt
+    if fp8:
+        k_own = torch.zeros(N, H, cap, D, dtype=torch.uint8, device=dev)
+        v_own = torch.zeros_like(k_own)
+        ks = torch.zeros(N, H, cap, dtype=torch.float32, device=dev)
+        vs = torch.zeros_like(ks)
+    else:
+        k_own = torch.zeros(N, H, cap, D, dtype=torch.bfloat16, device=dev)
+        v_own = torch.zeros_like(k_own)
+        ks = vs = None
+    state = (torch.empty(N, H, D, dtype=torch.float32, device=dev), torch.empty(N, H, 2, dtype=torch.float32, device=dev))
+    own_k, own_v = [], []                                   # reference: the values the cache should hold, [N, H, D] per step
+    for t in range(steps):
+        qkv = bf(torch.randn(N, ncol, generator=g))
+        pos = torch.randint(0, npos, (N,), generator=g, dtype=torch.int32)
+        x = qkv.float().view(N, 3, H, D)
+        q_ref = _rope_ref(x[:, 0], pos, cos, sin, mode)
+        k_new, v_new = _rope_ref(x[:, 1], pos, cos, sin, mode), x[:, 2]
+        if fp8:
+            k_new, ksc = _fq_rows_e4m3(k_new)
+            v_new, vsc = _fq_rows_e4m3(v_new)
+        own_k.append(k_new)
+        own_v.append(v_new)
+        qd = qkv.clone().to(dev)
+        ops.decode_own_attention(qd, N, H, D, D ** -0.5, k_own, v_own, cap, t, state, positions=pos.to(dev), cos=cos.to(dev), sin=sin.to(dev),
+                                 rope_mode=mode, k_scale=ks, v_scale=vs)
+        out = torch.full((N, H * D), float("nan"), dtype=torch.bfloat16, device=dev)
+        ops.attention(qd, (S * ncol, ncol, D), out, (S * H * D, H * D, D), P, S, H, H, D, D ** -0.5, [s0, s1], state_in=state)
+        # q rotated in place, exactly
+        assert torch.equal(qd[:, :H * D].float().cpu().view(N, H, D), q_ref)
+        # appended cache rows, exactly
+        if fp8:
+            got_k = k_own[:, :, t].cpu().view(torch.float8_e4m3fn).float() * ks[:, :, t].cpu()[..., None]
+            got_v = v_own[:, :, t].cpu().view(torch.float8_e4m3fn).float() * vs[:, :, t].cpu()[..., None]
+            assert torch.equal(ks[:, :, t].cpu(), ksc[..., 0]) and torch.equal(vs[:, :, t].cpu(), vsc[..., 0])
+        else:
+            got_k, got_v = k_own[:, :, t].float().cpu(), v_own[:, :, t].float().cpu()
+        assert torch.equal(got_k, k_new) and torch.equal(got_v, v_new)
+        if t in (0, 1, steps // 2, steps - 1):
+            kk_own, vv_own = torch.stack(own_k, 1), torch.stack(own_v, 1)                       # [N, t+1, H, D]
+            exp = torch.empty(N, H, D)
+            for n in range(N):
+                p, ln = n // S, int(len1[n // S])
+                kk = torch.cat([k0[0].float(), k1[p, :ln].float(), kk_own[n]], 0)
+                vv = torch.cat([v0[0].float(), v1[p, :ln].float(), vv_own[n]], 0)
+                sc = torch.einsum("hd,thd->ht", q_ref[n], kk) * D ** -0.5
+                exp[n] = torch.einsum("ht,thd->hd", torch.softmax(sc, -1), vv)
+            o, e = out.float().cpu(), exp.view(N, H * D)
+            assert torch.isfinite(o).all()
+            assert rel_l2(o, e) < 8e-3 and (o - e).abs().max() < 4e-2, (t, rel_l2(o, e), (o - e).abs().max())
+
+
 def _decode_attention_case(dev, D, H, N, write_t, mode, from_partials, permute_slots, slot_pattern="grouped", check_fp32=False):
     # one launch (RoPE + KV append + [shared | per-prompt | own] attention) == rope_kv_write + attention over 3 segments
     # (N = 144: more than 128 (candidate tile, head) units for H = 8, i.e. the unsplit VS = 1 variant; fewer: VS = 2)

@@ -32,13 +32,17 @@ def _case(seed=3, P=3, Lt=9, n_samples=2, n_cams=1, n_gen=7):
     return c, sd, frame, toks, lens, u
 
 
-@pytest.mark.parametrize("greedy,n_cams,horizon,wdtype", [(True, 1, 1, "bf16"), (False, 1, 1, "bf16"), (True, 2, 1, "bf16"), (False, 2, 1, "bf16"),
-                                                          (True, 1, 2, "bf16"), (False, 1, 2, "bf16"), (False, 1, 8, "bf16"),
-                                                          (False, 1, 2, "fp8"), (True, 1, 8, "fp8")])
-def test_openvla_small_matches_oracle(dev, greedy, n_cams, horizon, wdtype):
+@pytest.mark.parametrize("greedy,n_cams,horizon,wdtype,own_kv", [(True, 1, 1, "bf16", None), (False, 1, 1, "bf16", None), (True, 2, 1, "bf16", None),
+                                                                 (False, 2, 1, "bf16", None), (True, 1, 2, "bf16", None), (False, 1, 2, "bf16", None),
+                                                                 (False, 1, 8, "bf16", None), (False, 1, 2, "fp8", None), (True, 1, 8, "fp8", None),
+                                                                 (False, 1, 2, "bf16", "bf16"), (True, 1, 8, "bf16", "bf16"), (False, 2, 1, "bf16", "bf16"),
+                                                                 (False, 1, 2, "bf16", "fp8"), (False, 1, 8, "fp8", "fp8")])
+def test_openvla_small_matches_oracle(dev, greedy, n_cams, horizon, wdtype, own_kv):
     """n_cams = 2 is BASELINE config 4's observation (two 224^2 cameras -> 512 patch rows in the shared prefix); horizon > 1 is
     config 5's action chunk (7 x horizon action tokens per candidate: the own-token KV segment grows to 56 keys); wdtype "fp8" =
-    config 5's e4m3 decoder / lm_head weights, compared with the oracle on the DE-QUANTISED weights."""
+    config 5's e4m3 decoder / lm_head weights, compared with the oracle on the DE-QUANTISED weights; own_kv = the large-N
+    decode path (head-major own-token cache: own-token VALU pass + one MFMA pass over [shared | text]), "fp8" = config 5's fp8 KV,
+    compared with the oracle that quantises the own tokens' K / V rows the same way."""
     from cover_ref import blocks as Bk, openvla as OR
     from cover_vla_amd.openvla import OpenVLA
     n_gen = 7 * horizon
@@ -46,7 +50,7 @@ def test_openvla_small_matches_oracle(dev, greedy, n_cams, horizon, wdtype):
     n_samples = 1 if greedy else 2
     P = toks.shape[0]
     model = OpenVLA(sd, c, device="cuda:0", max_prompts=4, max_candidates=8, max_text=toks.shape[1], n_cams=n_cams, horizon=horizon,
-                    weight_dtype=wdtype)
+                    weight_dtype=wdtype, own_kv=own_kv)
     un = None if greedy else u[: P * n_samples]
     otr = {}
     if wdtype == "fp8":
@@ -55,7 +59,7 @@ def test_openvla_small_matches_oracle(dev, greedy, n_cams, horizon, wdtype):
     else:
         osd = Bk.to_bf16(sd)
     with torch.no_grad():
-        ref = OR.sample(c, osd, frame, toks, lens, n_samples, un, 0.9, n_gen=n_gen, trace=otr)
+        ref = OR.sample(c, osd, frame, toks, lens, n_samples, un, 0.9, n_gen=n_gen, trace=otr, kv_fp8_own=own_kv == "fp8")
     # teacher-forced on the oracle's trajectory so that all 7 steps are comparable (random-weight logits have tiny
     # top-1/top-2 margins: a free-running comparison diverges at the first near-tie and says nothing afterwards)
     tr = {}
