@@ -49,6 +49,7 @@ sys.path.insert(0, ROOT)
 N_PROMPTS, N_SAMPLES, LT = 8, 4, 24
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_PEAK_TF = 2500.0      # bf16 dense
+FP8_PEAK_TF = 5000.0       # MX-scaled fp8 dense (MI355X_MICROARCH.md chip table; measured 4.65 PF)
 BASE_METRIC = "candidate actions scored/sec (whole node), OpenVLA-7B N=32, 224^2 RGB"
 
 
@@ -284,7 +285,7 @@ def profile_decision(pipe, world, rank, cpu_gather):
     import ctypes as C
     from cover_vla_amd import _lib as L
     h = L.lib()
-    n = 7
+    n = 8
     ms, cnt, work = (C.c_double * n)(), (C.c_longlong * n)(), (C.c_double * n)()
     L.check(h.cover_profile_begin(32768), "profile_begin")
     try:
@@ -339,6 +340,16 @@ def roofline_objects(ms, cnt, work, ms_per_step, lib_sha):
             out["roofline_mfma"] = {"invalid": "a fraction > 1: refused"}
         else:
             out["roofline_mfma"] = obj
+    if len(cnt) > 7 and cnt[7] > 0 and ms[7] > 0:
+        # config 5: the decoder's projections on the MX-scaled fp8 matrix instruction -- priced against the 5 PFLOP/s fp8 peak
+        tf8 = work[7] / (ms[7] * 1e-3) / 1e12
+        obj = {"bound": "mfma", "kernel": "gemm_tiled_pc_f8 (v_mfma_scale_f32_16x16x128_f8f6f4: e4m3 activations per row x e4m3 weights per channel; the decoder's "
+                                          "projections in every pass with more than 64 rows)",
+               "achieved": round(tf8, 1), "peak": FP8_PEAK_TF, "unit": "TFLOP/s", "frac": round(tf8 / FP8_PEAK_TF, 4), "traffic": None,
+               "launches": int(cnt[7]), "avg_launch_us": round(1e3 * ms[7] / cnt[7], 2), "kernel_ms_per_decision": round(ms[7], 3), "flop_per_decision": work[7]}
+        guard("roofline_fp8_mfma", obj)
+        if "roofline" not in out and "frac" in out.get("roofline_fp8_mfma", {}):
+            out["roofline"] = dict(out["roofline_fp8_mfma"])
     if "roofline" not in out and isinstance(out.get("roofline_mfma"), dict) and "frac" in out["roofline_mfma"]:
         # no weight-streaming launch of >= 16 MB in this configuration (M > 64 decode rows, e.g. config 5: N = 512): the dominant
         # kernel class is the tiled GEMM, bounded by the matrix pipes
@@ -350,11 +361,11 @@ def roofline_objects(ms, cnt, work, ms_per_step, lib_sha):
                                         "launches": int(cnt[3]), "kernel_ms_per_decision": round(ms[3], 3)}
     if cnt[2] > 0:
         out["attention_kernels"] = {"launches": int(cnt[2]), "kernel_ms_per_decision": round(ms[2], 3)}
-    floor_ms = 1e3 * (work[0] / (HBM_PEAK_GBS * 1e9) + (work[1] + work[4]) / (MFMA_PEAK_TF * 1e12))
+    floor_ms = 1e3 * (work[0] / (HBM_PEAK_GBS * 1e9) + (work[1] + work[4]) / (MFMA_PEAK_TF * 1e12) + (work[7] if len(work) > 7 else 0.0) / (FP8_PEAK_TF * 1e12))
     if floor_ms > 0 and ms_per_step > 0:
         e2e = floor_ms / ms_per_step
         out["end_to_end"] = ({"floor_ms": round(floor_ms, 3), "measured_ms": round(ms_per_step, 3), "frac": round(e2e, 4),
-                              "floor": "decode weight bytes / 8 TB/s + tiled-GEMM FLOPs / 2.5 PFLOP/s (attention, norms, heads: 0)"}
+                              "floor": "decode weight bytes / 8 TB/s + bf16 tiled-GEMM FLOPs / 2.5 PFLOP/s + fp8 tiled-GEMM FLOPs / 5 PFLOP/s (attention, norms, heads: 0)"}
                              if e2e <= 1.0 else {"invalid": f"frac {e2e:.3f} > 1: refused"})
     return out
 

@@ -31,7 +31,8 @@ class GemmEpi(C.Structure):
     _fields_ = [("bias", c_p), ("residual", c_p), ("layer_scale", c_p), ("ld_residual", c_i), ("residual_f32", c_i),
                 ("act", c_i), ("glu", c_i), ("out_f32", c_i), ("out_scale", c_f),
                 ("norm_w", c_p), ("norm_out", c_p), ("ld_norm_out", c_i), ("norm_style", c_i), ("norm_w_offset", c_f),
-                ("norm_eps", c_f), ("norm_b", c_p), ("w8", c_p), ("w8_scale", c_p), ("a8", c_p), ("a8_scale", c_p), ("ld_a8", c_i), ("_pad_a8", c_i)]
+                ("norm_eps", c_f), ("norm_b", c_p), ("w8", c_p), ("w8_scale", c_p), ("a8", c_p), ("a8_scale", c_p), ("ld_a8", c_i), ("ld_norm_out8", c_i),
+                ("norm_out8", c_p), ("norm_out8_scale", c_p)]
 
 
 class KvSegment(C.Structure):
@@ -211,6 +212,7 @@ SYMBOLS = {
     "cover_actions_to_histories": (c_i, [c_p, c_ll, c_ll, c_i, c_i, c_p, c_p, c_i, c_f, c_p, c_p, c_p]),
     "cover_resample_axis": (c_i, [c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_i, c_p]),
     "cover_u8_hwc_to_f32_chw_norm": (c_i, [c_p, c_p, c_i, c_i, _P(c_f), _P(c_f), c_p]),
+    "cover_u8_hwc_to_f32_chw_scale_norm": (c_i, [c_p, c_p, c_i, c_i, c_f, _P(c_f), _P(c_f), c_p]),
     "cover_resize_bilinear_pad_f32": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p]),
     "cover_vit_workspace_bytes": (C.c_size_t, [_P(VitDesc), c_i, c_i]),
     "cover_vit_forward": (c_i, [_P(VitDesc), c_p, c_i, c_i, c_p, Workspace, c_i, c_p]),

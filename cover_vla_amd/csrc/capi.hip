@@ -249,13 +249,18 @@ int cover_resample_axis(const void* in, int in_is_f32, void* out, int out_is_f32
                         int axis, const int* bounds, const void* coefs, int ksize, int fixed_point, void* stream) {
     if (!in || !out || !bounds || !coefs || ksize <= 0 || (axis != 0 && axis != 1)) return fail(COVER_EINVAL, "cover_resample_axis: bad arguments");
     if ((axis == 0 && Win != Wout) || (axis == 1 && Hin != Hout)) return fail(COVER_EINVAL, "cover_resample_axis: the other axis must keep its size");
-    HIPCHK(launch_resample_axis(in, in_is_f32 ? 1 : 0, out, out_is_f32 ? 1 : 0, Hin, Win, C, Hout, Wout, axis, bounds, coefs, ksize, fixed_point, ST(stream)),
+    HIPCHK(launch_resample_axis(in, in_is_f32, out, out_is_f32, Hin, Win, C, Hout, Wout, axis, bounds, coefs, ksize, fixed_point, ST(stream)),
            "resample_axis (fixed point: uint8 -> uint8 only)");
     return COVER_OK;
 }
 int cover_u8_hwc_to_f32_chw_norm(const uint8_t* in, float* out, int H, int W, const float* mean3, const float* std3, void* stream) {
     if (!in || !out || !mean3 || !std3) return fail(COVER_EINVAL, "cover_u8_hwc_to_f32_chw_norm: null pointer");
     HIPCHK(launch_u8_to_chw_norm(in, out, H, W, 3, mean3, std3, ST(stream)), "u8_hwc_to_f32_chw_norm");
+    return COVER_OK;
+}
+int cover_u8_hwc_to_f32_chw_scale_norm(const uint8_t* in, float* out, int H, int W, float scale, const float* mean3, const float* std3, void* stream) {
+    if (!in || !out || !mean3 || !std3) return fail(COVER_EINVAL, "cover_u8_hwc_to_f32_chw_scale_norm: null pointer");
+    HIPCHK(launch_u8_to_chw_scale_norm(in, out, H, W, 3, scale, mean3, std3, ST(stream)), "u8_hwc_to_f32_chw_scale_norm");
     return COVER_OK;
 }
 int cover_resize_bilinear_pad_f32(const float* in, float* out, int NC, int Hin, int Win, int Hr, int Wr, int Hout, int Wout, int pad_top,
@@ -432,23 +437,28 @@ int cover_decoder_forward(const cover_dec_desc* d, const cover_dec_pass* p, void
     if (!ws.ptr || ws.bytes < need) return fail(COVER_EWORKSPACE, "cover_decoder_forward: workspace too small");
     const int dim = d->dim, Hq = d->Hq, Hkv = d->Hkv, D = d->D, nqkv = (Hq + 2 * Hkv) * D, HD = Hq * D;
 
-    // h = in_norm_0(x); afterwards every norm is folded into the epilogue of the GEMM that produces its input
-    {
-        const bool f32in = p->x_f32 != nullptr;
-        HIPCHK(launch_rmsnorm(f32in ? (const void*)p->x_f32 : (const void*)x, f32in ? 1 : 0, dim, d->layers_host[0].in_norm_w,
-                              d->norm_w_offset, d->norm_style, (bf16_t*)h, dim, rows, dim, d->norm_eps, st), "dec in_norm");
-    }
     // fp8 profile with more rows than the weight-streaming kernels take (config 5: M = 512 decode rows, and its prefill): the
     // projections run on the MX-scaled fp8 matrix instruction -- the input rows of every GEMM are quantised to e4m3 (per-row
     // power-of-two scale) right before it, into one shared buffer
     static const char* f8_env = getenv("COVER_FP8_MFMA");
     const bool f8 = rows > 64 && d->layers_host[0].qkv_w8 && d->layers_host[0].o_w8 && d->layers_host[0].gate_up_w8 && d->layers_host[0].down_w8 &&
                     !(f8_env && f8_env[0] == '0');
+    // the norms that produce h also emit its e4m3 twin (RMSNorm widths that are multiples of 128): two quantise launches per layer less
+    const bool f8q = f8 && (dim % 128) == 0;
+    auto use_q8 = [&](int K, cover_gemm_epi& e) { e.a8 = q8; e.a8_scale = (const float*)q8s; e.ld_a8 = (K + 127) / 128 * 128; };
+    auto norm_q8 = [&](cover_gemm_epi& e) { if (f8q) { e.norm_out8 = q8; e.norm_out8_scale = (float*)q8s; e.ld_norm_out8 = dim; } };
     auto quant = [&](const void* src, int K, cover_gemm_epi& e) -> hipError_t {
         const int kp = (K + 127) / 128 * 128;
         e.a8 = q8; e.a8_scale = (const float*)q8s; e.ld_a8 = kp;
         return launch_quantize_act_fp8((const bf16_t*)src, K, rows, K, (uint8_t*)q8, kp, (float*)q8s, st);
     };
+    // h = in_norm_0(x); afterwards every norm is folded into the epilogue of the GEMM that produces its input
+    {
+        const bool f32in = p->x_f32 != nullptr;
+        HIPCHK(launch_rmsnorm(f32in ? (const void*)p->x_f32 : (const void*)x, f32in ? 1 : 0, dim, d->layers_host[0].in_norm_w,
+                              d->norm_w_offset, d->norm_style, (bf16_t*)h, dim, rows, dim, d->norm_eps, st,
+                              f8q ? (uint8_t*)q8 : nullptr, f8q ? (dim + 127) / 128 * 128 : 0, f8q ? (float*)q8s : nullptr), "dec in_norm");
+    }
     for (int l = 0; l < d->n_layers; ++l) {
         const cover_dec_layer& L = d->layers_host[l];
         const bool first_f32 = (l == 0 && p->x_f32 != nullptr);
@@ -457,7 +467,8 @@ int cover_decoder_forward(const cover_dec_desc* d, const cover_dec_pass* p, void
         e.out_scale = 1.0f;
         e.bias = L.qkv_b;
         e.w8 = L.qkv_w8; e.w8_scale = L.qkv_s;
-        if (f8) HIPCHK(quant(h, dim, e), "dec quantise (qkv input)");
+        if (f8q) use_q8(dim, e);                               // h8 came with the norm that produced h
+        else if (f8) HIPCHK(quant(h, dim, e), "dec quantise (qkv input)");
         // weight-streaming path: leave the split-K partials for rope_kv_write to fold (one launch and one pass less)
         int qkv_splits = 0;
         if (rows <= 64 && p->n_groups == 1 && (variant == 0 || variant == 3) && p->groups[0].own_kv_mode == 0)
@@ -606,12 +617,14 @@ int cover_decoder_forward(const cover_dec_desc* d, const cover_dec_pass* p, void
         e.norm_w_offset = d->norm_w_offset; e.norm_eps = d->norm_eps;
         e.w8 = L.o_w8; e.w8_scale = L.o_s;
         if (f8) HIPCHK(quant(attn, HD, e), "dec quantise (o_proj input)");
+        norm_q8(e);
         HIPCHK(launch_gemm_bf16((const bf16_t*)attn, HD, (const bf16_t*)L.o_w, x, dim, rows, dim, HD, &e, (float*)sk, skb, variant, st), "dec o_proj (+post_norm)");
         memset(&e, 0, sizeof e);
         e.out_scale = 1.0f;
         e.act = d->act; e.glu = 1;
         e.w8 = L.gate_up_w8; e.w8_scale = L.gate_up_s;
-        if (f8) HIPCHK(quant(h, dim, e), "dec quantise (gate_up input)");
+        if (f8q) use_q8(dim, e);
+        else if (f8) HIPCHK(quant(h, dim, e), "dec quantise (gate_up input)");
         HIPCHK(launch_gemm_bf16((const bf16_t*)h, dim, (const bf16_t*)L.gate_up_w, mlp, d->mlp, rows, 2 * d->mlp, dim, &e, (float*)sk, skb, variant, st), "dec gate_up");
         memset(&e, 0, sizeof e);
         e.out_scale = 1.0f;
@@ -622,6 +635,7 @@ int cover_decoder_forward(const cover_dec_desc* d, const cover_dec_pass* p, void
         }
         e.w8 = L.down_w8; e.w8_scale = L.down_s;
         if (f8) HIPCHK(quant(mlp, d->mlp, e), "dec quantise (down input)");
+        if (l + 1 < d->n_layers) norm_q8(e);
         HIPCHK(launch_gemm_bf16((const bf16_t*)mlp, d->mlp, (const bf16_t*)L.down_w, x, dim, rows, dim, d->mlp, &e, (float*)sk, skb, variant, st), "dec down (+next in_norm)");
     }
     if (p->final_norm)

@@ -1202,7 +1202,34 @@ __global__ __launch_bounds__(512) void splitk_reduce_norm(const float* __restric
             uint4 u;
             u.x = pack_bf2(o[0], o[1]); u.y = pack_bf2(o[2], o[3]); u.z = pack_bf2(o[4], o[5]); u.w = pack_bf2(o[6], o[7]);
             *(uint4*)(epi.norm_out + (size_t)m * epi.ld_norm_out + n0) = u;
+            if (epi.nq8) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) vals[c][i] = bfround(o[i]);   // the stored bf16 row is what gets quantised
+            }
         }
+    }
+    if (epi.nq8) {   // e4m3 twin of the norm_out row (cover_quantize_act_fp8's arithmetic on the stored bf16 values)
+        float mx = 0.f;
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+            if ((int)(threadIdx.x + c * 512) * 8 < N)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) mx = fmaxf(mx, fabsf(vals[c][i]));
+        mx = wave_max(mx);
+        if ((threadIdx.x & 63) == 0) red[8 + (threadIdx.x >> 6)] = mx;     // (red[0..7] belong to the block sum above)
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) t = fmaxf(t, red[8 + i]);
+        const float sc = e4m3_pow2_scale(t), inv = 1.0f / sc;
+        if (threadIdx.x == 0) epi.nq8s[m] = sc;
+        uint8_t* qrow = epi.nq8 + (size_t)m * epi.ldnq8;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int n0 = (threadIdx.x + c * 512) * 8;
+            if (n0 < N) store_q8_chunk(qrow, n0, vals[c], inv);
+        }
+        // zero padding up to the row pitch's 128-multiple is the caller's (N % 128 == 0 for the decoder widths this serves)
     }
     RNT(5);
 }
@@ -1265,6 +1292,10 @@ static EpiDev make_epi(const cover_gemm_epi* e) {
     d.a8s = e ? e->a8_scale : nullptr;
     d.lda8 = e ? e->ld_a8 : 0;
     if (!d.a8 || !d.a8s || !d.w8) { d.a8 = nullptr; d.a8s = nullptr; }
+    d.nq8 = e ? (uint8_t*)e->norm_out8 : nullptr;
+    d.nq8s = e ? e->norm_out8_scale : nullptr;
+    d.ldnq8 = e ? e->ld_norm_out8 : 0;
+    if (!d.nq8 || !d.nq8s || !d.norm_out || d.norm_style == 2) { d.nq8 = nullptr; d.nq8s = nullptr; }
     return d;
 }
 
@@ -1446,7 +1477,8 @@ static hipError_t launch_skinny3(const Skinny3Plan& p, const bf16_t* A, int lda,
 static hipError_t run_norm(const EpiDev& epi, void* C, int ldc, int M, int Nout, hipStream_t st) {
     if (epi.norm_style == 2)
         return launch_layernorm_bf16((const bf16_t*)C, ldc, epi.norm_w, epi.norm_b, epi.norm_out, epi.ld_norm_out, M, Nout, epi.norm_eps, st);
-    return launch_rmsnorm(C, 0, ldc, epi.norm_w, epi.norm_w_offset, epi.norm_style, epi.norm_out, epi.ld_norm_out, M, Nout, epi.norm_eps, st);
+    return launch_rmsnorm(C, 0, ldc, epi.norm_w, epi.norm_w_offset, epi.norm_style, epi.norm_out, epi.ld_norm_out, M, Nout, epi.norm_eps, st,
+                          epi.nq8, epi.ldnq8, epi.nq8s);
 }
 
 hipError_t launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* Wp, void* C, int ldc, int M, int N, int K,
@@ -1540,7 +1572,7 @@ hipError_t launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* Wp, void* C,
     // ---- tile / split-K selection: fill >= ~1 block per CU when the problem allows it
     // tile configurations: {wave tile (WM, WN) in 16-row units, wave grid, stages}
     struct Cand { int wm, wn, wgm, wgn, nst; };
-    const Cand cands[18] = {
+    const Cand cands[19] = {
         {4, 4, 2, 2, 2},   // 0: 128x128, 4 waves of 64x64, 2 stages (64 KiB)
         {2, 4, 2, 2, 2},   // 1:  64x128, 4 waves of 32x64, 2 stages (48 KiB)
         {2, 2, 2, 2, 3},   // 2:  64x64,  4 waves of 32x32, 3 stages (48 KiB)
@@ -1561,6 +1593,7 @@ hipError_t launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* Wp, void* C,
         {7, 2, 2, 4, 3},   // f: 224x128, 8 MFMA waves of 112x32 + 4 loaders, 3 stages (132 KiB)
         {7, 3, 2, 4, 3},   // g: 224x192, 8 MFMA waves of 112x48 + 4 loaders, 3 stages (156 KiB)
         {7, 2, 2, 3, 4},   // h: 224x96,  6 MFMA waves of 112x32 + 4 loaders, 4 stages (160 KiB)
+        {4, 3, 2, 4, 3},   // i: 128x192, 8 MFMA waves of 64x48 + 4 loaders, 3 stages (120 KiB) -- fp8 instantiation only (gemm_fp8.hip)
     };
     // Measured on MI355X (tools/bench_kernels.py, M = 441): this single-barrier-per-k-tile structure is latency-bound per
     // block, so residency beats tile size until the tile grid oversubscribes the chip several times over, while 64x64
@@ -1589,6 +1622,22 @@ hipError_t launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* Wp, void* C,
     if (variant != 2 && Kp >= 2048 && M >= 512 && !(big_env && big_env[0] == '0')) {
         if (N > 4096 && nblocks(13) >= 176) pick = N >= 16384 ? 12 : 13;
         else if (N <= 4096 && Kp >= 8192 && (nblocks(12) >= 256 || (M < 1024 && ws != nullptr))) pick = 12;
+    }
+    // fp8 operands (config 5, M = 512 decode rows): with half the bytes per FLOP the 12-wave tiles are bound by how evenly the tile grid
+    // covers the 256 CUs, not by the fill: qkv (N = 12288) is 192 tiles of 256 x 128 / 128 x 256 -- a quarter of the chip idle -- but
+    // exactly 256 tiles of 128 x 192; gate_up (N = 22016) is 344 tiles (two rounds, the second a third full) or 460 of 128 x 192
+    // (two rounds of a 0.79 x tile). Cost = rounds x (0.55 area + 0.45 perimeter), normalised to the 256 x 128 tile; measured at
+    // M = 512: qkv 35 -> 28 us, gate_up 70 -> 54 us.
+    if (epi.a8 && variant != 2 && Kp >= 2048 && M >= 512 && N > 4096 && gemm_fp8_tiled_supported(18)) {
+        const int idx[3] = {12, 13, 18};
+        double best = 1e30;
+        for (int c = 0; c < 3; ++c) {
+            const int bm_ = cands[idx[c]].wm * cands[idx[c]].wgm * 16, bn_ = cands[idx[c]].wn * cands[idx[c]].wgn * 16;
+            if (epi.glu && (bn_ % 32)) continue;
+            const long long rounds = (nblocks(idx[c]) + 255) / 256;
+            const double cost = rounds * (0.55 * (double)bm_ * bn_ / 32768.0 + 0.45 * (double)(bm_ + bn_) / 384.0);
+            if (cost < best) { best = cost; pick = idx[c]; }
+        }
     }
     // 224-row tiles (picks 15-17): M = 448 -- the OpenVLA prefill pass: 256 patch rows + 8 prompts x 24 text rows -- is exactly two
     // of them, where 128-row tiles pad 12.5 % and 64 x 128 tiles need 1.3-2.7 rounds of blocks. The column width and the number of
@@ -1683,7 +1732,7 @@ hipError_t launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* Wp, void* C,
         S = (nk8 + kt8 - 1) / kt8;                                      // K slices of whole 128-deep tiles
         partial = S > 1 ? ws : nullptr;
         e = launch_gemm_fp8_tiled(pick, epi.a8, epi.lda8, epi.a8s, epi.w8, epi.w8s, C, ldc, M, N, Kp, epi, tiles_m, tiles_n, kt8, S, partial, lds,
-                                  tcls, 2.0 * (double)M * (double)N * (double)K, st);
+                                  7, 2.0 * (double)M * (double)N * (double)K, st);
     } else if (pc) {
         // loader waves: one wave issues an LDS-DMA piece every ~60 cycles, four keep the CU's vector memory path busy
         // (cold weights, M = 448: o_proj 36.0 -> 32.3 us, down 84.2 -> 76.0 us)

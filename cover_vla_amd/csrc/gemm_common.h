@@ -25,7 +25,30 @@ struct EpiDev {
     const uint8_t* a8;      // optional e4m3 twin of the activation rows + row scales (host side only: selects the fp8 tiled kernel)
     const float* a8s;
     int lda8;
+    uint8_t* nq8;           // optional e4m3 twin of norm_out (+ row scales), written by the norm that writes norm_out
+    float* nq8s;
+    int ldnq8;
 };
+
+// e4m3 quantisation of 8 consecutive bf16-valued elements k..k+7 of an activation row into the MX MFMA operand order
+// (cover_quantize_act_fp8): position 64 (k / 64) + 16 ((k / 8) % 4) + 8 ((k / 32) % 2)
+__device__ __forceinline__ void store_q8_chunk(uint8_t* row, int k, const float (&v)[8], float inv) {
+    int lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[0] * inv, v[1] * inv, 0, false);
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[2] * inv, v[3] * inv, lo, true);
+    int hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[4] * inv, v[5] * inv, 0, false);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[6] * inv, v[7] * inv, hi, true);
+    *(uint2*)(row + (k >> 6) * 64 + ((k >> 3) & 3) * 16 + ((k >> 5) & 1) * 8) = make_uint2((uint32_t)lo, (uint32_t)hi);
+}
+// smallest power of two s with mx / s <= 448 (the e4m3 maximum); 1 for an all-zero row
+__device__ __forceinline__ float e4m3_pow2_scale(float mx) {
+    float s = 1.0f;
+    if (mx > 0.f) {
+        int e;
+        const float f = frexpf(mx / 448.0f, &e);
+        s = ldexpf(1.0f, f == 0.5f ? e - 1 : e);
+    }
+    return s;
+}
 
 // val[4] are 4 consecutive columns n0..n0+3 of row m: bias / activation / layer-scale / residual / scale, in place.
 __device__ __forceinline__ void epi_value4(const EpiDev& e, int m, int n0, int N, float v[4]) {
@@ -303,6 +326,74 @@ __device__ __forceinline__ void tiled_epilogue_staged(f32x4 (&acc)[WN][WM], cons
     PCTL(6);
     const int cpr = (cvalid * esz_out) >> 4;                           // 16-byte chunks per output row
     const int total = BM * cpr;
+    if (generic && !epi.out_f32) {
+        // Generic epilogue, bf16 output, with the operand loads HOISTED: per-block timelines of the 64 x 64 tile at ViT sizes showed 4.0 of
+        // the 4.5 us epilogue in this store loop -- bias / layer-scale / residual were read element by element BEHIND the LDS reads, two
+        // dependent iterations per thread. Here the operands of two chunks (8 columns each) are requested up front as 16-byte loads, then
+        // the staged sums are read and the SAME arithmetic (epi_value4's rounding points) runs on registers.
+        const bool al = (!epi.bias || (((uintptr_t)epi.bias) & 15) == 0) && (!epi.lscale || (((uintptr_t)epi.lscale) & 15) == 0) && (n0 & 7) == 0 &&
+                        (!epi.residual || ((((uintptr_t)epi.residual) & 15) == 0 && ((epi.ldr * (epi.res_f32 ? 4 : 2)) & 15) == 0));
+        if (al) {
+            for (int c0 = t; c0 < total; c0 += 2 * nthr) {
+                int rowi[2], chi[2], mi[2];
+                bool ok[2];
+                float4 bb[2][2] = {}, ll[2][2] = {}, rf[2][2] = {};
+                uint4 rb[2] = {};
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int c = c0 + u * nthr;
+                    rowi[u] = c / cpr; chi[u] = c - rowi[u] * cpr; mi[u] = m0 + rowi[u];
+                    ok[u] = c < total && mi[u] < M;
+                    const int mm = ok[u] ? mi[u] : (M - 1), cc = ok[u] ? chi[u] : 0;        // clamped: loads stay unconditional
+                    const int n = n0 + cc * 8;
+                    if (epi.bias) { bb[u][0] = *(const float4*)(epi.bias + n); bb[u][1] = *(const float4*)(epi.bias + n + 4); }
+                    if (epi.lscale) { ll[u][0] = *(const float4*)(epi.lscale + n); ll[u][1] = *(const float4*)(epi.lscale + n + 4); }
+                    if (epi.residual) {
+                        if (epi.res_f32) {
+                            const float* rp = (const float*)epi.residual + (size_t)mm * epi.ldr + n;
+                            rf[u][0] = *(const float4*)rp; rf[u][1] = *(const float4*)(rp + 4);
+                        } else {
+                            rb[u] = *(const uint4*)((const bf16_t*)epi.residual + (size_t)mm * epi.ldr + n);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    if (!ok[u]) continue;
+                    const char* lrow = st + (size_t)rowi[u] * pitch;
+                    const float4 a4 = *(const float4*)(lrow + chi[u] * 32), b4 = *(const float4*)(lrow + chi[u] * 32 + 16);
+                    float v[8] = {a4.x, a4.y, a4.z, a4.w, b4.x, b4.y, b4.z, b4.w};
+                    const float bv[8] = {bb[u][0].x, bb[u][0].y, bb[u][0].z, bb[u][0].w, bb[u][1].x, bb[u][1].y, bb[u][1].z, bb[u][1].w};
+                    const float lv[8] = {ll[u][0].x, ll[u][0].y, ll[u][0].z, ll[u][0].w, ll[u][1].x, ll[u][1].y, ll[u][1].z, ll[u][1].w};
+                    float rv[8];
+                    if (epi.residual) {
+                        if (epi.res_f32) {
+                            rv[0] = rf[u][0].x; rv[1] = rf[u][0].y; rv[2] = rf[u][0].z; rv[3] = rf[u][0].w;
+                            rv[4] = rf[u][1].x; rv[5] = rf[u][1].y; rv[6] = rf[u][1].z; rv[7] = rf[u][1].w;
+                        } else {
+                            const uint32_t rw[4] = {rb[u].x, rb[u].y, rb[u].z, rb[u].w};
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) { rv[2 * i] = bf2f((bf16_t)(rw[i] & 0xffffu)); rv[2 * i + 1] = bf2f((bf16_t)(rw[i] >> 16)); }
+                        }
+                    }
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {   // epi_value4's arithmetic and rounding points
+                        float x = v[i];
+                        if (epi.bias) x += bv[i];
+                        x = bfround(x);
+                        if (epi.act != ACT_NONE) x = bfround(act_apply(x, epi.act));
+                        if (epi.lscale) x = bfround(x * lv[i]);
+                        if (epi.residual) x = x + rv[i];
+                        if (epi.out_scale != 1.0f) x *= epi.out_scale;
+                        v[i] = x;
+                    }
+                    char* dst = base + (size_t)mi[u] * ld_bytes + (size_t)oc0 * esz_out + chi[u] * 16;
+                    *(uint4*)dst = make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
+                }
+            }
+            return;
+        }
+    }
     for (int c = t; c < total; c += nthr) {
         const int row = c / cpr, ch = c - row * cpr;
         const int m = m0 + row;

@@ -19,8 +19,10 @@
 // XOR chunk swizzle and read pattern as the bf16 kernel (gemm_tiled_pc), with half the bytes per FLOP.
 //
 // Structure = gemm_tiled_pc: NL loader waves own every LDS-DMA piece (global_load_lds, counted vmcnt ring, NST stages), CGM x CGN
-// MFMA waves of (WM*16) x (WN*16). One barrier per k-tile; the MFMA waves read all fragments of a tile right after it and start
-// their MFMAs behind counted lgkmcnt waits (the first MFMA needs 4 of the 2(WM+WN) reads), the partner wave on the SIMD fills the gap.
+// MFMA waves of (WM*16) x (WN*16), one barrier per k-tile. The MFMA waves refill their fragment registers IN PLACE with the next
+// tile's data as soon as a fragment's last MFMA of the current tile has issued (see phase0 / mid_phases / last_phase below): the
+// LDS latency hides behind the MFMAs without a second fragment set (which would not fit the register budget of a 12-wave block).
+// (First version: all fragment reads right after the barrier, then the MFMAs behind counted waits -- qkv at M = 512 1478 TFLOP/s.)
 #include <stdlib.h>
 #include <hip/hip_ext.h>
 #include "gemm_common.h"
@@ -53,6 +55,14 @@ __device__ __forceinline__ void read_w_frags(u32x4 (&wlo)[WN], u32x4 (&whi)[WN],
         read_w_frags<B + 1, WN>(wlo, whi, ba);
     }
 }
+template <int B, int BEND, int WN>
+__device__ __forceinline__ void read_w_frags_range(u32x4 (&wlo)[WN], u32x4 (&whi)[WN], uint32_t ba) {
+    if constexpr (B < BEND) {
+        ds_read128<B * 2048>(wlo[B], ba);
+        ds_read128<B * 2048 + 1024>(whi[B], ba);
+        read_w_frags_range<B + 1, BEND, WN>(wlo, whi, ba);
+    }
+}
 __device__ __forceinline__ f32x4 mfma_f8(const u32x4& wl, const u32x4& wh, const u32x4& xl, const u32x4& xh, f32x4 c) {
     const i32x8 wa = {(int)wl[0], (int)wl[1], (int)wl[2], (int)wl[3], (int)wh[0], (int)wh[1], (int)wh[2], (int)wh[3]};
     const i32x8 xa = {(int)xl[0], (int)xl[1], (int)xl[2], (int)xl[3], (int)xh[0], (int)xh[1], (int)xh[2], (int)xh[3]};
@@ -73,6 +83,60 @@ __device__ __forceinline__ void mfma_tile(f32x4 (&acc)[WN][WM], u32x4 (&xlo)[WM]
         acc[B][F] = mfma_f8(wlo[B], whi[B], xlo[F], xhi[F], acc[B][F]);
         if constexpr (F + 1 < WM) mfma_tile<B, F + 1, WM, WN>(acc, xlo, xhi, wlo, whi);
         else mfma_tile<B + 1, 0, WM, WN>(acc, xlo, xhi, wlo, whi);
+    }
+}
+
+
+// ---- software-pipelined consumer: fragments are refilled IN PLACE, as soon as their last MFMA of the tile has issued -------------
+// Steady state of tile kt (registers hold every fragment of tile kt; the reads of x[0..WM) and w[WN-1] are the youngest in flight):
+//   phase 0        MFMA(w[0], x[f]) behind counted waits (x[f] and everything older landed)
+//   lgkmcnt(0), s_barrier          tile kt+1 published; every fragment of tile kt is in registers, so its stage may be refilled
+//   read w'[0]                     (next tile, into w[0]'s registers: dead after phase 0)
+//   phase b = 1 .. WN-2            MFMA(w[b], x[*]); read w'[b]
+//   phase WN-1     MFMA(w[WN-1], x[f]); read x'[f] after each; read w'[WN-1] at the end
+// so the LDS latency of tile kt+1's fragments hides behind tile kt's MFMAs and no second fragment set is needed (a full second
+// set does not fit the 168 registers of a 12-wave block). Issue order of the next tile's reads: w'[0..WN-2], x'[0..WM), w'[WN-1]
+// (two reads each: the k-halves c = 0, 1), which is what the waits of the next phase 0 count.
+template <int F, int WM, int WN>
+__device__ __forceinline__ void phase0(f32x4 (&acc)[WN][WM], u32x4 (&xlo)[WM], u32x4 (&xhi)[WM], u32x4 (&wlo)[WN], u32x4 (&whi)[WN]) {
+    if constexpr (F < WM) {
+        wait_lgkm<2 * (WM - 1 - F) + 2>();                       // younger reads allowed in flight: x[F+1..WM) and w[WN-1]
+        asm volatile("" : "+v"(wlo[0]), "+v"(whi[0]), "+v"(xlo[F]), "+v"(xhi[F]));
+        __builtin_amdgcn_sched_barrier(0);
+        acc[0][F] = mfma_f8(wlo[0], whi[0], xlo[F], xhi[F], acc[0][F]);
+        phase0<F + 1, WM, WN>(acc, xlo, xhi, wlo, whi);
+    }
+}
+template <int B, int WM, int WN, bool REFILL>
+__device__ __forceinline__ void mid_phases(f32x4 (&acc)[WN][WM], u32x4 (&xlo)[WM], u32x4 (&xhi)[WM], u32x4 (&wlo)[WN], u32x4 (&whi)[WN], uint32_t ba) {
+    if constexpr (B < WN - 1) {
+#pragma unroll
+        for (int f = 0; f < WM; ++f) acc[B][f] = mfma_f8(wlo[B], whi[B], xlo[f], xhi[f], acc[B][f]);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (REFILL) {
+            ds_read128<B * 2048>(wlo[B], ba);
+            ds_read128<B * 2048 + 1024>(whi[B], ba);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        mid_phases<B + 1, WM, WN, REFILL>(acc, xlo, xhi, wlo, whi, ba);
+    }
+}
+template <int F, int WM, int WN, bool REFILL>
+__device__ __forceinline__ void last_phase(f32x4 (&acc)[WN][WM], u32x4 (&xlo)[WM], u32x4 (&xhi)[WM], u32x4 (&wlo)[WN], u32x4 (&whi)[WN], uint32_t a0, uint32_t a1,
+                                           uint32_t ba) {
+    if constexpr (F < WM) {
+        acc[WN - 1][F] = mfma_f8(wlo[WN - 1], whi[WN - 1], xlo[F], xhi[F], acc[WN - 1][F]);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (REFILL) {
+            ds_read128<F * 2048>(xlo[F], a0);
+            ds_read128<F * 2048>(xhi[F], a1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        last_phase<F + 1, WM, WN, REFILL>(acc, xlo, xhi, wlo, whi, a0, a1, ba);
+    } else if constexpr (REFILL) {
+        ds_read128<(WN - 1) * 2048>(wlo[WN - 1], ba);
+        ds_read128<(WN - 1) * 2048 + 1024>(whi[WN - 1], ba);
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -166,19 +230,38 @@ __global__ __launch_bounds__(64 * (CGM * CGN + NL)) void gemm_tiled_pc_f8(const 
     const uint32_t a_addr0 = lds_addr_u32(As) + ((wm * (WM * 16) + r) * 8 + ((0 * 4 + g) ^ (r & 7))) * 16;
     const uint32_t a_addr1 = lds_addr_u32(As) + ((wm * (WM * 16) + r) * 8 + ((1 * 4 + g) ^ (r & 7))) * 16;
     const uint32_t b_addr = lds_addr_u32(Bs) + (wn * WN * 2 * 64 + lane) * 16;
+    static_assert(WN >= 2, "the pipelined consumer refills w[0] while w[WN-1] is still needed");
     u32x4 xlo[WM], xhi[WM], wlo[WN], whi[WN];
-    int cur = 0;
-    for (int kt = 0; kt < nk; ++kt) {
-        asm volatile("s_barrier" ::: "memory");   // tile kt published by the loaders (their vmcnt waits precede it)
-        const uint32_t a0 = a_addr0 + cur * A_BYTES, a1 = a_addr1 + cur * A_BYTES, ba = b_addr + cur * B_BYTES;
-        // issue order = need order of the MFMA sequence (b outer, f inner): w[0], x[0..WM), w[1..WN)
+    // prologue: tile 0 published; all of its fragments requested in the steady-state order w[0..WN-2], x[0..WM), w[WN-1]
+    asm volatile("s_barrier" ::: "memory");
+    {
+        const uint32_t ba = b_addr;
+        read_w_frags_range<0, WN - 1, WN>(wlo, whi, ba);
+        read_x_frags<0, WM>(xlo, xhi, a_addr0, a_addr1);
+        ds_read128<(WN - 1) * 2048>(wlo[WN - 1], ba);
+        ds_read128<(WN - 1) * 2048 + 1024>(whi[WN - 1], ba);
+    }
+    int nxt = NST > 1 ? 1 : 0;                                    // stage of tile kt + 1
+    for (int kt = 0; kt + 1 < nk; ++kt) {
+        phase0<0, WM, WN>(acc, xlo, xhi, wlo, whi);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // w[WN-1] landed too: stage kt is free; tile kt+1 is published
+        asm volatile("" : "+v"(wlo[WN - 1]), "+v"(whi[WN - 1]));
+        __builtin_amdgcn_sched_barrier(0);
+        const uint32_t a0 = a_addr0 + nxt * A_BYTES, a1 = a_addr1 + nxt * A_BYTES, ba = b_addr + nxt * B_BYTES;
         ds_read128<0>(wlo[0], ba);
         ds_read128<1024>(whi[0], ba);
-        read_x_frags<0, WM>(xlo, xhi, a0, a1);
-        read_w_frags<1, WN>(wlo, whi, ba);
-        mfma_tile<0, 0, WM, WN>(acc, xlo, xhi, wlo, whi);
         __builtin_amdgcn_sched_barrier(0);
-        cur = cur == NST - 1 ? 0 : cur + 1;
+        mid_phases<1, WM, WN, true>(acc, xlo, xhi, wlo, whi, ba);
+        last_phase<0, WM, WN, true>(acc, xlo, xhi, wlo, whi, a0, a1, ba);
+        nxt = nxt == NST - 1 ? 0 : nxt + 1;
+    }
+    {   // last tile: no refills
+        phase0<0, WM, WN>(acc, xlo, xhi, wlo, whi);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        asm volatile("" : "+v"(wlo[WN - 1]), "+v"(whi[WN - 1]));
+        __builtin_amdgcn_sched_barrier(0);
+        mid_phases<1, WM, WN, false>(acc, xlo, xhi, wlo, whi, 0u);
+        last_phase<0, WM, WN, false>(acc, xlo, xhi, wlo, whi, 0u, 0u, 0u);
     }
     // quantisation scales (constant along k): row scale of A x channel scale of W, on the fp32 sums
     {
@@ -273,8 +356,8 @@ hipError_t launch_quantize_act_fp8(const bf16_t* X, int ldx, int M, int K, uint8
     return hipGetLastError();
 }
 
-// pick: the tile configuration index of launch_gemm_bf16's table (10: 64x128, 12: 256x128, 13: 128x256, 15: 224x128, 17: 224x96; the 224x192 tile needs 84 accumulator + 80 fragment registers and spills at 3 waves per SIMD)
-bool gemm_fp8_tiled_supported(int pick) { return pick == 10 || pick == 12 || pick == 13 || pick == 15 || pick == 17; }
+// pick: the tile configuration index of launch_gemm_bf16's table (10: 64x128, 12: 256x128, 13: 128x256, 15: 224x128, 17: 224x96, 18: 128x192; the 224x192 tile needs 84 accumulator + 80 fragment registers and spills at 3 waves per SIMD)
+bool gemm_fp8_tiled_supported(int pick) { return pick == 10 || pick == 12 || pick == 13 || pick == 15 || pick == 17 || pick == 18; }
 
 hipError_t launch_gemm_fp8_tiled(int pick, const uint8_t* A8, int lda8, const float* a_scale, const uint8_t* W8, const float* w_scale, void* C, int ldc,
                                  int M, int N, int Kp, const EpiDev& epi, int tiles_m, int tiles_n, int kt_per, int S, float* partial, size_t lds,
@@ -303,6 +386,7 @@ hipError_t launch_gemm_fp8_tiled(int pick, const uint8_t* A8, int lda8, const fl
         case 13: LAUNCH_F8(4, 4, 3, 4, 2, 4); break;
         case 15: LAUNCH_F8(7, 2, 3, 4, 2, 4); break;
         case 17: LAUNCH_F8(7, 2, 4, 4, 2, 3); break;
+        case 18: LAUNCH_F8(4, 3, 3, 4, 2, 4); break;
         default: return hipErrorInvalidValue;
     }
 #undef LAUNCH_F8

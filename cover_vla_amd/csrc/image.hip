@@ -17,6 +17,34 @@
 #include "common.h"
 #include "kernels.h"
 
+// OpenCV's 8-bit fixed-point resize (imgproc resize.cpp, INTER_LANCZOS4 and the other non-area 8-bit paths): coefficients are
+// shorts with INTER_RESIZE_COEF_BITS = 11 fractional bits, the first pass keeps exact int32 sums, the second applies
+// FixedPtCast<int, uchar, 22>: saturate((sum + (1 << 21)) >> 22). LAST = false: uint8 -> int32; LAST = true: int32 -> uint8.
+template <typename TIn, typename TOut, bool LAST>
+__global__ __launch_bounds__(256) void resample_axis_cv_k(const TIn* __restrict__ in, TOut* __restrict__ out, int Hin, int Win, int C, int Hout,
+                                                          int Wout, int axis, const int* __restrict__ bounds, const int* __restrict__ coefs, int ksize) {
+    const long long total = (long long)Hout * Wout * C;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int c = (int)(idx % C);
+    const int x = (int)((idx / C) % Wout);
+    const int y = (int)(idx / ((long long)C * Wout));
+    const int o = axis == 0 ? y : x;
+    const int start = bounds[2 * o], cnt = bounds[2 * o + 1];
+    const TIn* p = axis == 0 ? in + ((size_t)start * Win + x) * C + c : in + ((size_t)y * Win + start) * C + c;
+    const size_t step = axis == 0 ? (size_t)Win * C : (size_t)C;
+    const int* k = coefs + (size_t)o * ksize;
+    int ss = 0;
+    for (int j = 0; j < cnt; ++j) ss += (int)p[j * step] * k[j];
+    if (LAST) {
+        int v = (ss + (1 << 21)) >> 22;
+        v = v < 0 ? 0 : (v > 255 ? 255 : v);
+        out[idx] = (TOut)v;
+    } else {
+        out[idx] = (TOut)ss;
+    }
+}
+
 template <typename TIn, typename TOut, bool FIXED>
 __global__ __launch_bounds__(256) void resample_axis_k(const TIn* __restrict__ in, TOut* __restrict__ out, int Hin, int Win, int C,
                                                        int Hout, int Wout, int axis, const int* __restrict__ bounds,
@@ -63,8 +91,16 @@ hipError_t launch_resample_axis(const void* in, int in_kind, void* out, int out_
     const long long total = (long long)Hout * Wout * C;
     if (total <= 0) return hipSuccess;
     const dim3 grid((unsigned)((total + 255) / 256)), block(256);
-    // kinds: 0 = uint8, 1 = float
-    if (fixed) {
+    // kinds: 0 = uint8, 1 = float, 2 = int32 (OpenCV fixed-point mode only)
+    if (fixed == 2) {
+        if (in_kind == 0 && out_kind == 2)
+            hipLaunchKernelGGL((resample_axis_cv_k<uint8_t, int, false>), grid, block, 0, st, (const uint8_t*)in, (int*)out, Hin, Win, C, Hout, Wout, axis,
+                               bounds, (const int*)coefs, ksize);
+        else if (in_kind == 2 && out_kind == 0)
+            hipLaunchKernelGGL((resample_axis_cv_k<int, uint8_t, true>), grid, block, 0, st, (const int*)in, (uint8_t*)out, Hin, Win, C, Hout, Wout, axis,
+                               bounds, (const int*)coefs, ksize);
+        else return hipErrorInvalidValue;
+    } else if (fixed) {
         if (in_kind != 0 || out_kind != 0) return hipErrorInvalidValue;
         hipLaunchKernelGGL((resample_axis_k<uint8_t, uint8_t, true>), grid, block, 0, st, (const uint8_t*)in, (uint8_t*)out, Hin, Win, C,
                            Hout, Wout, axis, bounds, coefs, ksize, 0);
@@ -93,6 +129,29 @@ __global__ __launch_bounds__(256) void u8_to_chw_norm_k(const uint8_t* __restric
     const float mean = c == 0 ? m0 : (c == 1 ? m1 : m2), sd = c == 0 ? s0 : (c == 1 ? s1 : s2);
     const float t = __fdiv_rn((float)in[((size_t)y * W + x) * C + c], 255.0f);   // ToTensor: .div(255)
     out[idx] = __fdiv_rn(__fsub_rn(t, mean), sd);                                 // Normalize: (t - mean) / std
+}
+// rescale-by-multiplication form: ((float)x * scale - mean) / std, the arithmetic of INT-ACT's process_images (src/utils/pipeline.py:55-67:
+// `image * rescale_factor`, then (image - mean) / std in fp32)
+__global__ __launch_bounds__(256) void u8_to_chw_scale_norm_k(const uint8_t* __restrict__ in, float* __restrict__ out, int H, int W, int C, float scale,
+                                                              float m0, float m1, float m2, float s0, float s1, float s2) {
+#pragma clang fp contract(off)
+    const long long total = (long long)H * W * C;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int x = (int)(idx % W), y = (int)((idx / W) % H), c = (int)(idx / ((long long)W * H));
+    const float mean = c == 0 ? m0 : (c == 1 ? m1 : m2), sd = c == 0 ? s0 : (c == 1 ? s1 : s2);
+    // plain operators under `fp contract(off)`: __fmul_rn / __fsub_rn are inline header functions whose multiply and subtract hipcc
+    // contracts into ONE v_fma_f32 (a single rounding: 1 ulp away from torch's separate multiply and subtract)
+    const float t = (float)in[((size_t)y * W + x) * C + c] * scale;
+    const float d = t - mean;
+    out[idx] = d / sd;
+}
+hipError_t launch_u8_to_chw_scale_norm(const uint8_t* in, float* out, int H, int W, int C, float scale, const float* mean, const float* stdv, hipStream_t st) {
+    if (C != 3) return hipErrorInvalidValue;
+    const long long total = (long long)H * W * C;
+    hipLaunchKernelGGL(u8_to_chw_scale_norm_k, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, in, out, H, W, C, scale, mean[0], mean[1], mean[2],
+                       stdv[0], stdv[1], stdv[2]);
+    return hipGetLastError();
 }
 hipError_t launch_u8_to_chw_norm(const uint8_t* in, float* out, int H, int W, int C, const float* mean, const float* stdv, hipStream_t st) {
     if (C != 3) return hipErrorInvalidValue;

@@ -30,8 +30,9 @@ hipError_t launch_decode_own_attention(const cover_own_attn_args* a, hipStream_t
 // ---- rowops.hip ----------------------------------------------------------------------------------
 hipError_t launch_layernorm_bf16(const bf16_t* x, int ldx, const float* w, const float* b, bf16_t* y, int ldy, int rows,
                                  int dim, float eps, hipStream_t st);
+// q8 / q8s (optional): e4m3 twin of the stored y rows + row scales, as launch_quantize_act_fp8 would produce them (dim % 128 == 0)
 hipError_t launch_rmsnorm(const void* x, int x_f32, int ldx, const float* w, float w_offset, int style, bf16_t* y, int ldy,
-                          int rows, int dim, float eps, hipStream_t st);
+                          int rows, int dim, float eps, hipStream_t st, uint8_t* q8 = nullptr, int ld8 = 0, float* q8s = nullptr);
 hipError_t launch_rope_kv_write(const cover_rope_args* a, hipStream_t st);
 hipError_t launch_rope_kv_write_pair(const cover_rope_args* a0, const cover_rope_args* a1, hipStream_t st);
 hipError_t launch_embed_gather(const bf16_t* table, int dim, const int64_t* ids, int n, float scale, bf16_t* out,
@@ -75,6 +76,7 @@ size_t gemm_workspace_bytes(int M, int N, int K);
 // ---- image.hip -----------------------------------------------------------------------------------
 hipError_t launch_resample_axis(const void* in, int in_kind, void* out, int out_kind, int Hin, int Win, int C, int Hout, int Wout,
                                 int axis, const int* bounds, const void* coefs, int ksize, int fixed, hipStream_t st);
+hipError_t launch_u8_to_chw_scale_norm(const uint8_t* in, float* out, int H, int W, int C, float scale, const float* mean, const float* stdv, hipStream_t st);
 hipError_t launch_u8_to_chw_norm(const uint8_t* in, float* out, int H, int W, int C, const float* mean, const float* stdv, hipStream_t st);
 hipError_t launch_bilinear_pad(const float* in, float* out, int NC, int Hin, int Win, int Hr, int Wr, int Hout, int Wout, int pad_top,
                                int pad_left, float pad_value, hipStream_t st);

@@ -76,12 +76,21 @@ __global__ __launch_bounds__(256) void layernorm_bf16_k(const bf16_t* __restrict
     }
 }
 
+__device__ __forceinline__ float e4m3_pow2_scale_rows(float mx) {   // smallest power of two s with mx / s <= 448; 1 for an all-zero row
+    float s = 1.0f;
+    if (mx > 0.f) {
+        int e;
+        const float f = frexpf(mx / 448.0f, &e);
+        s = ldexpf(1.0f, f == 0.5f ? e - 1 : e);
+    }
+    return s;
+}
 // style 0 (Gemma): y = bf16(x * rstd * (w_offset + w)) ; style 1 (Llama): y = bf16(w * bf16(x * rstd))
-template <bool IN_F32>
+template <bool IN_F32, bool Q8 = false>
 __global__ __launch_bounds__(256) void rmsnorm_bf16_k(const void* __restrict__ x, int ldx, const float* __restrict__ w,
                                                       float w_offset, int style, bf16_t* __restrict__ y, int ldy, int dim,
-                                                      float eps) {
-    __shared__ float red[16];
+                                                      float eps, uint8_t* __restrict__ q8 = nullptr, int ld8 = 0, float* __restrict__ q8s = nullptr) {
+    __shared__ float red[32];
     const int row = blockIdx.x;
     const int nch = dim >> 3;
     float v[NORM_MAX_CHUNKS][8];
@@ -109,6 +118,34 @@ __global__ __launch_bounds__(256) void rmsnorm_bf16_k(const void* __restrict__ x
                 else o[i] = v[c][i] * rstd * (w_offset + ww);
             }
             store_row8(y, (size_t)row * ldy + ch * 8, o);
+            if (Q8) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[c][i] = bfround(o[i]);   // the stored bf16 row is what gets quantised
+            }
+        }
+    }
+    if constexpr (Q8) {   // e4m3 twin of the y row in the MX MFMA operand order (cover_quantize_act_fp8's arithmetic)
+        float mx = 0.f;
+#pragma unroll
+        for (int c = 0; c < NORM_MAX_CHUNKS; ++c)
+            if ((int)(threadIdx.x + c * 256) < nch)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) mx = fmaxf(mx, fabsf(v[c][i]));
+        mx = block_max(mx, red + 16);
+        const float sc = e4m3_pow2_scale_rows(mx), inv = 1.0f / sc;
+        if (threadIdx.x == 0) q8s[row] = sc;
+        uint8_t* qrow = q8 + (size_t)row * ld8;
+#pragma unroll
+        for (int c = 0; c < NORM_MAX_CHUNKS; ++c) {
+            const int ch = threadIdx.x + c * 256;
+            if (ch < nch) {
+                const int k = ch * 8;
+                int lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[c][0] * inv, v[c][1] * inv, 0, false);
+                lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[c][2] * inv, v[c][3] * inv, lo, true);
+                int hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[c][4] * inv, v[c][5] * inv, 0, false);
+                hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[c][6] * inv, v[c][7] * inv, hi, true);
+                *(uint2*)(qrow + (k >> 6) * 64 + ((k >> 3) & 3) * 16 + ((k >> 5) & 1) * 8) = make_uint2((uint32_t)lo, (uint32_t)hi);
+            }
         }
     }
 }
@@ -121,13 +158,21 @@ hipError_t launch_layernorm_bf16(const bf16_t* x, int ldx, const float* w, const
     return hipGetLastError();
 }
 hipError_t launch_rmsnorm(const void* x, int x_f32, int ldx, const float* w, float w_offset, int style, bf16_t* y, int ldy,
-                          int rows, int dim, float eps, hipStream_t st) {
+                          int rows, int dim, float eps, hipStream_t st, uint8_t* q8, int ld8, float* q8s) {
     if (rows <= 0) return hipSuccess;
     if (dim % 8 || dim > NORM_MAX_CHUNKS * 256 * 8) return hipErrorInvalidValue;
+    if (q8 && q8s) {
+        if ((dim & 127) || ld8 < dim || (ld8 & 15)) return hipErrorInvalidValue;
+        if (x_f32)
+            hipLaunchKernelGGL((rmsnorm_bf16_k<true, true>), dim3(rows), dim3(256), 0, st, x, ldx, w, w_offset, style, y, ldy, dim, eps, q8, ld8, q8s);
+        else
+            hipLaunchKernelGGL((rmsnorm_bf16_k<false, true>), dim3(rows), dim3(256), 0, st, x, ldx, w, w_offset, style, y, ldy, dim, eps, q8, ld8, q8s);
+        return hipGetLastError();
+    }
     if (x_f32)
-        hipLaunchKernelGGL(rmsnorm_bf16_k<true>, dim3(rows), dim3(256), 0, st, x, ldx, w, w_offset, style, y, ldy, dim, eps);
+        hipLaunchKernelGGL((rmsnorm_bf16_k<true, false>), dim3(rows), dim3(256), 0, st, x, ldx, w, w_offset, style, y, ldy, dim, eps, (uint8_t*)nullptr, 0, (float*)nullptr);
     else
-        hipLaunchKernelGGL(rmsnorm_bf16_k<false>, dim3(rows), dim3(256), 0, st, x, ldx, w, w_offset, style, y, ldy, dim, eps);
+        hipLaunchKernelGGL((rmsnorm_bf16_k<false, false>), dim3(rows), dim3(256), 0, st, x, ldx, w, w_offset, style, y, ldy, dim, eps, (uint8_t*)nullptr, 0, (float*)nullptr);
     return hipGetLastError();
 }
 

@@ -16,6 +16,14 @@ algorithms of the un-vendored libraries the reference calls, in two forms that g
         PIL image calls Image.resize, so the host form IS that call; the device form restates Pillow's Resample.c 8-bit
         path (22-bit fixed-point coefficients) and is bit-exact against Pillow (tests/test_imaging_*.py).
   resize_with_pad(img, w, h, pad)      lerobot_custom/lerobot/common/policies/pi0/modeling_pi0.py:131-150 on the device.
+  cv2_resize_lanczos4(img, (w, h))     the policy-side adapter's cv2.resize(..., interpolation=cv2.INTER_LANCZOS4)
+        (INT-ACT/src/experiments/env_adapters/simpler.py:48-52) followed by process_images (src/utils/pipeline.py:55-67:
+        x * (1 / 255), then (x - 0.5) / 0.5). OpenCV is not in this image and not in /root/reference: restated from OpenCV's
+        published imgproc/src/resize.cpp -- 8 taps per axis at sx - 3 .. sx + 4 with sx = floor((dx + 0.5) * scale - 0.5), NO
+        antialiasing when shrinking, interpolateLanczos4's closed-form weights normalised to sum 1, stored as shorts with 11
+        fractional bits (cvRound), taps beyond the border replicated, exact int32 row pass, then saturate((sum + 2^21) >> 22).
+        PARITY UNPINNED at OpenCV (no cv2 here to generate vectors); the device form is bit-exact against this host form, and both
+        are cross-checked against Pillow's LANCZOS (a = 3, antialiased) on smooth images within a stated bound.
 """
 from __future__ import annotations
 
@@ -112,7 +120,77 @@ def tf_spans(in_size: int, out_size: int) -> Tuple[np.ndarray, np.ndarray, int]:
     return bounds, weights, span_size
 
 
+def cv2_lanczos4_coeffs(in_size: int, out_size: int) -> Tuple[np.ndarray, np.ndarray, int]:
+    """OpenCV resize() tables for INTER_LANCZOS4 on 8-bit images along one axis -> (bounds int32 [out,2] = (start, count),
+    coefficients int32 [out, 8] holding the 11-bit fixed-point shorts, 8). Taps that fall outside the image are REPLICATED border
+    pixels in OpenCV (HResizeLanczos4 / the clip() of the vertical pass); integer sums are linear, so their weights are folded
+    into the border pixel here and the span stays contiguous -- the same sum, exactly."""
+    scale = 1.0 / (float(out_size) / float(in_size))          # double inv_scale_x = dsize / ssize; scale_x = 1. / inv_scale_x
+    s45 = 0.70710678118654752440084436210485
+    cs = [(1, 0), (-s45, -s45), (0, 1), (s45, -s45), (-1, 0), (s45, s45), (0, -1), (-s45, s45)]
+    bounds = np.zeros((out_size, 2), dtype=np.int32)
+    kk = np.zeros((out_size, 8), dtype=np.int32)
+    for dx in range(out_size):
+        fx = np.float32((dx + 0.5) * scale - 0.5)             # fx = (float)((dx + 0.5) * scale_x - 0.5)
+        sx = int(math.floor(float(fx)))                       # cvFloor
+        fx = np.float32(fx - np.float32(sx))
+        co = np.zeros(8, dtype=np.float32)
+        if fx < np.finfo(np.float32).eps:                     # interpolateLanczos4: x < FLT_EPSILON
+            co[3] = 1.0
+        else:
+            x = float(fx)
+            y0 = -(x + 3) * math.pi * 0.25
+            s0, c0 = math.sin(y0), math.cos(y0)
+            total = np.float32(0.0)
+            for i in range(8):
+                y = -(x + 3 - i) * math.pi * 0.25
+                co[i] = np.float32((cs[i][0] * s0 + cs[i][1] * c0) / (y * y))
+                total = np.float32(total + co[i])
+            inv = np.float32(1.0) / total
+            co = (co * inv).astype(np.float32)
+        q = np.rint(co.astype(np.float32) * np.float32(2048.0)).astype(np.int64)      # saturate_cast<short>(cbuf * INTER_RESIZE_COEF_SCALE): cvRound
+        q = np.clip(q, -32768, 32767)
+        taps = [min(max(sx - 3 + j, 0), in_size - 1) for j in range(8)]                # replicated border
+        lo, hi = taps[0], taps[-1]
+        w = np.zeros(8, dtype=np.int64)
+        for t, v in zip(taps, q):
+            w[t - lo] += v
+        bounds[dx] = (lo, hi - lo + 1)
+        kk[dx] = w.astype(np.int32)
+    return bounds, kk, 8
+
+
 # ------------------------------------------------------------------------------------------------ host forms
+def cv2_resize_lanczos4(image: np.ndarray, size: Tuple[int, int]) -> np.ndarray:
+    """cv2.resize(image, (width, height), interpolation=cv2.INTER_LANCZOS4) for uint8 HWC images, host form (numpy int64 sums)."""
+    a = np.asarray(image)
+    if a.dtype != np.uint8 or a.ndim != 3:
+        raise ValueError("uint8 HWC image expected")
+    W, H = size
+    bw, kw, _ = cv2_lanczos4_coeffs(a.shape[1], W)
+    bh, kh, _ = cv2_lanczos4_coeffs(a.shape[0], H)
+    x = a.astype(np.int64)
+    rows = np.zeros((a.shape[0], W, a.shape[2]), dtype=np.int64)
+    for o in range(W):
+        s, n = int(bw[o, 0]), int(bw[o, 1])
+        rows[:, o] = np.tensordot(x[:, s:s + n], kw[o, :n].astype(np.int64), axes=([1], [0]))
+    out = np.zeros((H, W, a.shape[2]), dtype=np.int64)
+    for o in range(H):
+        s, n = int(bh[o, 0]), int(bh[o, 1])
+        out[o] = np.tensordot(kh[o, :n].astype(np.int64), rows[s:s + n], axes=([0], [0]))
+    return np.clip((out + (1 << 21)) >> 22, 0, 255).astype(np.uint8)
+
+
+def simpler_preprocess_image(frame: np.ndarray, image_size=(224, 224)):
+    """BridgeSimplerAdapter.preprocess, image half (simpler.py:48-65): LANCZOS4 resize -> uint8 [1,3,H,W] -> x * (1/255) -> (x - 0.5) / 0.5,
+    fp32 in [-1, 1]. Host form (torch CPU)."""
+    import torch
+    img = cv2_resize_lanczos4(frame, image_size)
+    t = torch.as_tensor(img, dtype=torch.uint8).permute(2, 0, 1)[None]
+    t = t * (1 / 255.0)                                       # rescale(): uint8 tensor * python float -> fp32
+    return (t - torch.tensor([0.5, 0.5, 0.5])[None, :, None, None]) / torch.tensor([0.5, 0.5, 0.5])[None, :, None, None]
+
+
 def _to_rgb_u8(image) -> np.ndarray:
     """The shape handling of process_raw_image_to_jpg (eval_utils.py:253-268): grey -> 3 channels, RGBA -> RGB."""
     a = np.asarray(image)
@@ -229,6 +307,46 @@ class DeviceImagePipeline:
         if isinstance(frame_u8, np.ndarray):
             frame_u8 = torch.from_numpy(np.ascontiguousarray(_to_rgb_u8(frame_u8))).to(self.dev)
         return self.siglip(self.raw_to_jpg(frame_u8.contiguous()))
+
+    # ---- policy side (second half): cv2 LANCZOS4 to the policy's input size + process_images, on the device
+    def _cv_tables(self, H, W, size):
+        import torch
+        key = ("cv", H, W, size)
+        if key not in self._tf:
+            bw, kw, _ = cv2_lanczos4_coeffs(W, size[0])
+            bh, kh, _ = cv2_lanczos4_coeffs(H, size[1])
+            self._tf[key] = tuple(torch.from_numpy(x).to(self.dev) for x in (bw, kw, bh, kh))
+        return self._tf[key]
+
+    def policy_resize(self, frame_u8, size=(224, 224)):
+        """uint8 [H,W,3] (device) -> uint8 [size[1], size[0], 3] (device): cv2.resize(frame, size, INTER_LANCZOS4), simpler.py:48-52."""
+        import torch
+        from . import _lib as L
+        h = L.lib()
+        H, W, Cc = frame_u8.shape
+        bw, kw, bh, kh = self._cv_tables(H, W, tuple(size))
+        st = torch.cuda.current_stream().cuda_stream
+        rows = torch.empty(H, size[0], Cc, dtype=torch.int32, device=self.dev)
+        L.check(h.cover_resample_axis(frame_u8.data_ptr(), 0, rows.data_ptr(), 2, H, W, Cc, H, size[0], 1, bw.data_ptr(), kw.data_ptr(), 8, 2, st),
+                "lanczos4 horizontal")
+        out = torch.empty(size[1], size[0], Cc, dtype=torch.uint8, device=self.dev)
+        L.check(h.cover_resample_axis(rows.data_ptr(), 2, out.data_ptr(), 0, H, size[0], Cc, size[1], size[0], 0, bh.data_ptr(), kh.data_ptr(), 8, 2, st),
+                "lanczos4 vertical")
+        return out
+
+    def policy_image(self, frame_u8, size=(224, 224)):
+        """raw camera frame -> the policy's fp32 [1,3,H,W] input in [-1, 1] on the device (simpler.py:48-65): LANCZOS4 resize, then
+        process_images (x * (1/255), (x - 0.5) / 0.5)."""
+        import torch
+        from . import _lib as L
+        if isinstance(frame_u8, np.ndarray):
+            frame_u8 = torch.from_numpy(np.ascontiguousarray(_to_rgb_u8(frame_u8))).to(self.dev)
+        img = self.policy_resize(frame_u8.contiguous(), size)
+        out = torch.empty(1, 3, size[1], size[0], dtype=torch.float32, device=self.dev)
+        half = (C.c_float * 3)(0.5, 0.5, 0.5)
+        L.check(L.lib().cover_u8_hwc_to_f32_chw_scale_norm(img.data_ptr(), out.data_ptr(), size[1], size[0], C.c_float(np.float32(1 / 255.0)), half, half,
+                                                           torch.cuda.current_stream().cuda_stream), "scale + normalise")
+        return out
 
 
 def resize_with_pad(img, width: int, height: int, pad_value: float = -1.0):

@@ -82,7 +82,11 @@ typedef struct cover_gemm_epi {
     const void* a8;
     const float* a8_scale;
     int ld_a8;               /* row pitch of a8 in BYTES (>= cover_packed_k(K), multiple of 16) */
-    int _pad_a8;
+    int ld_norm_out8;        /* row pitch of norm_out8 in BYTES */
+    /* Optional e4m3 twin of norm_out (RMSNorm styles only): norm_out8 / norm_out8_scale receive exactly what cover_quantize_act_fp8
+     * would make of the stored bf16 norm_out rows -- the next GEMM's fp8 operand without another launch. */
+    void* norm_out8;
+    float* norm_out8_scale;
 } cover_gemm_epi;
 
 /* bytes needed for the packed form of an [N, K] weight (K padded to a multiple of 128, N to 16) */
@@ -497,6 +501,13 @@ int cover_stream_sync(void* stream);
  * cover_resize_bilinear_pad_f32: F.interpolate(bilinear, align_corners=False) of an fp32 [NC, Hin, Win] stack to Hr x Wr,
  *   placed at (pad_top, pad_left) of an Hout x Wout canvas filled with pad_value = resize_with_pad,
  *   lerobot_custom/lerobot/common/policies/pi0/modeling_pi0.py:131-150. */
+/* fixed_point = 2: OpenCV's 8-bit fixed-point resize arithmetic (imgproc resize.cpp; cv2.resize(..., INTER_LANCZOS4) of the policy-side
+ *   adapter, INT-ACT/src/experiments/env_adapters/simpler.py:48-52): int32 coefficients holding shorts with 11 fractional bits;
+ *   first pass uint8 -> int32 exact sums (out kind 2), second pass int32 (in kind 2) -> uint8 = saturate((sum + (1 << 21)) >> 22).
+ *   The in / out kinds are 0 = uint8, 1 = fp32, 2 = int32 (this mode only).
+ * cover_u8_hwc_to_f32_chw_scale_norm: ((float)x * scale - mean) / std, HWC uint8 -> CHW fp32: process_images of
+ *   INT-ACT/src/utils/pipeline.py:55-67 (rescale by multiplication, then normalise). */
+int cover_u8_hwc_to_f32_chw_scale_norm(const uint8_t* in, float* out, int H, int W, float scale, const float* mean3, const float* std3, void* stream);
 int cover_resample_axis(const void* in, int in_is_f32, void* out, int out_is_f32, int Hin, int Win, int C, int Hout, int Wout,
                         int axis, const int* bounds, const void* coefs, int ksize, int fixed_point, void* stream);
 int cover_u8_hwc_to_f32_chw_norm(const uint8_t* in, float* out, int H, int W, const float* mean3, const float* std3, void* stream);
@@ -508,10 +519,11 @@ int cover_resize_bilinear_pad_f32(const float* in, float* out, int NC, int Hin, 
  *   0 weight-streaming GEMM with >= 16 MB of weights (work = weight bytes)   1 LDS-tiled GEMM, ViT-sized (work = FLOPs)
  *   2 attention (work = 0)   3 small weight-streaming GEMMs (work = weight bytes)
  *   4 LDS-tiled GEMM, LLM-sized (N*K >= 16 M; work = FLOPs)   5 / 6 split-K reductions behind a weight-streaming / an LDS-tiled GEMM (work = 0)
+ *   7 LDS-tiled GEMM on the MX-scaled fp8 matrix instruction (work = FLOPs; priced against the 5 PFLOP/s fp8 peak)
  * Thread-safe (records are claimed atomically). Launches replayed from a hipGraph are not seen (neither time nor work).
  * end_n() synchronises the device and fills ms[n], count[n], work[n] (n <= COVER_PROF_CLASSES); it returns
  * COVER_EWORKSPACE when more launches were issued than max_events (sums incomplete). end() = end_n(.., 4). */
-#define COVER_PROF_CLASSES 7
+#define COVER_PROF_CLASSES 8
 int cover_profile_begin(int max_events);
 int cover_profile_end(double* ms, long long* count, double* work);
 int cover_profile_end_n(double* ms, long long* count, double* work, int n_classes);

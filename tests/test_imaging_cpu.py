@@ -77,3 +77,35 @@ def test_siglip_preprocess_matches_manual_transform():
     ref = (torch.from_numpy(np.asarray(pil).copy()).permute(2, 0, 1).float().div(255) - 0.5) / 0.5
     assert torch.equal(t, ref)
     assert torch.equal(IM.siglip_preprocess(Image.fromarray(img), 384), t)   # PIL input == ndarray input (:334-337)
+
+
+def test_cv2_lanczos4_restatement_properties():
+    """The policy-side resize (cv2.resize(..., INTER_LANCZOS4), INT-ACT/src/experiments/env_adapters/simpler.py:48-52). PARITY UNPINNED
+    at OpenCV (cv2 is neither installed nor vendored): the restatement of resize.cpp's 8-bit fixed-point path is checked on what the
+    algorithm guarantees -- identity geometry is the identity (fx = 0 -> weight 1 on the pixel itself), constants are preserved, the
+    11-bit coefficient rows sum to 2048 +- 2, border taps replicate -- and cross-checked against Pillow's LANCZOS (a = 3, antialiased:
+    another kernel) on smooth images: within 1 grey level, mean |difference| < 0.5."""
+    imgs = _images()
+    noise, smooth = imgs["noise"], imgs["smooth"]
+    assert np.array_equal(IM.cv2_resize_lanczos4(noise, (noise.shape[1], noise.shape[0])), noise)
+    const = np.full((37, 53, 3), 201, dtype=np.uint8)
+    assert (IM.cv2_resize_lanczos4(const, (224, 224)) == 201).all()
+    b, k, ks = IM.cv2_lanczos4_coeffs(640, 224)
+    assert ks == 8 and (np.abs(k.sum(1) - 2048) <= 2).all()
+    assert (b[:, 0] >= 0).all() and (b[:, 0] + b[:, 1] <= 640).all() and (b[:, 1] <= 8).all()
+    # interior spans are the eight taps sx - 3 .. sx + 4 around floor((dx + 0.5) * 640 / 224 - 0.5)
+    dx = 100
+    sx = int(np.floor((dx + 0.5) * (640 / 224) - 0.5))
+    assert tuple(b[dx]) == (sx - 3, 8)
+    out = IM.cv2_resize_lanczos4(smooth, (224, 224))
+    assert out.shape == (224, 224, 3) and out.dtype == np.uint8
+    pil = np.asarray(Image.fromarray(smooth).resize((224, 224), Image.LANCZOS)).astype(np.int32)
+    d = np.abs(out.astype(np.int32) - pil)
+    assert d.max() <= 2 and d.mean() < 0.5, (d.max(), d.mean())
+    up = IM.cv2_resize_lanczos4(smooth[:120, :160], (320, 240))
+    pu = np.asarray(Image.fromarray(smooth[:120, :160]).resize((320, 240), Image.LANCZOS)).astype(np.int32)
+    assert np.abs(up.astype(np.int32) - pu).max() <= 2
+    # the adapter's image half: uint8 [1,3,H,W] * (1/255), (x - 0.5) / 0.5
+    t = IM.simpler_preprocess_image(smooth, (224, 224))
+    ref = (torch.from_numpy(out).permute(2, 0, 1)[None] * (1 / 255.0) - 0.5) / 0.5
+    assert t.dtype == torch.float32 and torch.equal(t, ref) and float(t.min()) >= -1.0 and float(t.max()) <= 1.0

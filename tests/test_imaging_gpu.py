@@ -33,3 +33,18 @@ def test_device_pipeline_other_geometry(dev):
     g = np.random.default_rng(3).integers(0, 256, size=(224, 224, 3), dtype=np.uint8)      # an upscale through the TF stage
     pipe = IM.DeviceImagePipeline(device="cuda:0")
     assert np.array_equal(pipe.raw_to_jpg(torch.from_numpy(g).to(dev)).cpu().numpy(), IM.process_raw_image_to_jpg(g))
+
+
+@pytest.mark.parametrize("name,size", [("noise", (224, 224)), ("smooth", (224, 224)), ("blocks", (256, 192)), ("noise", (700, 500))])
+def test_device_lanczos4_policy_resize_equals_host_form(dev, name, size):
+    """SURVEY 8 f2, policy side: cv2.resize(frame, size, INTER_LANCZOS4) + process_images (simpler.py:48-65) on the device (the OpenCV
+    8-bit fixed-point mode of cover_resample_axis + cover_u8_hwc_to_f32_chw_scale_norm) against the host restatement: same integers,
+    same fp32 operations -> bit-exact. (Parity with OpenCV itself is unpinned: cv2 is not in the image -- tests/test_imaging_cpu.py.)"""
+    raw = _images()[name]
+    pipe = IM.DeviceImagePipeline(device="cuda:0")
+    out = pipe.policy_resize(torch.from_numpy(raw).to(dev), size)
+    host = IM.cv2_resize_lanczos4(raw, size)
+    assert out.dtype == torch.uint8 and tuple(out.shape) == (size[1], size[0], 3)
+    assert np.array_equal(out.cpu().numpy(), host)
+    x = pipe.policy_image(raw, size)
+    assert torch.equal(x.cpu(), IM.simpler_preprocess_image(raw, size))

@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Prefill GEMMs of a 7B decoder at M = 448 (256 patch rows + 8 x 24 text rows), weights rotating over enough copies to stay out of
+the Infinity Cache: us per launch and TFLOP/s per shape, plus the sum over a layer (what roofline_mfma.prefill measures).
+Usage: python tools/dbg/bench_prefill.py [M] [reps]   (environment knobs of gemm_bf16.hip apply: COVER_TILE_PICK, COVER_LIB_PATH ...)"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from cover_vla_amd import ops  # noqa: E402
+
+dev = torch.device("cuda:0")
+M = int(sys.argv[1]) if len(sys.argv) > 1 else 448
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 6
+shapes = [("qkv", 12288, 4096, False, False), ("o_proj", 4096, 4096, False, True), ("gate_up", 22016, 4096, True, False), ("down", 4096, 11008, False, True)]
+tot_us, tot_fl = 0.0, 0.0
+for name, N, K, glu, norm in shapes:
+    g = torch.Generator(device=dev).manual_seed(N + K)
+    copies = max(2, int(600e6 // (N * K * 2)) + 1)
+    lins = [ops.pack_linear(torch.randn(N, K, device=dev, generator=g) * 0.02, glu=glu) for _ in range(copies)]
+    a = torch.randn(M, lins[0].kp, device=dev, generator=g).bfloat16()
+    out = torch.empty(M, lins[0].n_out, dtype=torch.bfloat16, device=dev)
+    res = torch.randn(M, N, device=dev, generator=g).bfloat16() if norm else None
+    kw = dict(norm_w=torch.ones(N, device=dev), norm_out=torch.empty(M, N, dtype=torch.bfloat16, device=dev), norm_style=1, norm_eps=1e-5) if norm else {}
+    ws = ops.gemm_workspace(M, N, K, dev)
+    run = lambda i: ops.gemm(a, lins[i % copies], act="silu" if glu else "none", out=out, ws=ws, residual=res, **kw)
+    for i in range(copies):
+        run(i)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    n = reps * copies
+    e0.record()
+    for i in range(n):
+        run(i)
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) / n * 1e3
+    fl = 2.0 * M * N * K
+    tot_us += us
+    tot_fl += fl
+    print(f"M={M} {name:8s} {us:7.1f} us  {fl / us / 1e6:6.0f} TF  (incl. its split-K reduction / norm launch)", flush=True)
+    del lins
+    torch.cuda.empty_cache()
+print(f"layer: {tot_us:7.1f} us  {tot_fl / tot_us / 1e6:6.0f} TF = {tot_fl / tot_us / 1e6 / 2500:.3f} of 2.5 PF; x32 layers = {tot_us * 32 / 1e3:.2f} ms")
