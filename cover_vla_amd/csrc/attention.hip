@@ -317,7 +317,12 @@ static hipError_t launch_d(const AttnDev& a, hipStream_t st) {
     const long long qtiles = (long long)tiles * a.Hkv * a.B;
     static const char* e_max = getenv("COVER_ATTN_KSPLIT_MAX");
     static const char* e_nw8 = getenv("COVER_ATTN_NW8_MAX");
-    const long long ks_max = e_max ? atoll(e_max) : 1023, nw8_max = e_nw8 ? atoll(e_nw8) : 0;
+    long long ks_max = e_max ? atoll(e_max) : 1023;
+    const long long nw8_max = e_nw8 ? atoll(e_nw8) : 0;
+    // a pass RESUMED from a state (the chained decode pass of large-N candidate decode: 8 prompts x 64 samples x 32 heads = 1024 query
+    // tiles over ~280 keys) is a chain of ~10 dependent key tiles per wave: split the keys over the block's waves there too
+    // (config 5: 24.7 -> see profiles/ us per layer)
+    if (a.si_o != nullptr && !e_max && D <= 128) ks_max = 4095;
     if (qtiles <= ks_max) {
         // too few query tiles to fill the chip (single-token decode, ViT-sized sequences): split the key tiles over the
         // 4 (or, when even 4 waves per tile leave most CUs idle and D allows the LDS merge buffer, 8) waves of a block

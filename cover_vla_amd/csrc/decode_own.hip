@@ -59,6 +59,31 @@ __global__ __launch_bounds__(256) void decode_own_attn_k(OwnAttnDev a) {
         pos = a.positions[n];
         pos = pos < 0 ? 0 : (pos >= a.n_pos ? a.n_pos - 1 : pos);
     }
+    // ---- the cached K rows (and, while they fit the registers, V rows) are requested FIRST: they depend on nothing but the slot, and
+    //      the q / k / v + RoPE work below then runs under their latency (the chain was: indices -> qkv -> LDS -> K -> scores -> V) ----
+    constexpr bool VEARLY = NIT <= 8;
+    const int j = lane % LPK, kq = lane / LPK;            // this lane's d range [j*DPL, (j+1)*DPL) of key (KPL * it + kq)
+    const int nkeys = a.write_t;                          // cached keys (the appended one comes from LDS)
+    const size_t blk = (size_t)slot * a.slot_stride + (size_t)h * a.t_cap * D;      // elements to this (slot, h) block
+    const size_t sblk = ((size_t)slot * a.H + h) * a.t_cap;
+    uint4 kr[NIT], vr[NIT];
+    float ksc[NIT], vsc[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        int t = it * KPL + kq;
+        t = t < nkeys ? t : (nkeys > 0 ? nkeys - 1 : 0);
+        kr[it] = *(const uint4*)((const char*)a.k + (blk + (size_t)t * D) * ES + j * 16);
+        if constexpr (F8) ksc[it] = a.k_scale[sblk + t];
+    }
+    if constexpr (VEARLY) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            int t = it * KPL + kq;
+            t = t < nkeys ? t : (nkeys > 0 ? nkeys - 1 : 0);
+            vr[it] = *(const uint4*)((const char*)a.v + (blk + (size_t)t * D) * ES + j * 16);
+            if constexpr (F8) vsc[it] = a.v_scale[sblk + t];
+        }
+    }
     // ---- q / k_new / v_new of (n, h): rotation pair (i, i + HALF) per lane ----
     bf16_t* row = a.qkv + (size_t)n * a.ld_qkv;
     const int i = lane;                             // D = 64: lanes >= 32 idle in this part
@@ -134,11 +159,9 @@ __global__ __launch_bounds__(256) void decode_own_attn_k(OwnAttnDev a) {
         xs[w][2][i] = v1; xs[w][2][i + HALF] = v2;
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // one wave: LDS writes of the wave are visible to its later reads in order
-    const int j = lane % LPK, kq = lane / LPK;            // this lane's d range [j*DPL, (j+1)*DPL) of key (KPL * it + kq)
     float qv[DPL];
 #pragma unroll
     for (int e = 0; e < DPL; ++e) qv[e] = xs[w][0][j * DPL + e];
-    const int nkeys = a.write_t;                          // cached keys (the appended one comes from LDS)
     auto unpack = [&](const uint4& raw, float (&x)[DPL]) {
         const uint32_t wv[4] = {raw.x, raw.y, raw.z, raw.w};
         if constexpr (F8) {
@@ -155,18 +178,7 @@ __global__ __launch_bounds__(256) void decode_own_attn_k(OwnAttnDev a) {
             }
         }
     };
-    const size_t blk = (size_t)slot * a.slot_stride + (size_t)h * a.t_cap * D;      // elements to this (slot, h) block
-    const size_t sblk = ((size_t)slot * a.H + h) * a.t_cap;
     // ---- pass 1: scores of the cached keys + the new key ----
-    uint4 kr[NIT];
-    float ksc[NIT];
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-        int t = it * KPL + kq;
-        t = t < nkeys ? t : (nkeys > 0 ? nkeys - 1 : 0);
-        kr[it] = *(const uint4*)((const char*)a.k + (blk + (size_t)t * D) * ES + j * 16);
-        if constexpr (F8) ksc[it] = a.k_scale[sblk + t];
-    }
     float sc[NIT + 1];
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
@@ -188,15 +200,15 @@ __global__ __launch_bounds__(256) void decode_own_attn_k(OwnAttnDev a) {
         for (int o = 1; o < LPK; o <<= 1) s += __shfl_xor(s, o);
         sc[NIT] = kq == 0 ? s * a.scale_log2e : -INFINITY;
     }
-    // ---- V loads in flight while the softmax statistics are formed ----
-    uint4 vr[NIT];
-    float vsc[NIT];
+    // ---- long segments: V loads in flight while the softmax statistics are formed (K's registers are free by now) ----
+    if constexpr (!VEARLY) {
 #pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-        int t = it * KPL + kq;
-        t = t < nkeys ? t : (nkeys > 0 ? nkeys - 1 : 0);
-        vr[it] = *(const uint4*)((const char*)a.v + (blk + (size_t)t * D) * ES + j * 16);
-        if constexpr (F8) vsc[it] = a.v_scale[sblk + t];
+        for (int it = 0; it < NIT; ++it) {
+            int t = it * KPL + kq;
+            t = t < nkeys ? t : (nkeys > 0 ? nkeys - 1 : 0);
+            vr[it] = *(const uint4*)((const char*)a.v + (blk + (size_t)t * D) * ES + j * 16);
+            if constexpr (F8) vsc[it] = a.v_scale[sblk + t];
+        }
     }
     float m = -INFINITY;
 #pragma unroll

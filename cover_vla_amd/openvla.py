@@ -61,6 +61,12 @@ class OpenVLA:
             raise ValueError("own_kv must be None, 'bf16' or 'fp8'")
         self.own_kv = own_kv
         self.lm_head = ops.pack_linear(sd["lm_head.weight"].to(dev), fp8=fp8)
+        # Sampling draws from the softmax over the n_bins ACTION tokens only (the last n_bins entries of the tokenizer vocabulary,
+        # policy_wrapper.py:259-266): their logits are n_bins rows of the lm_head -- 2 MB instead of the 262 MB the full head streams
+        # per step. Same rows, same arithmetic, same logits for those tokens; greedy decoding (arg-max over the whole vocabulary)
+        # and traced runs keep the full head.
+        lo, hi = c["tok_vocab"] - c["n_bins"], c["tok_vocab"]
+        self.lm_head_actions = ops.pack_linear(sd["lm_head.weight"][lo:hi].to(dev), fp8=fp8)
         self.n_gen = 7 * horizon
         self.T0 = 1 + self.n_patches * n_cams          # [BOS] + patches
         geom = KvGeometry(c["Hkv"], c["D"], [1, max_prompts, max_candidates], [self.T0, max_text, self.n_gen])
@@ -77,6 +83,8 @@ class OpenVLA:
         self.h_sel = torch.empty(max_candidates, D, dtype=BF, device=dev)
         self.logits = torch.empty(max_candidates, c["vocab"], dtype=torch.float32, device=dev)
         self.head_ws = ops.gemm_workspace(max_candidates, c["vocab"], D, dev)
+        self.logits_actions = torch.empty(max_candidates, c["n_bins"], dtype=torch.float32, device=dev)
+        self.head_ws_actions = ops.gemm_workspace(max_candidates, c["n_bins"], D, dev)
         self.zero_slots = torch.zeros(max(max_prompts, max_candidates), dtype=torch.int32, device=dev)
         self.bos = torch.tensor([1], dtype=torch.int64, device=dev)
         self._side = None
@@ -86,6 +94,7 @@ class OpenVLA:
         # measurement switches (bench.py's profiled decision): hipGraph replay hides launches from the in-library kernel
         # timer, and the SigLIP tower on a side stream inflates the durations of the kernels it overlaps
         self.vision_graph = os.environ.get("COVER_VISION_GRAPH", "1") != "0"
+        self.slice_action_head = os.environ.get("COVER_ACTION_HEAD", "1") != "0"   # A/B knob: 0 = always the full lm_head
         self.vision_overlap = True
 
     def _ensure_bos_kv(self):
@@ -237,6 +246,12 @@ class OpenVLA:
     def _head_select(self, h, uniforms, i, temperature, tokens, sel, trace):
         N = h.shape[0]
         hn = ops.rmsnorm(h, self.llm.final_norm, 1e-5, w_offset=0.0, style=1)
+        if uniforms is not None and (trace is None or "events" in trace) and self.slice_action_head:
+            lg = ops.gemm(hn, self.lm_head_actions, out=self.logits_actions[:N], ws=self.head_ws_actions)
+            t, s = ops.token_select(lg, 0, self.c["n_bins"], uniform=uniforms[:, i].contiguous(), temperature=temperature)
+            tokens[:, i].copy_(t + self.action_lo)
+            sel[:, i].copy_(s)
+            return
         lg = ops.gemm(hn, self.lm_head, out=self.logits[:N], ws=self.head_ws)
         if trace is not None and "events" not in trace:
             trace.setdefault("logits", []).append(lg.clone())

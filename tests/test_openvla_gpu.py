@@ -125,6 +125,24 @@ def test_openvla_small_matches_oracle(dev, greedy, n_cams, horizon, wdtype, own_
         assert free.shape == (P, n_gen)
 
 
+def test_openvla_action_head_slice_equals_full_head(dev):
+    """Sampling needs the logits of the n_bins action tokens only: the sliced lm_head (n_bins rows) must reproduce the full head's picks.
+    Same weight rows and arithmetic; only the K-slice plan of the weight-streaming GEMM (hence the fp32 summation order) may differ, so
+    the sampled tokens are required to agree except where a uniform sits within fp32 rounding of a CDF edge (none expected in 168 draws)."""
+    from cover_vla_amd.openvla import OpenVLA
+    c, sd, frame, toks, lens, u = _case(seed=21, n_samples=4, n_gen=14)
+    model = OpenVLA(sd, c, device="cuda:0", max_prompts=4, max_candidates=12, max_text=toks.shape[1], horizon=2)
+    args = (frame.to(dev), toks.to(dev), lens.to(dev), 4, u.to(dev), 0.9)
+    assert model.slice_action_head
+    t_slice, s_slice = model.sample(*args)
+    model.slice_action_head = False
+    t_full, s_full = model.sample(*args)
+    assert t_slice.shape == (12, 14) and int(t_slice.min()) >= c["tok_vocab"] - c["n_bins"] and int(t_slice.max()) < c["tok_vocab"]
+    assert (t_slice == t_full).float().mean().item() >= 0.99
+    same = t_slice == t_full
+    assert torch.allclose(s_slice[same], s_full[same], atol=1e-4)
+
+
 def test_siglip2_features_match_oracle(dev):
     from cover_ref import blocks as Bk, openvla as OR
     from cover_vla_amd.verifier import SigLIP2Encoder
