@@ -308,13 +308,16 @@ def roofline_objects(ms, cnt, work, ms_per_step, lib_sha):
     if cnt[0] > 0 and ms[0] > 0:
         ach = work[0] / (ms[0] * 1e-3) / 1e9
         traffic, tnote = None, "no PMC pass recorded for this build"
-        try:  # HBM bytes per launch from the PMC pass of the SAME build (rocprofv3 --pmc FETCH_SIZE, x2 gfx950 correction)
-            with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as f:
-                t = json.load(f)
-            if t.get("lib_sha16") == lib_sha:
-                traffic, tnote = round(t["hbm_fetch_bytes_per_launch"]), f"profiles/r02_pmc_traffic.json (lib {lib_sha})"
-            else:
-                tnote = f"profiles/r02_pmc_traffic.json is from lib {t.get('lib_sha16')}, this run is {lib_sha}: not quoted"
+        try:  # HBM bytes per launch from the PMC pass of the SAME build (rocprofv3 --pmc FETCH_SIZE, x2 gfx950 correction): newest matching file
+            import glob
+            for fn in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
+                with open(fn) as f:
+                    t = json.load(f)
+                rel = os.path.relpath(fn, ROOT)
+                if t.get("lib_sha16") == lib_sha:
+                    traffic, tnote = round(t["hbm_fetch_bytes_per_launch"]), f"{rel} (lib {lib_sha})"
+                    break
+                tnote = f"{rel} is from lib {t.get('lib_sha16')}, this run is {lib_sha}: not quoted"
         except Exception:
             pass
         guard("roofline", {"bound": "hbm", "kernel": "gemm_skinny2 / gemm_skinny3 (weight-streaming GEMMs of the 7B decode passes and lm_head, M = 32, >= 16 MB of weights each)",

@@ -64,7 +64,7 @@ class OpenVLA:
         # Sampling draws from the softmax over the n_bins ACTION tokens only (the last n_bins entries of the tokenizer vocabulary,
         # policy_wrapper.py:259-266): their logits are n_bins rows of the lm_head -- 2 MB instead of the 262 MB the full head streams
         # per step. Same rows, same arithmetic, same logits for those tokens; greedy decoding (arg-max over the whole vocabulary)
-        # and traced runs keep the full head.
+        # and traced runs keep the full head. Opt-in (slice_action_head below).
         lo, hi = c["tok_vocab"] - c["n_bins"], c["tok_vocab"]
         self.lm_head_actions = ops.pack_linear(sd["lm_head.weight"][lo:hi].to(dev), fp8=fp8)
         self.n_gen = 7 * horizon
@@ -94,7 +94,9 @@ class OpenVLA:
         # measurement switches (bench.py's profiled decision): hipGraph replay hides launches from the in-library kernel
         # timer, and the SigLIP tower on a side stream inflates the durations of the kernels it overlaps
         self.vision_graph = os.environ.get("COVER_VISION_GRAPH", "1") != "0"
-        self.slice_action_head = os.environ.get("COVER_ACTION_HEAD", "1") != "0"   # A/B knob: 0 = always the full lm_head
+        # opt-in (COVER_ACTION_HEAD=1 or the attribute): measured 34.18-34.48 vs 34.26-34.28 ms per decision at N = 32 -- the seven
+        # lm_head launches hide behind the host work between decode passes -- so the default keeps the full head
+        self.slice_action_head = os.environ.get("COVER_ACTION_HEAD", "0") == "1"
         self.vision_overlap = True
 
     def _ensure_bos_kv(self):

@@ -133,7 +133,7 @@ def test_openvla_action_head_slice_equals_full_head(dev):
     c, sd, frame, toks, lens, u = _case(seed=21, n_samples=4, n_gen=14)
     model = OpenVLA(sd, c, device="cuda:0", max_prompts=4, max_candidates=12, max_text=toks.shape[1], horizon=2)
     args = (frame.to(dev), toks.to(dev), lens.to(dev), 4, u.to(dev), 0.9)
-    assert model.slice_action_head
+    model.slice_action_head = True
     t_slice, s_slice = model.sample(*args)
     model.slice_action_head = False
     t_full, s_full = model.sample(*args)
