@@ -218,6 +218,14 @@ extern "C" int cover_pc_debug(unsigned long long* out, int reset) {
 #define PCT() __builtin_readcyclecounter()
 extern "C" int cover_pc_timeline(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pc_tl), sizeof(g_pc_tl)); }
 #endif
+#ifdef COVER_PC_ABL
+// Ablation builds (tools/dbg/abl_prefill.sh, -DCOVER_PC_ABL=<bits>, compile-time): bit 0 = the MFMA waves skip their MFMAs, bit 1 = they
+// skip the LDS fragment reads, bit 2 = the loaders skip the weight pieces, bit 3 = the loaders skip the activation pieces.
+// Results are garbage by design. (A run-time flag trips a backend bug: "V_CMP_NE_U32 0, $src_shared_base: incorrect register class".)
+#define PC_ABL(bit) ((COVER_PC_ABL) & (bit))
+#else
+#define PC_ABL(bit) 0
+#endif
 template <int WM, int WN, int NST, int NL = 1, int CGM = 2, int CGN = 2>
 __global__ __launch_bounds__(64 * (CGM * CGN + NL)) void gemm_tiled_pc(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ Wp,
                                                      void* C, int ldc, int M, int N, int Kp, EpiDev epi, int tiles_m,
@@ -287,8 +295,11 @@ __global__ __launch_bounds__(64 * (CGM * CGN + NL)) void gemm_tiled_pc(const bf1
         // 540-690 at the barrier. s_setprio 3 on the loaders changes nothing.)
         auto issue = [&](int buf, int kt) {
 #pragma unroll
-            for (int i = 0; i < PT; ++i)
-                glds16_asm(src[i] + kt * step[i], dst[i] + buf * ((l + i * NL) < AT ? A_BYTES : B_BYTES));
+            for (int i = 0; i < PT; ++i) {
+                const bool is_a = (l + i * NL) < AT;
+                if (!((PC_ABL(4) && !is_a) || (PC_ABL(8) && is_a)))
+                    glds16_asm(src[i] + kt * step[i], dst[i] + buf * (is_a ? A_BYTES : B_BYTES));
+            }
         };
 #pragma unroll
         for (int s = 0; s < NST - 1; ++s)
@@ -347,10 +358,12 @@ __global__ __launch_bounds__(64 * (CGM * CGN + NL)) void gemm_tiled_pc(const bf1
     auto read_frags = [&](int stage, int ks, u32x4(&xf)[WM], u32x4(&wf)[WN]) {
         const uint32_t aa = (ks ? a_addr1 : a_addr0) + stage * A_BYTES;
         const uint32_t ba = b_addr + stage * B_BYTES + ks * 1024;
+        if (!PC_ABL(2)) {
 #pragma unroll
-        for (int f = 0; f < WM; ++f) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(xf[f]) : "v"(aa), "n"(f * 2048));
+            for (int f = 0; f < WM; ++f) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(xf[f]) : "v"(aa), "n"(f * 2048));
 #pragma unroll
-        for (int b = 0; b < WN; ++b) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(wf[b]) : "v"(ba), "n"(b * 2048));
+            for (int b = 0; b < WN; ++b) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(wf[b]) : "v"(ba), "n"(b * 2048));
+        }
     };
     auto landed = [&](u32x4(&xf)[WM], u32x4(&wf)[WN]) {   // ties the fragments to the wait that precedes this call
 #pragma unroll
@@ -359,13 +372,19 @@ __global__ __launch_bounds__(64 * (CGM * CGN + NL)) void gemm_tiled_pc(const bf1
         for (int b = 0; b < WN; ++b) asm volatile("" : "+v"(wf[b]));
     };
     auto mfmas = [&](const u32x4(&xf)[WM], const u32x4(&wf)[WN]) {
+        if (!PC_ABL(1)) {
 #pragma unroll
-        for (int b = 0; b < WN; ++b)
+            for (int b = 0; b < WN; ++b)
 #pragma unroll
-            for (int f = 0; f < WM; ++f)
-                acc[b][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[b]), __builtin_bit_cast(bf16x8, xf[f]), acc[b][f], 0, 0, 0);
+                for (int f = 0; f < WM; ++f)
+                    acc[b][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[b]), __builtin_bit_cast(bf16x8, xf[f]), acc[b][f], 0, 0, 0);
+        }
     };
+#ifdef COVER_PC_ABL
+    u32x4 xa[WM] = {}, wa[WN] = {}, xb[WM] = {}, wb[WN] = {};   // (the read-skipping arm multiplies whatever is here)
+#else
     u32x4 xa[WM], wa[WN], xb[WM], wb[WN];
+#endif
     int cur = 0;
     __builtin_amdgcn_s_barrier();
     PCTL(1);

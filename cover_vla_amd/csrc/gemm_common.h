@@ -437,3 +437,4 @@ bool gemm_fp8_tiled_supported(int pick);
 hipError_t launch_gemm_fp8_tiled(int pick, const uint8_t* A8, int lda8, const float* a_scale, const uint8_t* W8, const float* w_scale, void* C, int ldc,
                                  int M, int N, int Kp, const EpiDev& epi, int tiles_m, int tiles_n, int kt_per, int S, float* partial, size_t lds,
                                  int prof_cls, double prof_work, hipStream_t st);
+
