@@ -160,3 +160,38 @@ def test_fullsize_verifier_permutation(pipe, dev):
     bi = int(s.view(8, 4)[bg].argmax())
     assert r["result"].cpu().tolist()[:3] == [bg * 4 + bi, bg, bi]
     assert abs(float((pf[0] ** 2).sum(-1).mean()) - 1.0) < 1e-3 and abs(float((tf[0] ** 2).sum(-1).mean()) - 1.0) < 1e-3
+
+
+def test_fullsize_config5_fp8_n512_horizon8(pipe, dev):
+    """BASELINE config 5 at FULL size: OpenVLA-7B, N = 512 = 8 prompts x 64 samples, action-chunk horizon 8 (56 action tokens per
+    candidate), e4m3 weights AND per-row e4m3 activations on the fp8 MFMA (M = 512 decode rows), e4m3 own-token KV cache, verifier
+    histories from the first four actions of every chunk. Size-independent properties (the CPU oracle cannot run this in seconds; the
+    small-size oracle parity of every piece is tests/test_openvla_gpu.py, tests/test_fp8_gpu.py, tests/test_kernels_gpu.py):
+    determinism, token range, row independence (samples of a prompt given IDENTICAL uniforms produce identical rows -- through the fp8
+    GEMMs' row tiles, the per-row activation scales and the per-candidate own-token cache), prompt-permutation equivariance."""
+    import bench
+    del pipe                                                   # (fixture ordering only: the 7B bf16 pipeline is built once per module)
+    torch.cuda.empty_cache()
+    p5 = bench.Pipeline(dev, small=False, n_samples=64, weight_dtype="fp8", horizon=8)
+    assert p5.own_kv == "fp8" and p5.policy.llm.fp8_weights and p5.policy.n_gen == 56
+    i, P, S, G = p5.inp, 8, 64, 56
+    idx1, tok1, _ = p5.decision()
+    idx2, tok2, _ = p5.decision()
+    assert idx1 == idx2 and torch.equal(tok1, tok2)
+    assert tok1.shape == (P * S, G) and 0 <= idx1 < P * S
+    lo, hi = p5.c["tok_vocab"] - p5.c["n_bins"], p5.c["tok_vocab"]
+    assert int(tok1.min()) >= lo and int(tok1.max()) < hi
+    assert torch.isfinite(p5.last_scores).all()
+    # row independence: every sample of a prompt draws the uniforms of the prompt's first sample
+    u = i["u"].view(P, S, G)[:, :1].expand(P, S, G).reshape(P * S, G).contiguous()
+    tok, _ = p5.policy.sample(i["frame"], i["toks"], i["lens"], S, u, 1.0)
+    tv = tok.view(P, S, G)
+    assert torch.equal(tv, tv[:, :1].expand_as(tv))
+    # different uniforms do give different candidates (the check above is not vacuous)
+    assert not torch.equal(tok1.view(P, S, G)[:, 0], tok1.view(P, S, G)[:, 1])
+    # prompt-permutation equivariance
+    perm = torch.tensor([3, 0, 7, 1, 6, 2, 5, 4], device=dev)
+    tokp, _ = p5.policy.sample(i["frame"], i["toks"][perm], i["lens"][perm], S, u.view(P, S, G)[perm].reshape(P * S, G).contiguous(), 1.0)
+    assert torch.equal(tokp.view(P, S, G), tv[perm])
+    del p5
+    torch.cuda.empty_cache()
