@@ -474,8 +474,15 @@ int cover_decoder_forward(const cover_dec_desc* d, const cover_dec_pass* p, void
         if (rows <= 64 && p->n_groups == 1 && (variant == 0 || variant == 3) && p->groups[0].own_kv_mode == 0)
             HIPCHK(launch_gemm_skinny_partial((const bf16_t*)h, dim, (const bf16_t*)L.qkv_w, (float*)sk, skb, rows, nqkv, dim, &qkv_splits, st,
                                               L.qkv_w8, L.qkv_s), "dec qkv (partials)");
-        else
-            HIPCHK(launch_gemm_bf16((const bf16_t*)h, dim, (const bf16_t*)L.qkv_w, qkv, nqkv, rows, nqkv, dim, &e, (float*)sk, skb, variant, st), "dec qkv");
+        else {
+            // few-token groups on the LDS tiles (the pi0 action expert: 200 rows, T = 5): a split-K launch leaves its slabs for
+            // rope_kv_write to fold as well (same sums, same order, same rounding as the reduction launch it replaces)
+            const char* fold_env = getenv("COVER_QKV_FOLD");   // A/B knob (read per call: the tests toggle it): 0 keeps the reduction launch
+            const bool fold = rows > 64 && p->n_groups == 1 && p->groups[0].own_kv_mode == 0 && p->groups[0].T < 16 && !f8 &&
+                              !(p->groups[0].seg0_shared && p->groups[0].T == 1) && !(fold_env && fold_env[0] == '0');
+            HIPCHK(launch_gemm_bf16((const bf16_t*)h, dim, (const bf16_t*)L.qkv_w, qkv, nqkv, rows, nqkv, dim, &e, (float*)sk, skb, variant, st,
+                                    fold ? &qkv_splits : nullptr), "dec qkv");
+        }
         cover_rope_args ras[2];
         cover_attn_args aas[2];
         bool pending[2] = {false, false};

@@ -1501,7 +1501,8 @@ static hipError_t run_norm(const EpiDev& epi, void* C, int ldc, int M, int Nout,
 }
 
 hipError_t launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* Wp, void* C, int ldc, int M, int N, int K,
-                            const cover_gemm_epi* epi_in, float* ws, size_t ws_bytes, int variant, hipStream_t st) {
+                            const cover_gemm_epi* epi_in, float* ws, size_t ws_bytes, int variant, hipStream_t st, int* splits_out) {
+    if (splits_out) *splits_out = 0;
     if (M <= 0 || N <= 0) return hipSuccess;
     const int Kp = (K + 127) / 128 * 128;
     EpiDev epi = make_epi(epi_in);
@@ -1787,6 +1788,11 @@ hipError_t launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* Wp, void* C,
 #undef LAUNCH_T
     if (e == hipSuccess) e = hipGetLastError();
     bool norm_done = false;
+    if (e == hipSuccess && S > 1 && splits_out && !epi.residual && !epi.lscale && epi.act == ACT_NONE && epi.out_scale == 1.0f && !epi.glu &&
+        !epi.norm_out) {
+        *splits_out = S;   // the caller folds the slabs (+ bias, bf16 rounding) itself
+        return e;
+    }
     if (e == hipSuccess && S > 1) {
         const bool want_norm = epi.norm_w != nullptr && epi.norm_out != nullptr;
         if (want_norm && !epi.glu && !epi.out_f32 && (N % 8) == 0 && N <= 8192 && (ldc % 8) == 0 && (epi.ld_norm_out % 8) == 0 && (((uintptr_t)epi.norm_w) & 15) == 0) {

@@ -11,7 +11,9 @@ typedef uint16_t bf16_t;
 // C[M,N] = epi(A[M,K] x W[N,K]^T); W pre-packed by cover_pack_weight_bf16 (fragment-major).
 hipError_t launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* Wp, void* C, int ldc, int M, int N, int K,
                             const cover_gemm_epi* epi, float* splitk_ws, size_t splitk_ws_bytes, int variant,
-                            hipStream_t st);
+                            hipStream_t st, int* splits_out = nullptr);
+// splits_out (optional): a split-K launch of the LDS-tiled kernels with a bias-only epilogue leaves its S raw fp32 slabs [S][M][N] in ws
+// and returns S here instead of folding them (the decoder folds them in rope_kv_write: one launch less per layer); 0 = C is written.
 hipError_t launch_gemm_skinny_partial(const bf16_t* A, int lda, const bf16_t* Wp, float* ws, size_t ws_bytes, int M, int N,
                                       int K, int* S_out, hipStream_t st, const void* w8 = nullptr, const float* w8s = nullptr);
 hipError_t launch_quantize_rows_fp8(const bf16_t* W, int ldw, int N, int K, float* scales, bf16_t* Wdq, hipStream_t st);

@@ -449,6 +449,53 @@ def test_full_width_gemma_layers_match_reference_g2(dev):
     assert rk < 2e-3 and rv < 2e-3
 
 
+def test_expert_layer_200_rows_qkv_slabs_folded_by_rope_equals_reduction_launch(dev):
+    """The pi0 action expert at its real shapes and the P1 batch (40 candidates x 5 suffix tokens = 200 rows over 8 prompts' cached
+    prefixes): the split-K slabs of the tiled QKV GEMM are folded by rope_kv_write (capi.hip, COVER_QKV_FOLD) -- bit-identical layer
+    output and suffix K / V to the path with the separate reduction launch."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_oracle_golden import _g2_case
+    from cover_vla_amd import ops
+    from cover_vla_amd.models import BF, Decoder, KvGeometry
+    g2, seed, (prefix, pad, att, suffix, s_pad, s_att), gold = _g2_case()
+    sd = synth.pi0_state(g2, seed=seed)
+    sub = lambda p: {k[len(p):]: v for k, v in sd.items() if k.startswith(p)}
+    P, T, D = prefix.shape
+    S, W = suffix.shape[1], suffix.shape[2]
+    B = 40
+    geom = KvGeometry(g2["Hkv"], g2["D"], [P, B], [T, S])
+    n_pos = T + S + 8
+    lm = Decoder(sub("lm."), dim=g2["lm_dim"], layers=1, Hq=g2["Hq"], Hkv=g2["Hkv"], D=g2["D"], mlp=g2["lm_mlp"], act="gelu_tanh",
+                 norm="gemma", eps=1e-6, rope="pi0", n_pos=n_pos, device="cuda:0", cache=geom)
+    ex = Decoder(sub("expert."), dim=g2["ex_dim"], layers=1, Hq=g2["Hq"], Hkv=g2["Hkv"], D=g2["D"], mlp=g2["ex_mlp"], act="gelu_tanh",
+                 norm="gemma", eps=1e-6, rope="pi0", n_pos=n_pos, device="cuda:0", share_cache_with=lm, final_norm_bf16=False)
+    plen = pad.sum(1).to(torch.int32).to(dev)
+    ppos = (torch.cumsum(pad, dim=1) - 1).clamp(min=0).to(torch.int32).contiguous().to(dev)
+    x = prefix.clone().to(dev).view(P * T, D)
+    lm.forward(x, [lm.group(P, T, ppos.view(-1), [dict(region=0, length=T, len_of_batch=plen)], 0)], final_norm=True)
+    gen = torch.Generator().manual_seed(5)
+    suf = (suffix[:1].repeat(B, 1, 1) + 0.1 * torch.randn(B, S, W, generator=gen)).to(dev)
+    row_prompt = (torch.arange(B, dtype=torch.int32) % P).to(dev)
+    row_plen = plen[row_prompt.long()].contiguous()
+    vis_len = torch.tensor([1] + [S] * (S - 1), dtype=torch.int32, device=dev)
+    spos = (row_plen[:, None] + torch.arange(S, device=dev, dtype=torch.int32)[None]).contiguous()
+    g1 = ex.group(B, S, spos.view(-1), [dict(region=0, length=T, len_of_batch=row_plen, slot_of_batch=row_prompt),
+                                         dict(region=1, length=S, mask=ops.MASK_VISLEN, vis_len=vis_len)], 1)
+    outs = []
+    for fold in ("0", "1"):
+        os.environ["COVER_QKV_FOLD"] = fold
+        try:
+            xb = torch.empty(B * S, W, dtype=BF, device=dev)
+            ex.forward(xb, [g1], final_norm=True, x_f32=suf.view(B * S, W).contiguous())
+            torch.cuda.synchronize()
+            outs.append((xb.clone(), ex.k_cache[0].clone(), ex.vt_cache[0].clone()))
+        finally:
+            os.environ.pop("COVER_QKV_FOLD", None)
+    assert torch.isfinite(outs[0][0].float()).all() and outs[0][0].float().abs().max() > 0
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a, b)
+
+
 # ------------------------------------------------------------------------------------------------ serving boundary on the device
 def test_policy_server_composes_real_sampler_and_verifier(dev):
     """one served request end to end -- packed observation -> PolicySession -> VerifiedPolicy(sample = the OpenVLA
