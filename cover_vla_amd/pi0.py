@@ -58,6 +58,7 @@ class PI0FlowMatching:
         self.vis_len = torch.tensor([1] + [S] * self.chunk, dtype=torch.int32, device=dev)
         self.max_batch, self.max_prompts, self.max_lang = max_batch, max_prompts, max_lang
         self._den = {}     # static buffers (+ hipGraph) of the denoise loop per batch size
+        self._fold = {}    # folded suffix-embedding constants per step size (_suffix_fold)
         self._cap = None   # capture stream
 
     # ---------------------------------------------------------------------------------------------- prefix
@@ -100,6 +101,33 @@ class PI0FlowMatching:
                 cls[r] = len(reps)
                 reps.append(r)
         return cls
+
+    def _suffix_fold(self, dt: float):
+        """Constants of the folded suffix embedding, built once per step size on the device with the library's own fp32 GEMM.
+        embed_suffix (modeling_pi0.py:593-609) computes, all in fp32, hid = silu(W1 [W_in x + b_in ; bf16(time_emb(t))] + b1). Nothing
+        between x and the SiLU is non-linear or rounded to bf16, and the Euler schedule t = 1, 1 + dt, ... is fixed (:697-715), so with
+        W1 = [W1a | W1b]:  hid = silu(x (W1a W_in)^T + c_t),  c_t = W1a b_in + W1b bf16(time_emb(t)) + b1 -- a 32-deep contraction per
+        step instead of a 2048-deep one, and no time-embedding / concat launches. Same value up to the order of the fp32 sums."""
+        key = round(float(dt), 9)
+        f = self._fold.get(key)
+        if f is not None:
+            return f
+        W = self.W
+        w_in, b_in = self.p["action_in_proj"]
+        w1, b1 = self.p["action_time_mlp_in"]
+        w1a, w1b = w1[:, :W], w1[:, W:]
+        times, t, dt32 = [], torch.tensor(1.0, dtype=torch.float32), torch.tensor(dt, dtype=torch.float32)
+        while t >= -dt32 / 2:
+            times.append(float(t))
+            t = t + dt32
+        tv = torch.tensor(times, dtype=torch.float32, device=self.dev)
+        temb = ops.cast_bf16_to_f32(ops.sincos_time_embed(tv, W, 4e-3, 4.0))                   # [steps, W], bf16-rounded as the reference's
+        wc = ops.gemm_f32(w1a, w_in, b_is_kn=True)                                               # [W, A] = W1a @ W_in
+        v0 = ops.gemm_f32(b_in.view(1, W).contiguous(), w1a)                                      # [1, W] = W1a b_in
+        ctab = ops.gemm_f32(temb, w1b, bias=b1, residual=v0.expand(len(times), W).contiguous())  # [steps, W]
+        f = dict(Wc=wc.contiguous(), ctab=ctab.contiguous(), steps=len(times))
+        self._fold[key] = f
+        return f
 
     def sample_actions(self, images: List[torch.Tensor], img_masks: List[torch.Tensor], lang_tokens: torch.Tensor,
                        lang_masks: torch.Tensor, state: torch.Tensor, noise: Optional[torch.Tensor] = None,
@@ -203,16 +231,25 @@ class PI0FlowMatching:
         dt = -1.0 / self.num_steps
         vs = []
 
+        fold = self._suffix_fold(dt) if os.environ.get("COVER_PI0_SUFFIX_FOLD", "1") != "0" else None
+
         def euler_loop():
             # the reference loops `while time >= -dt/2` on an fp32 tensor: exactly num_steps iterations (modeling_pi0.py:697-715)
             time = torch.tensor(1.0, dtype=torch.float32)
             dt32 = torch.tensor(dt, dtype=torch.float32)
+            step = 0
             while time >= -dt32 / 2:
-                tvec.fill_(float(time))
-                ops.sincos_time_embed(tvec, W, 4e-3, 4.0, out=temb)
-                ops.cast_bf16_to_f32(temb, out=cat[:, W:])
-                ops.gemm_f32(x_t.view(B * self.chunk, A), self.p["action_in_proj"][0], bias=self.p["action_in_proj"][1], out=cat[:, :W])
-                ops.gemm_f32(cat, self.p["action_time_mlp_in"][0], bias=self.p["action_time_mlp_in"][1], act="silu", out=hid)
+                if fold is not None:
+                    # embed_suffix (modeling_pi0.py:569-629) with its two linear maps in front of the SiLU folded (see _suffix_fold):
+                    # hid = silu(x_t Wc^T + c_step): two launches per step instead of six
+                    ops.gemm_f32(x_t.view(B * self.chunk, A), fold["Wc"], bias=fold["ctab"][step], act="silu", out=hid)
+                else:
+                    tvec.fill_(float(time))
+                    ops.sincos_time_embed(tvec, W, 4e-3, 4.0, out=temb)
+                    ops.cast_bf16_to_f32(temb, out=cat[:, W:])
+                    ops.gemm_f32(x_t.view(B * self.chunk, A), self.p["action_in_proj"][0], bias=self.p["action_in_proj"][1], out=cat[:, :W])
+                    ops.gemm_f32(cat, self.p["action_time_mlp_in"][0], bias=self.p["action_time_mlp_in"][1], act="silu", out=hid)
+                step += 1
                 wo, bo = self.p["action_time_mlp_out"]
                 ops.gemm_f32_raw(hid.data_ptr(), W, 1, wo.data_ptr(), W, 1, suffix.data_ptr() + 4 * W, W, self.chunk, W, W,
                                  bias=bo, batch=B, a_bs=self.chunk * W, c_bs=S * W)  # rows 1..chunk of every suffix
