@@ -14,6 +14,8 @@ dev = torch.device("cuda:0")
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 448
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 6
 shapes = [("qkv", 12288, 4096, False, False), ("o_proj", 4096, 4096, False, True), ("gate_up", 22016, 4096, True, False), ("down", 4096, 11008, False, True)]
+if os.environ.get("SHAPES") == "pi0":   # Gemma-2B prefix pass of the pi0 policy (M = 8 prompts x 328 tokens = 2624)
+    shapes = [("qkv", 2560, 2048, False, False), ("o_proj", 2048, 2048, False, True), ("gate_up", 32768, 2048, True, False), ("down", 2048, 16384, False, True)]
 tot_us, tot_fl = 0.0, 0.0
 for name, N, K, glu, norm in shapes:
     g = torch.Generator(device=dev).manual_seed(N + K)
