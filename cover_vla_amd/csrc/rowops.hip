@@ -204,16 +204,76 @@ __device__ __forceinline__ void rope_v_body(const cover_rope_args& a, int wid) {
     }
 }
 
+// q / k heads of multi-token groups, vectorised: a lane owns 8 consecutive elements of BOTH halves of one (row, head) -- two 16-byte
+// loads, the 2 x 32 bytes of its cos / sin entries, two 16-byte stores -- so a wave rotates 64 / (D / 16) heads instead of one
+// (prefill of a 7B decoder, 448 rows x 64 q / k heads: 28 672 one-head waves of 2-byte accesses were 5 rounds of resident waves, each a
+// chain of three dependent loads). Same per-element arithmetic as the scalar body below.
+__host__ __device__ __forceinline__ bool rope_qk_vec(const cover_rope_args& a) {
+    return a.T >= 16 && a.n_splits <= 0 && (a.ld_qkv & 7) == 0 && (((uintptr_t)a.qkv) & 15) == 0 && (a.D == 64 || a.D == 128 || a.D == 256) &&
+           a.rope_mode != 0 && (((uintptr_t)a.cos_table | (uintptr_t)a.sin_table) & 15) == 0 &&
+           (!a.k_cache || ((((uintptr_t)a.k_cache) & 15) == 0 && ((a.k_slot_stride | a.k_t_stride | a.k_h_stride) & 7) == 0));
+}
+__device__ __forceinline__ void rope_qk_vec_body(const cover_rope_args& a, int wid) {
+    const int lane = threadIdx.x & 63;
+    const int half = a.D >> 1, lpi = half >> 3, ipw = 64 / lpi;
+    const int nqk = a.Hq + a.Hkv;
+    const long long item = (long long)wid * ipw + lane / lpi;
+    if (item >= (long long)a.B * a.T * nqk) return;
+    const int c = lane % lpi;
+    const int row = (int)(item / nqk), hh = (int)(item - (long long)row * nqk);
+    const int b = row / a.T, t = row - b * a.T;
+    bf16_t* src = (bf16_t*)a.qkv + (size_t)row * a.ld_qkv + (size_t)hh * a.D;
+    bf16_t* dst = src;
+    if (hh >= a.Hq && a.k_cache) {
+        const int slot = a.slot_of_batch ? a.slot_of_batch[b] : b;
+        const int tt = a.t_offset + (a.t_offset_of_batch ? a.t_offset_of_batch[b] : 0) + t;
+        dst = (bf16_t*)a.k_cache + (size_t)slot * a.k_slot_stride + (size_t)tt * a.k_t_stride + (size_t)(hh - a.Hq) * a.k_h_stride;
+    }
+    int pos = a.positions ? a.positions[row] : t;
+    pos = pos < 0 ? 0 : (pos >= a.n_pos ? a.n_pos - 1 : pos);
+    const float* ct = a.cos_table + (size_t)pos * half + c * 8;
+    const float* sn = a.sin_table + (size_t)pos * half + c * 8;
+    const uint4 u1 = *(const uint4*)(src + c * 8), u2 = *(const uint4*)(src + half + c * 8);
+    const float4 c0 = *(const float4*)ct, c1 = *(const float4*)(ct + 4), s0 = *(const float4*)sn, s1 = *(const float4*)(sn + 4);
+    const uint32_t w1[4] = {u1.x, u1.y, u1.z, u1.w}, w2[4] = {u2.x, u2.y, u2.z, u2.w};
+    const float cv[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w}, sv[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+    float o1[8], o2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float x1 = __uint_as_float((e & 1) ? (w1[e >> 1] & 0xffff0000u) : (w1[e >> 1] << 16));
+        const float x2 = __uint_as_float((e & 1) ? (w2[e >> 1] & 0xffff0000u) : (w2[e >> 1] << 16));
+        float cc = cv[e], ss = sv[e];
+        if (a.rope_mode == 2) {  // HF rotate_half in bf16 arithmetic
+            cc = bfround(cc); ss = bfround(ss);
+            o1[e] = bfround(bfround(x1 * cc) + bfround(-x2 * ss));
+            o2[e] = bfround(bfround(x2 * cc) + bfround(x1 * ss));
+        } else {  // apply_rope (paligemma_with_expert.py:34-57): fp32, one rounding
+#pragma clang fp contract(off)   // torch rounds each product: no FMA here
+            o1[e] = x1 * cc - x2 * ss;
+            o2[e] = x2 * cc + x1 * ss;
+        }
+    }
+    uint4 r1, r2;
+    r1.x = pack_bf2(o1[0], o1[1]); r1.y = pack_bf2(o1[2], o1[3]); r1.z = pack_bf2(o1[4], o1[5]); r1.w = pack_bf2(o1[6], o1[7]);
+    r2.x = pack_bf2(o2[0], o2[1]); r2.y = pack_bf2(o2[2], o2[3]); r2.z = pack_bf2(o2[4], o2[5]); r2.w = pack_bf2(o2[6], o2[7]);
+    *(uint4*)(dst + c * 8) = r1;
+    *(uint4*)(dst + half + c * 8) = r2;
+}
+
 __device__ __forceinline__ void rope_kv_body(const cover_rope_args& a, int wid) {
     const int lane = threadIdx.x & 63;
     const int nh = a.Hq + 2 * a.Hkv;
     const int rows = a.B * a.T;
-    if (rope_v_tokens(a)) {   // q / k heads one wave per (row, head) as below; the V heads by token groups
+    if (rope_v_tokens(a)) {   // q / k heads one wave per (row, head) as below (or vectorised); the V heads by token groups
         const int nqk = a.Hq + a.Hkv;
-        if (wid >= rows * nqk) {
-            if (wid < rows * nqk + rope_v_waves(a)) rope_v_body(a, wid - rows * nqk);
+        const bool vec = rope_qk_vec(a);
+        const int ipw = vec ? 64 / (a.D >> 4) : 1;
+        const int qk_waves = (rows * nqk + ipw - 1) / ipw;
+        if (wid >= qk_waves) {
+            if (wid < qk_waves + rope_v_waves(a)) rope_v_body(a, wid - qk_waves);
             return;
         }
+        if (vec) { rope_qk_vec_body(a, wid); return; }
         const int row = wid / nqk, hh = wid - row * nqk;
         wid = row * nh + hh;
     }
@@ -288,7 +348,8 @@ static bool rope_args_ok(const cover_rope_args* a) {
 static long long rope_waves_host(const cover_rope_args* a) {
     const bool vt = a->T >= 16 && a->n_splits <= 0 && (a->D & 7) == 0 && (a->ld_qkv & 7) == 0 && (((uintptr_t)a->qkv) & 15) == 0;
     if (!vt) return (long long)a->B * a->T * (a->Hq + 2 * a->Hkv);
-    return (long long)a->B * a->T * (a->Hq + a->Hkv) + (long long)a->B * a->Hkv * (a->D >> 3) * ((a->T + 63) >> 6);
+    const long long ipw = rope_qk_vec(*a) ? 64 / (a->D >> 4) : 1;
+    return ((long long)a->B * a->T * (a->Hq + a->Hkv) + ipw - 1) / ipw + (long long)a->B * a->Hkv * (a->D >> 3) * ((a->T + 63) >> 6);
 }
 hipError_t launch_rope_kv_write_pair(const cover_rope_args* a0, const cover_rope_args* a1, hipStream_t st) {
     const long long w0 = rope_waves_host(a0), w1 = rope_waves_host(a1);

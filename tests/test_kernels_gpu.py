@@ -292,9 +292,10 @@ def test_norms(dev, dim):
     assert torch.allclose(out.float().cpu(), bf(x32 * rstd * (1 + w)).float(), atol=2e-2, rtol=1e-2)
 
 
+@pytest.mark.parametrize("T,D", [(7, 128), (24, 128), (70, 64), (19, 256)])   # T >= 16: vectorised q / k rotation + token-group V placement
 @pytest.mark.parametrize("mode", [0, 1, 2])
-def test_rope_kv_write(dev, mode):
-    B, T, Hq, Hkv, D, tcap, npos = 2, 7, 4, 2, 128, 32, 64
+def test_rope_kv_write(dev, mode, T, D):
+    B, Hq, Hkv, tcap, npos = 2, 4, 2, 128, 64
     g = torch.Generator().manual_seed(mode)
     qkv = bf(torch.randn(B * T, (Hq + 2 * Hkv) * D, generator=g))
     pos = torch.randint(0, npos, (B * T,), generator=g, dtype=torch.int32)
@@ -302,13 +303,13 @@ def test_rope_kv_write(dev, mode):
     inv = 1.0 / (10000.0 ** (torch.arange(0, D, 2).float() / D))
     ang = torch.arange(npos).float()[:, None] * inv[None]
     cos, sin = ang.cos(), ang.sin()
-    kc = torch.zeros(3, 16, Hkv, D, dtype=torch.bfloat16, device=dev)
+    kc = torch.zeros(3, tcap, Hkv, D, dtype=torch.bfloat16, device=dev)
     vt = torch.zeros(3, Hkv, D, tcap, dtype=torch.bfloat16, device=dev)
     slot = torch.tensor([2, 0], dtype=torch.int32)
     toff = torch.tensor([1, 4], dtype=torch.int32)
     d_qkv = qkv.clone().to(dev)
     ops.rope_kv_write(d_qkv, B, T, Hq, Hkv, D, positions=pos.to(dev), cos=cos.to(dev), sin=sin.to(dev), rope_mode=mode,
-                      k_cache=kc, k_strides=(16 * Hkv * D, Hkv * D, D), vt_cache=vt, vt_strides=(Hkv * D * tcap, D * tcap, tcap),
+                      k_cache=kc, k_strides=(tcap * Hkv * D, Hkv * D, D), vt_cache=vt, vt_strides=(Hkv * D * tcap, D * tcap, tcap),
                       slot_of_batch=slot.to(dev), t_offset_of_batch=toff.to(dev), t_offset=2)
     x = qkv.float().reshape(B, T, Hq + 2 * Hkv, D)
     c = cos[pos.long()].reshape(B, T, 1, half)
