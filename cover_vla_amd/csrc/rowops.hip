@@ -268,7 +268,8 @@ __device__ __forceinline__ void rope_kv_body(const cover_rope_args& a, int wid) 
         const int nqk = a.Hq + a.Hkv;
         const bool vec = rope_qk_vec(a);
         const int ipw = vec ? 64 / (a.D >> 4) : 1;
-        const int qk_waves = (rows * nqk + ipw - 1) / ipw;
+        // no rotation and no K cache (the ViT towers' V transposition): the q / k heads stay where they are, no waves for them
+        const int qk_waves = (a.rope_mode == 0 && !a.k_cache) ? 0 : (rows * nqk + ipw - 1) / ipw;
         if (wid >= qk_waves) {
             if (wid < qk_waves + rope_v_waves(a)) rope_v_body(a, wid - qk_waves);
             return;
@@ -349,7 +350,8 @@ static long long rope_waves_host(const cover_rope_args* a) {
     const bool vt = a->T >= 16 && a->n_splits <= 0 && (a->D & 7) == 0 && (a->ld_qkv & 7) == 0 && (((uintptr_t)a->qkv) & 15) == 0;
     if (!vt) return (long long)a->B * a->T * (a->Hq + 2 * a->Hkv);
     const long long ipw = rope_qk_vec(*a) ? 64 / (a->D >> 4) : 1;
-    return ((long long)a->B * a->T * (a->Hq + a->Hkv) + ipw - 1) / ipw + (long long)a->B * a->Hkv * (a->D >> 3) * ((a->T + 63) >> 6);
+    const long long qk_waves = (a->rope_mode == 0 && !a->k_cache) ? 0 : ((long long)a->B * a->T * (a->Hq + a->Hkv) + ipw - 1) / ipw;
+    return qk_waves + (long long)a->B * a->Hkv * (a->D >> 3) * ((a->T + 63) >> 6);
 }
 hipError_t launch_rope_kv_write_pair(const cover_rope_args* a0, const cover_rope_args* a1, hipStream_t st) {
     const long long w0 = rope_waves_host(a0), w1 = rope_waves_host(a1);
