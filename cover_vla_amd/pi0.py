@@ -173,6 +173,17 @@ class PI0FlowMatching:
         ic_first = torch.from_numpy(np.array([int(np.nonzero(img_class == k)[0][0]) for k in range(n_ic)], dtype=np.int64)).to(dev)
         ic_of_group = torch.from_numpy(img_class[first_h].astype(np.int64)).to(dev)
         n_img_all = self.n_img * len(cams)
+        # ---- trailing pad columns: the tokenizer pads every prompt on the right to max_length (modeling_pi0.py:398-407: L = 48..72 for
+        # ~20 real tokens). A pad token is never a key (pad mask, :547-560 / :731-735), positions do not advance over it (:685) and its own
+        # rows are never read back, so the prefix pass only needs the columns up to the longest real prompt of the batch: at P1 sizes
+        # 8 x (256 + 23) = 2232 rows instead of 8 x 328 = 2624. Only when every mask row is a contiguous run from column 0 (checked
+        # on the host copy that the dedup above already made); otherwise all L columns are kept.
+        Lfull = Lg
+        mh = key[:, 1 + Lg:] != 0
+        lens_h = mh.sum(axis=1)
+        if os.environ.get("COVER_PI0_TRIM_PAD", "1") != "0" and bool(np.array_equal(mh, np.arange(Lg)[None, :] < lens_h[:, None])):
+            Lg = max(int(lens_h.max()), 1)
+            lang_tokens, lang_masks = lang_tokens[:, :Lg], lang_masks[:, :Lg]
         Tp = n_img_all + Lg
         D = c["lm_dim"]
         prefix = torch.empty(U, Tp, D, dtype=BF, device=dev)
@@ -187,8 +198,10 @@ class PI0FlowMatching:
         lang = ops.embed_gather(self.embed, utok.view(-1), math.sqrt(D))
         didx = (torch.arange(U, device=dev)[:, None] * Tp + n_img_all + torch.arange(Lg, device=dev)[None]).reshape(-1)
         ops.copy_rows(lang, prefix.view(-1, D), U * Lg, D, None, didx.to(torch.int32))
-        if trace is not None:
-            trace["prefix_embs"] = prefix[prompt_of_row].clone()
+        if trace is not None:   # at the reference's full width (trimmed pad columns: zeros)
+            pe = torch.zeros(B, n_img_all + Lfull, D, dtype=BF, device=dev)
+            pe[:, :Tp] = prefix[prompt_of_row]
+            trace["prefix_embs"] = pe
         # lengths / positions (prompts are right padded: valid keys are a contiguous prefix)
         plen = (n_img_all + umask.sum(dim=1)).to(torch.int32)
         pad = torch.cat([torch.ones(U, n_img_all, dtype=torch.bool, device=dev), umask.bool()], dim=1)
