@@ -131,7 +131,10 @@ __device__ __forceinline__ void attn_body(const AttnDev& a, int bx, int kvh, int
                 kr0[ks] = *(const uint4*)(k0p + ks * 32);
                 kr1[ks] = *(const uint4*)(k1p + ks * 32);
             }
-            constexpr bool V_EARLY = (D <= 128);
+            // D = 256: 64 registers of V^T fragments beside 64 of K, 64 of O and 32 of Q only fit when the block is the 4-wave key-split
+            // one (launch bounds 256 below: one wave per SIMD). Without them a tile is TWO dependent round trips (K, softmax, then V):
+            // six per wave over the ~330 keys of a pi0 denoise step instead of three.
+            constexpr bool V_EARLY = (D <= 128) || KSPLIT;
             uint4 vr[V_EARLY ? DB : 1];
             if (V_EARLY) {
 #pragma unroll
@@ -284,7 +287,7 @@ __device__ __forceinline__ void attn_body(const AttnDev& a, int bx, int kvh, int
 }
 
 template <int D, bool KSPLIT, int NWS = 4>
-__global__ __launch_bounds__(512) void attn_kernel(AttnDev a) {
+__global__ __launch_bounds__((KSPLIT && D > 128) ? 64 * NWS : 512) void attn_kernel(AttnDev a) {
     attn_body<D, KSPLIT, NWS>(a, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
