@@ -6,8 +6,10 @@ compression=None, max_size=None)`, binary msgpack frames, a TEXT frame with the 
 package is not in this image, so the few pieces of the protocol the path uses are restated here from the RFC: the HTTP/1.1
 Upgrade handshake (Sec-WebSocket-Accept = base64(sha1(key + GUID))), unfragmented and fragmented data frames with 7 / 16 /
 64-bit lengths, client-to-server masking, ping/pong and the close handshake. No extensions (the reference disables
-compression), no size limit. `cover_vla_amd.server.serve_websocket` runs on this when `websockets` is absent; an unmodified
-`websockets` client (the simulator side) talks to it.
+compression). Message size: unlimited by default like the reference's `max_size=None`; `max_message_bytes` (serve / ServerConnection)
+closes with 1009 before buffering a larger message. An unmasked client frame fails the connection with 1002 (RFC 6455 5.1).
+`cover_vla_amd.server.serve_websocket` runs on this when `websockets` is absent; an unmodified `websockets` client (the
+simulator side) talks to it.
 """
 from __future__ import annotations
 
@@ -69,28 +71,37 @@ def decode_header(b0: int, b1: int) -> Tuple[bool, int, bool, int]:
 class ServerConnection:
     """One accepted connection: `await recv()` -> bytes (binary) or str (text), `await send(bytes | str)`, `await close(code, reason)`."""
 
-    def __init__(self, reader: asyncio.StreamReader, writer: asyncio.StreamWriter):
+    def __init__(self, reader: asyncio.StreamReader, writer: asyncio.StreamWriter, max_message_bytes: Optional[int] = None):
         self._r, self._w, self._closed = reader, writer, False
+        self._max = max_message_bytes
         self.remote_address = writer.get_extra_info("peername")
 
-    async def _read_frame(self):
+    async def _fail(self, code: int, reason: str):
+        await self.close(code, reason)
+        raise ConnectionClosed(code, reason)
+
+    async def _read_frame(self, have: int):
         h = await self._r.readexactly(2)
         fin, op, masked, n = decode_header(h[0], h[1])
         if n == 126:
             n = struct.unpack("!H", await self._r.readexactly(2))[0]
         elif n == 127:
             n = struct.unpack("!Q", await self._r.readexactly(8))[0]
-        key = await self._r.readexactly(4) if masked else None
+        if not masked:                                   # RFC 6455 5.1: a server MUST close on an unmasked client frame
+            await self._fail(1002, "unmasked client frame")
+        if op >= 0x8 and (n > 125 or not fin):           # 5.5: control frames are short and never fragmented
+            await self._fail(1002, "malformed control frame")
+        if self._max is not None and have + n > self._max:   # refuse BEFORE buffering what the peer announces
+            await self._fail(1009, "message too big")
+        key = await self._r.readexactly(4)
         payload = await self._r.readexactly(n) if n else b""
-        if key is not None:
-            payload = _unmask(payload, key)
-        return fin, op, payload
+        return fin, op, _unmask(payload, key)
 
     async def recv(self) -> Union[bytes, str]:
-        parts, kind = [], None
+        parts, kind, have = [], None, 0
         while True:
             try:
-                fin, op, payload = await self._read_frame()
+                fin, op, payload = await self._read_frame(have)
             except (asyncio.IncompleteReadError, ConnectionError):
                 self._closed = True
                 raise ConnectionClosed(1006, "connection lost")
@@ -111,6 +122,7 @@ class ServerConnection:
             if op in (OP_TEXT, OP_BINARY):
                 kind = op
             parts.append(payload)
+            have += len(payload)
             if fin:
                 data = b"".join(parts)
                 return data.decode() if kind == OP_TEXT else data
@@ -134,7 +146,13 @@ class ServerConnection:
 
 
 async def _handshake_server(reader: asyncio.StreamReader, writer: asyncio.StreamWriter) -> bool:
-    request = await reader.readuntil(b"\r\n\r\n")
+    try:
+        request = await reader.readuntil(b"\r\n\r\n")
+    except (asyncio.LimitOverrunError, ValueError):      # a header block beyond the stream limit (64 KiB)
+        writer.write(b"HTTP/1.1 400 Bad Request\r\nConnection: close\r\n\r\n")
+        await writer.drain()
+        writer.close()
+        return False
     lines = request.decode(errors="replace").split("\r\n")
     headers = {}
     for ln in lines[1:]:
@@ -153,12 +171,14 @@ async def _handshake_server(reader: asyncio.StreamReader, writer: asyncio.Stream
     return True
 
 
-async def serve(handler: Callable[[ServerConnection], Awaitable[None]], host: str, port: int, ready: Optional[Callable[[int], None]] = None):
-    """Run `handler(connection)` for every client until cancelled. `ready(port)` is called once the socket listens."""
+async def serve(handler: Callable[[ServerConnection], Awaitable[None]], host: str, port: int, ready: Optional[Callable[[int], None]] = None,
+                max_message_bytes: Optional[int] = None):
+    """Run `handler(connection)` for every client until cancelled. `ready(port)` is called once the socket listens.
+    max_message_bytes: None = unlimited (the reference's max_size=None); otherwise larger messages close the connection with 1009."""
     async def on_client(reader, writer):
         try:
             if await _handshake_server(reader, writer):
-                await handler(ServerConnection(reader, writer))
+                await handler(ServerConnection(reader, writer, max_message_bytes))
         except (ConnectionClosed, asyncio.IncompleteReadError, ConnectionError):
             pass
         finally:

@@ -176,3 +176,75 @@ def test_websocket_frame_codec_known_answers():
     assert f[:2] == bytes([0x82, 0x7F]) and f[2:10] == (65536).to_bytes(8, "big")
     m = wsproto.encode_frame(wsproto.OP_TEXT, b"Hello", True)                            # masked: key at [2:6]
     assert m[1] == 0x85 and bytes(b ^ m[2 + (i & 3)] for i, b in enumerate(m[6:])) == b"Hello"
+
+
+def test_websocket_transport_limits_and_protocol_errors():
+    """wsproto server side: max_message_bytes closes with 1009 BEFORE buffering what the peer announces (single frame and fragments),
+    an unmasked client frame fails the connection with 1002 (RFC 6455 5.1), an oversized handshake gets a 400, and the default
+    (None) stays unlimited like the reference's max_size=None."""
+    import asyncio
+    import socket
+    import struct
+    import threading
+    from cover_vla_amd import wsproto
+
+    async def echo(conn):
+        while True:
+            await conn.send(await conn.recv())
+
+    def start(limit):
+        box, ev = [], threading.Event()
+
+        def run():
+            asyncio.run(wsproto.serve(echo, "127.0.0.1", 0, ready=lambda p: (box.append(p), ev.set()), max_message_bytes=limit))
+
+        threading.Thread(target=run, daemon=True).start()
+        assert ev.wait(20)
+        return box[0]
+
+    port = start(1000)
+    c = wsproto.ClientConnection("127.0.0.1", port)
+    c.send(b"x" * 1000)
+    assert c.recv() == b"x" * 1000                                  # at the limit: fine
+    c.send(b"y" * 1001)
+    with pytest.raises(wsproto.ConnectionClosed) as e:
+        c.recv()
+    assert e.value.code == 1009
+    # fragments that add up beyond the limit; the announced 2^40-byte frame is refused from its header alone
+    c = wsproto.ClientConnection("127.0.0.1", port)
+    key = b"\x01\x02\x03\x04"
+    frag = bytes([0x02, 0x80 | 126]) + struct.pack("!H", 600) + key + wsproto._unmask(b"a" * 600, key)     # BINARY, FIN = 0
+    cont = bytes([0x80, 0x80 | 126]) + struct.pack("!H", 600) + key + wsproto._unmask(b"b" * 600, key)     # CONT, FIN = 1
+    c._s.sendall(frag + cont)
+    with pytest.raises(wsproto.ConnectionClosed) as e:
+        c.recv()
+    assert e.value.code == 1009
+    c = wsproto.ClientConnection("127.0.0.1", port)
+    c._s.sendall(bytes([0x82, 0x80 | 127]) + struct.pack("!Q", 1 << 40) + key)
+    with pytest.raises(wsproto.ConnectionClosed) as e:
+        c.recv()
+    assert e.value.code == 1009
+    # unmasked client frame
+    c = wsproto.ClientConnection("127.0.0.1", port)
+    c._s.sendall(wsproto.encode_frame(wsproto.OP_BINARY, b"plain", False))
+    with pytest.raises(wsproto.ConnectionClosed) as e:
+        c.recv()
+    assert e.value.code == 1002
+    # handshake with a header block beyond the stream limit: 400, no task exception
+    s = socket.create_connection(("127.0.0.1", port), timeout=20)
+    s.sendall(b"GET / HTTP/1.1\r\nX-Junk: " + b"j" * (80 * 1024) + b"\r\n")
+    got = b""
+    while b"\r\n\r\n" not in got:
+        chunk = s.recv(4096)
+        if not chunk:
+            break
+        got += chunk
+    assert got.startswith(b"HTTP/1.1 400")
+    s.close()
+    # default: unlimited
+    port2 = start(None)
+    c = wsproto.ClientConnection("127.0.0.1", port2)
+    big = os.urandom(300000)
+    c.send(big)
+    assert c.recv() == big
+    c.close()
