@@ -118,9 +118,10 @@ async def _serve(conn_recv_send_close, session: PolicySession) -> None:
 
 
 def serve_websocket(policy: Any, host: str = "0.0.0.0", port: int = 8000, metadata: Optional[dict] = None,
-                    ready: Optional[Callable[[int], None]] = None) -> None:
-    """Blocking websocket server with the reference's framing (binary msgpack frames, no compression, no size limit; traceback
-    as a text frame + close code 1011 on error). Runs on the `websockets` package when it is installed (the reference's
+                    ready: Optional[Callable[[int], None]] = None, max_message_bytes: Optional[int] = None) -> None:
+    """Blocking websocket server with the reference's framing (binary msgpack frames, no compression, no size limit unless
+    `max_message_bytes` is given -- the reference passes max_size=None, websocket_policy_server.py:44-49; traceback as a text
+    frame + close code 1011 on error). Runs on the `websockets` package when it is installed (the reference's
     transport), else on the RFC 6455 transport in cover_vla_amd.wsproto (standard library only). `ready(port)` is called once the
     socket listens (port 0 = pick a free one)."""
     import asyncio
@@ -138,7 +139,7 @@ def serve_websocket(policy: Any, host: str = "0.0.0.0", port: int = 8000, metada
                 return
 
         async def run():
-            async with websockets.asyncio.server.serve(handler, host, port, compression=None, max_size=None) as server:
+            async with websockets.asyncio.server.serve(handler, host, port, compression=None, max_size=max_message_bytes) as server:
                 if ready is not None:
                     ready(server.sockets[0].getsockname()[1])   # the BOUND port (port = 0 picks a free one)
                 await server.serve_forever()
@@ -152,7 +153,7 @@ def serve_websocket(policy: Any, host: str = "0.0.0.0", port: int = 8000, metada
                 return
 
         async def run():
-            await wsproto.serve(handler, host, port, ready=ready)
+            await wsproto.serve(handler, host, port, ready=ready, max_message_bytes=max_message_bytes)
 
     asyncio.run(run())
 
