@@ -227,6 +227,38 @@ def test_pi0_sampler_matches_reference_golden(dev, name):
     assert torch.equal(x3, x3e)
 
 
+def test_pi0_prefix_without_trailing_pad_columns_equals_full_width(dev):
+    """sample_actions runs the prefix pass on the columns up to the longest real prompt only (pi0.py, COVER_PI0_TRIM_PAD): a pad token
+    is never a key and its row is never read, so the sampled chunk equals the full-width pass up to the order of the fp32 sums (the
+    GEMMs see a different row count). A mask that is not a contiguous run from column 0 keeps the full width (bit-identical to it)."""
+    from cover_vla_amd.pi0 import PI0FlowMatching
+    from tests.helpers import pi0_case
+    z, tiny, sd, (images, img_masks, toks, masks, state, noise) = pi0_case(os.path.join(GOLD, "pi0_tiny_b6.npz"))
+    B = state.shape[0]
+    assert int(masks.sum(1).max()) < masks.shape[1]                       # the case has trailing pad columns
+    model = PI0FlowMatching(sd, tiny, device="cuda:0", max_batch=8, max_prompts=8, max_lang=toks.shape[1])
+    args = lambda m: ([im.to(dev) for im in images], [x.to(dev) for x in img_masks], toks.to(dev), m.to(dev), state.to(dev))
+    run = lambda m: model.sample_actions(*args(m), noise=noise.to(dev)).cpu().numpy()
+    x_trim = run(masks)
+    os.environ["COVER_PI0_TRIM_PAD"] = "0"
+    try:
+        x_full = run(masks)
+    finally:
+        os.environ.pop("COVER_PI0_TRIM_PAD", None)
+    upd = x_full - noise.numpy()
+    assert np.linalg.norm(x_trim - x_full) / np.linalg.norm(upd) < 1e-2
+    assert np.abs(x_trim - z["actions"]).max() < 8e-2                     # and both sit on the reference's golden
+    holes = masks.clone()
+    holes[0, 1] = False                                                   # not right-padded: the full width is kept
+    x_h = run(holes)
+    os.environ["COVER_PI0_TRIM_PAD"] = "0"
+    try:
+        x_h_full = run(holes)
+    finally:
+        os.environ.pop("COVER_PI0_TRIM_PAD", None)
+    assert np.array_equal(x_h, x_h_full)
+
+
 def test_pi0_policy_api_from_pretrained(dev, tmp_path):
     """PI0Policy drop-in surface (modeling_pi0.py:226-307): from_pretrained on the reference's on-disk layout, select_action
     returns the policy-owned deque of n_action_steps [B,7] tensors, tolerates the caller's copy()/clear(), reuses the queue."""
