@@ -222,20 +222,22 @@ class OpenVLA:
         cand_len = prompt_lens.to(torch.int32)[prompt_of_cand.long()].contiguous()
         last_row = (Tp + prompt_of_cand * Lt + cand_len - 1).to(torch.int32)
         ops.copy_rows(x, self.h_sel, N, D, last_row, None)
-        tokens = torch.empty(N, self.n_gen, dtype=torch.int64, device=dev)
-        sel = torch.empty(N, self.n_gen, dtype=torch.float32, device=dev)
+        # step-major buffers: row i of each is contiguous, so the kernels of step i read / write them in place (no per-step slice copies)
+        tokens = torch.empty(self.n_gen, N, dtype=torch.int64, device=dev)
+        sel = torch.empty(self.n_gen, N, dtype=torch.float32, device=dev)
+        uniforms = None if uniforms is None else uniforms.to(torch.float32).t().contiguous()
+        fed = tokens if force_tokens is None else force_tokens.t().contiguous()
         self._head_select(self.h_sel[:N], uniforms, 0, temperature, tokens, sel, trace)
         # ---- decode
-        pos_base = (T0 + cand_len).contiguous()
+        pos_all = ((T0 + cand_len)[None, :] + torch.arange(self.n_gen, dtype=torch.int32, device=dev)[:, None]).contiguous()
         xd = self.x_dec[:N]
         own = {}
         if self.own_kv is not None:   # regular structure of the batch: the n_samples candidates of prompt p are rows [p S, (p + 1) S)
             own = dict(own_kv=self.own_kv, seg1_group=n_samples, seg1_slot_of_group=torch.arange(P, dtype=torch.int32, device=dev),
                        seg1_len_of_group=prompt_lens.to(torch.int32).contiguous())
         for i in range(1, self.n_gen):
-            fed = tokens if force_tokens is None else force_tokens
-            ops.embed_gather(self.embed, fed[:, i - 1].contiguous(), out=xd)
-            pos = (pos_base + (i - 1)).contiguous()
+            ops.embed_gather(self.embed, fed[i - 1], out=xd)
+            pos = pos_all[i - 1]
             g = self.llm.group(N, 1, pos,
                                [dict(region=0, length=T0, slot_of_batch=self.zero_slots),
                                 dict(region=1, length=Lt, len_of_batch=cand_len, slot_of_batch=prompt_of_cand),
@@ -243,27 +245,24 @@ class OpenVLA:
             self.llm.forward(xd, [g], final_norm=False)
             self._head_select(xd, uniforms, i, temperature, tokens, sel, trace)
             mark(f"decode{i}")
-        return tokens, sel
+        return tokens.t().contiguous(), sel.t().contiguous()
 
     def _head_select(self, h, uniforms, i, temperature, tokens, sel, trace):
         N = h.shape[0]
         hn = ops.rmsnorm(h, self.llm.final_norm, 1e-5, w_offset=0.0, style=1)
         if uniforms is not None and (trace is None or "events" in trace) and self.slice_action_head:
             lg = ops.gemm(hn, self.lm_head_actions, out=self.logits_actions[:N], ws=self.head_ws_actions)
-            t, s = ops.token_select(lg, 0, self.c["n_bins"], uniform=uniforms[:, i].contiguous(), temperature=temperature)
-            tokens[:, i].copy_(t + self.action_lo)
-            sel[:, i].copy_(s)
+            t, _ = ops.token_select(lg, 0, self.c["n_bins"], uniform=uniforms[i], temperature=temperature, out_logit=sel[i])
+            torch.add(t, self.action_lo, out=tokens[i])
             return
         lg = ops.gemm(hn, self.lm_head, out=self.logits[:N], ws=self.head_ws)
         if trace is not None and "events" not in trace:
             trace.setdefault("logits", []).append(lg.clone())
         if uniforms is None:
-            t, s = ops.token_select(lg, 0, self.c["tok_vocab"])
+            ops.token_select(lg, 0, self.c["tok_vocab"], out_tok=tokens[i], out_logit=sel[i])
         else:
-            t, s = ops.token_select(lg, self.action_lo, self.action_hi, uniform=uniforms[:, i].contiguous(),
-                                    temperature=temperature)
-        tokens[:, i].copy_(t)
-        sel[:, i].copy_(s)
+            ops.token_select(lg, self.action_lo, self.action_hi, uniform=uniforms[i], temperature=temperature, out_tok=tokens[i],
+                             out_logit=sel[i])
 
     # ---------------------------------------------------------------------------------------------- de-tokeniser
     def tokens_to_actions(self, tokens: np.ndarray) -> np.ndarray:

@@ -483,11 +483,14 @@ def sincos_time_embed(time, dim, min_period, max_period, out=None):
 
 
 # ------------------------------------------------------------------------------------------------ selection
-def token_select(logits, lo, hi, uniform=None, temperature=1.0):
-    _chk_dev(logits)
+def token_select(logits, lo, hi, uniform=None, temperature=1.0, out_tok=None, out_logit=None):
+    """out_tok int64 [rows] / out_logit fp32 [rows] (contiguous, e.g. a row of a [steps, rows] buffer): written in place of fresh tensors."""
+    _chk_dev(logits, uniform, out_tok, out_logit)
     rows = logits.shape[0]
-    tok = torch.empty(rows, dtype=torch.int64, device=logits.device)
-    lg = torch.empty(rows, dtype=torch.float32, device=logits.device)
+    tok = torch.empty(rows, dtype=torch.int64, device=logits.device) if out_tok is None else out_tok
+    lg = torch.empty(rows, dtype=torch.float32, device=logits.device) if out_logit is None else out_logit
+    assert tok.dtype == torch.int64 and lg.dtype == torch.float32 and tok.is_contiguous() and lg.is_contiguous() and tok.numel() == rows == lg.numel()
+    assert uniform is None or (uniform.is_contiguous() and uniform.dtype == torch.float32 and uniform.numel() == rows)
     a = L.TokenSelectArgs()
     a.logits, a.ld, a.rows, a.lo, a.hi = logits.data_ptr(), logits.stride(0), rows, lo, hi
     a.uniform, a.temperature = _ptr(uniform), temperature
