@@ -144,14 +144,27 @@ class PI0FlowMatching:
         # (modeling_pi0.py:372-385); its tokens are padding -- never attended by a valid query, positions do not advance
         # over them (cumsum of the pad mask, :685), their own rows are never read back -- so dropping that camera from the
         # prefix leaves every used output unchanged. Per-row mixed masks do not occur on this path.
-        cams = []
-        for ci, (im, mk) in enumerate(zip(images, img_masks)):
-            mk = mk.to(torch.bool)
-            if bool(mk.all()):
-                cams.append(im)
-            elif bool(mk.any()):
-                raise NotImplementedError("img_masks that differ across the rows of one camera are not supported "
-                                          "(prepare_images only produces all-True / all-False masks, modeling_pi0.py:372-385)")
+        # Masks that differ across the rows of one camera (embed_prefix carries them per row, :529-547; the CoVer driver never produces
+        # them): the same argument row by row -- the rows are partitioned by their camera pattern and every part is sampled with
+        # exactly its present cameras (its own prefix width; same noise rows, so the parts are what one call would have produced).
+        mk_h = torch.stack([m.to(torch.bool).reshape(-1) for m in img_masks], dim=1).cpu().numpy()            # [B, cameras]
+        if mk_h.shape[0] != B:
+            raise ValueError("img_masks must have one entry per batch row")
+        pats = np.unique(mk_h, axis=0)
+        if pats.shape[0] > 1:
+            if trace is not None:
+                raise NotImplementedError("trace with camera masks that differ across rows")
+            out = torch.empty(B, self.chunk, self.max_action_dim, dtype=torch.float32, device=dev)
+            for pat in pats:
+                if not pat.any():
+                    raise ValueError("every camera is masked out")
+                idx = torch.from_numpy(np.nonzero((mk_h == pat[None]).all(axis=1))[0]).to(dev)
+                on = [ci for ci in range(len(images)) if pat[ci]]
+                ones = torch.ones(idx.numel(), dtype=torch.bool, device=dev)
+                out[idx] = self.sample_actions([images[ci][idx] for ci in on], [ones for _ in on], lang_tokens[idx], lang_masks[idx],
+                                               state[idx], noise=noise[idx], noise_std=noise_std)
+            return out
+        cams = [im for ci, im in enumerate(images) if pats[0][ci]]
         if not cams:
             raise ValueError("every camera is masked out")
         if len(cams) > self.n_cams:

@@ -343,7 +343,7 @@ def test_pi0_rows_with_different_frames_share_no_prefix(dev):
         small.sample_actions([im.to(dev)], ones, tk.to(dev), mk.to(dev), state.to(dev), noise=noise.to(dev))
 
 
-def test_pi0_empty_camera_is_dropped_and_mixed_masks_raise(dev):
+def test_pi0_empty_camera_is_dropped_and_per_row_camera_masks(dev):
     """An absent camera (all-False mask over an all -1 image, modeling_pi0.py:372-385) is padding in the reference's prefix:
     never attended, positions do not advance over it. Dropping it must reproduce the one-camera golden bit for bit."""
     from cover_vla_amd.pi0 import PI0FlowMatching
@@ -360,10 +360,23 @@ def test_pi0_empty_camera_is_dropped_and_mixed_masks_raise(dev):
     assert torch.equal(one, two)
     upd = z["actions"] - noise.numpy()
     assert np.linalg.norm(two.cpu().numpy() - z["actions"]) / np.linalg.norm(upd) < 3e-2
-    mixed = torch.ones(B, dtype=torch.bool, device=dev)
-    mixed[1] = False
-    with pytest.raises(NotImplementedError):
-        model.sample_actions([images[0].to(dev)], [mixed], *args, noise=noise.to(dev))
+    # masks that differ across the rows of a camera (embed_prefix :529-547): rows 1, 3, 5 lose the second camera; every row must
+    # come out as in a call over exactly its present cameras (different batch compositions: bf16-level agreement, not bit equality)
+    cam2 = (images[0] * 0.5).to(dev)
+    on = torch.ones(B, dtype=torch.bool, device=dev)
+    mixed = on.clone()
+    mixed[1::2] = False
+    both = model.sample_actions([images[0].to(dev), cam2], [on, on], *args, noise=noise.to(dev))
+    got = model.sample_actions([images[0].to(dev), cam2], [on, mixed], *args, noise=noise.to(dev))
+    nz = noise.to(dev)
+    rel = lambda a, b, sl: ((a[sl] - b[sl]).norm() / (b[sl] - nz[sl]).norm()).item()
+    ev, od = slice(0, None, 2), slice(1, None, 2)
+    assert rel(got, both, ev) < 1e-2 and rel(got, one, od) < 1e-2
+    assert rel(got, both, od) > 5e-2                                       # and the second camera does matter
+    none = torch.zeros(B, dtype=torch.bool, device=dev)
+    none[0] = True
+    with pytest.raises(ValueError):                                        # a row without any camera
+        model.sample_actions([images[0].to(dev)], [none], *args, noise=noise.to(dev))
 
 
 def test_resize_with_pad_matches_torch(dev):
