@@ -194,6 +194,249 @@ class Pipeline:
         return int(r["result"][0]), tokens, None
 
 
+class Pi0Pipeline:
+    """Profile P1 -- what the reference ships and evaluates: pi0 = SigLIP-So400m + PaliGemma-3B prefix + 300 M
+    action expert, 10 Euler steps, chunk 4; B = 40 candidates = 8 rephrased prompts x 5 samples on ONE 224^2 observation
+    (run_simpler_eval_with_openpi.py:296-319), then the CoVer verifier (SigLIP2-L/16-384 + 3-member ensemble) on the 40 chunks and
+    the grouped arg-max. Batch construction as the reference's harness shapes it (lerobot_custom/.../pi0/conversion_scripts/
+    benchmark.py:52-77 times select_action on such a batch); tokenizer max_length 72 (prompts of 16..23 real tokens, right padded)."""
+
+    def __init__(self, dev, B=40, P=8, L=72, members=3, max_prompts=None, seed=1234):
+        from cover_vla_amd import host, synth
+        from cover_vla_amd.pi0 import PI0FlowMatching
+        from cover_vla_amd.verifier import EfficientEnsembleMerged, SigLIP2Encoder
+        self.dev, self.B, self.P, self.L, self.S = dev, B, P, L, B // P
+        self.c = dict(synth.PI0_FULL)
+        sd = synth.pi0_state(self.c, seed=seed, nontrivial=False, std=0.02, device=dev, wdtype=torch.bfloat16)
+        self.model = PI0FlowMatching(sd, self.c, device=str(dev), max_batch=B, max_prompts=max_prompts or P, max_lang=L)
+        del sd
+        torch.cuda.empty_cache()
+        self.sc = dict(synth.SIGLIP2_L)
+        ssd = synth.siglip2_state(self.sc, seed=4321, nontrivial=False, device=dev, wdtype=torch.bfloat16)
+        self.enc = SigLIP2Encoder(ssd, device=str(dev))
+        del ssd
+        torch.cuda.empty_cache()
+        self.ver = EfficientEnsembleMerged(synth.verifier_checkpoint(members, seed=1234), device=str(dev), encoder=self.enc)
+        gen = torch.Generator().manual_seed(0)
+        img = (torch.rand(1, 3, 224, 224, generator=gen) * 2 - 1).repeat(B, 1, 1, 1)
+        toks, masks = torch.zeros(B, L, dtype=torch.long), torch.zeros(B, L, dtype=torch.bool)
+        for p in range(P):
+            n = 16 + (p % 8)
+            row = torch.randint(1, 257000, (n,), generator=gen)
+            toks[p * self.S:(p + 1) * self.S, :n] = row
+            masks[p * self.S:(p + 1) * self.S, :n] = True
+        state = torch.zeros(B, 32)
+        state[:, :7] = torch.rand(1, 7, generator=gen) * 2 - 1
+        noise = torch.randn(B, self.c["chunk"], 32, generator=gen)
+        img384 = torch.randn(1, 3, 384, 384, generator=gen)
+        text = torch.randint(0, 32000, (1, 64), generator=gen)
+        past = (torch.randn(6, 7, generator=gen) * 0.02).double().numpy()
+        self.inp = dict(img=img.to(dev), toks=toks.to(dev), masks=masks.to(dev), state=state.to(dev), noise=noise.to(dev),
+                        img384=img384.to(dev), text=text.to(dev), past=past)
+        st = host.bridge_statistics()["action"]
+        self.lo_hi = torch.tensor(list(st["p01"][:6]) + list(st["p99"][:6]), dtype=torch.float32, device=dev)
+        self.past_dev = torch.tensor(past, dtype=torch.float32, device=dev)
+        self.all_valid = torch.ones(B, dtype=torch.bool, device=dev)
+        self.side, self.pool = None, None
+
+    def _side_work(self):
+        pf, tf = self.ver.extract_shared_features(self.inp["img384"], self.inp["text"])
+        return self.ver.image_text_embeddings(pf, tf)
+
+    def decision(self, serial=False, on_phase=None, noise=None):
+        """One decision -> (winner index, actions [B, chunk, 32]). serial: everything on the main stream from this thread (the profiled
+        decision); on_phase(name) is then called after the verifier towers, after the prefix pass and after the Euler loop."""
+        from cover_vla_amd import ops
+        i = self.inp
+        main = torch.cuda.current_stream()
+        if self.side is None:
+            self.side = torch.cuda.Stream(device=self.dev)
+        noise = i["noise"] if noise is None else noise
+        if serial:
+            its = self._side_work()
+            if on_phase:
+                on_phase("verifier_towers")
+            x = self.model.sample_actions([i["img"]], [self.all_valid], i["toks"], i["masks"], i["state"], noise=noise,
+                                          on_prefix_enqueued=(lambda: on_phase("prefix")) if on_phase else None)
+            if on_phase:
+                on_phase("denoise")
+        else:
+            if self.pool is None:
+                import concurrent.futures
+                self.pool = concurrent.futures.ThreadPoolExecutor(max_workers=1)
+            ev = torch.cuda.Event()
+            ev.record(main)
+
+            def threaded():   # the verifier's frozen towers: queued by a second host thread from t = 0 (see Pipeline.decision)
+                torch.cuda.set_device(self.dev)
+                self.side.wait_event(ev)
+                with torch.cuda.stream(self.side):
+                    return self._side_work()
+
+            fut = self.pool.submit(threaded)
+            x = self.model.sample_actions([i["img"]], [self.all_valid], i["toks"], i["masks"], i["state"], noise=noise)
+            its = fut.result()
+            main.wait_stream(self.side)
+        hists, pad = ops.actions_to_histories(x, self.c["chunk"], self.past_dev, self.lo_hi)
+        r = self.ver.score_histories(its, hists, self.S, pad=pad)
+        self.last_scores = r["scores"]
+        return int(r["result"][0]), x
+
+
+def _profile_phases(pipe):
+    """One serialised pi0 decision with the in-library kernel timers read out at every phase boundary."""
+    import ctypes as C
+    from cover_vla_amd import _lib as L
+    h = L.lib()
+    n = 8
+    out = {}
+
+    def begin():
+        L.check(h.cover_profile_begin(32768), "profile_begin")
+
+    def end(name):
+        ms, cnt, work = (C.c_double * n)(), (C.c_longlong * n)(), (C.c_double * n)()
+        L.check(h.cover_profile_end_n(ms, cnt, work, n), "profile_end")
+        out[name] = (list(ms), list(cnt), list(work))
+
+    def on_phase(name):
+        end(name)
+        begin()
+
+    begin()
+    try:
+        pipe.decision(serial=True, on_phase=on_phase)
+    finally:
+        end("verifier_heads")
+    return out
+
+
+def pi0_cpu_baseline(pipe, batch):
+    """The CPU oracle (oracle/cover_ref/pi0.py + verifier.py, PyTorch-CPU eager, bf16 PaliGemma / fp32 projections as the reference casts
+    them) executing the decision AS THE REFERENCE EXECUTES IT: ONE sample_actions call on the whole batch of `batch` rows -- the vision
+    tower and the 18-layer prefix run on every row, no dedup (modeling_pi0.py:672-715; run_simpler_eval_with_openpi.py:305-326) --
+    then the verifier. Beside it the de-duplicated schedule this repo runs (tower once, prefix once per distinct prompt), timed, not
+    composed: the oracle's prefix pass on the 8 distinct rows + its Euler loop on all rows."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    from cover_ref import blocks as Bk, pi0 as PR, openvla as OR, verifier as V
+    from cover_vla_amd import host, synth
+    t_all = time.time()
+    c, dev = pipe.c, pipe.dev
+    sd = PR.cast_like_reference({k: v.cpu() for k, v in synth.pi0_state(c, seed=1234, nontrivial=False, std=0.02, device=dev, wdtype=torch.bfloat16).items()})
+    ssd = Bk.to_bf16({k: v.cpu() for k, v in synth.siglip2_state(pipe.sc, seed=4321, nontrivial=False, device=dev, wdtype=torch.bfloat16).items()})
+    torch.cuda.empty_cache()
+    vit = Bk.VitCfg(c["vit_dim"], c["vit_layers"], c["vit_heads"], c["vit_mlp"], c["patch"], "gelu_tanh", 1e-6)
+    lm = Bk.DecoderCfg(c["lm_dim"], c["layers"], c["Hq"], c["Hkv"], c["D"], c["lm_mlp"], "gelu_tanh", "gemma", 1e-6, "pi0")
+    ex = Bk.DecoderCfg(c["ex_dim"], c["layers"], c["Hq"], c["Hkv"], c["D"], c["ex_mlp"], "gelu_tanh", "gemma", 1e-6, "pi0")
+    cfg = PR.Pi0Cfg(vit, lm, ex, proj_width=c["ex_dim"], chunk_size=c["chunk"], n_img_tokens=(c["image"] // c["patch"]) ** 2)
+    i = pipe.inp
+    B = min(batch, pipe.B)
+    rows = list(range(B))
+    img, toks, masks, state, noise = (i[k][rows].cpu() for k in ("img", "toks", "masks", "state", "noise"))
+    ck = synth.verifier_checkpoint(3, seed=1234)
+    stt = host.bridge_statistics()["action"]
+    ph = {}
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        x = PR.sample_actions(cfg, sd, [img], [torch.ones(B, dtype=torch.bool)], toks, masks, state, noise)
+        ph["policy_as_executed"] = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        pf, tf = OR.siglip2_features(pipe.sc, ssd, i["img384"].cpu(), i["text"].cpu())
+        ph["verifier_towers"] = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        xa = x[:, : c["chunk"], :7].double().numpy()
+        hists = host.process_inputs([xa[:, t] for t in range(c["chunk"])], True, [i["past"][k] for k in range(6)], c["chunk"])
+        V.compute_max_similarity_scores(ck["ensemble_components"], pf, tf, hists, max(1, B // pipe.P))
+        ph["verifier_heads"] = time.perf_counter() - t0
+        # the de-duplicated schedule, timed: prefix (vision + 18 layers) on ONE row per distinct prompt, Euler loop on all rows
+        first = [p * pipe.S for p in range(pipe.P) if p * pipe.S < B]
+        t0 = time.perf_counter()
+        tr = {}
+        PR.sample_actions(cfg, sd, [img[first]], [torch.ones(len(first), dtype=torch.bool)], toks[first], masks[first], state[first], noise[first], trace=tr)
+        ph["policy_on_distinct_prompts_only"] = time.perf_counter() - t0
+    as_exec = ph["policy_as_executed"] + ph["verifier_towers"] + ph["verifier_heads"]
+    # dedup: distinct-prompt run covers the prefix; its Euler loop ran on len(first) rows, the remaining rows' loop scales by rows
+    model, isa = _cpu_info()
+    r2 = lambda v: round(float(v), 2)
+    return {"value": round(B / as_exec, 4), "unit": "candidates/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"ONE decision, batch of {B} rows in one sample_actions call exactly as the reference executes it (vision tower + 18-layer prefix on every row, "
+                      f"10 Euler steps) + verifier towers + 3-member heads; cold (first call in the process), one run",
+            "decision_seconds_as_executed": r2(as_exec), "phase_seconds": {k: round(v, 3) for k, v in ph.items()},
+            "dedup_variant": {"note": "sample_actions on the distinct prompts only (the prefix work this repo's schedule does) -- a lower bound of the "
+                                      "de-duplicated CPU decision: the other rows add their Euler loops only",
+                              "rows": len(first), "seconds": r2(ph["policy_on_distinct_prompts_only"] + ph["verifier_towers"] + ph["verifier_heads"])},
+            "total_cpu_leg_seconds": r2(time.time() - t_all), "cpu_model": model, "isa": isa,
+            "dtype": "bf16 PaliGemma + expert layers, fp32 projections (to_bfloat16_like_physical_intelligence), eager PyTorch-CPU"}
+
+
+def main_pi0(a):
+    """`--profile pi0`: the contractual line for P1 (same JSON schema as the headline)."""
+    if not torch.cuda.is_available():
+        print(json.dumps({"error": "no GPU: bench.py measures the HIP path only (no CPU fallback)"}))
+        sys.exit(2)
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda:0")
+    pipe = Pi0Pipeline(dev)
+    for _ in range(a.warmup):
+        pipe.decision()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        idx, x = pipe.decision()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert torch.isfinite(x).all()
+    ms_per_step = 1e3 * dt / a.steps
+    B, c = pipe.B, pipe.c
+    out = {"metric": "candidate actions scored/sec (whole node), pi0 (PaliGemma-3B + 300M action expert) B=40, 224^2 RGB",
+           "value": round(B * a.steps / dt, 3), "unit": "candidates/s", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup,
+           "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+           "data": "synthetic",
+           "config": {"workload": f"pi0 (SigLIP-So400m + Gemma-2B prefix + 300M expert) B={B} = {pipe.P} prompts x {pipe.S} samples, chunk {c['chunk']}, 10 Euler steps, "
+                                  f"tokenizer max_length {pipe.L}, one 224x224 RGB frame; CoVer verifier SigLIP2-L/16-384 + 3-member ensemble; random-init weights",
+                      "candidates_total": B, "parallelism": "one GPU", "lib_sha16": lib_hash(), "selected": idx}}
+    if not a.no_profile:
+        ph = _profile_phases(pipe)
+        M_exp = B * (1 + c["chunk"])
+        ms_d, cnt_d, work_d = ph["denoise"]
+        ms_p, cnt_p, work_p = ph["prefix"]
+        ms_v, cnt_v, work_v = ph["verifier_towers"]
+        exp_bytes = work_d[1] / M_exp            # tiled-GEMM work is 2 M N K FLOP; the weight bytes of the same launches are 2 N K
+        ach = exp_bytes / (ms_d[1] * 1e-3) / 1e9 if ms_d[1] > 0 else 0.0
+        out["roofline"] = {"bound": "hbm", "kernel": f"gemm_tiled at M = {M_exp} rows (the action expert's 4 projections x 18 layers x 10 Euler steps): bound by weight bytes "
+                                                     "on paper, by the latency of a 5-15 us launch in practice (latency-bound: see launches / avg_launch_us)",
+                           "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                           "launches": int(cnt_d[1]), "avg_launch_us": round(1e3 * ms_d[1] / max(cnt_d[1], 1), 2),
+                           "algorithmic_bytes_per_launch": round(exp_bytes / max(cnt_d[1], 1)), "algorithmic_bytes_per_decision": exp_bytes,
+                           "kernel_ms_per_decision": round(ms_d[1], 3), "splitk_reduce_ms_per_decision": round(ms_d[6], 3),
+                           "attention_ms_per_decision": round(ms_d[2], 3), "attention_launches": int(cnt_d[2])}
+        tp = ms_p[1] + ms_p[4] + ms_p[6]
+        fp = work_p[1] + work_p[4]
+        if tp > 0:
+            tf = fp / (tp * 1e-3) / 1e12
+            out["roofline_mfma"] = {"bound": "mfma", "kernel": "gemm_tiled / gemm_tiled_pc: SigLIP-So400m tower + projector + the 18-layer Gemma-2B prefix pass "
+                                                               f"(M = {pipe.P} x (256 + longest real prompt) rows), split-K reductions included",
+                                    "achieved": round(tf, 1), "peak": MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": round(tf / MFMA_PEAK_TF, 4),
+                                    "launches": int(cnt_p[1] + cnt_p[4]), "kernel_ms_per_decision": round(tp, 3), "flop_per_decision": fp}
+            if ms_p[4] > 0:
+                t4 = work_p[4] / (ms_p[4] * 1e-3) / 1e12
+                out["roofline_mfma"]["prefix_mlp"] = {"achieved": round(t4, 1), "frac": round(t4 / MFMA_PEAK_TF, 4), "launches": int(cnt_p[4]),
+                                                      "kernel_ms_per_decision": round(ms_p[4], 3)}
+        fv = work_v[1] + work_v[4]
+        floor_ms = 1e3 * (exp_bytes / (HBM_PEAK_GBS * 1e9) + (fp + fv) / (MFMA_PEAK_TF * 1e12))
+        out["end_to_end"] = {"floor_ms": round(floor_ms, 3), "measured_ms": round(ms_per_step, 3), "frac": round(floor_ms / ms_per_step, 4),
+                             "floor": "expert weight bytes (10 steps) / 8 TB/s + (tower + prefix + verifier-tower tiled FLOPs) / 2.5 PFLOP/s (attention, norms, fp32 heads: 0)"}
+        out["phase_kernel_ms"] = {k: {"gemm_tiled_small": round(v[0][1], 3), "gemm_tiled_llm": round(v[0][4], 3), "splitk_reduce": round(v[0][6] + v[0][5], 3),
+                                      "attention": round(v[0][2], 3), "weight_streaming": round(v[0][0] + v[0][3], 3),
+                                      "launches": int(sum(v[1]))} for k, v in ph.items()}
+        for k in ("roofline", "roofline_mfma"):
+            if k in out and out[k]["frac"] > 1.0:
+                out[k] = {"invalid": f"frac {out[k]['frac']} > 1: refused"}
+    if not a.no_cpu_baseline:
+        out["cpu_baseline"] = pi0_cpu_baseline(pipe, a.cpu_batch)
+    print(json.dumps(out), flush=True)
+
+
 def _cpu_info():
     model, flags = "unknown", set()
     try:
@@ -234,7 +477,10 @@ def cpu_baseline(pipe, timed=3):
     frame, img384, text = i["frame"][:1].cpu(), i["img384"].cpu(), i["text"].cpu()
     S = pipe.n_samples
 
+    n_local = len(pipe.prompt_ids)
+
     def one_candidate(p, greedy):
+        p = p % n_local                                        # (--config 3 on one GPU: a single local prompt group)
         toks, lens = i["toks"][p:p + 1].cpu(), i["lens"][p:p + 1].cpu()
         u = None if greedy else i["u"][p * S:p * S + 1].cpu()
         tr = {"seconds": {}}
@@ -261,8 +507,11 @@ def cpu_baseline(pipe, timed=3):
     model, isa = _cpu_info()
     r2 = lambda x: round(float(x), 2)
     return {"value": round(1.0 / per_cand, 4), "unit": "candidates/s", "cores": torch.get_num_threads(), "kind": "port",
+            "extrapolation": f"N={N} as executed = {N} x ONE timed single-candidate forward (batch 1). The reference runs the N candidates as ONE batch "
+                             "(run_simpler_eval_with_openpi.py:305-326); a batched CPU forward re-uses every weight read for N rows, so the true "
+                             "as-executed CPU rate is higher than this per-candidate figure -- it is a pessimistic bound, reported as such",
             "sample": f"1 cold run (config 1: N=1 greedy) + {timed} timed FULL candidates, median; candidates are timed, not decisions. One candidate = "
-                      f"an eager un-deduplicated forward (all layers of every tower, 32 Llama layers prefill T~{1 + 256 + int(i['lens'][1])} + 6 decode "
+                      f"an eager un-deduplicated forward (all layers of every tower, 32 Llama layers prefill T~{1 + 256 + int(i['lens'][1 % n_local])} + 6 decode "
                       f"steps, lm_head x7, verifier towers + 3-member heads). N={N} as executed (no dedup) = {N} x median = {N * per_cand:.0f} s per decision",
             "seconds_per_candidate": r2(per_cand), "seconds_per_candidate_runs": [r2(r["total"]) for r in runs],
             "phase_seconds_median": {k: round(v, 3) for k, v in med.items()},
@@ -271,6 +520,65 @@ def cpu_baseline(pipe, timed=3):
             "dedup_variant": {"decision_seconds": r2(dedup), "candidates_per_s": round(N / dedup, 4),
                               "composition": f"vision + verifier towers once + {P} prefills + {N} x (decode + heads), from the phase medians"},
             "total_cpu_leg_seconds": r2(time.time() - t_all), "cpu_model": model, "isa": isa, "dtype": "bf16 weights, eager PyTorch-CPU"}
+
+
+def fp8_agreement(pipe, dev, a, n_prompts_global, prompt_ids):
+    """What quantisation changes ("report arg-max agreement rate and score RMSE"), per decode step and per source:
+    the SAME decision (frame, prompts, uniforms) through a bf16 pipeline of the same synthetic checkpoint, then -- TEACHER-FORCED on
+    the bf16 run's tokens, so that step t compares like with like instead of two diverged histories -- through (a) this fp8 pipeline
+    as it runs (e4m3 weights; e4m3 activations in every pass with more than 64 rows: the 448-row prefill at N = 32, every pass at
+    N = 512) and (b) the same pipeline with COVER_FP8_MFMA=0 (e4m3 WEIGHTS only, bf16 activations everywhere). Per step: rel-L2 of
+    the action-bin logits against bf16, top-1 agreement over the action bins, and the agreement among the rows whose bf16 top-1 / top-2
+    margin exceeds twice the row's max logit error (the picks the data decide). Random-init weights have no margin to spare
+    (top-1 / top-2 gaps of ~0.3 logits against quantisation noise of the same size), so raw agreement on them is a noise-to-margin
+    ratio, not a verdict on the kernels: the decided-row agreement and the logit errors are the numbers that transfer."""
+    gi8, tok8, _ = pipe.decision()
+    sc8 = pipe.last_scores.clone()
+    ref = Pipeline(dev, small=a.small, n_prompts=n_prompts_global, n_samples=a.samples, n_cams=a.cams, members=a.members,
+                   prompt_ids=prompt_ids, weight_dtype="bf16", horizon=a.horizon, own_kv=pipe.own_kv if pipe.own_kv != "fp8" else "bf16")
+    gi16, tok16, _ = ref.decision()
+    sc16 = ref.last_scores
+    i, S = pipe.inp, pipe.n_samples
+    lo, hi = pipe.c["tok_vocab"] - pipe.c["n_bins"], pipe.c["tok_vocab"]
+    n_steps = min(tok16.shape[1], 7)           # (config 5 decodes 56 tokens: the first chunk's seven carry the comparison)
+
+    def forced_logits(p):
+        tr = {}
+        p.policy.sample(i["frame"], i["toks"], i["lens"], S, i["u"], 1.0, trace=tr, force_tokens=tok16)
+        return [lg[:, lo:hi].float() for lg in tr["logits"][:n_steps]]
+
+    l16 = forced_logits(ref)
+    l8 = forced_logits(pipe)
+    os.environ["COVER_FP8_MFMA"] = "0"
+    try:
+        l8w = forced_logits(pipe)
+    finally:
+        os.environ.pop("COVER_FP8_MFMA", None)
+
+    def per_step(lq):
+        rows = []
+        for t in range(n_steps):
+            b, q = l16[t], lq[t]
+            err = (q - b).abs().amax(dim=1)
+            top2 = b.topk(2, dim=1).values
+            decided = (top2[:, 0] - top2[:, 1]) > 2 * err
+            same = q.argmax(1) == b.argmax(1)
+            rows.append({"logit_rel_l2": round(float((q - b).norm() / b.norm()), 4), "top1_agreement": round(float(same.float().mean()), 4),
+                         "decided_rows": int(decided.sum()), "decided_agreement": (round(float(same[decided].float().mean()), 4) if bool(decided.any()) else None)})
+        return rows
+
+    dbin = (tok8 - tok16).abs().float()
+    res = {"token_agreement_free_running": round(float((tok8 == tok16).float().mean()), 4), "mean_bin_distance": round(float(dbin.mean()), 3),
+           "first_token_agreement": round(float((tok8[:, 0] == tok16[:, 0]).float().mean()), 4),
+           "score_rmse": round(float((sc8 - sc16).pow(2).mean().sqrt()), 5), "winner_same": bool(gi8 == gi16),
+           "teacher_forced_per_step": {"weights_and_activations_e4m3 (as run)": per_step(l8), "weights_only_e4m3 (COVER_FP8_MFMA=0)": per_step(l8w)},
+           "logit_spread": round(float(l16[0].std()), 3),
+           "note": "free-running numbers compare two diverged token histories after the first disagreement; the teacher-forced table isolates each step. "
+                   "e4m3 weights: per-channel 2^e scales (the e4m3 stream is bit-identical to a bf16 GEMM on the de-quantised weights, tests/test_fp8_gpu.py); "
+                   "e4m3 activations: per-row 2^e scales in every pass with more than 64 rows (error bound: tests/test_fp8_gpu.py::test_fp8_activation_error_bound_with_outliers)"}
+    del ref
+    torch.cuda.empty_cache()
+    return res
 
 
 def lib_hash():
@@ -394,7 +702,14 @@ def main():
                     help="own-token KV cache of the decode passes: auto = head-major (e4m3 with --dtype fp8) above 64 candidates per GPU, legacy below")
     ap.add_argument("--horizon", type=int, default=1, help="action-chunk horizon: 7 x horizon action tokens per candidate (config 5: 8)")
     ap.add_argument("--check-out", default=None, help="write this rank's selection (winner index / tokens) as JSON (plumbing tests)")
+    ap.add_argument("--profile", choices=["openvla", "pi0"], default="openvla",
+                    help="pi0 = profile P1 (what the reference ships: pi0 sampler B = 40 + verifier), one GPU; the default is the BASELINE.json metric (OpenVLA-7B shapes)")
+    ap.add_argument("--cpu-batch", type=int, default=40, help="--profile pi0: rows of the CPU-baseline decision (40 = as the reference executes it)")
     a = ap.parse_args()
+    if a.profile == "pi0":
+        if a.gpus != 1:
+            raise SystemExit("--profile pi0 is a one-GPU line")
+        return main_pi0(a)
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` without a launcher: start one rank per GPU as CHILD processes (torch.distributed.run) before
         # anything here touches the GPU, and leave with their exit code (never exec from a process that may have initialised HIP)
@@ -427,8 +742,8 @@ def main():
         else:
             dist.init_process_group(a.backend, rank=rank, world_size=world)
     strong = a.scaling == "strong" and world > 1 and a.config != 3
-    if strong and N_PROMPTS % world:
-        raise SystemExit(f"--scaling strong shards the {N_PROMPTS} prompt groups: world size must divide {N_PROMPTS}")
+    if strong and world > N_PROMPTS:
+        raise SystemExit(f"--scaling strong shards the {N_PROMPTS} prompt groups: at most {N_PROMPTS} ranks")
     if a.config == 3:       # W prompt groups x 32 samples, rank r owns group r
         a.samples = 32
         n_prompts_global = world
@@ -495,23 +810,7 @@ def main():
         ms, cnt, work = profile_decision(pipe, world, rank, cpu_gather)
         out.update(roofline_objects(ms, cnt, work, ms_per_step, out["config"]["lib_sha16"]))
     if a.dtype == "fp8" and world == 1 and not a.no_agreement:
-        # what quantisation changes ("report arg-max agreement rate and score RMSE"): the same decision through a bf16
-        # pipeline of the same synthetic checkpoint, same frame / prompts / uniforms
-        gi8, tok8, _ = pipe.decision()
-        sc8 = pipe.last_scores.clone()
-        ref = Pipeline(dev, small=a.small, n_prompts=n_prompts_global, n_samples=a.samples, n_cams=a.cams, members=a.members,
-                       prompt_ids=prompt_ids, weight_dtype="bf16", horizon=a.horizon)
-        gi16, tok16, _ = ref.decision()
-        sc16 = ref.last_scores
-        dbin = (tok8 - tok16).abs().float()
-        out["fp8_vs_bf16"] = {"token_agreement": round(float((tok8 == tok16).float().mean()), 4), "mean_bin_distance": round(float(dbin.mean()), 3),
-                              "first_token_agreement": round(float((tok8[:, 0] == tok16[:, 0]).float().mean()), 4),
-                              "score_rmse": round(float((sc8 - sc16).pow(2).mean().sqrt()), 5), "winner_same": bool(gi8 == gi16),
-                              "note": "random-init weights: logits are near-flat over the 256 action bins, so sampled picks are maximally "
-                                      "sensitive to quantisation; the e4m3 stream itself is bit-identical to bf16 on the de-quantised weights "
-                                      "(tests/test_fp8_gpu.py)"}
-        del ref
-        torch.cuda.empty_cache()
+        out["fp8_vs_bf16"] = fp8_agreement(pipe, dev, a, n_prompts_global, prompt_ids)
     if rank == 0 and world == 1 and not a.no_cpu_baseline and not a.small:
         out["cpu_baseline"] = cpu_baseline(pipe)
     if rank == 0:

@@ -71,6 +71,11 @@ int cover_quantize_act_fp8(const void* X, int ldx, int M, int K, void* out8, int
     return COVER_OK;
 }
 size_t cover_gemm_workspace_bytes(int M, int N, int K) { return gemm_workspace_bytes(M, N, K); }
+int cover_gemm_plan_counts(long long* counts, int n, int reset) {
+    if (n < 0 || (n > 0 && !counts)) return fail(COVER_EINVAL, "cover_gemm_plan_counts: bad arguments");
+    gemm_plan_counts(counts, n, reset);
+    return COVER_GEMM_PLANS;
+}
 int cover_gemm_bf16(const void* A, int lda, const void* Wp, void* C, int ldc, int M, int N, int K,
                     const cover_gemm_epi* epi, void* ws, size_t ws_bytes, int variant, void* stream) {
     if (!A || !Wp || !C) return fail(COVER_EINVAL, "cover_gemm_bf16: null pointer");
@@ -440,7 +445,7 @@ int cover_decoder_forward(const cover_dec_desc* d, const cover_dec_pass* p, void
     // fp8 profile with more rows than the weight-streaming kernels take (config 5: M = 512 decode rows, and its prefill): the
     // projections run on the MX-scaled fp8 matrix instruction -- the input rows of every GEMM are quantised to e4m3 (per-row
     // power-of-two scale) right before it, into one shared buffer
-    static const char* f8_env = getenv("COVER_FP8_MFMA");
+    const char* f8_env = getenv("COVER_FP8_MFMA");   // read per call (bench.py's agreement run toggles it inside one process)
     const bool f8 = rows > 64 && d->layers_host[0].qkv_w8 && d->layers_host[0].o_w8 && d->layers_host[0].gate_up_w8 && d->layers_host[0].down_w8 &&
                     !(f8_env && f8_env[0] == '0');
     // the norms that produce h also emit its e4m3 twin (RMSNorm widths that are multiples of 128): two quantise launches per layer less

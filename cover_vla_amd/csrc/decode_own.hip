@@ -231,9 +231,12 @@ __global__ __launch_bounds__(256) void decode_own_attn_k(OwnAttnDev a) {
     for (int e = 0; e < DPL; ++e) acc[e] = p[NIT] * xs[w][2][j * DPL + e];   // (p[NIT] is 0 outside lane group 0)
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
+        // a masked slot (index clamped to a row that may never have been written: write_t == 0 reads row 0 before the append lands)
+        // contributes exactly nothing -- its bits and its scale are replaced, not multiplied by a zero probability (0 * NaN)
+        const bool vis = it * KPL + kq < nkeys;
         float x[DPL];
-        unpack(vr[it], x);
-        const float pw = F8 ? p[it] * vsc[it] : p[it];   // the row scale is a power of two: exact
+        unpack(vis ? vr[it] : make_uint4(0u, 0u, 0u, 0u), x);
+        const float pw = vis ? (F8 ? p[it] * vsc[it] : p[it]) : 0.f;   // the row scale is a power of two: exact
 #pragma unroll
         for (int e = 0; e < DPL; ++e) acc[e] += pw * x[e];
     }

@@ -15,6 +15,7 @@
 //                (no LDS round trip for the streamed operand), split-K over grid.y with fp32 partials that a
 //                small reduce kernel folds together with the epilogue.
 #include <stdlib.h>
+#include <atomic>
 #include <hip/hip_ext.h>
 #include "common.h"
 #include "kernels.h"
@@ -1449,9 +1450,21 @@ size_t gemm_workspace_bytes(int M, int N, int K) {
 }
 
 // second-generation weight streaming; e4m3 weights for M <= 32 when a twin is given
+// which plan every GEMM launch took since the last reset (cover_gemm_plan_counts: tests assert the tile a shape really ran on):
+// [0..18] LDS-tiled picks (index into cands below), [19] gemm_skinny2, [20] gemm_skinny3, [21] fp8 tiled (any pick), [22] gemm_skinny (gen 1)
+static std::atomic<long long> g_plan_counts[COVER_GEMM_PLANS];
+static inline void plan_hit(int i) { g_plan_counts[i].fetch_add(1, std::memory_order_relaxed); }
+void gemm_plan_counts(long long* out, int n, int reset) {
+    for (int i = 0; i < COVER_GEMM_PLANS; ++i) {
+        const long long v = reset ? g_plan_counts[i].exchange(0, std::memory_order_relaxed) : g_plan_counts[i].load(std::memory_order_relaxed);
+        if (out && i < n) out[i] = v;
+    }
+}
+
 static void launch_skinny2(const Skinny2Plan& p, const bf16_t* A, int lda, const bf16_t* Wp, float* ws, int M, int N, int K, int Kp,
                            const uint8_t* w8, const float* w8s, hipStream_t st) {
     dim3 grid(p.gx, p.S), block(512);
+    plan_hit(19);
 #define SK2(MF_, KS_, NBW_, W8_) launch_streaming(sk_class(N, K), (W8_ ? 1.0 : 2.0) * (double)N * (double)K, gemm_skinny2<MF_, KS_, NBW_, W8_>, grid, block, p.lds, st, A, lda, W8_ ? (const bf16_t*)w8 : Wp, ws, M, N, Kp, w8s)
     if (w8 && w8s && p.MF <= 2) {
         if (p.MF == 1) { if (p.NBW == 6) SK2(1, 4, 6, true); else if (p.NBW == 4) SK2(1, 4, 4, true); else if (p.NBW == 3) SK2(1, 4, 3, true); else SK2(1, 4, 2, true); }
@@ -1469,6 +1482,7 @@ static hipError_t launch_skinny3(const Skinny3Plan& p, const bf16_t* A, int lda,
                                  int Kp, const EpiDev& epi, float* partial, hipStream_t st) {
     hipError_t e = hipSuccess;
     dim3 grid(p.gx, p.S), block(512);
+    plan_hit(20);
 #define SK3(MF_, NBW_, W8_)                                                                                                  \
     do {                                                                                                                    \
         auto kfn = gemm_skinny3<MF_, 4, NBW_, NBW_, W8_>;                                                                   \
@@ -1565,6 +1579,7 @@ hipError_t launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* Wp, void* C,
         if (ws == nullptr || ws_bytes < p.ws_bytes) return hipErrorInvalidValue;
         dim3 grid(p.gx, p.S), block(512);
         const int pid = prof_enabled() ? prof_open(st, sk_class(N, K), 2.0 * (double)N * (double)K) : -1;
+        plan_hit(22);
         switch (p.MF) {
             case 1: hipLaunchKernelGGL(gemm_skinny<1>, grid, block, p.lds, st, A, lda, Wp, ws, M, N, Kp, p.KC, p.nbpb); break;
             case 2: hipLaunchKernelGGL(gemm_skinny<2>, grid, block, p.lds, st, A, lda, Wp, ws, M, N, Kp, p.KC, p.nbpb); break;
@@ -1648,7 +1663,9 @@ hipError_t launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* Wp, void* C,
     // exactly 256 tiles of 128 x 192; gate_up (N = 22016) is 344 tiles (two rounds, the second a third full) or 460 of 128 x 192
     // (two rounds of a 0.79 x tile). Cost = rounds x (0.55 area + 0.45 perimeter), normalised to the 256 x 128 tile; measured at
     // M = 512: qkv 35 -> 28 us, gate_up 70 -> 54 us.
-    if (epi.a8 && variant != 2 && Kp >= 2048 && M >= 512 && N > 4096 && gemm_fp8_tiled_supported(18)) {
+    const char* f8_env = epi.a8 ? getenv("COVER_FP8_MFMA") : nullptr;   // experiment knob, read per call: 0 keeps the bf16 MFMA path on fp8 operands
+    const bool f8_on = epi.a8 && !(f8_env && f8_env[0] == '0');
+    if (f8_on && variant != 2 && Kp >= 2048 && M >= 512 && N > 4096 && gemm_fp8_tiled_supported(18)) {
         const int idx[3] = {12, 13, 18};
         double best = 1e30;
         for (int c = 0; c < 3; ++c) {
@@ -1675,7 +1692,7 @@ hipError_t launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* Wp, void* C,
             double best = 1e30;
             for (int c = 0; c < 3; ++c) {
                 if (epi.glu && (bns[c] % 32)) continue;
-                if (epi.a8 && bns[c] == 192) continue;   // no fp8 instantiation of the 224 x 192 tile (registers)
+                if (f8_on && bns[c] == 192) continue;   // no fp8 instantiation of the 224 x 192 tile (registers)
                 for (int S = 1; S <= 8; S *= 2) {
                     if (S > 1 && (ws == nullptr || (size_t)S * M * N * sizeof(float) > ws_bytes || epi.glu || (Kp / BK) / S < 8)) break;
                     const long long blocks = (long long)t224 * ((N + bns[c] - 1) / bns[c]) * S;
@@ -1694,6 +1711,7 @@ hipError_t launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* Wp, void* C,
         if (force && force[0] >= 'a' && force[0] <= 'h') pick = 10 + (force[0] - 'a');
     }
     if (variant == 2 && pick > 2) pick = 0;
+    if (pick == 18 && !(f8_on && gemm_fp8_tiled_supported(18))) return hipErrorInvalidValue;   // 128 x 192 exists as an fp8 kernel only
     const Cand cd = cands[pick];
     const int bm = cd.wm * cd.wgm * 16, bn = cd.wn * cd.wgn * 16;
     const int tiles_m = (M + bm - 1) / bm, tiles_n = (N + bn - 1) / bn;
@@ -1743,8 +1761,8 @@ hipError_t launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* Wp, void* C,
         if (e == hipSuccess)                                                                                                \
             launch_streaming(tcls, twork, kfn, grid, block, lds, st, A, lda, Wp, C, ldc, M, N, Kp, epi, tiles_m, tiles_n, kt_per, partial); \
     } while (0)
-    static const char* f8_env = getenv("COVER_FP8_MFMA");   // experiment knob: 0 keeps the bf16 MFMA path on fp8 operands
-    if (epi.a8 && gemm_fp8_tiled_supported(pick) && !(f8_env && f8_env[0] == '0')) {
+    if (f8_on && gemm_fp8_tiled_supported(pick)) {
+        plan_hit(21);
         // both operands e4m3: the MX-scaled matrix instruction, 128 k per k-tile (same LDS bytes per tile as 64 k of bf16)
         if (epi.lda8 < Kp || (epi.lda8 & 15)) return hipErrorInvalidValue;
         const int nk8 = Kp / 128;
@@ -1754,6 +1772,7 @@ hipError_t launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* Wp, void* C,
         e = launch_gemm_fp8_tiled(pick, epi.a8, epi.lda8, epi.a8s, epi.w8, epi.w8s, C, ldc, M, N, Kp, epi, tiles_m, tiles_n, kt8, S, partial, lds,
                                   7, 2.0 * (double)M * (double)N * (double)K, st);
     } else if (pc) {
+        plan_hit(pick);
         // loader waves: one wave issues an LDS-DMA piece every ~60 cycles, four keep the CU's vector memory path busy
         // (cold weights, M = 448: o_proj 36.0 -> 32.3 us, down 84.2 -> 76.0 us)
         static const char* nl_env = getenv("COVER_PC_LOADERS");
@@ -1769,10 +1788,12 @@ hipError_t launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* Wp, void* C,
         else if (pick == 16) LAUNCH_PC(7, 3, 3, 4, 2, 4);
         else LAUNCH_PC(7, 2, 4, 4, 2, 3);
     } else if (variant == 2) {
+        plan_hit(pick);
         if (pick == 0) LAUNCH_T(4, 4, false, 2, 2, 2);
         else if (pick == 1) LAUNCH_T(2, 4, false, 2, 2, 2);
         else LAUNCH_T(2, 2, false, 2, 2, 2);
     } else {
+        plan_hit(pick);
         switch (pick) {
             case 0: LAUNCH_T(4, 4, true, 2, 2, 2); break;
             case 1: LAUNCH_T(2, 4, true, 2, 2, 2); break;

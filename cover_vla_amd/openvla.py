@@ -34,8 +34,12 @@ class OpenVLA:
     def __init__(self, sd: Dict[str, torch.Tensor], c: dict, *, device="cuda:0", max_prompts=8, max_candidates=32,
                  max_text=32, horizon=1, n_cams=1, weight_dtype="bf16", own_kv=None):
         """weight_dtype "fp8" (BASELINE config 5): the Llama projections and the lm_head are quantised to e4m3 with per-channel
-        power-of-two scales; the HBM-bound decode passes stream the e4m3 image, the MFMA-bound prefill the bf16 image of the same
-        quantised values (cover_vla_amd.ops.pack_linear). The vision towers and the projector stay bf16 (MFMA-bound).
+        power-of-two scales (cover_vla_amd.ops.pack_linear). Passes with at most 64 rows (the decode passes up to N = 64) stream the e4m3
+        weight image with bf16 activations -- bit-identical to a bf16 GEMM on the de-quantised weights. Passes with MORE than 64 rows --
+        the 448-row prefill of every fp8 run, and every decode pass of config 5 (N = 512) -- also quantise the input rows of each
+        projection to e4m3 (per-row power-of-two scale) and run on the MX-scaled fp8 MFMA; COVER_FP8_MFMA=0 keeps those passes on the
+        bf16 MFMA with the bf16 image of the same quantised weights (weights-only quantisation). The vision towers and the projector
+        stay bf16.
         own_kv "bf16" / "fp8" (large N, config 5): the candidates' own-token KV segment is kept head-major (K and V [slot][h][t][d],
         bf16 or e4m3 with per-row scales = the "fp8 KV" of config 5) and every decode pass runs the own-token VALU pass + ONE MFMA pass
         over [shared prefix | prompt text] instead of the fused 16-candidate kernel (cover_decode_own_attention). None = legacy layout."""

@@ -143,6 +143,15 @@ def gemm(a: torch.Tensor, lin: PackedLinear, *, act: str = "none", residual: Opt
     return out
 
 
+def gemm_plan_counts(reset: bool = False) -> list:
+    """Launch counters per GEMM kernel plan since the last reset (cover_gemm_plan_counts): [0..18] tiled picks (14..17 = 224-row
+    tiles), [19] / [20] / [22] weight-streaming generations 2 / 3 / 1, [21] fp8 MFMA tiles."""
+    n = 23
+    buf = (C.c_longlong * n)()
+    L.lib().cover_gemm_plan_counts(buf, n, 1 if reset else 0)
+    return list(buf)
+
+
 # ------------------------------------------------------------------------------------------------ attention
 @dataclass
 class Segment:

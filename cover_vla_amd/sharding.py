@@ -53,13 +53,21 @@ def gather_records_and_select(local_scores: torch.Tensor, samples_per_prompt: in
         rec = torch.cat([rec, local_payload.reshape(n_loc, P).to(torch.float32)], dim=1)
     rec = rec.contiguous()
     if world > 1:
-        # equal shards are the contract (prompts % world == 0); a ragged tail would need all_gather with padding
-        assert n_prompts_total % world == 0 and n_local_prompts * world == n_prompts_total, \
-            "prompt count must be a multiple of the world size"
-        buf = torch.empty(world * n_loc, 1 + P, dtype=torch.float32, device=rec.device)
-        dist.all_gather_into_tensor(buf, rec)
-        # rank r's j-th prompt is global prompt r + j*world  -> scatter back into global prompt order
-        allrec = buf.view(world, n_local_prompts, S, 1 + P).permute(1, 0, 2, 3).reshape(n_prompts_total * S, 1 + P)
+        # rank r owns global prompts r, r + W, ...: ceil((G - r) / W) of them. Shards may be ragged (8 prompts on 3 or 5 GPUs): every
+        # rank pads its records up to ceil(G / W) prompts for the ONE equal-size all-gather; the padded records are dropped when the
+        # gathered buffer is put back into global prompt order (they never reach the arg-max).
+        G = n_prompts_total
+        expect = (G - rank + world - 1) // world if rank < G else 0
+        if n_local_prompts * S != n_loc or n_local_prompts != expect:
+            raise ValueError(f"rank {rank} of {world} owns prompts {rank}, {rank + world}, ... of {G}: expected {expect} prompt groups x {S} "
+                             f"samples, got {n_loc} local scores")
+        max_local = (G + world - 1) // world
+        if n_local_prompts < max_local:
+            rec = torch.cat([rec, torch.zeros((max_local - n_local_prompts) * S, 1 + P, dtype=torch.float32, device=rec.device)], dim=0)
+        buf = torch.empty(world * max_local * S, 1 + P, dtype=torch.float32, device=rec.device)
+        dist.all_gather_into_tensor(buf, rec.contiguous())
+        # rank r's j-th prompt is global prompt r + j * world -> [j][r] order is global prompt order; the first G groups are the real ones
+        allrec = buf.view(world, max_local, S, 1 + P).permute(1, 0, 2, 3).reshape(max_local * world * S, 1 + P)[: G * S]
     else:
         allrec = rec
     scores = allrec[:, 0].contiguous()

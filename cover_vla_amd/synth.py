@@ -222,10 +222,13 @@ def decoder_state(g: _G, *, dim: int, layers: int, Hq: int, Hkv: int, D: int, ml
 
 
 # ------------------------------------------------------------------------------------------------ pi0 (P1)
-def pi0_state(c: dict, seed: int = 1234, nontrivial: bool = True, std: float = 0.1) -> Dict[str, Tensor]:
+def pi0_state(c: dict, seed: int = 1234, nontrivial: bool = True, std: float = 0.1, device="cpu",
+              wdtype=torch.float32) -> Dict[str, Tensor]:
     """Neutral pi0 state dict (fp32 master copy) for a config dict with keys lm_dim, lm_mlp, ex_dim, ex_mlp, layers,
-    Hq, Hkv, D, vocab, vit_dim, vit_mlp, vit_layers, vit_heads, patch, image. Key layout: see oracle/cover_ref/pi0.py."""
-    g = _G(seed, nontrivial, std)
+    Hq, Hkv, D, vocab, vit_dim, vit_mlp, vit_layers, vit_heads, patch, image. Key layout: see oracle/cover_ref/pi0.py.
+    device / wdtype: draw the checkpoint directly in HBM in bf16 (bench: PI0_FULL is 3.3 G parameters); pi0's own five
+    projections are always returned in fp32 (the reference keeps them fp32, modeling_pi0.py:488-494)."""
+    g = _G(seed, nontrivial, std, device, wdtype)
     n_patches = (c["image"] // c["patch"]) ** 2
     sd = {}
     for k, v in vit_state(g, dim=c["vit_dim"], layers=c["vit_layers"], heads=c["vit_heads"], mlp=c["vit_mlp"],
@@ -242,7 +245,7 @@ def pi0_state(c: dict, seed: int = 1234, nontrivial: bool = True, std: float = 0
     pw = c["ex_dim"]
     for n, (o, i) in {"state_proj": (pw, 32), "action_in_proj": (pw, 32), "action_out_proj": (32, pw),
                       "action_time_mlp_in": (pw, 2 * pw), "action_time_mlp_out": (pw, pw)}.items():
-        sd[n + ".weight"] = g.w(o, i)
+        sd[n + ".weight"] = g.w(o, i).float()
         sd[n + ".bias"] = g.b(o)
     return sd
 

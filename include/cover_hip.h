@@ -123,6 +123,11 @@ int cover_quantize_act_fp8(const void* X, int ldx, int M, int K, void* out8, int
 size_t cover_gemm_workspace_bytes(int M, int N, int K);
 int cover_gemm_bf16(const void* A, int lda, const void* Wp, void* C, int ldc, int M, int N, int K,
                     const cover_gemm_epi* epi, void* splitk_ws, size_t splitk_ws_bytes, int variant, void* stream);
+/* Which kernel plan every GEMM launch of this process took since the last reset (test / audit hook: a parity test can assert
+ * that a shape really ran on the tile it means to cover). counts[0..18] = LDS-tiled configurations (14..17 = the 224-row
+ * loader-wave tiles of the M = 448 prefill pass, 12/13 = 256x128 / 128x256), [19] = second-generation weight streaming,
+ * [20] = third generation, [21] = fp8 MFMA tiles, [22] = first generation. Copies min(n, 23) counters, returns 23. */
+int cover_gemm_plan_counts(long long* counts, int n, int reset);
 
 /* ------------------------------------------------------------------------------------------------
  * Flash-style attention on MFMA, fp32 softmax, over up to 3 KV segments per query row.

@@ -83,13 +83,21 @@ def apply_rope_hf(x, positions, cos_t, sin_t):
 
 
 # ------------------------------------------------------------------------------------------------ attention
-def eager_attention(q, k, v, mask, scale):
+def eager_attention(q, k, v, mask, scale, scores_bf16=False):
     """q [B,Tq,Hq,D], k/v [B,Tk,Hkv,D] (bf16), mask bool [B,Tq,Tk] -> [B,Tq,Hq*D] bf16.
-    paligemma_with_expert.py:376-434 semantics."""
+    paligemma_with_expert.py:376-434 semantics. scores_bf16: HF transformers' eager_attention_forward of the Llama family instead
+    (models/llama/modeling_llama.py: QK^T and the scaling in the TENSOR dtype -- bf16 scores --, additive mask, softmax in fp32, cast
+    back, PV in bf16): used to pin the restatement to HF's bf16 outputs; the default keeps the reference's fp32 scores."""
     B, Tq, Hq, D = q.shape
     G = Hq // k.shape[2]
     k = k.repeat_interleave(G, dim=2)
     v = v.repeat_interleave(G, dim=2)
+    if scores_bf16:
+        att = torch.matmul(q.transpose(1, 2), k.transpose(1, 2).transpose(2, 3)) * scale
+        att = att + torch.where(mask[:, None, :, :], 0.0, torch.finfo(att.dtype).min).to(att.dtype)
+        probs = torch.softmax(att, dim=-1, dtype=torch.float32).to(q.dtype)
+        out = torch.matmul(probs, v.permute(0, 2, 1, 3))
+        return out.permute(0, 2, 1, 3).reshape(B, Tq, Hq * D)
     qf = q.float().transpose(1, 2)
     kf = k.float().transpose(1, 2)
     att = torch.matmul(qf, kf.transpose(2, 3))
@@ -102,9 +110,10 @@ def eager_attention(q, k, v, mask, scale):
 
 # ------------------------------------------------------------------------------------------------ decoder
 class DecoderCfg:
-    def __init__(self, dim, layers, Hq, Hkv, D, mlp, act, norm, eps, rope):
+    def __init__(self, dim, layers, Hq, Hkv, D, mlp, act, norm, eps, rope, scores_bf16=False):
         self.dim, self.layers, self.Hq, self.Hkv, self.D, self.mlp = dim, layers, Hq, Hkv, D, mlp
         self.act, self.norm, self.eps, self.rope = act, norm, eps, rope  # norm: "gemma"|"llama"; rope: "pi0"|"hf"
+        self.scores_bf16 = scores_bf16   # HF Llama eager attention (bf16 scores) instead of the reference's fp32 scores
 
     def rms(self, x, w):
         return gemma_rmsnorm(x, w, self.eps) if self.norm == "gemma" else llama_rmsnorm(x, w, self.eps)
@@ -155,7 +164,7 @@ def decoder_forward(cfg: DecoderCfg, sd, x, positions, mask, past=None, keep_kv=
             kk, vv = k, v
         if keep_kv:
             new_kv.append((kk, vv))
-        a = fq(eager_attention(q, kk, vv, mask, cfg.D ** -0.5).to(BF))
+        a = fq(eager_attention(q, kk, vv, mask, cfg.D ** -0.5, scores_bf16=cfg.scores_bf16).to(BF))
         o = lin(a, sd[p + "self_attn.o_proj.weight"])
         o += x  # in-place add into the bf16 o_proj output (paligemma_with_expert.py:332): fp32 x is rounded here
         res = o.clone()

@@ -86,9 +86,10 @@ def _decision_properties(pipe, dev, P, S):
     tv = tok.view(P, S, 7)
     assert torch.equal(tv, tv[:, :1].expand_as(tv))
     # (c) prompt-permutation equivariance: the slot a prompt occupies in the batch must not matter
-    perm = torch.tensor([3, 0, 7, 1, 6, 2, 5, 4], device=dev)
-    tokp, _ = pipe.policy.sample(i["frame"], i["toks"][perm], i["lens"][perm], S, u.view(P, S, 7)[perm].reshape(P * S, 7).contiguous(), 1.0)
-    assert torch.equal(tokp.view(P, S, 7), tv[perm])
+    if P == 8:
+        perm = torch.tensor([3, 0, 7, 1, 6, 2, 5, 4], device=dev)
+        tokp, _ = pipe.policy.sample(i["frame"], i["toks"][perm], i["lens"][perm], S, u.view(P, S, 7)[perm].reshape(P * S, 7).contiguous(), 1.0)
+        assert torch.equal(tokp.view(P, S, 7), tv[perm])
     # (d) greedy decoding of a single prompt equals the first row of a batched greedy run (M = 1 vs M = 8 rows)
     g8, _ = pipe.policy.sample(i["frame"], i["toks"], i["lens"], 1)
     g1, _ = pipe.policy.sample(i["frame"], i["toks"][:1], i["lens"][:1], 1)
@@ -117,6 +118,76 @@ def test_fullsize_config2_n16(pipe, dev):
         assert torch.equal(tok16.view(8, 2, 7), tok32.view(8, 4, 7)[:, :2])
     finally:
         pipe.n_samples, pipe.inp["u"] = keep
+
+
+def test_fullsize_config3_one_prompt_group_of_32_samples(pipe, dev):
+    """BASELINE config 3, the per-rank workload at FULL size (W prompt groups x 32 samples, rank r owns group r): ONE
+    prompt group, 32 samples -- one prefill row group of 24 text rows behind the shared prefix (M = 280 prefill rows), M = 32 decode
+    rows that all attend ONE prompt slot (both 16-candidate tiles of the fused decode attention on the same slot). Properties as the
+    headline's, plus a cross-configuration identity: candidate (prompt 0, sample s) draws uniform row s in both runs, so samples
+    0..3 of this run must equal the headline run's prompt-0 candidates bit for bit (same frame, prompt, uniforms; other batch)."""
+    import bench
+    p3 = bench.Pipeline(dev, small=False, n_prompts=1, n_samples=32)
+    assert len(p3.prompt_ids) == 1 and p3.inp["u"].shape == (32, 7) and p3.policy.max_prompts == 1
+    _decision_properties(p3, dev, 1, 32)
+    _, tok3, _ = p3.decision()
+    _, tok32, _ = pipe.decision()
+    assert torch.equal(p3.inp["toks"][0], pipe.inp["toks"][0]) and torch.equal(p3.inp["u"][:4], pipe.inp["u"][:4])
+    assert torch.equal(tok3[:4], tok32[:4])
+    assert len({tuple(r) for r in tok3.tolist()}) > 8          # the 32 samples are not copies of each other
+    del p3
+    torch.cuda.empty_cache()
+
+
+def test_fullsize_pi0_profile_b40(dev):
+    """Profile P1 at FULL size -- the reference's shipped run (modeling_pi0.py:672-715 on the batch of
+    run_simpler_eval_with_openpi.py:296-319): PI0_FULL (SigLIP-So400m, 18-layer Gemma-2B prefix, 300 M expert), B = 40 = 8 prompts
+    x 5 samples, chunk 4, 10 Euler steps, 3-member verifier. The CPU oracle cannot run this in seconds; size-independent properties:
+    determinism; rows of a prompt with IDENTICAL noise produce identical actions; the de-duplicated schedule (tower once, prefix
+    once per distinct prompt) == the reference's schedule (every row its own tower + prefix pass: _image_classes forced to B classes)
+    to bf16 tolerance; the three shortcuts (trailing pad columns dropped, suffix embedding folded, QKV slabs folded by the RoPE launch)
+    on vs off: fold / trim change only the order of fp32 sums or the GEMM tile (bf16 tolerance), the slab fold is bit-identical."""
+    import os
+    import bench
+    torch.cuda.empty_cache()
+    pp = bench.Pi0Pipeline(dev, max_prompts=40)
+    i, B, P, S = pp.inp, 40, 8, 5
+    idx1, x1 = pp.decision()
+    idx2, x2 = pp.decision()
+    assert idx1 == idx2 and torch.equal(x1, x2) and 0 <= idx1 < B
+    assert x1.shape == (B, 4, 32) and torch.isfinite(x1).all() and torch.isfinite(pp.last_scores).all()
+    _, xs = pp.decision(serial=True)
+    assert torch.equal(xs, x1)                                                    # the serialised (profiled) decision computes the same
+    rel = lambda a, b: ((a - b).norm() / (b - i["noise"]).norm()).item()          # relative to the size of the update, as the golden tests
+    # rows of one prompt with identical noise are identical; different noise gives different rows
+    nz = i["noise"].view(P, S, 4, 32)[:, :1].expand(P, S, 4, 32).reshape(B, 4, 32).contiguous()
+    _, xe = pp.decision(noise=nz)
+    xv = xe.view(P, S, 4, 32)
+    assert torch.equal(xv, xv[:, :1].expand_as(xv))
+    assert not torch.equal(x1.view(P, S, 4, 32)[:, 0], x1.view(P, S, 4, 32)[:, 1])
+    # dedup == no dedup
+    keep = pp.model._image_classes
+    try:
+        pp.model._image_classes = lambda cams, B_: np.arange(B_, dtype=np.int64)
+        _, xn = pp.decision()
+    finally:
+        pp.model._image_classes = keep
+    r_dedup = rel(xn, x1)
+    # shortcuts on vs off
+    r = {}
+    for var in ("COVER_PI0_TRIM_PAD", "COVER_PI0_SUFFIX_FOLD", "COVER_QKV_FOLD"):
+        os.environ[var] = "0"
+        try:
+            _, xo = pp.decision()
+        finally:
+            os.environ.pop(var, None)
+        r[var] = rel(xo, x1)
+        if var == "COVER_QKV_FOLD":
+            assert torch.equal(xo, x1)
+    print(f"P1 full size: dedup vs per-row rel {r_dedup:.2e}; shortcuts off vs on {r}")
+    assert r_dedup < 2e-2 and all(v < 2e-2 for v in r.values())
+    del pp
+    torch.cuda.empty_cache()
 
 
 def test_fullsize_config4_two_cameras_n64_ensemble2(dev):

@@ -109,12 +109,12 @@ def test_no_cpu_fallback_on_host_tensors():
 
 
 # ------------------------------------------------------------------------------------------------ multi-process
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, n_prompts=8):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from cover_vla_amd.sharding import gather_records_and_select, shard_prompts
-    prompts = [f"p{i}" for i in range(8)]
+    prompts = [f"p{i}" for i in range(n_prompts)]
     mine = shard_prompts(prompts, rank, world)
     # rank r scores its candidates with a known function of the GLOBAL candidate index; the payload of a candidate is its
     # 7 action tokens (int64, a known function of the global index too) -- what the driver needs of the winner and of the
@@ -153,6 +153,32 @@ def test_candidate_sharding_gloo_world2():
         assert outs[r]["winner_payload"] == tok(bg * S + bi)                       # exact: token ids < 2^24 survive fp32
         assert outs[r]["group_payload"] == [tok(bg * S + s) for s in range(S)]
         assert outs[r]["payload"] == [tok(g) for g in range(32)]
+        assert np.allclose(outs[r]["scores"], all_scores.view(-1).numpy(), atol=0)
+    assert outs[0] == outs[1]
+
+
+def test_candidate_sharding_gloo_world2_ragged_shards():
+    """7 prompt groups on 2 ranks (4 + 3): the short rank pads its records for the equal-size all-gather and the padding never
+    reaches the arg-max; a rank that passes the wrong number of local scores gets a ValueError naming the rule."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    ps = [ctx.Process(target=_worker, args=(r, 2, port, q, 7)) for r in range(2)]
+    for p in ps:
+        p.start()
+    outs = dict(q.get(timeout=120) for _ in ps)
+    for p in ps:
+        p.join(60)
+    S = 4
+    all_scores = torch.tensor([((g * 37) % 101) / 101.0 for g in range(28)]).view(7, S)
+    bg = int(all_scores.mean(1).argmax())
+    bi = int(all_scores[bg].argmax())
+    tok = lambda g: [31744 + (g * 13 + j * 7) % 256 for j in range(7)]
+    for r in range(2):
+        assert outs[r]["global_idx"] == bg * S + bi and outs[r]["group"] == bg
+        assert outs[r]["winner_payload"] == tok(bg * S + bi)
+        assert outs[r]["payload"] == [tok(g) for g in range(28)]
         assert np.allclose(outs[r]["scores"], all_scores.view(-1).numpy(), atol=0)
     assert outs[0] == outs[1]
 

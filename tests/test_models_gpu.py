@@ -205,11 +205,14 @@ def test_pi0_sampler_matches_reference_golden(dev, name):
     # suffix embedding at t = 1 (fp32 projections, float64 time embedding): valid rows
     se = trace["suffix_embs_t1"].cpu().numpy()
     assert np.allclose(se, z["suffix_embs_t1"], atol=2e-3, rtol=2e-3)
-    # sampled action chunk: judged on the flow-matching update, relative L2 <= 3e-2, max-abs <= 8e-2
+    # sampled action chunk: judged on the flow-matching update, relative L2 <= 3e-2, and element-wise atol 3e-2 -- the loosest rung the
+    # reference itself accepted for its converted checkpoint (conversion_scripts/compare_with_jax.py:131-133)
     upd = z["actions"] - noise.numpy()
     rel = np.linalg.norm(x - z["actions"]) / np.linalg.norm(upd)
+    mx = float(np.abs(x - z["actions"]).max())
+    print(f"pi0 {name}: rel-L2 of the update {rel:.4f}, max-abs {mx:.4f}")
     assert rel < 3e-2, rel
-    assert np.abs(x - z["actions"]).max() < 8e-2
+    assert mx < 3e-2, mx
     # the denoise loop as a replayed hipGraph (call 2 captures, call 3 replays) == the eager loop, bit for bit; and a
     # different noise / prompt assignment flows through the same graph
     args = ([im.to(dev) for im in images], [m.to(dev) for m in img_masks], toks.to(dev), masks.to(dev), state.to(dev))

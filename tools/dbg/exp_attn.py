@@ -1,7 +1,7 @@
 """Decode-attention experiment: phase A (shared image prefix, candidates as query rows, state out) + phase B (per-candidate
 segments, state in) at the OpenVLA-7B decode shape, 32 layers' worth of distinct caches captured into one hipGraph."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from cover_vla_amd import ops
 dev = torch.device("cuda:0")

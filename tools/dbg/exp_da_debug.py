@@ -2,8 +2,8 @@
 v_new in LDS), tile phase done, end -- relative to the earliest block start. OpenVLA-7B decode shape: N = 32, H = 32, D = 128.
 MODE=cold: 600 MB written between launches (data and code evicted); MODE=back2back: the same launch three times in a row."""
 import os, sys, ctypes as C
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests"))
 import numpy as np, torch
 from cover_vla_amd import ops, _lib as L
 from test_kernels_gpu import bf, make_cache

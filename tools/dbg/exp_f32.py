@@ -1,6 +1,6 @@
 """fp32 GEMM (verifier heads) micro-benchmark at the ensemble shapes, hipGraph-captured."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from cover_vla_amd import ops
 dev = torch.device("cuda:0")

@@ -1,7 +1,7 @@
 """Cycle breakdown inside gemm_tiled_pc (library built with -DCOVER_PC_DEBUG): loader wave 0 and MFMA wave 0 of every block.
-Usage: COVER_TILE_PICK=d M=2624 python tools/exp_pc_debug.py"""
+Usage: COVER_TILE_PICK=d M=2624 python tools/dbg/exp_pc_debug.py"""
 import os, sys, ctypes as C
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from cover_vla_amd import ops, _lib as L
 dev = torch.device("cuda:0")

@@ -1,7 +1,7 @@
 """Per-block timeline of the third-generation weight-streaming kernel (library built with -DCOVER_SK_DEBUG):
 start spread, first chunk staged, last MFMA, end -- relative to the earliest block start. EXP_SHAPE=qkv|gate_up|down|lm_head"""
 import os, sys, ctypes as C
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from cover_vla_amd import ops, _lib as L
 dev = torch.device("cuda:0")

@@ -2,7 +2,7 @@
 rotation of distinct weight copies (> 256 MiB so the Infinity Cache cannot hold the stream; no host launch overhead in
 the timing). Prints per shape: us per GEMM (kernel + reduce) and GB/s of weight bytes."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from cover_vla_amd import ops
 

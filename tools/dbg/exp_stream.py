@@ -1,7 +1,7 @@
 """HBM ceiling probe: pure streaming read of B bytes with the weight-streaming kernel's launch shape, captured in a graph
 over rotating buffers (> Infinity Cache)."""
 import ctypes as C, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from cover_vla_amd import ops, _lib as L
 h = L.lib()

@@ -1,7 +1,7 @@
 """Tiled-GEMM tile-configuration experiment at the OpenVLA-7B prefill shapes (M = 449). One process per COVER_TILE_PICK:
-   for p in 0 1 2 3 4 5 6; do COVER_TILE_PICK=$p python tools/exp_tiles.py; done"""
+   for p in 0 1 2 3 4 5 6; do COVER_TILE_PICK=$p python tools/dbg/exp_tiles.py; done"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from cover_vla_amd import ops
 

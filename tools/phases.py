@@ -22,7 +22,11 @@ for _ in range(R):
     e0 = torch.cuda.Event(enable_timing=True); e0.record()
     out = {}
 
-    MODE = int(os.environ.get("SIDE_MODE", "0"))   # diagnostic: 1 = no side work (stale embeddings), 2 = towers on the side stream, heads in the tail
+    # 4 (default) = what bench.py's timed decisions do: the verifier's side work queued by a second host thread from t = 0.
+    # Diagnostics: 0 = side work queued from the sampler's after-prefill hook (it then runs UNDER decode passes 1-2 and slows them:
+    # the "decode1 / decode2 excess" of profiles/r03_phases.txt was this mode, not a property of the bench's schedule),
+    # 1 = no side work (stale embeddings), 2 = towers on the side stream, heads in the tail, 3 = side work queued before the policy
+    MODE = int(os.environ.get("SIDE_MODE", "4"))
 
     def side_work():
         if MODE == 1 and "its" in globals().get("_cache", {}):
@@ -75,4 +79,4 @@ for _ in range(R):
     for (n0, a), (n1, b) in zip(evs[:-1], evs[1:]):
         acc[n1] = acc.get(n1, 0.0) + a.elapsed_time(b)
     acc["total"] = acc.get("total", 0.0) + e0.elapsed_time(e3)
-print({k: round(v / R, 3) for k, v in acc.items()})
+print(f"SIDE_MODE={MODE}", {k: round(v / R, 3) for k, v in acc.items()})

@@ -68,3 +68,38 @@ for a, b, n in tail:
 print(f"tail after the last token_select: {len(tail)} kernels, busy {sum(v[1] for v in agg.values()) / 1e6:.3f} ms")
 for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[:12]:
     print(f"   {k:50s} x{v[0]:4d} {v[1] / 1e3:9.1f} us")
+
+# ---- per-pass table: the main stream cut at the token_select launches -- phase 0 = vision + prefill + the first
+# head, phases 1..6 = the six decode passes (32 layers + lm_head + token_select each), then the verifier tail
+cuts = [k for k, (a, b, n) in enumerate(main) if "token_select" in n]
+if len(cuts) >= 2:
+    print("per-pass table (main stream, cut at token_select): kernels | sum of kernel durations ms | sum of gaps ms | span ms | co-running side-stream kernel ms")
+    others = [v for k, v in streams.items() if v is not main]
+    lo_k = 0
+    for pi, c in enumerate(cuts):
+        seg = main[lo_k:c + 1]
+        if seg:
+            k_ms = sum(b - a for a, b, _ in seg) / 1e6
+            span = (seg[-1][1] - seg[0][0]) / 1e6
+            side = sum(max(0, min(b, seg[-1][1]) - max(a, seg[0][0])) for v in others for a, b, _ in v) / 1e6
+            print(f"  phase {pi}: {len(seg):5d} | {k_ms:7.3f} | {span - k_ms:6.3f} | {span:7.3f} | {side:6.3f}")
+        lo_k = c + 1
+    # the slowest kernels of the first two decode passes against the same kernel's median over passes 3-6
+    import statistics
+    if len(cuts) >= 7:
+        def by_name(seg):
+            d = {}
+            for a, b, n in seg:
+                d.setdefault(short(n), []).append((b - a) / 1e3)
+            return d
+        late = by_name(main[cuts[2] + 1:cuts[6] + 1])
+        for pi in (1, 2):
+            d = by_name(main[cuts[pi - 1] + 1:cuts[pi] + 1])
+            rows = []
+            for n, v in d.items():
+                if n in late and len(v) >= 8:
+                    rows.append((sum(v) - statistics.median(late[n]) * len(v), n, statistics.median(v), statistics.median(late[n])))
+            rows.sort(reverse=True)
+            print(f"  decode pass {pi} vs passes 3-6 (excess us over the late median x launches | kernel | median here | median late):")
+            for ex, n, m0, m1 in rows[:5]:
+                print(f"     {ex:8.1f} | {n:50s} | {m0:7.2f} | {m1:7.2f}")
