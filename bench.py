@@ -767,6 +767,8 @@ def main():
         last = pipe.decision(world, rank, cpu_gather)
     sync()
     dt = time.perf_counter() - t0
+    from cover_vla_amd import ops as _ops
+    _ops.decode_chain_status()      # a grid barrier of the persistent decode chain that gave up = invalid results: fail loudly, never report them
     if world > 1:
         t = torch.tensor([dt], device=dev if a.backend == "nccl" else "cpu")
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)

@@ -6,6 +6,7 @@
 #include <string.h>
 #include <string>
 #include "kernels.h"
+#include "decode_chain.h"
 
 static thread_local std::string g_err;
 static int fail(int code, const char* what, hipError_t e = hipSuccess) {
@@ -98,6 +99,13 @@ int cover_decode_attention_fused(const cover_decode_attn_args* a, void* stream) 
     if (!a || !a->out || (a->n_splits <= 0 && !a->qkv) || (a->n_splits > 0 && !a->partial))
         return fail(COVER_EINVAL, "cover_decode_attention_fused: null pointer");
     HIPCHK(launch_decode_attention_fused(a, ST(stream)), "decode_attention_fused (D in {64,128}, COVER_MASK_LEN segments, 0 <= write_t < seg[2].len)");
+    return COVER_OK;
+}
+
+int cover_decode_chain_status(void) {
+    const int e = decode_chain_status();
+    if (e != 0) return fail(COVER_EHIP, e < 0 ? "cover_decode_chain_status: could not read the status word" :
+                                               "cover_decode_chain_status: a grid barrier of the persistent decode chain ran into its spin bound (results of that pass are invalid)");
     return COVER_OK;
 }
 
@@ -388,7 +396,7 @@ int cover_vit_forward(const cover_vit_desc* d, void* x, int n_seq, int T, void* 
 }
 
 static size_t dec_ws(const cover_dec_desc* d, int rows, Carver* c, void** h, void** qkv, void** attn, void** mlp, void** sk,
-                     size_t* sk_bytes, void** st_o = nullptr, void** st_ml = nullptr, void** q8 = nullptr, void** q8s = nullptr) {
+                     size_t* sk_bytes, void** st_o = nullptr, void** st_ml = nullptr, void** q8 = nullptr, void** q8s = nullptr, void** ssq = nullptr) {
     Carver tmp{nullptr, 0, 0};
     Carver& cc = c ? *c : tmp;
     const int nqkv = (d->Hq + 2 * d->Hkv) * d->D;
@@ -416,6 +424,7 @@ static size_t dec_ws(const cover_dec_desc* d, int rows, Carver* c, void** h, voi
     }
     p = cc.take(skb); if (sk) *sk = p;
     if (sk_bytes) *sk_bytes = skb;
+    p = cc.take(decode_chain_ws_bytes()); if (ssq) *ssq = p;   // partial sums of squares of the persistent decode chain (rows <= 32)
     return cc.off + 256;
 }
 size_t cover_decoder_workspace_bytes(const cover_dec_desc* d, int rows) {
@@ -436,11 +445,52 @@ int cover_decoder_forward(const cover_dec_desc* d, const cover_dec_pass* p, void
         rows += G.B * G.T;
     }
     Carver c{(char*)ws.ptr, ws.bytes, 0};
-    void *h, *qkv, *attn, *mlp, *sk, *st_o, *st_ml, *q8, *q8s;
+    void *h, *qkv, *attn, *mlp, *sk, *st_o, *st_ml, *q8, *q8s, *ssq;
     size_t skb;
-    const size_t need = dec_ws(d, rows, &c, &h, &qkv, &attn, &mlp, &sk, &skb, &st_o, &st_ml, &q8, &q8s);
+    const size_t need = dec_ws(d, rows, &c, &h, &qkv, &attn, &mlp, &sk, &skb, &st_o, &st_ml, &q8, &q8s, &ssq);
     if (!ws.ptr || ws.bytes < need) return fail(COVER_EWORKSPACE, "cover_decoder_forward: workspace too small");
     const int dim = d->dim, Hq = d->Hq, Hkv = d->Hkv, D = d->D, nqkv = (Hq + 2 * Hkv) * D, HD = Hq * D;
+
+    // ---- persistent decode chain (decode_chain.hip): a single-token candidate pass of <= 32 rows at the 7B decoder shapes runs as
+    //      [ssq + qkv(0)]  then per layer  [fused decode attention] + [o_proj -> gate_up -> down -> qkv(next)]  = 2 launches per layer
+    //      instead of 7. COVER_DECODE_CHAIN=0 keeps the separate launches; =2 launches every phase of the chain on its own (no in-kernel
+    //      barrier: bit-identical to the fused form, the A/B that isolates the hand-offs from the arithmetic).
+    if (p->n_groups == 1 && !p->x_f32 && variant == 0) {
+        const cover_dec_group& G = p->groups[0];
+        const bool da_long = ((G.B + 15) / 16) * Hq >= 768 && G.segs[2].len > 16;
+        const bool fused_attn_ok = G.T == 1 && G.seg0_shared && G.n_seg == 3 && G.write_seg == 2 && Hq == Hkv && (D == 64 || D == 128) && !da_long &&
+                                   G.own_kv_mode == 0 && G.segs[0].mask_mode == COVER_MASK_LEN && G.segs[1].mask_mode == COVER_MASK_LEN &&
+                                   G.segs[2].mask_mode == COVER_MASK_LEN && G.write_t_offset_of_batch == nullptr && G.segs[2].len_of_batch == nullptr &&
+                                   G.segs[0].len_of_batch == nullptr;
+        if (fused_attn_ok && rows == G.B && decode_chain_supported(d, rows)) {
+            const char* ce = getenv("COVER_DECODE_CHAIN");
+            const bool split = ce && ce[0] == '2';
+            HIPCHK(launch_decode_chain(d, 0, &d->layers_host[0], nullptr, x, qkv, attn, mlp, (float*)ssq, rows, split, st), "decode chain (ssq + qkv)");
+            for (int l = 0; l < d->n_layers; ++l) {
+                const cover_dec_layer& L = d->layers_host[l];
+                cover_decode_attn_args da;
+                memset(&da, 0, sizeof da);
+                da.qkv = (bf16_t*)qkv; da.ld_qkv = nqkv;       // complete bf16 rows (bias included): no split-K partials on this path
+                da.N = G.B; da.H = Hq; da.D = D; da.scale = d->attn_scale;
+                da.positions = G.positions; da.cos_table = d->cos_table; da.sin_table = d->sin_table; da.n_pos = d->n_pos;
+                da.rope_mode = d->rope_mode;
+                for (int s = 0; s < 3; ++s) {
+                    da.seg[s] = G.segs[s];
+                    da.seg[s].k = (const bf16_t*)L.k_cache + G.seg_k_offset[s];
+                    da.seg[s].vt = (const bf16_t*)L.vt_cache + G.seg_vt_offset[s];
+                }
+                da.seg[2].slot_of_batch = G.write_slot_of_batch ? G.write_slot_of_batch : G.segs[2].slot_of_batch;
+                da.write_t = G.write_t_offset;
+                da.out = (bf16_t*)attn; da.out_row_stride = HD;
+                HIPCHK(launch_decode_attention_fused(&da, st), "decode chain: fused decode attention");
+                HIPCHK(launch_decode_chain(d, 1, &L, l + 1 < d->n_layers ? &d->layers_host[l + 1] : nullptr, x, qkv, attn, mlp, (float*)ssq, rows, split, st),
+                       "decode chain (o_proj -> gate_up -> down -> qkv)");
+            }
+            if (p->final_norm)
+                HIPCHK(launch_rmsnorm(x, 0, dim, d->final_norm_w, d->norm_w_offset, d->norm_style, (bf16_t*)x, dim, rows, dim, d->norm_eps, st), "dec final_norm");
+            return COVER_OK;
+        }
+    }
 
     // fp8 profile with more rows than the weight-streaming kernels take (config 5: M = 512 decode rows, and its prefill): the
     // projections run on the MX-scaled fp8 matrix instruction -- the input rows of every GEMM are quantised to e4m3 (per-row

@@ -1,0 +1,552 @@
+// Persistent decode chain: the weight-streaming projections of a candidate-decode layer (M <= 32 rows) as PHASES OF ONE LAUNCH.
+//
+//   launch l:   o_proj(l) + residual  ->  [RMSNorm]  gate_up(l) + SiLU-GLU  ->  down(l) + residual  ->  [RMSNorm]  qkv(l + 1)
+//   (the fused decode attention of layer l + 1 stays its own launch between two chain launches; the first launch of a pass is
+//    sums-of-squares(x) -> [RMSNorm] qkv(0), the last one ends after down)
+//
+// Why: as separate launches the seven kernels of a layer-step cost ~108 us for 405 MB of weights (3.7 TB/s): every launch pays its
+// own ramp (first weights ~2 us after launch, first activation chunk later still), its tail, the boundary, and the two split-K
+// reduce + norm launches stream nothing at all. Here every workgroup (one per CU, 256) requests the first WINDOW of the next
+// phase's weights (24 KiB per wave, 48 MiB chip-wide = ~8 us of HBM time) BEFORE it waits at the seam, so HBM keeps streaming while
+// the grid synchronises, and the seams themselves get shorter:
+//   * every phase gives a workgroup WHOLE output columns (n-blocks x the full K): no split-K slabs, no reduction launches;
+//   * RMSNorm is split in two: the producer leaves, beside its 16 output columns, the rows' partial sums of squares (one fp32 per
+//     row per workgroup); the consumer adds the 256 partials of a row in a fixed order and applies the norm while it stages the
+//     activation chunk into LDS (same arithmetic and rounding points as rmsnorm_bf16_k / splitk_reduce_norm);
+//   * hand-off = MI355X guide, Guideline 16: payload stored write-through (agent-scope relaxed atomic stores -> `sc1`), every
+//     storing wave drains vmcnt, ONE lane arrives on a counter; ONE wave polls ONE word relaxed with s_sleep, ONE agent acquire,
+//     block barrier, then plain loads. The barrier is sense-reversing and hierarchical (8 group counters -> top counter ->
+//     per-group generation words), needs no per-launch reset, and every spin is BOUNDED: on a timeout the workgroup records an
+//     error code, stops waiting for the rest of the launch (the results are then garbage, the launch still ends) and the host
+//     reports it (cover_decode_chain_status).
+// Residency comes from the grid size alone: 256 workgroups of 512 threads with ~145 KiB of LDS each = one per CU; the launcher
+// refuses devices with fewer CUs.
+//
+// A workgroup = 8 waves; wave w owns the 128-deep k-slice w of every 1024-deep activation chunk for ALL of the workgroup's
+// n-blocks; weights go HBM -> VGPR (non-temporal, 1 KiB per wave instruction, fragment-major packing) -> MFMA, activations through a
+// double-buffered 64 KiB LDS chunk in fragment-major order; the k-slices are summed through LDS at the end of a phase. The phase
+// bodies are fully unrolled per (n-blocks per workgroup, K) so that every wait is a counted vmcnt (see gemm_skinny3).
+// Shapes: dim = Hq * D = 4096, mlp = 11008 (Llama-2-7B); anything else takes the separate-launch path.
+#include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
+#include <mutex>
+#include <stdlib.h>
+#include <string.h>
+#include "common.h"
+#include "kernels.h"
+#include "decode_chain.h"
+
+namespace {
+
+enum { EPI_PLAIN = 0, EPI_RESIDUAL_SSQ = 1, EPI_GLU = 2 };
+enum { PH_GEMM = 0, PH_SSQ = 1 };
+
+struct ChainPhase {
+    int kind;                  // PH_GEMM / PH_SSQ (sums of squares of A's rows only: feeds the first norm of a pass)
+    int nbw;                   // n-blocks (16 output columns) per workgroup: 1, 3 or 6
+    int ktot;                  // contraction length: 4096 or 11008
+    int N;                     // GEMM columns (2 * mlp for the GLU phase)
+    const bf16_t* A; int lda;  // activation panel [M][lda]
+    const bf16_t* Wp;          // packed weights [N/16][K/32][64 lanes][8]
+    int norm_in, norm_style;   // 1: A's rows go through RMSNorm while they are staged (rstd from ssq_in)
+    float norm_eps, norm_w_offset;
+    const float* norm_w; const float* ssq_in;
+    int epi, act;
+    bf16_t* C; int ldc;        // EPI_RESIDUAL_SSQ: C is the residual stream, updated in place
+    float* ssq_out;            // EPI_RESIDUAL_SSQ / PH_SSQ: [M][256] partial sums of squares, one per workgroup
+    const float* bias;         // EPI_PLAIN only (may be NULL)
+};
+struct ChainArgs {
+    ChainPhase ph[4];
+    int n_phases, M;
+    unsigned* sync;            // SYNC_WORDS words, zeroed once; persists across launches
+};
+
+constexpr int NWG = 256;                       // workgroups = CUs
+constexpr int NGRP = 8;                        // barrier groups (key = blockIdx & 7: the XCD a block is observed to land on)
+constexpr int LINE = 32;                       // words per 128-byte line
+constexpr int SYNC_WORDS = (2 * NGRP + 2) * LINE;
+constexpr unsigned SPIN_LIMIT = 1u << 21;      // polls before a workgroup gives up (~1 s)
+constexpr int KC = 1024, XB = 2 * 16 * KC * 2; // activation chunk: 32 rows x 1024 k bf16 = 64 KiB, fragment-major
+constexpr int LDS_NORMW = 2 * XB, LDS_RSTD = LDS_NORMW + 4096 * 4, LDS_TOTAL = LDS_RSTD + 32 * 4;
+
+typedef __attribute__((address_space(1))) unsigned gu32;
+typedef __attribute__((address_space(1))) unsigned long long gu64;
+__device__ __forceinline__ unsigned ld_agent(unsigned* p) { return __hip_atomic_load((gu32*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_agent(unsigned* p, unsigned v) { __hip_atomic_store((gu32*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st8_agent(void* p, uint32_t lo, uint32_t hi) {   // write-through 8-byte payload store
+    __hip_atomic_store((gu64*)p, ((unsigned long long)hi << 32) | lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void stf_agent(float* p, float v) { st_agent((unsigned*)p, __float_as_uint(v)); }
+
+struct Sync {
+    unsigned* w;
+    unsigned g0;       // generation at launch start
+    int k;             // barriers passed in this launch
+    bool dead;         // a spin ran into its bound: stop waiting
+    __device__ __forceinline__ unsigned* cnt(int g) const { return w + g * LINE; }
+    __device__ __forceinline__ unsigned* top() const { return w + NGRP * LINE; }
+    __device__ __forceinline__ unsigned* gen(int g) const { return w + (NGRP + 1 + g) * LINE; }
+    __device__ __forceinline__ unsigned* err() const { return w + (2 * NGRP + 1) * LINE; }
+};
+
+// ONE lane of the workgroup (wave 0, lane 0): arrive. Called after every storing wave has drained its stores and the block barrier.
+__device__ __forceinline__ void grid_arrive(Sync& s) {
+    const int g = blockIdx.x & (NGRP - 1);
+    const unsigned gsize = (unsigned)((gridDim.x - g + NGRP - 1) / NGRP);
+    const unsigned target = s.g0 + (unsigned)(s.k + 1);
+    const unsigned old = __hip_atomic_fetch_add((gu32*)s.cnt(g), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (old == gsize - 1) {                                        // last of the group: reset, then one arrival at the top
+        (void)__hip_atomic_exchange((gu32*)s.cnt(g), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the reset is done before anybody can be released
+        const unsigned ngroups = gridDim.x < NGRP ? gridDim.x : NGRP;
+        const unsigned old2 = __hip_atomic_fetch_add((gu32*)s.top(), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old2 == ngroups - 1) {
+            (void)__hip_atomic_exchange((gu32*)s.top(), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            for (int i = 0; i < NGRP; ++i) st_agent(s.gen(i), target);
+        }
+    }
+}
+// The same lane: wait for the release of barrier k + 1 (the caller's wave then issues ONE agent-scope acquire, a block barrier follows).
+__device__ __forceinline__ void grid_wait(Sync& s) {
+    const int g = blockIdx.x & (NGRP - 1);
+    const unsigned target = s.g0 + (unsigned)(s.k + 1);
+    if (!s.dead) {
+        unsigned spins = 0;
+        while (ld_agent(s.gen(g)) != target) {
+            __builtin_amdgcn_s_sleep(8);
+            if (++spins > SPIN_LIMIT || ((spins & 1023u) == 0 && ld_agent(s.err()) != 0u)) {
+                st_agent(s.err(), 0x1000u + (unsigned)s.k);      // give-up code: barrier index of this launch
+                s.dead = true;
+                break;
+            }
+        }
+    }
+}
+
+// RMSNorm of 8 consecutive elements of one row (rmsnorm_bf16_k arithmetic): style 1 (Llama) w * bf16(x * rstd), else x * rstd * (off + w)
+__device__ __forceinline__ uint4 norm8(uint4 raw, float rstd, const float* wl, int style, float woff) {
+    const uint32_t rw[4] = {raw.x, raw.y, raw.z, raw.w};
+    const float4 w0 = *(const float4*)wl, w1 = *(const float4*)(wl + 4);
+    const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+    float o[8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float a = bf2f((bf16_t)(rw[i] & 0xffffu)), b = bf2f((bf16_t)(rw[i] >> 16));
+        if (style == 1) { o[2 * i] = wv[2 * i] * bfround(a * rstd); o[2 * i + 1] = wv[2 * i + 1] * bfround(b * rstd); }
+        else { o[2 * i] = a * rstd * (woff + wv[2 * i]); o[2 * i + 1] = b * rstd * (woff + wv[2 * i + 1]); }
+    }
+    return make_uint4(pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3]), pack_bf2(o[4], o[5]), pack_bf2(o[6], o[7]));
+}
+
+// One GEMM phase of the chain for this workgroup. `wait_seam`: a grid barrier (arrived at by the previous phase) stands between
+// the previous phase's outputs and this phase's activation loads; the weight window is requested before it is waited for.
+// NBW fixes the phase's role: 1 = o_proj / down (residual + sums of squares, raw input rows), 3 = qkv (plain store, normed input rows),
+// 6 = gate_up (GLU epilogue, normed input rows).
+template <int NBW, int KTOT>
+__device__ __forceinline__ void gemm_phase(const ChainPhase& ph, int M, char* smem, Sync& sy, bool wait_seam, bool arrive_after) {
+    constexpr bool NORM = NBW != 1;
+    constexpr int EPI = NBW == 1 ? EPI_RESIDUAL_SSQ : (NBW == 3 ? EPI_PLAIN : EPI_GLU);
+    constexpr int NCH = (KTOT + KC - 1) / KC;            // activation chunks
+    constexpr int WIN = 6;                                // weight items (chunk, n-block) in flight per wave: 6 x 4 loads x 1 KiB
+    constexpr int T = NCH * NBW;                          // items of a wave
+    constexpr int K32 = KTOT / 32;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int N16 = ph.N >> 4;
+    const int nb_begin = blockIdx.x * NBW;
+    const bool active = nb_begin < N16;                   // (the GLU phase fills 230 of the 256 workgroups)
+    const int kw0 = w * 128;                              // this wave's k-slice inside every chunk
+    u32x4 buf[WIN][4];
+    f32x4 acc[NBW][2];
+#pragma unroll
+    for (int i = 0; i < NBW; ++i) { acc[i][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[i][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+
+    auto load_item = [&](u32x4(&dst)[4], int t) {          // t is a compile-time constant at every call site
+        const int c = t / NBW, i = t - c * NBW;
+        int nb = nb_begin + i;
+        nb = nb < N16 ? nb : N16 - 1;                      // clamped: the output of a clamped n-block is never stored
+        int k = c * KC + kw0;
+        k = k + 128 <= KTOT ? k : KTOT - 128;              // ragged last chunk: re-read a valid slice (its activations are zero)
+        const u32x4* src = (const u32x4*)(ph.Wp + ((size_t)nb * K32 + (k >> 5)) * 512) + lane;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) dst[u] = __builtin_nontemporal_load(src + u * 64);
+    };
+    auto issue_window = [&]() {
+#pragma unroll
+        for (int t = 0; t < WIN; ++t)
+            if (t < T) load_item(buf[t], t);
+    };
+
+    // ---- seam: weights first (they depend on nothing), then the wait ----
+    if (active) issue_window();
+    if constexpr (NORM) {                                  // the norm weights of the 4096-wide panel -> LDS (immutable: no ordering needed)
+        float* nwl = (float*)(smem + LDS_NORMW);
+        const float4 a = *(const float4*)(ph.norm_w + tid * 8), b = *(const float4*)(ph.norm_w + tid * 8 + 4);
+        *(float4*)(nwl + tid * 8) = a;
+        *(float4*)(nwl + tid * 8 + 4) = b;
+    }
+    // ONE lane polls ONE word (bounded, relaxed). Its wave's window loads were issued first and return first (loads return in order): the
+    // poll costs that wave the window's latency only when the barrier is already complete, and the seam is then short anyway
+    if (wait_seam && tid == 0) grid_wait(sy);
+    if (wait_seam && w == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // ONE acquire per workgroup; the block barrier below publishes it
+    if (wait_seam) sy.k += 1;
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // LDS-only: the weight windows stay in flight
+
+    // ---- per-row 1 / rms from the 256 partial sums of squares (fixed order: 4 sequential per lane, then the wave butterfly) ----
+    const int srr = lane & 15, sgg = lane >> 4;
+    const int sf = w & 1;                                  // MF = 2: a wave stages fragments of ONE row half
+    int srow = sf * 16 + srr;
+    srow = srow < M ? srow : M - 1;
+    float rstd = 1.0f;
+    if constexpr (NORM) {
+        float* rl = (float*)(smem + LDS_RSTD);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int row = w * 4 + j;
+            row = row < M ? row : M - 1;
+            const float4 q = *(const float4*)(ph.ssq_in + (size_t)row * NWG + lane * 4);
+            float sq = q.x;
+            sq += q.y; sq += q.z; sq += q.w;
+            sq = wave_sum(sq);
+            if (lane == 0) rl[w * 4 + j] = rsqrtf(sq / (float)KTOT + ph.norm_eps);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        rstd = rl[sf * 16 + srr < M ? sf * 16 + srr : M - 1];
+    }
+    if (!active) {                                         // nothing to compute in this phase: only the seam behind it
+        if (arrive_after) {
+            asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if (tid == 0) grid_arrive(sy);
+        }
+        return;
+    }
+
+    // ---- activation chunk staging: wave w moves fragments fi = j * 8 + w (kst = fi >> 1 = j * 4 + (w >> 1), f = w & 1); lane (rr, gg)
+    //      owns the 16 bytes of row f * 16 + rr, k = kst * 32 + gg * 8: the LDS image of a fragment is lane-linear ----
+    uint4 xr[8];
+    const bf16_t* arow = ph.A + (size_t)srow * ph.lda;
+    auto x_load = [&](int c) {                             // c compile-time
+        if ((c + 1) * KC <= KTOT) {                        // (constant after unrolling) whole chunk in range: one base, immediate offsets
+            const bf16_t* p0 = arow + c * KC + (w >> 1) * 32 + sgg * 8;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) xr[j] = *(const uint4*)(p0 + j * 128);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int kst = j * 4 + (w >> 1);
+                int k = c * KC + kst * 32 + sgg * 8;
+                const bool in = k < KTOT;
+                k = in ? k : KTOT - 8;
+                uint4 v = *(const uint4*)(arow + k);
+                if (!in) v = make_uint4(0u, 0u, 0u, 0u);
+                xr[j] = v;
+            }
+        }
+    };
+    auto x_write = [&](int c) {
+        const float* nwl = (const float*)(smem + LDS_NORMW);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            uint4 v = xr[j];
+            if constexpr (NORM) {
+                const int kst = j * 4 + (w >> 1);
+                v = norm8(v, rstd, nwl + c * KC + kst * 32 + sgg * 8, ph.norm_style, ph.norm_w_offset);
+            }
+            *(uint4*)(smem + (c & 1) * XB + (j * 8 + w) * 1024 + lane * 16) = v;
+            if constexpr (NORM) __builtin_amdgcn_sched_barrier(0);   // one fragment at a time: batching the 16 weight reads costs 64 registers
+        }
+    };
+    x_load(0);
+    x_write(0);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+
+    // ---- main loop: fully unrolled, every slot and refill a compile-time decision ----
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        if (c + 1 < NCH) x_load(c + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        const char* xb = smem + (c & 1) * XB;
+        // NBW = 1: the wave's 8 activation fragments of the chunk are read up front (eight LDS reads in flight instead of eight read -> wait ->
+        // MFMA round trips). NBW >= 3: read at their MFMAs -- holding them (32 registers) beside the 96-register weight window, the next
+        // chunk's 32 staging registers and the accumulators sends the allocator into scratch (hundreds of spills, weights included).
+        bf16x8 xf[NBW == 1 ? 4 : 1][2];
+        if constexpr (NBW == 1) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int f = 0; f < 2; ++f) xf[u][f] = as_bf16x8(*(const uint4*)(xb + (((w * 4 + u) * 2 + f) * 64 + lane) * 16));
+        }
+#pragma unroll
+        for (int i = 0; i < NBW; ++i) {
+            const int t = c * NBW + i, slot = t % WIN;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const bf16x8 wf = __builtin_bit_cast(bf16x8, buf[slot][u]);
+#pragma unroll
+                for (int f = 0; f < 2; ++f) {
+                    bf16x8 xv;
+                    if constexpr (NBW == 1) xv = xf[u][f];
+                    else xv = as_bf16x8(*(const uint4*)(xb + (((w * 4 + u) * 2 + f) * 64 + lane) * 16));
+                    acc[i][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xv, acc[i][f], 0, 0, 0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (t + WIN < T) load_item(buf[slot], t + WIN);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (c + 1 < NCH) {
+            x_write(c + 1);
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+    }
+
+    // ---- sum the 8 k-slices through LDS (fixed wave order), epilogue, write-through stores ----
+    float* red = (float*)smem;                             // [w][i][f][e][lane]
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // every wave is done reading the activation chunks
+#pragma unroll
+    for (int i = 0; i < NBW; ++i)
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) red[((((w * NBW + i) * 2 + f) * 4 + e) << 6) + lane] = acc[i][f][e];
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    const int r = lane & 15, g = lane >> 4;
+    auto slice_sum = [&](int i, int f, float (&v)[4]) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < 8; ++ww)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += red[((((ww * NBW + i) * 2 + f) * 4 + e) << 6) + lane];
+    };
+    if constexpr (EPI == EPI_GLU) {
+        {
+            constexpr int NU = (NBW / 2) * 2;               // (gate, up) pairs x 2 row halves
+            for (int j = w; j < NU; j += 8) {
+                const int pi = j >> 1, f = j & 1;
+                const int nb = nb_begin + 2 * pi, m = f * 16 + r;
+                float gv[4], uv[4];
+                slice_sum(2 * pi, f, gv);
+                slice_sum(2 * pi + 1, f, uv);
+                if (nb + 1 < N16 && m < M) {
+                    float o[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {           // epi_store4_glu's arithmetic
+                        float gg = bfround(gv[e]);
+                        const float uu = bfround(uv[e]);
+                        gg = bfround(act_apply(gg, ph.act));
+                        o[e] = bfround(gg * uu);
+                    }
+                    st8_agent(ph.C + (size_t)m * ph.ldc + (nb >> 1) * 16 + 4 * g, pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3]));
+                }
+            }
+        }
+    } else {
+        constexpr int NU = NBW * 2;
+        for (int j = w; j < NU; j += 8) {
+            const int i = j >> 1, f = j & 1;
+            const int nb = nb_begin + i, m = f * 16 + r, n0 = nb * 16 + 4 * g;
+            float v[4];
+            slice_sum(i, f, v);
+            const bool ok = nb < N16 && m < M;
+            if constexpr (EPI == EPI_PLAIN) {
+                if (ok) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = ph.bias ? v[e] + ph.bias[n0 + e] : v[e];
+                    st8_agent(ph.C + (size_t)m * ph.ldc + n0, pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+                }
+            } else {                                        // x = bf16(bf16(o) + x), partial sum of squares of the STORED values
+                float q = 0.f;
+                if (ok) {
+                    bf16_t* xp = ph.C + (size_t)m * ph.ldc + n0;
+                    const uint2 xo = *(const uint2*)xp;
+                    const float xv[4] = {bf2f((bf16_t)(xo.x & 0xffffu)), bf2f((bf16_t)(xo.x >> 16)), bf2f((bf16_t)(xo.y & 0xffffu)), bf2f((bf16_t)(xo.y >> 16))};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[e] = bfround(bfround(v[e]) + xv[e]);
+                        q += v[e] * v[e];
+                    }
+                    st8_agent(xp, pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+                }
+                q += __shfl_xor(q, 16);                     // the row's 16 columns: 4 lanes (g = 0..3)
+                q += __shfl_xor(q, 32);
+                if (ok && g == 0) stf_agent(ph.ssq_out + (size_t)m * NWG + nb, q);
+            }
+        }
+    }
+    if (arrive_after) {
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // every storing wave has drained
+        if (tid == 0) grid_arrive(sy);
+    } else {
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                          // LDS is reused by the next phase
+    }
+}
+
+// Partial sums of squares of A's rows over this workgroup's 16 columns (the norm in front of the first GEMM of a pass).
+__device__ __forceinline__ void ssq_phase(const ChainPhase& ph, int M, Sync& sy, bool arrive_after) {
+    const int tid = threadIdx.x;
+    const int row = tid >> 4, col = blockIdx.x * 16 + (tid & 15);
+    float q = 0.f;
+    if (row < M) {
+        const float v = bf2f(ph.A[(size_t)row * ph.lda + col]);
+        q = v * v;
+    }
+    q += __shfl_xor(q, 1); q += __shfl_xor(q, 2); q += __shfl_xor(q, 4); q += __shfl_xor(q, 8);
+    if (row < M && (tid & 15) == 0) stf_agent(ph.ssq_out + (size_t)row * NWG + blockIdx.x, q);
+    if (arrive_after) {
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (tid == 0) grid_arrive(sy);
+    }
+}
+
+__global__ __launch_bounds__(512) void decode_chain_k(ChainArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    Sync sy;
+    sy.w = a.sync;
+    sy.k = 0;
+    sy.dead = false;
+    {   // generation at launch start: it cannot advance before this workgroup has arrived at the first barrier
+        unsigned g0 = 0;
+        if (threadIdx.x == 0) g0 = ld_agent(sy.gen(blockIdx.x & (NGRP - 1)));
+        sy.g0 = __builtin_amdgcn_readfirstlane(g0);
+    }
+    for (int p = 0; p < a.n_phases; ++p) {
+        const ChainPhase& ph = a.ph[p];
+        const bool seam = p > 0, more = p + 1 < a.n_phases;
+        if (ph.kind == PH_SSQ) { ssq_phase(ph, a.M, sy, more); continue; }
+        if (ph.nbw == 1 && ph.ktot == 4096) gemm_phase<1, 4096>(ph, a.M, smem, sy, seam, more);
+        else if (ph.nbw == 1) gemm_phase<1, 11008>(ph, a.M, smem, sy, seam, more);
+        else if (ph.nbw == 3) gemm_phase<3, 4096>(ph, a.M, smem, sy, seam, more);
+        else gemm_phase<6, 4096>(ph, a.M, smem, sy, seam, more);
+    }
+}
+
+unsigned* g_sync[16] = {};
+std::mutex g_mu;
+
+}  // namespace
+
+// ---- host side ---------------------------------------------------------------------------------------------------------------
+bool decode_chain_supported(const cover_dec_desc* d, int rows) {
+    const char* env = getenv("COVER_DECODE_CHAIN");          // read per call (tests A/B the two paths inside one process): 0 = separate launches
+    if (env && env[0] == '0') return false;
+    if (rows < 1 || rows > 32) return false;
+    if (d->dim != 4096 || d->Hq * d->D != 4096 || d->mlp != 11008 || (d->Hq + 2 * d->Hkv) * d->D != 12288) return false;
+    if (d->act != ACT_SILU && d->act != ACT_GELU_TANH) return false;
+    for (int l = 0; l < d->n_layers; ++l)
+        if (d->layers_host[l].qkv_w8) return false;         // e4m3 weight stream: separate-launch path
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return false;
+    static int cus[16] = {};
+    if (cus[dev] == 0) {
+        hipDeviceProp_t p;
+        if (hipGetDeviceProperties(&p, dev) != hipSuccess) return false;
+        cus[dev] = p.multiProcessorCount;
+    }
+    return cus[dev] >= NWG;
+}
+size_t decode_chain_ws_bytes() { return (size_t)2 * 32 * NWG * sizeof(float); }
+
+static hipError_t chain_sync_words(unsigned** out) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!g_sync[dev]) {
+        unsigned* p = nullptr;
+        e = hipMalloc((void**)&p, SYNC_WORDS * sizeof(unsigned));
+        if (e != hipSuccess) return e;
+        e = hipMemset(p, 0, SYNC_WORDS * sizeof(unsigned));
+        if (e != hipSuccess) return e;
+        g_sync[dev] = p;
+    }
+    *out = g_sync[dev];
+    return hipSuccess;
+}
+
+// error word of the last launches on this device: 0 = every barrier completed; resets the word (and the barrier state after an error)
+int decode_chain_status() {
+    unsigned* s = nullptr;
+    if (chain_sync_words(&s) != hipSuccess) return -1;
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    unsigned e = 0;
+    if (hipMemcpy(&e, s + (2 * NGRP + 1) * LINE, sizeof e, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    if (e != 0) (void)hipMemset(s, 0, SYNC_WORDS * sizeof(unsigned));
+    return (int)e;
+}
+
+static void gemm_ph(ChainPhase& p, int nbw, int ktot, int N, const void* A, int lda, const void* Wp, void* C, int ldc, int epi, int act) {
+    memset(&p, 0, sizeof p);
+    p.kind = PH_GEMM; p.nbw = nbw; p.ktot = ktot; p.N = N;
+    p.A = (const bf16_t*)A; p.lda = lda; p.Wp = (const bf16_t*)Wp;
+    p.C = (bf16_t*)C; p.ldc = ldc; p.epi = epi; p.act = act;
+}
+
+// stage: 0 = [sums of squares(x) -> norm -> qkv(layer 0)];  1 = [o_proj(l) -> gate_up(l) -> down(l) (-> qkv(l + 1) when next != NULL)]
+// split: every phase as its own launch (no in-kernel barrier): the debugging / A-B form, bit-identical to the fused one
+hipError_t launch_decode_chain(const cover_dec_desc* d, int stage, const cover_dec_layer* L, const cover_dec_layer* next, void* x, void* qkv,
+                               void* attn, void* mlp, float* ssq, int rows, bool split, hipStream_t st) {
+    ChainArgs a;
+    memset(&a, 0, sizeof a);
+    hipError_t e = chain_sync_words(&a.sync);
+    if (e != hipSuccess) return e;
+    a.M = rows;
+    const int dim = d->dim, nqkv = (d->Hq + 2 * d->Hkv) * d->D;
+    float* ssq_a = ssq;                 // behind o_proj
+    float* ssq_b = ssq + 32 * NWG;      // behind down (and of the pass input)
+    auto norm_from = [&](ChainPhase& p, const float* w, const float* sq) {
+        p.norm_in = 1; p.norm_style = d->norm_style; p.norm_eps = d->norm_eps; p.norm_w_offset = d->norm_w_offset; p.norm_w = w; p.ssq_in = sq;
+    };
+    int n = 0;
+    if (stage == 0) {
+        ChainPhase& s = a.ph[n++];
+        memset(&s, 0, sizeof s);
+        s.kind = PH_SSQ; s.A = (const bf16_t*)x; s.lda = dim; s.ssq_out = ssq_b;
+        ChainPhase& q = a.ph[n++];
+        gemm_ph(q, 3, 4096, nqkv, x, dim, L->qkv_w, qkv, nqkv, EPI_PLAIN, 0);
+        q.bias = L->qkv_b;
+        norm_from(q, L->in_norm_w, ssq_b);
+    } else {
+        ChainPhase& o = a.ph[n++];
+        gemm_ph(o, 1, 4096, dim, attn, d->Hq * d->D, L->o_w, x, dim, EPI_RESIDUAL_SSQ, 0);
+        o.ssq_out = ssq_a;
+        ChainPhase& g = a.ph[n++];
+        gemm_ph(g, 6, 4096, 2 * d->mlp, x, dim, L->gate_up_w, mlp, d->mlp, EPI_GLU, d->act);
+        norm_from(g, L->post_norm_w, ssq_a);
+        ChainPhase& dn = a.ph[n++];
+        gemm_ph(dn, 1, 11008, dim, mlp, d->mlp, L->down_w, x, dim, EPI_RESIDUAL_SSQ, 0);
+        dn.ssq_out = ssq_b;
+        if (next) {
+            ChainPhase& q = a.ph[n++];
+            gemm_ph(q, 3, 4096, nqkv, x, dim, next->qkv_w, qkv, nqkv, EPI_PLAIN, 0);
+            q.bias = next->qkv_b;
+            norm_from(q, next->in_norm_w, ssq_b);
+        }
+    }
+    static hipError_t attr = hipFuncSetAttribute((const void*)decode_chain_k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (attr != hipSuccess) return attr;
+    auto launch = [&](const ChainArgs& aa, double bytes) {
+        hipEvent_t ea, eb;
+        if (prof_enabled() && prof_reserve(0, bytes, &ea, &eb) >= 0)
+            hipExtLaunchKernelGGL(decode_chain_k, dim3(NWG), dim3(512), (uint32_t)LDS_TOTAL, st, ea, eb, 0, aa);
+        else
+            hipLaunchKernelGGL(decode_chain_k, dim3(NWG), dim3(512), LDS_TOTAL, st, aa);
+    };
+    auto wbytes = [&](const ChainPhase& p) { return p.kind == PH_GEMM ? 2.0 * (double)p.N * (double)p.ktot : 0.0; };
+    if (!split) {
+        a.n_phases = n;
+        double b = 0.0;
+        for (int i = 0; i < n; ++i) b += wbytes(a.ph[i]);
+        launch(a, b);
+    } else {
+        for (int i = 0; i < n; ++i) {
+            ChainArgs one = a;
+            one.ph[0] = a.ph[i];
+            one.n_phases = 1;
+            launch(one, wbytes(a.ph[i]));
+        }
+    }
+    return hipGetLastError();
+}

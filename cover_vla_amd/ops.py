@@ -143,6 +143,11 @@ def gemm(a: torch.Tensor, lin: PackedLinear, *, act: str = "none", residual: Opt
     return out
 
 
+def decode_chain_status() -> None:
+    """Raises if a grid barrier of the persistent decode chain gave up since the last call (synchronises the device)."""
+    L.check(L.lib().cover_decode_chain_status(), "decode_chain_status")
+
+
 def gemm_plan_counts(reset: bool = False) -> list:
     """Launch counters per GEMM kernel plan since the last reset (cover_gemm_plan_counts): [0..18] tiled picks (14..17 = 224-row
     tiles), [19] / [20] / [22] weight-streaming generations 2 / 3 / 1, [21] fp8 MFMA tiles."""

@@ -251,6 +251,7 @@ def test_full_width_llama7b_layer_matches_hf_g3(dev):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from test_oracle_golden import _g3_case
     from gen_golden_llama7b import HEADS, LT, N_PATCH, P, S
+    from cover_vla_amd import ops
     from cover_vla_amd.models import BF, Decoder, KvGeometry
     l7, sd, i, gold = _g3_case()
     T0, N, Dm, H, D = 1 + N_PATCH, P * S, l7["dim"], l7["Hq"], l7["D"]
@@ -295,19 +296,29 @@ def test_full_width_llama7b_layer_matches_hf_g3(dev):
     # decode: one row per candidate at position T0 + len(prompt), three KV segments, fused decode attention
     prompt_of_cand = (torch.arange(N, device=dev) // S).to(torch.int32)
     cand_len = lens.to(dev)[prompt_of_cand.long()].contiguous()
-    xd = i["dec"].clone().to(dev)
     g = llm.group(N, 1, (T0 + cand_len).contiguous(),
                   [dict(region=0, length=T0, slot_of_batch=zero_slots), dict(region=1, length=LT, len_of_batch=cand_len, slot_of_batch=prompt_of_cand),
                    dict(region=2, length=1)], 2, write_t_off=0, seg0_shared=True)
-    ops.gemm_plan_counts(reset=True)
-    llm.forward(xd, [g], final_norm=True)
-    counts = ops.gemm_plan_counts()
-    assert counts[19] + counts[20] == 4 and sum(counts) == 4, counts      # four weight-streaming launches
-    r["dec16"], r["dec32"] = rel(xd, gold["decode_rows"]), rel(xd, gold["f32_decode_rows"])
+    # the decode pass twice: as separate kernels (split-K weight streaming + reduce / norm launches) and as the persistent decode chain
+    for mode, tag in (("0", "dec"), ("1", "chain")):
+        os.environ["COVER_DECODE_CHAIN"] = mode
+        try:
+            xd = i["dec"].clone().to(dev)
+            ops.gemm_plan_counts(reset=True)
+            llm.forward(xd, [g], final_norm=True)
+            counts = ops.gemm_plan_counts()
+        finally:
+            os.environ.pop("COVER_DECODE_CHAIN", None)
+        if mode == "0":
+            assert counts[19] + counts[20] == 4 and sum(counts) == 4, counts      # four weight-streaming launches
+        else:
+            assert sum(counts) == 0, counts                                        # no GEMM launcher ran: the chain did
+            ops.decode_chain_status()
+        r[tag + "16"], r[tag + "32"] = rel(xd, gold["decode_rows"]), rel(xd, gold["f32_decode_rows"])
     print("G3 rel-L2:", {k: round(v, 4) for k, v in r.items()}, "HF-bf16 own", round(hf_own, 4), "K/V (rel, bit-equal):", {k: (round(a, 5), round(b, 4)) for k, (a, b) in kv.items()})
-    for k in ("prefix32", "text5_32", "last32", "dec32"):
+    for k in ("prefix32", "text5_32", "last32", "dec32", "chain32"):
         assert r[k] <= 1.2e-2 and r[k] <= 1.25 * hf_own, (k, r[k], hf_own)
-    for k in ("prefix16", "text0", "text5", "last16", "dec16"):
+    for k in ("prefix16", "text0", "text5", "last16", "dec16", "chain16"):
         assert r[k] <= 1.6e-2, (k, r[k])
     for k, (a, b) in kv.items():
         assert a < 2e-3 and b >= 0.97, (k, a, b)

@@ -32,8 +32,8 @@ for (n, g), ds in sorted(agg.items(), key=lambda kv: -sum(d["dur"] for d in kv[1
     get = lambda k: sum(d["c"].get(k, 0.0) for d in ds)
     busy, gui, wc = get("SQ_VALU_MFMA_BUSY_CYCLES"), get("GRBM_GUI_ACTIVE"), get("SQ_WAVE_CYCLES")
     clk = gui / dur if gui > 0 else 2.4                  # cycles per ns = GHz
-    if clk > 3.0:                                        # the counter was summed over the 8 XCDs
-        clk /= 8.0
+    if clk > 2.4:                                        # GRBM_GUI_ACTIVE also covers the dispatch's ramp outside the kernel's own stamps: the
+        clk = 2.4                                        # ratio then exceeds the 2.4 GHz maximum clock -- capped (utilisation = a lower bound)
     util = busy / (1024.0 * dur * clk) if dur > 0 else 0.0
     tf = busy * 1024.0 / dur / 1e3 if dur > 0 else 0.0   # FLOP / ns = GFLOP/s -> TFLOP/s
     frac = lambda k: (get(k) / wc) if wc > 0 else float("nan")
