@@ -453,8 +453,9 @@ int cover_decoder_forward(const cover_dec_desc* d, const cover_dec_pass* p, void
 
     // ---- persistent decode chain (decode_chain.hip): a single-token candidate pass of <= 32 rows at the 7B decoder shapes runs as
     //      [ssq + qkv(0)]  then per layer  [fused decode attention] + [o_proj -> gate_up -> down -> qkv(next)]  = 2 launches per layer
-    //      instead of 7. COVER_DECODE_CHAIN=0 keeps the separate launches; =2 launches every phase of the chain on its own (no in-kernel
-    //      barrier: bit-identical to the fused form, the A/B that isolates the hand-offs from the arithmetic).
+    //      instead of 7. Opt-in (COVER_DECODE_CHAIN=1: measured at parity with the separate launches, which stay the default); =2 launches
+    //      every phase of the chain on its own (no in-kernel barrier: bit-identical to the fused form, the A/B that isolates the hand-offs
+    //      from the arithmetic).
     if (p->n_groups == 1 && !p->x_f32 && variant == 0) {
         const cover_dec_group& G = p->groups[0];
         const bool da_long = ((G.B + 15) / 16) * Hq >= 768 && G.segs[2].len > 16;

@@ -27,6 +27,14 @@
 // double-buffered 64 KiB LDS chunk in fragment-major order; the k-slices are summed through LDS at the end of a phase. The phase
 // bodies are fully unrolled per (n-blocks per workgroup, K) so that every wait is a counted vmcnt (see gemm_skinny3).
 // Shapes: dim = Hq * D = 4096, mlp = 11008 (Llama-2-7B); anything else takes the separate-launch path.
+//
+// OUTCOME (MI355X, round 4; per-phase timelines and ablations in docs/OPTIMISATION_LOG.md): correct (fused == split phases bit for bit,
+// also with co-running tenants; HF pin G3), and at PARITY with the separate kernels, not ahead: 114 vs 109.6 us per layer. The seams
+// behave as designed (7.6 / 4.8 us, covered by the 48 MiB window that loads meanwhile); what eats the gain at M = 32 is the ACTIVATION
+// panel: with whole output columns per workgroup every CU reads the full M x K panel of every phase (367 MB per layer from L2 beside
+// 405 MB of weights from HBM), and a CU pulls ~60 GB/s whatever the source -- the down projection (704 KiB of activations + 352 KiB of
+// weights per CU) is bound by that, not by HBM. Split-K (what the separate kernels do) trades that traffic for partial slabs and a
+// reduction launch and comes out the same. Opt-in: COVER_DECODE_CHAIN=1.
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 #include <mutex>
@@ -67,9 +75,20 @@ constexpr int NGRP = 8;                        // barrier groups (key = blockIdx
 constexpr int LINE = 32;                       // words per 128-byte line
 constexpr int SYNC_WORDS = (2 * NGRP + 2) * LINE;
 constexpr unsigned SPIN_LIMIT = 1u << 21;      // polls before a workgroup gives up (~1 s)
-constexpr int KC = 1024, XB = 2 * 16 * KC * 2; // activation chunk: 32 rows x 1024 k bf16 = 64 KiB, fragment-major
-constexpr int LDS_NORMW = 2 * XB, LDS_RSTD = LDS_NORMW + 4096 * 4, LDS_TOTAL = LDS_RSTD + 32 * 4;
+constexpr int KC = 1024;                       // a wave owns one 128-deep slice of every 1024-deep chunk of K
+constexpr int LDS_RED = 6 * 16 * 1024;         // k-slice reduction buffer: [8 waves][NBW <= 6][2][4][64 lanes] fp32
+constexpr int LDS_XT = 0;                      // wave-private activation scratch, 8 x 4 KiB (aliases the reduction buffer: used before it)
+constexpr int LDS_NORMW = LDS_RED, LDS_RSTD = LDS_NORMW + 4096 * 4, LDS_TOTAL = LDS_RSTD + 32 * 4;
 
+#ifdef COVER_DC_DEBUG
+}  // namespace
+__device__ unsigned long long g_dc_dbg[256 * 4 * 8];   // [workgroup][phase of the launch][slot]: 100 MHz wall clock, thread 0
+extern "C" int cover_dc_debug(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dc_dbg), sizeof(g_dc_dbg)); }
+namespace {
+#define DCT(slot) do { if (threadIdx.x == 0) g_dc_dbg[(blockIdx.x * 4 + (sy.p & 3)) * 8 + (slot)] = wall_clock64(); } while (0)
+#else
+#define DCT(slot) do { } while (0)
+#endif
 typedef __attribute__((address_space(1))) unsigned gu32;
 typedef __attribute__((address_space(1))) unsigned long long gu64;
 __device__ __forceinline__ unsigned ld_agent(unsigned* p) { return __hip_atomic_load((gu32*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -83,6 +102,7 @@ struct Sync {
     unsigned* w;
     unsigned g0;       // generation at launch start
     int k;             // barriers passed in this launch
+    int p;             // phase index of the launch (debug stamps)
     bool dead;         // a spin ran into its bound: stop waiting
     __device__ __forceinline__ unsigned* cnt(int g) const { return w + g * LINE; }
     __device__ __forceinline__ unsigned* top() const { return w + NGRP * LINE; }
@@ -125,32 +145,41 @@ __device__ __forceinline__ void grid_wait(Sync& s) {
     }
 }
 
-// RMSNorm of 8 consecutive elements of one row (rmsnorm_bf16_k arithmetic): style 1 (Llama) w * bf16(x * rstd), else x * rstd * (off + w)
-__device__ __forceinline__ uint4 norm8(uint4 raw, float rstd, const float* wl, int style, float woff) {
+// RMSNorm of 8 consecutive elements of one row (rmsnorm_bf16_k arithmetic), branch-free: `wl` holds the EFFECTIVE weights the phase
+// put into LDS -- w for style 1 (Llama: w * bf16(x * rstd)), off + w otherwise (Gemma: (x * rstd) * (off + w)) -- and `rnd` selects the
+// intermediate bf16 rounding of style 1.
+__device__ __forceinline__ uint4 norm8(uint4 raw, float rstd, const float* wl, bool rnd) {
     const uint32_t rw[4] = {raw.x, raw.y, raw.z, raw.w};
     const float4 w0 = *(const float4*)wl, w1 = *(const float4*)(wl + 4);
     const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
     float o[8];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const float a = bf2f((bf16_t)(rw[i] & 0xffffu)), b = bf2f((bf16_t)(rw[i] >> 16));
-        if (style == 1) { o[2 * i] = wv[2 * i] * bfround(a * rstd); o[2 * i + 1] = wv[2 * i + 1] * bfround(b * rstd); }
-        else { o[2 * i] = a * rstd * (woff + wv[2 * i]); o[2 * i + 1] = b * rstd * (woff + wv[2 * i + 1]); }
+        const float a = bf2f((bf16_t)(rw[i] & 0xffffu)) * rstd, b = bf2f((bf16_t)(rw[i] >> 16)) * rstd;
+        const float ar = bfround(a), br = bfround(b);
+        o[2 * i] = (rnd ? ar : a) * wv[2 * i];
+        o[2 * i + 1] = (rnd ? br : b) * wv[2 * i + 1];
     }
     return make_uint4(pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3]), pack_bf2(o[4], o[5]), pack_bf2(o[6], o[7]));
 }
 
-// One GEMM phase of the chain for this workgroup. `wait_seam`: a grid barrier (arrived at by the previous phase) stands between
-// the previous phase's outputs and this phase's activation loads; the weight window is requested before it is waited for.
 // NBW fixes the phase's role: 1 = o_proj / down (residual + sums of squares, raw input rows), 3 = qkv (plain store, normed input rows),
 // 6 = gate_up (GLU epilogue, normed input rows).
+//
+// Inside a phase NOTHING is shared between the waves of a workgroup until the final k-slice sum: wave w owns k-slice w of every
+// 1024-deep chunk for all of the workgroup's n-blocks, so it is also the ONLY consumer of that slice of the activation rows. Each wave
+// therefore loads its own MFMA B-operand fragments straight from global memory (row f * 16 + rr, k = kst * 32 + gg * 8: 16 bytes per
+// lane, 1 KiB per instruction, L2 hits: every workgroup reads the same panel), applies the RMSNorm to them in registers, and never
+// touches LDS or a block barrier in the main loop. (A first version staged 64 KiB chunks through LDS like gemm_skinny3, whose two
+// n-groups do share them: the 1-n-block phases then moved 2 bytes of activations through LDS per byte of weights behind a block barrier
+// per chunk and ran at half the HBM rate.)
 template <int NBW, int KTOT>
 __device__ __forceinline__ void gemm_phase(const ChainPhase& ph, int M, char* smem, Sync& sy, bool wait_seam, bool arrive_after) {
-    constexpr bool NORM = NBW != 1;
-    constexpr int EPI = NBW == 1 ? EPI_RESIDUAL_SSQ : (NBW == 3 ? EPI_PLAIN : EPI_GLU);
-    constexpr int NCH = (KTOT + KC - 1) / KC;            // activation chunks
-    constexpr int WIN = 6;                                // weight items (chunk, n-block) in flight per wave: 6 x 4 loads x 1 KiB
-    constexpr int T = NCH * NBW;                          // items of a wave
+    constexpr bool NORM = NBW >= 3;
+    constexpr int EPI = NBW <= 2 ? EPI_RESIDUAL_SSQ : (NBW == 3 ? EPI_PLAIN : EPI_GLU);
+    constexpr int NCH = (KTOT + KC - 1) / KC;            // 1024-deep chunks; this wave's slice of a chunk = 128 k
+    constexpr int NP = NCH * 2;                           // step PAIRS of a wave: pair p = 64 k = (chunk p / 2, half p % 2 of its slice)
+    constexpr int DP = NBW <= 2 ? 6 : (NBW == 3 ? 3 : 2); // pairs in flight: DP x (2 NBW weight KiB + 4 activation KiB) per wave
     constexpr int K32 = KTOT / 32;
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -158,32 +187,44 @@ __device__ __forceinline__ void gemm_phase(const ChainPhase& ph, int M, char* sm
     const int nb_begin = blockIdx.x * NBW;
     const bool active = nb_begin < N16;                   // (the GLU phase fills 230 of the 256 workgroups)
     const int kw0 = w * 128;                              // this wave's k-slice inside every chunk
-    u32x4 buf[WIN][4];
+    u32x4 ws[DP][2][NBW];                                 // weight fragments of a pair: [k-step][n-block], one 1 KiB load each
+    uint4 xl[DP][2][2];                                   // activation LINES of a pair: [row half f][8-row tile h]: lane = (row h*8 + l/8, 16 B l%8)
     f32x4 acc[NBW][2];
 #pragma unroll
     for (int i = 0; i < NBW; ++i) { acc[i][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[i][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
 
-    auto load_item = [&](u32x4(&dst)[4], int t) {          // t is a compile-time constant at every call site
-        const int c = t / NBW, i = t - c * NBW;
-        int nb = nb_begin + i;
-        nb = nb < N16 ? nb : N16 - 1;                      // clamped: the output of a clamped n-block is never stored
-        int k = c * KC + kw0;
-        k = k + 128 <= KTOT ? k : KTOT - 128;              // ragged last chunk: re-read a valid slice (its activations are zero)
-        const u32x4* src = (const u32x4*)(ph.Wp + ((size_t)nb * K32 + (k >> 5)) * 512) + lane;
+    // first k of pair p (compile-time p); a slice beyond K (ragged last chunk) re-reads valid weights against zero activations
+    auto k_of = [&](int p) { return (p >> 1) * KC + kw0 + (p & 1) * 64; };
+    auto w_load = [&](u32x4(&dst)[2][NBW], int p) {
+        int k = k_of(p);
+        k = k + 64 <= KTOT ? k : KTOT - 64;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) dst[u] = __builtin_nontemporal_load(src + u * 64);
-    };
-    auto issue_window = [&]() {
+        for (int u = 0; u < 2; ++u)
 #pragma unroll
-        for (int t = 0; t < WIN; ++t)
-            if (t < T) load_item(buf[t], t);
+            for (int i = 0; i < NBW; ++i) {
+                int nb = nb_begin + i;
+                nb = nb < N16 ? nb : N16 - 1;              // clamped: the output of a clamped n-block is never stored
+#if defined(COVER_DC_ABL) && (COVER_DC_ABL & 1)
+                dst[u][i] = (u32x4){(unsigned)k, (unsigned)nb, 0x3f803f80u, 0x3f803f80u};   // ablation: no weight stream
+#else
+                dst[u][i] = __builtin_nontemporal_load((const u32x4*)(ph.Wp + ((size_t)nb * K32 + (k >> 5) + u) * 512) + lane);
+#endif
+            }
     };
 
     // ---- seam: weights first (they depend on nothing), then the wait ----
-    if (active) issue_window();
+    DCT(0);
+    if (active) {
+#pragma unroll
+        for (int p = 0; p < DP; ++p)
+            if (p < NP) w_load(ws[p], p);
+    }
+    DCT(1);
     if constexpr (NORM) {                                  // the norm weights of the 4096-wide panel -> LDS (immutable: no ordering needed)
         float* nwl = (float*)(smem + LDS_NORMW);
-        const float4 a = *(const float4*)(ph.norm_w + tid * 8), b = *(const float4*)(ph.norm_w + tid * 8 + 4);
+        float4 a = *(const float4*)(ph.norm_w + tid * 8), b = *(const float4*)(ph.norm_w + tid * 8 + 4);
+        const float off = ph.norm_style == 1 ? 0.0f : ph.norm_w_offset;   // effective weights: see norm8
+        a.x += off; a.y += off; a.z += off; a.w += off; b.x += off; b.y += off; b.z += off; b.w += off;
         *(float4*)(nwl + tid * 8) = a;
         *(float4*)(nwl + tid * 8 + 4) = b;
     }
@@ -193,13 +234,64 @@ __device__ __forceinline__ void gemm_phase(const ChainPhase& ph, int M, char* sm
     if (wait_seam && w == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // ONE acquire per workgroup; the block barrier below publishes it
     if (wait_seam) sy.k += 1;
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // LDS-only: the weight windows stay in flight
+    DCT(2);
 
-    // ---- per-row 1 / rms from the 256 partial sums of squares (fixed order: 4 sequential per lane, then the wave butterfly) ----
-    const int srr = lane & 15, sgg = lane >> 4;
-    const int sf = w & 1;                                  // MF = 2: a wave stages fragments of ONE row half
-    int srow = sf * 16 + srr;
-    srow = srow < M ? srow : M - 1;
-    float rstd = 1.0f;
+    const int rr = lane & 15, gg = lane >> 4;             // MFMA operand coordinates
+    const int r8 = lane >> 3, j8 = lane & 7;              // line coordinates: row r8 of an 8-row tile, 16-byte piece j8 of its 128-byte line
+    if (!active) {                                         // nothing to compute in this phase: only the seam behind it
+        if (arrive_after) {
+            asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if (tid == 0) grid_arrive(sy);
+        }
+        return;
+    }
+
+    // ---- activations. Every workgroup reads the whole panel (M x K, L2-resident), so HOW it is read decides the phase: MFMA-operand
+    //      shaped loads (16 rows x 64 B per instruction: half lines) come out of the L2s at ~8 TB/s chip-wide -- measured: the 180 MB
+    //      that the 256 workgroups of the down projection read took 22.7 us, the 90 MB weight stream beside them 11.8 -- whole 128-byte
+    //      lines at several times that. So a lane group reads LINES (8 rows x 128 B = the 64 k of a step pair per instruction), the RMSNorm
+    //      is applied to them in registers, and a wave-private 4 KiB LDS scratch turns them into the four operand fragments of the pair
+    //      (XOR-swizzled 16-byte slots: writes and reads conflict-free; same wave: no barrier, LDS ops are in order).
+    const bf16_t* arow[2][2];
+#pragma unroll
+    for (int f = 0; f < 2; ++f)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            int row = f * 16 + h * 8 + r8;
+            row = row < M ? row : M - 1;
+            arow[f][h] = ph.A + (size_t)row * ph.lda + kw0 + j8 * 8;
+        }
+    auto x_load = [&](uint4 (&dst)[2][2], int p) {         // p compile-time
+        const int koff = (p >> 1) * KC + (p & 1) * 64;
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+#if defined(COVER_DC_ABL) && (COVER_DC_ABL & 2)
+                if (true) { dst[f][h] = make_uint4((unsigned)koff, 0x3f803f80u, 0x3f803f80u, (unsigned)f); } else   // ablation: no activation loads
+#endif
+                if (KTOT % KC == 0) {                      // every chunk whole
+                    dst[f][h] = *(const uint4*)(arow[f][h] + koff);
+                } else {                                   // ragged last chunk: slices beyond K contribute zeros
+                    const bool in = koff + kw0 + 64 <= KTOT;
+                    uint4 v = *(const uint4*)(arow[f][h] + (in ? koff : 0));
+                    if (!in) v = make_uint4(0u, 0u, 0u, 0u);
+                    dst[f][h] = v;
+                }
+            }
+    };
+    const float* nwl = (const float*)(smem + LDS_NORMW);
+    char* xt = smem + LDS_XT + w * 4096;                   // [f][h][row r8: 128 B, slot j ^ r8]
+    const int wr_off = r8 * 128 + ((j8 ^ r8) << 4);
+    int rd_off[2];                                         // fragment (k-step u) of rows rr: tile h = rr / 8, row rr % 8, piece u * 4 + gg
+#pragma unroll
+    for (int u = 0; u < 2; ++u) rd_off[u] = (rr >> 3) * 1024 + (rr & 7) * 128 + (((u * 4 + gg) ^ (rr & 7)) << 4);
+#pragma unroll
+    for (int p = 0; p < DP; ++p)
+        if (p < NP) x_load(xl[p], p);
+    // ---- per-row 1 / rms from the 256 partial sums of squares (fixed order: 4 sequential per lane, then the wave butterfly), computed
+    //      UNDER the latency of the activation window requested above ----
+    float rstd[2][2] = {{1.0f, 1.0f}, {1.0f, 1.0f}};       // of this lane's line rows f * 16 + h * 8 + r8
     if constexpr (NORM) {
         float* rl = (float*)(smem + LDS_RSTD);
 #pragma unroll
@@ -213,98 +305,60 @@ __device__ __forceinline__ void gemm_phase(const ChainPhase& ph, int M, char* sm
             if (lane == 0) rl[w * 4 + j] = rsqrtf(sq / (float)KTOT + ph.norm_eps);
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        rstd = rl[sf * 16 + srr < M ? sf * 16 + srr : M - 1];
-    }
-    if (!active) {                                         // nothing to compute in this phase: only the seam behind it
-        if (arrive_after) {
-            asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            if (tid == 0) grid_arrive(sy);
-        }
-        return;
-    }
-
-    // ---- activation chunk staging: wave w moves fragments fi = j * 8 + w (kst = fi >> 1 = j * 4 + (w >> 1), f = w & 1); lane (rr, gg)
-    //      owns the 16 bytes of row f * 16 + rr, k = kst * 32 + gg * 8: the LDS image of a fragment is lane-linear ----
-    uint4 xr[8];
-    const bf16_t* arow = ph.A + (size_t)srow * ph.lda;
-    auto x_load = [&](int c) {                             // c compile-time
-        if ((c + 1) * KC <= KTOT) {                        // (constant after unrolling) whole chunk in range: one base, immediate offsets
-            const bf16_t* p0 = arow + c * KC + (w >> 1) * 32 + sgg * 8;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) xr[j] = *(const uint4*)(p0 + j * 128);
-        } else {
+        for (int f = 0; f < 2; ++f)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int kst = j * 4 + (w >> 1);
-                int k = c * KC + kst * 32 + sgg * 8;
-                const bool in = k < KTOT;
-                k = in ? k : KTOT - 8;
-                uint4 v = *(const uint4*)(arow + k);
-                if (!in) v = make_uint4(0u, 0u, 0u, 0u);
-                xr[j] = v;
+            for (int h = 0; h < 2; ++h) {
+                const int row = f * 16 + h * 8 + r8;
+                rstd[f][h] = rl[row < M ? row : M - 1];
             }
-        }
-    };
-    auto x_write = [&](int c) {
-        const float* nwl = (const float*)(smem + LDS_NORMW);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            uint4 v = xr[j];
-            if constexpr (NORM) {
-                const int kst = j * 4 + (w >> 1);
-                v = norm8(v, rstd, nwl + c * KC + kst * 32 + sgg * 8, ph.norm_style, ph.norm_w_offset);
-            }
-            *(uint4*)(smem + (c & 1) * XB + (j * 8 + w) * 1024 + lane * 16) = v;
-            if constexpr (NORM) __builtin_amdgcn_sched_barrier(0);   // one fragment at a time: batching the 16 weight reads costs 64 registers
-        }
-    };
-    x_load(0);
-    x_write(0);
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    DCT(3);
 
-    // ---- main loop: fully unrolled, every slot and refill a compile-time decision ----
+    // ---- main loop: fully unrolled; a pair's loads were issued DP pairs earlier, its slots are refilled in place right behind its MFMAs;
+    //      no block barrier: the eight waves drift freely ----
 #pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-        if (c + 1 < NCH) x_load(c + 1);
+    for (int p = 0; p < NP; ++p) {
+        const int slot = p % DP;
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                uint4 v = xl[slot][f][h];
+                if constexpr (NORM) v = norm8(v, rstd[f][h], nwl + (p >> 1) * KC + kw0 + (p & 1) * 64 + j8 * 8, ph.norm_style == 1);
+                *(uint4*)(xt + (f * 2 + h) * 1024 + wr_off) = v;
+            }
+        bf16x8 xf[2][2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int f = 0; f < 2; ++f) xf[u][f] = as_bf16x8(*(const uint4*)(xt + f * 2048 + rd_off[u]));
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int i = 0; i < NBW; ++i) {
+                const bf16x8 wf = __builtin_bit_cast(bf16x8, ws[slot][u][i]);
+#pragma unroll
+                for (int f = 0; f < 2; ++f) acc[i][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf[u][f], acc[i][f], 0, 0, 0);
+            }
         __builtin_amdgcn_sched_barrier(0);
-        const char* xb = smem + (c & 1) * XB;
-        // NBW = 1: the wave's 8 activation fragments of the chunk are read up front (eight LDS reads in flight instead of eight read -> wait ->
-        // MFMA round trips). NBW >= 3: read at their MFMAs -- holding them (32 registers) beside the 96-register weight window, the next
-        // chunk's 32 staging registers and the accumulators sends the allocator into scratch (hundreds of spills, weights included).
-        bf16x8 xf[NBW == 1 ? 4 : 1][2];
-        if constexpr (NBW == 1) {
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-#pragma unroll
-                for (int f = 0; f < 2; ++f) xf[u][f] = as_bf16x8(*(const uint4*)(xb + (((w * 4 + u) * 2 + f) * 64 + lane) * 16));
+        if (p + DP < NP) {
+            x_load(xl[slot], p + DP);
+            w_load(ws[slot], p + DP);
         }
-#pragma unroll
-        for (int i = 0; i < NBW; ++i) {
-            const int t = c * NBW + i, slot = t % WIN;
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const bf16x8 wf = __builtin_bit_cast(bf16x8, buf[slot][u]);
-#pragma unroll
-                for (int f = 0; f < 2; ++f) {
-                    bf16x8 xv;
-                    if constexpr (NBW == 1) xv = xf[u][f];
-                    else xv = as_bf16x8(*(const uint4*)(xb + (((w * 4 + u) * 2 + f) * 64 + lane) * 16));
-                    acc[i][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xv, acc[i][f], 0, 0, 0);
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            if (t + WIN < T) load_item(buf[slot], t + WIN);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        if (c + 1 < NCH) {
-            x_write(c + 1);
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        }
+        __builtin_amdgcn_sched_barrier(0);
+#ifdef COVER_DC_DEBUG
+        if (p == 0) { asm volatile("s_nop 0" :: "v"(acc[0][0][0])); DCT(4); }
+#endif
     }
+#ifdef COVER_DC_DEBUG
+    asm volatile("s_nop 0" :: "v"(acc[0][0][0]), "v"(acc[NBW - 1][1][3]));
+#endif
+    DCT(5);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // every wave is done with its scratch (the reduction buffer aliases it)
 
     // ---- sum the 8 k-slices through LDS (fixed wave order), epilogue, write-through stores ----
     float* red = (float*)smem;                             // [w][i][f][e][lane]
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // every wave is done reading the activation chunks
 #pragma unroll
     for (int i = 0; i < NBW; ++i)
 #pragma unroll
@@ -312,6 +366,7 @@ __device__ __forceinline__ void gemm_phase(const ChainPhase& ph, int M, char* sm
 #pragma unroll
             for (int e = 0; e < 4; ++e) red[((((w * NBW + i) * 2 + f) * 4 + e) << 6) + lane] = acc[i][f][e];
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    DCT(6);
     const int r = lane & 15, g = lane >> 4;
     auto slice_sum = [&](int i, int f, float (&v)[4]) {
 #pragma unroll
@@ -378,8 +433,10 @@ __device__ __forceinline__ void gemm_phase(const ChainPhase& ph, int M, char* sm
     }
     if (arrive_after) {
         asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // every storing wave has drained
+        DCT(7);
         if (tid == 0) grid_arrive(sy);
     } else {
+        DCT(7);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                          // LDS is reused by the next phase
     }
 }
@@ -414,6 +471,7 @@ __global__ __launch_bounds__(512) void decode_chain_k(ChainArgs a) {
     }
     for (int p = 0; p < a.n_phases; ++p) {
         const ChainPhase& ph = a.ph[p];
+        sy.p = p;
         const bool seam = p > 0, more = p + 1 < a.n_phases;
         if (ph.kind == PH_SSQ) { ssq_phase(ph, a.M, sy, more); continue; }
         if (ph.nbw == 1 && ph.ktot == 4096) gemm_phase<1, 4096>(ph, a.M, smem, sy, seam, more);
@@ -430,8 +488,11 @@ std::mutex g_mu;
 
 // ---- host side ---------------------------------------------------------------------------------------------------------------
 bool decode_chain_supported(const cover_dec_desc* d, int rows) {
-    const char* env = getenv("COVER_DECODE_CHAIN");          // read per call (tests A/B the two paths inside one process): 0 = separate launches
-    if (env && env[0] == '0') return false;
+    // OPT-IN (COVER_DECODE_CHAIN=1; 2 = every phase its own launch). Measured on MI355X (docs/OPTIMISATION_LOG.md, round 4): the chain
+    // runs a 7B decode layer in 114 us against 109.6 us for the separate kernels, the headline decision in 34.9-35.3 ms against 34.7:
+    // parity, so the separate launches stay the default. Read per call (the tests A/B the two paths inside one process).
+    const char* env = getenv("COVER_DECODE_CHAIN");
+    if (!env || (env[0] != '1' && env[0] != '2')) return false;
     if (rows < 1 || rows > 32) return false;
     if (d->dim != 4096 || d->Hq * d->D != 4096 || d->mlp != 11008 || (d->Hq + 2 * d->Hkv) * d->D != 12288) return false;
     if (d->act != ACT_SILU && d->act != ACT_GELU_TANH) return false;

@@ -478,8 +478,9 @@ size_t cover_decoder_workspace_bytes(const cover_dec_desc* d, int rows);
 int cover_decoder_forward(const cover_dec_desc* d, const cover_dec_pass* p, void* x, cover_workspace ws,
                           int gemm_variant, void* stream);
 
-/* Persistent decode chain (cover_decoder_forward takes it by itself for single-token candidate passes of <= 32 rows at the 7B decoder
- * shapes; COVER_DECODE_CHAIN=0 keeps the separate launches): its grid barriers spin with a bound and record a code instead of hanging.
+/* Persistent decode chain (opt-in, COVER_DECODE_CHAIN=1: cover_decoder_forward then takes it for single-token candidate passes of <= 32
+ * rows at the 7B decoder shapes; measured at parity with the separate launches, which are the default): its grid barriers spin with a
+ * bound and record a code instead of hanging.
  * Synchronises the device and returns COVER_OK when every barrier since the last call completed, COVER_EHIP (+ cover_last_error)
  * otherwise -- the outputs of that pass are then invalid; the barrier state is reset. */
 int cover_decode_chain_status(void);

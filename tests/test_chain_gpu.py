@@ -41,8 +41,7 @@ class _Env:
                 os.environ[k] = v
 
 
-@pytest.fixture(scope="module")
-def llm(dev):
+def build_llm(dev):
     """Two full-width layers with caches holding a random prefix / prompt text (what a prefill would have left)."""
     g = synth._G(91, True, 0.02)
     sd = synth.decoder_state(g, dim=L7["dim"], layers=2, Hq=L7["Hq"], Hkv=L7["Hkv"], D=L7["D"], mlp=L7["mlp"], rms_base=1.0)
@@ -55,6 +54,11 @@ def llm(dev):
         m.k_cache[l].copy_((torch.randn(geom.elems, device=dev, generator=gg) * 0.5).to(BF))
         m.vt_cache[l].copy_((torch.randn(geom.elems, device=dev, generator=gg) * 0.5).to(BF))
     return m, sd
+
+
+@pytest.fixture(scope="module")
+def llm(dev):
+    return build_llm(dev)
 
 
 def _group(m, dev, N, write_t=0):
