@@ -155,15 +155,24 @@ class Pipeline:
                 self.pool = concurrent.futures.ThreadPoolExecutor(max_workers=1)
             ev = torch.cuda.Event()
             ev.record(main)
+            after_vision = os.environ.get("COVER_SIDE_AFTER_VISION", "0") == "1"   # experiment: towers under the prefill instead of the vision phase
+            import threading
+            gate = threading.Event()
 
             def threaded():
                 torch.cuda.set_device(self.dev)
+                if after_vision:
+                    gate.wait()
                 self.side.wait_event(ev)
                 with torch.cuda.stream(self.side):
                     return side_work()
 
+            def vision_hook():
+                ev.record(main)
+                gate.set()
+
             fut = self.pool.submit(threaded)
-            tokens, _ = self.policy.sample(i["frame"], i["toks"], i["lens"], S, i["u"], 1.0)
+            tokens, _ = self.policy.sample(i["frame"], i["toks"], i["lens"], S, i["u"], 1.0, on_vision_enqueued=vision_hook if after_vision else None)
             its = fut.result()
         else:
             def hook():

@@ -387,6 +387,9 @@ __global__ __launch_bounds__(64 * (CGM * CGN + NL)) void gemm_tiled_pc(const bf1
     u32x4 xa[WM], wa[WN], xb[WM], wb[WN];
 #endif
     int cur = 0;
+#if defined(COVER_PC_PRIO) && COVER_PC_PRIO
+    __builtin_amdgcn_s_setprio(COVER_PC_PRIO);   // experiment: static issue priority for the MFMA waves over the loader waves (guide T5, static form)
+#endif
     __builtin_amdgcn_s_barrier();
     PCTL(1);
 #ifdef COVER_PC_DEBUG

@@ -181,7 +181,7 @@ class OpenVLA:
     # ---------------------------------------------------------------------------------------------- sampler
     def sample(self, frame_u8: torch.Tensor, prompt_tokens: torch.Tensor, prompt_lens: torch.Tensor, n_samples: int,
                uniforms: Optional[torch.Tensor] = None, temperature: float = 1.0, trace: Optional[dict] = None,
-               force_tokens: Optional[torch.Tensor] = None, on_prefill_enqueued=None):
+               force_tokens: Optional[torch.Tensor] = None, on_prefill_enqueued=None, on_vision_enqueued=None):
         """frame_u8 [n_cams,H,W,3] uint8; prompt_tokens int64 [P, Lt] right padded, prompt_lens int32 [P] (device);
         n_samples candidates per prompt (N = P*n_samples, candidate i belongs to prompt i // n_samples);
         uniforms fp32 [N, n_gen] in [0,1) for inverse-CDF sampling over the 256 action tokens, None = greedy over the
@@ -208,6 +208,8 @@ class OpenVLA:
         x = self.x_pre[: Tp + P * Lt]
         mark("start")
         x[:Tp].copy_(self.encode_image(frame_u8))
+        if on_vision_enqueued is not None:
+            on_vision_enqueued()
         mark("vision")
         ops.embed_gather(self.embed, prompt_tokens.reshape(-1).contiguous(), out=x[Tp:])
         pos0 = 1 + torch.arange(Tp, dtype=torch.int32, device=dev)
