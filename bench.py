@@ -142,13 +142,13 @@ class Pipeline:
             return self.ver.image_text_embeddings(pf, tf)
 
         if serial:
-            keep = (self.policy.vision_graph, self.policy.vision_overlap)
-            self.policy.vision_graph, self.policy.vision_overlap = False, False
+            keep = (self.policy.vision_graph, self.policy.vision_overlap, self.policy.decode_graph)
+            self.policy.vision_graph, self.policy.vision_overlap, self.policy.decode_graph = False, False, False
             try:
                 its = side_work()
                 tokens, _ = self.policy.sample(i["frame"], i["toks"], i["lens"], S, i["u"], 1.0)
             finally:
-                self.policy.vision_graph, self.policy.vision_overlap = keep
+                self.policy.vision_graph, self.policy.vision_overlap, self.policy.decode_graph = keep
         elif os.environ.get("COVER_SIDE_THREAD", "1") != "0":
             if self.pool is None:
                 import concurrent.futures

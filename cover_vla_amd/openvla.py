@@ -89,6 +89,7 @@ class OpenVLA:
         self.head_ws = ops.gemm_workspace(max_candidates, c["vocab"], D, dev)
         self.logits_actions = torch.empty(max_candidates, c["n_bins"], dtype=torch.float32, device=dev)
         self.head_ws_actions = ops.gemm_workspace(max_candidates, c["n_bins"], D, dev)
+        self.hn = torch.empty(max_candidates, D, dtype=BF, device=dev)
         self.zero_slots = torch.zeros(max(max_prompts, max_candidates), dtype=torch.int32, device=dev)
         self.bos = torch.tensor([1], dtype=torch.int64, device=dev)
         self._side = None
@@ -102,6 +103,11 @@ class OpenVLA:
         # lm_head launches hide behind the host work between decode passes -- so the default keeps the full head
         self.slice_action_head = os.environ.get("COVER_ACTION_HEAD", "0") == "1"
         self.vision_overlap = True
+        # the head + decode loop of a decision (first action token, then n_gen - 1 passes of 32 layers + head: ~1 350 launches at 7 B) replayed
+        # as ONE hipGraph over static buffers: bit-identical to the eager loop; the GPU time is the same (the loop is
+        # GPU-bound), the host is done with a decision's policy side after the prefill. COVER_DECODE_GRAPH=0 keeps the eager loop.
+        self.decode_graph = os.environ.get("COVER_DECODE_GRAPH", "1") != "0"
+        self._dec = {}
 
     def _ensure_bos_kv(self):
         """The BOS token sits at position 0 of a causal prefix: it attends only to itself, so its hidden states and its K/V
@@ -227,35 +233,70 @@ class OpenVLA:
         prompt_of_cand = (torch.arange(N, device=dev) // n_samples).to(torch.int32)
         cand_len = prompt_lens.to(torch.int32)[prompt_of_cand.long()].contiguous()
         last_row = (Tp + prompt_of_cand * Lt + cand_len - 1).to(torch.int32)
-        ops.copy_rows(x, self.h_sel, N, D, last_row, None)
+        pos_all = ((T0 + cand_len)[None, :] + torch.arange(self.n_gen, dtype=torch.int32, device=dev)[:, None]).contiguous()
+        u_t = None if uniforms is None else uniforms.to(torch.float32).t().contiguous()
+        if self.decode_graph and trace is None and force_tokens is None and not self.slice_action_head:
+            # static buffers per batch shape; the per-decision values (prompt lengths -> rows / positions, uniforms) are copied in
+            key = (P, n_samples, Lt, uniforms is None, float(temperature), self.slice_action_head)
+            st = self._dec.get(key)
+            if st is None:
+                st = dict(graph=None, prompt_of_cand=prompt_of_cand.clone(), cand_len=torch.empty_like(cand_len), last_row=torch.empty_like(last_row),
+                          pos_all=torch.empty_like(pos_all), tokens=torch.empty(self.n_gen, N, dtype=torch.int64, device=dev),
+                          sel=torch.empty(self.n_gen, N, dtype=torch.float32, device=dev),
+                          u=None if u_t is None else torch.empty_like(u_t),
+                          prompt_slots=torch.arange(P, dtype=torch.int32, device=dev), prompt_lens=torch.empty(P, dtype=torch.int32, device=dev))
+                self._dec[key] = st
+            st["cand_len"].copy_(cand_len); st["last_row"].copy_(last_row); st["pos_all"].copy_(pos_all)
+            st["prompt_lens"].copy_(prompt_lens.to(torch.int32))
+            if u_t is not None:
+                st["u"].copy_(u_t)
+            body = lambda: self._decode_body(x, N, n_samples, Lt, st["prompt_of_cand"], st["cand_len"], st["last_row"], st["pos_all"], st["u"], temperature,
+                                             st["tokens"], st["sel"], st["tokens"], None, st["prompt_slots"], st["prompt_lens"])
+            if st["graph"] is None:
+                body()                                                  # eager once (also sizes every workspace), then recorded
+                cur = torch.cuda.current_stream()
+                if self._cap is None:
+                    self._cap = torch.cuda.Stream(device=self.dev)
+                self._cap.wait_stream(cur)
+                with torch.cuda.stream(self._cap):
+                    with ops.Graph() as g:
+                        body()
+                st["graph"] = g
+                cur.wait_stream(self._cap)
+            else:
+                st["graph"].launch()
+            return st["tokens"].t().contiguous(), st["sel"].t().contiguous()
         # step-major buffers: row i of each is contiguous, so the kernels of step i read / write them in place (no per-step slice copies)
         tokens = torch.empty(self.n_gen, N, dtype=torch.int64, device=dev)
         sel = torch.empty(self.n_gen, N, dtype=torch.float32, device=dev)
-        uniforms = None if uniforms is None else uniforms.to(torch.float32).t().contiguous()
         fed = tokens if force_tokens is None else force_tokens.t().contiguous()
+        self._decode_body(x, N, n_samples, Lt, prompt_of_cand, cand_len, last_row, pos_all, u_t, temperature, tokens, sel, fed, trace,
+                          torch.arange(P, dtype=torch.int32, device=dev), prompt_lens.to(torch.int32).contiguous(), mark)
+        return tokens.t().contiguous(), sel.t().contiguous()
+
+    def _decode_body(self, x, N, n_samples, Lt, prompt_of_cand, cand_len, last_row, pos_all, uniforms, temperature, tokens, sel, fed, trace,
+                     prompt_slots, prompt_lens_i32, mark=lambda name: None):
+        """Head on the last prompt rows, then n_gen - 1 decode passes + heads. Launches only (no allocation, no host read): recordable."""
+        D, T0 = self.c["llm_dim"], self.T0
+        ops.copy_rows(x, self.h_sel, N, D, last_row, None)
         self._head_select(self.h_sel[:N], uniforms, 0, temperature, tokens, sel, trace)
-        # ---- decode
-        pos_all = ((T0 + cand_len)[None, :] + torch.arange(self.n_gen, dtype=torch.int32, device=dev)[:, None]).contiguous()
         xd = self.x_dec[:N]
         own = {}
         if self.own_kv is not None:   # regular structure of the batch: the n_samples candidates of prompt p are rows [p S, (p + 1) S)
-            own = dict(own_kv=self.own_kv, seg1_group=n_samples, seg1_slot_of_group=torch.arange(P, dtype=torch.int32, device=dev),
-                       seg1_len_of_group=prompt_lens.to(torch.int32).contiguous())
+            own = dict(own_kv=self.own_kv, seg1_group=n_samples, seg1_slot_of_group=prompt_slots, seg1_len_of_group=prompt_lens_i32)
         for i in range(1, self.n_gen):
             ops.embed_gather(self.embed, fed[i - 1], out=xd)
-            pos = pos_all[i - 1]
-            g = self.llm.group(N, 1, pos,
+            g = self.llm.group(N, 1, pos_all[i - 1],
                                [dict(region=0, length=T0, slot_of_batch=self.zero_slots),
                                 dict(region=1, length=Lt, len_of_batch=cand_len, slot_of_batch=prompt_of_cand),
                                 dict(region=2, length=i)], 2, write_t_off=i - 1, seg0_shared=True, **own)
             self.llm.forward(xd, [g], final_norm=False)
             self._head_select(xd, uniforms, i, temperature, tokens, sel, trace)
             mark(f"decode{i}")
-        return tokens.t().contiguous(), sel.t().contiguous()
 
     def _head_select(self, h, uniforms, i, temperature, tokens, sel, trace):
         N = h.shape[0]
-        hn = ops.rmsnorm(h, self.llm.final_norm, 1e-5, w_offset=0.0, style=1)
+        hn = ops.rmsnorm(h, self.llm.final_norm, 1e-5, w_offset=0.0, style=1, out=self.hn[:N])
         if uniforms is not None and (trace is None or "events" in trace) and self.slice_action_head:
             lg = ops.gemm(hn, self.lm_head_actions, out=self.logits_actions[:N], ws=self.head_ws_actions)
             t, _ = ops.token_select(lg, 0, self.c["n_bins"], uniform=uniforms[i], temperature=temperature, out_logit=sel[i])

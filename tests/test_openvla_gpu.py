@@ -189,6 +189,28 @@ def test_openvla_vision_graph_replay_equals_eager_and_cached_bos(dev):
     assert torch.equal(t0, t1)
 
 
+@pytest.mark.parametrize("own_kv,horizon", [(None, 1), ("bf16", 2)])
+def test_openvla_decode_graph_replay_equals_eager_loop(dev, own_kv, horizon):
+    """The head + decode loop of sample() as ONE replayed hipGraph over static buffers (call 1 runs eagerly and records, later calls
+    replay): tokens and selected logits bit-identical to the eager loop -- also when the replay sees OTHER prompt lengths and uniforms
+    than the recording did (they are copied into the static buffers, not baked in), sampled and greedy."""
+    from cover_vla_amd.openvla import OpenVLA
+    c, sd, frame, toks, lens, u = _case(seed=13, n_gen=7 * horizon)
+    kw = dict(device="cuda:0", max_prompts=4, max_candidates=8, max_text=toks.shape[1], horizon=horizon, own_kv=own_kv)
+    eager = OpenVLA(sd, c, **kw)
+    eager.decode_graph = False
+    model = OpenVLA(sd, c, **kw)
+    assert model.decode_graph
+    f, tk, ud = frame.to(dev), toks.to(dev), u.to(dev)
+    lens2 = (lens - torch.tensor([2, 0, 1], dtype=torch.int32)).to(dev)
+    u2 = torch.flip(ud, dims=[0]).contiguous()
+    for ln, uu in ((lens.to(dev), ud), (lens.to(dev), ud), (lens2, u2), (lens2, None), (lens.to(dev), None)):
+        a_t, a_l = model.sample(f, tk, ln, 2, uu, 1.0)
+        b_t, b_l = eager.sample(f, tk, ln, 2, uu, 1.0)
+        assert torch.equal(a_t, b_t) and torch.equal(a_l, b_l)
+    assert all(st["graph"] is not None for st in model._dec.values()) and len(model._dec) == 2      # sampled and greedy shapes
+
+
 def test_openvla_end_to_end_matches_hf_composition(dev):
     """END-TO-END pin of the headline profile at a public implementation: the HIP path (vision towers -> projector -> shared
     prefix + per-prompt prefill -> 6 decode passes -> lm_head -> greedy pick) against HF Dinov2WithRegisters + SiglipVision +
