@@ -3,6 +3,7 @@
 // projections / Euler update (modeling_pi0.py:569-629,748-751,713-714).
 // The GEMM runs on v_mfma_f32_16x16x4_f32 (exact fp32 FMA chain, k-ordered), everything else is VALU.
 #include "common.h"
+#include <stdlib.h>
 #include "kernels.h"
 
 // ---------------------------------------------------------------------------------------------------
@@ -97,9 +98,10 @@ __global__ __launch_bounds__(256) void gemm_f32_k(cover_gemm_f32_args a) {
 // of 16-byte loads in flight each; lane (r, g) loads k = 16s + 4g .. 4g+3 of its row, and the j-th of four MFMAs per step
 // takes component j from both operands (the 16x16x4 MFMA sums over the four lane groups, so any k <-> (g, j) bijection
 // that is the same for A and B is valid). The four partial tiles meet in LDS and leave through the usual epilogue.
-template <int FM>
+// UNR = k-steps a wave keeps in flight per round trip: the kernel is a chain of dependent load rounds (a 2048-deep contraction is 32 steps
+// per wave: 8 rounds at UNR = 4, 4 at UNR = 8); the order in which a wave adds its steps does not depend on UNR (same sums, bit for bit).
+template <int FM, int UNR = 4>
 __global__ __launch_bounds__(256) void gemm_f32_direct_k(cover_gemm_f32_args a) {
-    constexpr int UNR = 4;
     __shared__ float red[4][FM * 2][4][64];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -189,12 +191,18 @@ hipError_t launch_gemm_f32(const cover_gemm_f32_args* a, hipStream_t st) {
                           (a->b_row_stride & 3) == 0 && (a->a_batch_stride & 3) == 0 && (a->b_batch_stride & 3) == 0 &&
                           (((uintptr_t)a->A | (uintptr_t)a->B) & 15) == 0;
     if (k_contig && blocks64 < 1024) {
+        // experiment knob COVER_F32_UNR=8: eight steps in flight for K >= 512. Measured (round 4): the verifier tail got SLOWER, 0.563 vs 0.525 ms
+        // -- the deeper window costs occupancy (126 registers: 3 waves per SIMD instead of 6) and these grids live off occupancy. Default 4.
+        static const char* unr_env = getenv("COVER_F32_UNR");
+        const bool deep = a->K >= 512 && unr_env && unr_env[0] == '8';
         if (a->M <= 16) {
             dim3 grid((a->N + 31) / 32, (a->M + 15) / 16, nb);
-            hipLaunchKernelGGL(gemm_f32_direct_k<1>, grid, dim3(256), 0, st, *a);
+            if (deep) hipLaunchKernelGGL((gemm_f32_direct_k<1, 8>), grid, dim3(256), 0, st, *a);
+            else hipLaunchKernelGGL((gemm_f32_direct_k<1, 4>), grid, dim3(256), 0, st, *a);
         } else {
             dim3 grid((a->N + 31) / 32, (a->M + 31) / 32, nb);
-            hipLaunchKernelGGL(gemm_f32_direct_k<2>, grid, dim3(256), 0, st, *a);
+            if (deep) hipLaunchKernelGGL((gemm_f32_direct_k<2, 8>), grid, dim3(256), 0, st, *a);
+            else hipLaunchKernelGGL((gemm_f32_direct_k<2, 4>), grid, dim3(256), 0, st, *a);
         }
         return hipGetLastError();
     }
