@@ -182,6 +182,7 @@ SYMBOLS = {
     "cover_gemm_bf16": (c_i, [c_p, c_i, c_p, c_p, c_i, c_i, c_i, c_i, _P(GemmEpi), c_p, C.c_size_t, c_i, c_p]),
     "cover_gemm_plan_counts": (c_i, [C.POINTER(C.c_longlong), c_i, c_i]),
     "cover_decode_chain_status": (c_i, []),
+    "cover_gemm_tail_status": (c_i, []),
     "cover_attention_bf16": (c_i, [_P(AttnArgs), c_p]),
     "cover_decode_attention_fused": (c_i, [_P(DecodeAttnArgs), c_p]),
     "cover_decode_own_attention": (c_i, [_P(OwnAttnArgs), c_p]),

@@ -72,6 +72,12 @@ int cover_quantize_act_fp8(const void* X, int ldx, int M, int K, void* out8, int
     return COVER_OK;
 }
 size_t cover_gemm_workspace_bytes(int M, int N, int K) { return gemm_workspace_bytes(M, N, K); }
+int cover_gemm_tail_status(void) {
+    const int v = gemm_tail_status();
+    if (v < 0) return fail(COVER_EHIP, "cover_gemm_tail_status: could not read the status word");
+    if (v != 0) return fail(COVER_EHIP, "a bounded wait of the tail reduction gave up (gemm_bf16.hip): results of that pass are invalid");
+    return COVER_OK;
+}
 int cover_gemm_plan_counts(long long* counts, int n, int reset) {
     if (n < 0 || (n > 0 && !counts)) return fail(COVER_EINVAL, "cover_gemm_plan_counts: bad arguments");
     gemm_plan_counts(counts, n, reset);
@@ -396,7 +402,8 @@ int cover_vit_forward(const cover_vit_desc* d, void* x, int n_seq, int T, void* 
 }
 
 static size_t dec_ws(const cover_dec_desc* d, int rows, Carver* c, void** h, void** qkv, void** attn, void** mlp, void** sk,
-                     size_t* sk_bytes, void** st_o = nullptr, void** st_ml = nullptr, void** q8 = nullptr, void** q8s = nullptr, void** ssq = nullptr) {
+                     size_t* sk_bytes, void** st_o = nullptr, void** st_ml = nullptr, void** q8 = nullptr, void** q8s = nullptr, void** ssq = nullptr,
+                     void** tsync = nullptr) {
     Carver tmp{nullptr, 0, 0};
     Carver& cc = c ? *c : tmp;
     const int nqkv = (d->Hq + 2 * d->Hkv) * d->D;
@@ -425,6 +432,7 @@ static size_t dec_ws(const cover_dec_desc* d, int rows, Carver* c, void** h, voi
     p = cc.take(skb); if (sk) *sk = p;
     if (sk_bytes) *sk_bytes = skb;
     p = cc.take(decode_chain_ws_bytes()); if (ssq) *ssq = p;   // partial sums of squares of the persistent decode chain (rows <= 32)
+    p = cc.take(256); if (tsync) *tsync = p;                   // ticket words of the tail reduction (gemm_bf16.hip), zeroed per pass
     return cc.off + 256;
 }
 size_t cover_decoder_workspace_bytes(const cover_dec_desc* d, int rows) {
@@ -445,9 +453,9 @@ int cover_decoder_forward(const cover_dec_desc* d, const cover_dec_pass* p, void
         rows += G.B * G.T;
     }
     Carver c{(char*)ws.ptr, ws.bytes, 0};
-    void *h, *qkv, *attn, *mlp, *sk, *st_o, *st_ml, *q8, *q8s, *ssq;
+    void *h, *qkv, *attn, *mlp, *sk, *st_o, *st_ml, *q8, *q8s, *ssq, *tsync;
     size_t skb;
-    const size_t need = dec_ws(d, rows, &c, &h, &qkv, &attn, &mlp, &sk, &skb, &st_o, &st_ml, &q8, &q8s, &ssq);
+    const size_t need = dec_ws(d, rows, &c, &h, &qkv, &attn, &mlp, &sk, &skb, &st_o, &st_ml, &q8, &q8s, &ssq, &tsync);
     if (!ws.ptr || ws.bytes < need) return fail(COVER_EWORKSPACE, "cover_decoder_forward: workspace too small");
     const int dim = d->dim, Hq = d->Hq, Hkv = d->Hkv, D = d->D, nqkv = (Hq + 2 * Hkv) * D, HD = Hq * D;
 
@@ -508,6 +516,17 @@ int cover_decoder_forward(const cover_dec_desc* d, const cover_dec_pass* p, void
         e.a8 = q8; e.a8_scale = (const float*)q8s; e.ld_a8 = kp;
         return launch_quantize_act_fp8((const bf16_t*)src, K, rows, K, (uint8_t*)q8, kp, (float*)q8s, st);
     };
+    // weight-streaming passes (<= 64 rows): the split-K reductions of o_proj / down (+ residual + RMSNorm) run at the tail of the launch
+    // that wrote the slabs instead of as launches of their own (gemm_bf16.hip "Tail reduction": same code, bit-identical results).
+    // COVER_TAIL_REDUCE=0 keeps the reduction launches (read per call: the tests toggle it).
+    unsigned* tail_sync = nullptr;
+    {
+        const char* te = getenv("COVER_TAIL_REDUCE");
+        if (rows <= 64 && !(te && te[0] == '0') && (te && te[0] == '1')) {
+            tail_sync = (unsigned*)tsync;
+            HIPCHK(hipMemsetAsync(tail_sync, 0, 256, st), "memset tail-reduction tickets");
+        }
+    }
     // h = in_norm_0(x); afterwards every norm is folded into the epilogue of the GEMM that produces its input
     {
         const bool f32in = p->x_f32 != nullptr;
@@ -681,7 +700,7 @@ int cover_decoder_forward(const cover_dec_desc* d, const cover_dec_pass* p, void
         e.w8 = L.o_w8; e.w8_scale = L.o_s;
         if (f8) HIPCHK(quant(attn, HD, e), "dec quantise (o_proj input)");
         norm_q8(e);
-        HIPCHK(launch_gemm_bf16((const bf16_t*)attn, HD, (const bf16_t*)L.o_w, x, dim, rows, dim, HD, &e, (float*)sk, skb, variant, st), "dec o_proj (+post_norm)");
+        HIPCHK(launch_gemm_bf16((const bf16_t*)attn, HD, (const bf16_t*)L.o_w, x, dim, rows, dim, HD, &e, (float*)sk, skb, variant, st, nullptr, tail_sync), "dec o_proj (+post_norm)");
         memset(&e, 0, sizeof e);
         e.out_scale = 1.0f;
         e.act = d->act; e.glu = 1;
@@ -699,7 +718,7 @@ int cover_decoder_forward(const cover_dec_desc* d, const cover_dec_pass* p, void
         e.w8 = L.down_w8; e.w8_scale = L.down_s;
         if (f8) HIPCHK(quant(mlp, d->mlp, e), "dec quantise (down input)");
         if (l + 1 < d->n_layers) norm_q8(e);
-        HIPCHK(launch_gemm_bf16((const bf16_t*)mlp, d->mlp, (const bf16_t*)L.down_w, x, dim, rows, dim, d->mlp, &e, (float*)sk, skb, variant, st), "dec down (+next in_norm)");
+        HIPCHK(launch_gemm_bf16((const bf16_t*)mlp, d->mlp, (const bf16_t*)L.down_w, x, dim, rows, dim, d->mlp, &e, (float*)sk, skb, variant, st, nullptr, tail_sync), "dec down (+next in_norm)");
     }
     if (p->final_norm)
         HIPCHK(launch_rmsnorm(x, 0, dim, d->final_norm_w, d->norm_w_offset, d->norm_style, (bf16_t*)x, dim, rows, dim, d->norm_eps, st), "dec final_norm");

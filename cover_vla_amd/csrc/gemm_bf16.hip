@@ -15,6 +15,7 @@
 //                (no LDS round trip for the streamed operand), split-K over grid.y with fp32 partials that a
 //                small reduce kernel folds together with the epilogue.
 #include <stdlib.h>
+#include <string.h>
 #include <atomic>
 #include <hip/hip_ext.h>
 #include "common.h"
@@ -550,6 +551,254 @@ __global__ __launch_bounds__(512) void gemm_skinny(const bf16_t* __restrict__ A,
     }
 }
 
+// out = epi(sum_s partial[s]) AND norm_out = rmsnorm(out) / layernorm(out): one 512-thread block per output row
+// (N % 8 == 0, N <= 8192, no GLU, bf16 output). The statistics are taken over the bf16-ROUNDED outputs, i.e. exactly what
+// the separate norm kernel would read back, with that kernel's arithmetic.
+// block sum of a 512-thread block through LDS with an LDS-ONLY barrier: __syncthreads() would also wait for the stores
+// of C still in flight (their acknowledgement is ~1 us on the critical path of a kernel that lasts ~6). `red` is written
+// once per call: a second call in the same kernel takes a different slice.
+__device__ __forceinline__ float block_sum_lds(float v, float* red) {
+    v = wave_sum(v);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) red[w] = v;
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t += red[i];
+    return t;
+}
+
+#ifdef COVER_RN_DEBUG
+__device__ unsigned long long g_rn_dbg[512 * 8];   // per block (thread 0): start, slabs landed, epilogue done, before / after the block sum, end
+extern "C" int cover_rn_debug(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_rn_dbg), sizeof(g_rn_dbg)); }
+#define RNT(slot) do { if (threadIdx.x == 0) g_rn_dbg[(blockIdx.x & 511) * 8 + (slot)] = wall_clock64(); } while (0)
+#else
+#define RNT(slot) do { } while (0)
+#endif
+// (one row by one 512-thread block; red = 16 floats of LDS: the standalone kernel below and the tail reduction of the weight-streaming kernels)
+__device__ __forceinline__ void reduce_norm_row(const float* __restrict__ partial, int S, bf16_t* C, int ldc, int M, int N, const EpiDev& epi,
+                                                const int m, float* red) {
+    RNT(0);
+    float vals[2][8];
+    float q = 0.f;
+    // the norm weights do not depend on anything: requested first, so their latency hides under the slab loads instead
+    // of following the block reduction (the stores to C in between keep the compiler from hoisting them itself)
+    float4 nw[2][2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const int n0 = (threadIdx.x + c * 512) * 8;
+        if (n0 < N) {
+            nw[c][0] = *(const float4*)(epi.norm_w + n0);
+            nw[c][1] = *(const float4*)(epi.norm_w + n0 + 4);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const int n0 = (threadIdx.x + c * 512) * 8;
+        if (n0 < N) {
+            float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            const float* p0 = partial + (size_t)m * N + n0;
+            const size_t sstride = (size_t)M * N;
+            int s = 0;
+            for (; s + 4 <= S; s += 4) {  // four slices in flight
+                float4 a[4], b[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    a[j] = *(const float4*)(p0 + (s + j) * sstride);
+                    b[j] = *(const float4*)(p0 + (s + j) * sstride + 4);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    v[0] += a[j].x; v[1] += a[j].y; v[2] += a[j].z; v[3] += a[j].w;
+                    v[4] += b[j].x; v[5] += b[j].y; v[6] += b[j].z; v[7] += b[j].w;
+                }
+            }
+            for (; s < S; ++s) {
+                const float4 a = *(const float4*)(p0 + s * sstride), b = *(const float4*)(p0 + s * sstride + 4);
+                v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w; v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
+            }
+            if (c == 0) RNT(1);
+            // (the bf16 residual row is read in here, eight 2-byte loads BEHIND the slabs: 1.2 of the kernel's 3.5 us by the
+            // timeline -- yet requesting it as one 16-byte load ahead of the slabs made the decision 0.4 ms slower in a same-box
+            // A/B (35.0 vs 35.4 ms), so it stays)
+            epi_value4(epi, m, n0, N, v);
+            epi_value4(epi, m, n0 + 4, N, v + 4);
+            if (c == 0) RNT(2);
+            uint4 u;
+            u.x = pack_bf2(v[0], v[1]); u.y = pack_bf2(v[2], v[3]); u.z = pack_bf2(v[4], v[5]); u.w = pack_bf2(v[6], v[7]);
+            *(uint4*)(C + (size_t)m * ldc + n0) = u;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                vals[c][i] = bfround(v[i]);
+                q += vals[c][i] * vals[c][i];
+            }
+        }
+    }
+    float mean = 0.f, rstd;
+    if (epi.norm_style == 2) {   // LayerNorm (layernorm_bf16_k arithmetic: mean, then the centred second moment)
+        float sum = 0.f;
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+            if ((int)(threadIdx.x + c * 512) * 8 < N)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) sum += vals[c][i];
+        mean = block_sum_lds(sum, red) / N;
+        float q2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+            if ((int)(threadIdx.x + c * 512) * 8 < N)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float d = vals[c][i] - mean;
+                    q2 += d * d;
+                }
+        rstd = rsqrtf(block_sum_lds(q2, red + 8) / N + epi.norm_eps);
+    } else {
+        RNT(3);
+        rstd = rsqrtf(block_sum_lds(q, red) / N + epi.norm_eps);
+        RNT(4);
+    }
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const int n0 = (threadIdx.x + c * 512) * 8;
+        if (n0 < N) {
+            float o[8];
+            const float wv[8] = {nw[c][0].x, nw[c][0].y, nw[c][0].z, nw[c][0].w, nw[c][1].x, nw[c][1].y, nw[c][1].z, nw[c][1].w};
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float ww = wv[i];
+                if (epi.norm_style == 2) o[i] = (vals[c][i] - mean) * rstd * ww + (epi.norm_b ? epi.norm_b[n0 + i] : 0.f);
+                else o[i] = epi.norm_style == 1 ? ww * bfround(vals[c][i] * rstd) : vals[c][i] * rstd * (epi.norm_w_offset + ww);
+            }
+            uint4 u;
+            u.x = pack_bf2(o[0], o[1]); u.y = pack_bf2(o[2], o[3]); u.z = pack_bf2(o[4], o[5]); u.w = pack_bf2(o[6], o[7]);
+            *(uint4*)(epi.norm_out + (size_t)m * epi.ld_norm_out + n0) = u;
+            if (epi.nq8) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) vals[c][i] = bfround(o[i]);   // the stored bf16 row is what gets quantised
+            }
+        }
+    }
+    if (epi.nq8) {   // e4m3 twin of the norm_out row (cover_quantize_act_fp8's arithmetic on the stored bf16 values)
+        float mx = 0.f;
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+            if ((int)(threadIdx.x + c * 512) * 8 < N)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) mx = fmaxf(mx, fabsf(vals[c][i]));
+        mx = wave_max(mx);
+        if ((threadIdx.x & 63) == 0) red[8 + (threadIdx.x >> 6)] = mx;     // (red[0..7] belong to the block sum above)
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) t = fmaxf(t, red[8 + i]);
+        const float sc = e4m3_pow2_scale(t), inv = 1.0f / sc;
+        if (threadIdx.x == 0) epi.nq8s[m] = sc;
+        uint8_t* qrow = epi.nq8 + (size_t)m * epi.ldnq8;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int n0 = (threadIdx.x + c * 512) * 8;
+            if (n0 < N) store_q8_chunk(qrow, n0, vals[c], inv);
+        }
+        // zero padding up to the row pitch's 128-multiple is the caller's (N % 128 == 0 for the decoder widths this serves)
+    }
+    RNT(5);
+}
+__global__ __launch_bounds__(512) void splitk_reduce_norm(const float* __restrict__ partial, int S, bf16_t* C, int ldc, int M,
+                                                          int N, EpiDev epi) {
+    __shared__ float red[16];
+    reduce_norm_row(partial, S, C, ldc, M, N, epi, blockIdx.x, red);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Tail reduction. A split-K weight-streaming launch whose slabs end in splitk_reduce_norm (o_proj and down of a candidate-decode
+// layer: residual + RMSNorm) can fold them ITSELF: every workgroup writes its slab through to memory (agent-scope stores), drains,
+// and takes a ticket; the LAST min(M, grid) arrivals wait until the ticket count says every slab is out, then run reduce_norm_row --
+// the standalone kernel's code, one row each, bit-identical results -- and the launch ends. The reduction launch (~5 us) and its
+// kernel boundary (~1.5 us) leave the chain for ~4 us at the tail of the producer.
+//   * who waits: only workgroups that have finished their own slab, for workgroups that are running or will be dispatched
+//     without their help -- no residency assumption, no deadlock; the wait is bounded (1 s of the 100 MHz clock), a give-up sets
+//     g_tail_error (cover_gemm_tail_status) and lets the launch finish
+//   * no acquire: nobody reads a slab in this launch before the count is complete, so no cache of this launch holds a stale line
+//     of one (the launch boundary invalidated what earlier launches left), and the slabs were written through
+//     (-DCOVER_TAIL_ACQUIRE=1 adds the agent-scope acquire for A/B runs)
+//   * sync[0] = arrivals, sync[1] = reducers that have seen them all; the last of those zeroes both (the caller zeroes them once
+//     per decoder pass as well, so a give-up cannot poison later passes)
+// ---------------------------------------------------------------------------------------------------
+struct TailReduce {
+    unsigned* sync;   // nullptr: plain split-K launch (the caller folds the slabs)
+    int S;
+    bf16_t* C;
+    int ldc;
+    EpiDev epi;
+};
+__device__ unsigned g_tail_error;
+int gemm_tail_status() {
+    unsigned v = 0;
+    if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_tail_error), sizeof v) != hipSuccess) return -1;
+    return (int)v;
+}
+#ifndef COVER_TAIL_ACQUIRE
+#define COVER_TAIL_ACQUIRE 0
+#endif
+// slab store of 4 consecutive columns; WT = write-through (the tail reduction reads them from other XCDs inside the same launch)
+__device__ __forceinline__ void slab_store4(float* o, const float (&v)[4], int n, int N, bool wt) {
+    if (n + 3 < N && ((((uintptr_t)o) & 15) == 0)) {
+        if (wt) {
+            unsigned long long* po = (unsigned long long*)o;
+            __hip_atomic_store(po, (unsigned long long)__float_as_uint(v[0]) | ((unsigned long long)__float_as_uint(v[1]) << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(po + 1, (unsigned long long)__float_as_uint(v[2]) | ((unsigned long long)__float_as_uint(v[3]) << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            *(float4*)o = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    } else {
+        for (int e = 0; e < 4; ++e)
+            if (n + e < N) {
+                if (wt) __hip_atomic_store(o + e, v[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else o[e] = v[e];
+            }
+    }
+}
+// called by every thread of the block after its slab stores have been issued; smem = the block's LDS (>= 128 B, free by now)
+__device__ __forceinline__ void tail_reduce(const TailReduce& tr, const float* __restrict__ partial, int M, int N, char* smem) {
+    unsigned* sh = (unsigned*)smem;        // [0] ticket ; floats [16..32) = reduce_norm_row's scratch
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's slab stores have been acknowledged (written through)
+    __syncthreads();                                     // ... every wave's (and the LDS k-slice buffer is dead)
+    const unsigned total = gridDim.x * gridDim.y;
+    const unsigned nred = total < (unsigned)M ? total : (unsigned)M;
+    if (threadIdx.x == 0) sh[0] = __hip_atomic_fetch_add(tr.sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const unsigned ticket = sh[0];
+    if (ticket + nred < total) return;                   // not one of the last nred arrivals
+    if (threadIdx.x == 0 && ticket + 1 < total) {   // (the last arrival has just seen the full count itself)
+        const unsigned long long t0 = wall_clock64();
+        while (__hip_atomic_load(tr.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < total) {
+            if (wall_clock64() - t0 > 100000000ull) {
+                __hip_atomic_store(&g_tail_error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+    }
+    __syncthreads();
+#if COVER_TAIL_ACQUIRE
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#endif
+    asm volatile("" ::: "memory");
+    // partial is laundered: it is __restrict__ in the callers, and the slabs read here were written by OTHER workgroups
+    const float* pl = partial;
+    asm volatile("" : "+s"(pl)::"memory");
+    for (unsigned m = ticket - (total - nred); m < (unsigned)M; m += nred) {
+        reduce_norm_row(pl, tr.S, tr.C, tr.ldc, M, N, tr.epi, (int)m, (float*)smem + 16);
+        __syncthreads();   // the scratch is reused by the next row of this block (only when the grid has fewer blocks than rows)
+    }
+    // every reducer has seen the full count by now: the last one to say so zeroes both words (off the critical path: after the rows)
+    if (threadIdx.x == 0 && __hip_atomic_fetch_add(tr.sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nred - 1) {
+        __hip_atomic_store(tr.sync + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(tr.sync, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // Weight-streaming kernel, second generation: the 8 waves of a block are NG n-groups x KS k-slices. A wave streams
 // NBW n-blocks over ITS 256-wide k-slice of the block's K chunk (KC = 256*KS, staged once in LDS), keeps one
@@ -558,7 +807,8 @@ __global__ __launch_bounds__(512) void gemm_skinny(const bf16_t* __restrict__ A,
 // ---------------------------------------------------------------------------------------------------
 template <int MF, int KS, int NBW, bool W8 = false>
 __global__ __launch_bounds__(512) void gemm_skinny2(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ Wp,
-                                                    float* __restrict__ partial, int M, int N, int Kp, const float* __restrict__ wscale) {
+                                                    float* __restrict__ partial, int M, int N, int Kp, const float* __restrict__ wscale,
+                                                    TailReduce tr) {
     constexpr int NG = 8 / KS, KC = 256 * KS, NBPB = NG * NBW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -724,17 +974,10 @@ __global__ __launch_bounds__(512) void gemm_skinny2(const bf16_t* __restrict__ A
                 const float4 sc = *(const float4*)(wscale + (size_t)(nb < N16 ? nb : N16 - 1) * 16 + 4 * g);
                 v[0] *= sc.x; v[1] *= sc.y; v[2] *= sc.z; v[3] *= sc.w;
             }
-            if (nb < N16 && m < M && n < N) {
-                float* o = partial + ((size_t)s * M + m) * N + n;
-                if (n + 3 < N && ((((uintptr_t)o) & 15) == 0)) {
-                    *(float4*)o = make_float4(v[0], v[1], v[2], v[3]);
-                } else {
-                    for (int e = 0; e < 4; ++e)
-                        if (n + e < N) o[e] = v[e];
-                }
-            }
+            if (nb < N16 && m < M && n < N) slab_store4(partial + ((size_t)s * M + m) * N + n, v, n, N, tr.sync != nullptr);
         }
     }
+    if (tr.sync != nullptr) tail_reduce(tr, partial, M, N, smem);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -759,7 +1002,8 @@ extern "C" int cover_sk_debug(unsigned long long* out) {
 template <int MF, int KS, int NBW, int NBUF, bool W8 = false>
 __global__ __launch_bounds__(512) void gemm_skinny3(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ Wp,
                                                     void* C, int ldc, int M, int N, int Kp, EpiDev epi,
-                                                    float* __restrict__ partial, int kper, const float* __restrict__ wscale) {
+                                                    float* __restrict__ partial, int kper, const float* __restrict__ wscale,
+                                                    TailReduce tr) {
     SKT(0);
     constexpr int NG = 8 / KS, KC = 256 * KS, NBPB = NG * NBW;
     constexpr int XB = MF * 16 * KC * 2;          // bytes of one activation chunk (fragment-major)
@@ -1006,13 +1250,7 @@ __global__ __launch_bounds__(512) void gemm_skinny3(const bf16_t* __restrict__ A
                 if (nb < N16 && m < M && n < N) {
                     float v[4];
                     slice_sum(gsel, ii, f, v);
-                    float* o = partial + ((size_t)blockIdx.y * M + m) * N + n;
-                    if (n + 3 < N && ((((uintptr_t)o) & 15) == 0)) {
-                        *(float4*)o = make_float4(v[0], v[1], v[2], v[3]);
-                    } else {
-                        for (int e = 0; e < 4; ++e)
-                            if (n + e < N) o[e] = v[e];
-                    }
+                    slab_store4(partial + ((size_t)blockIdx.y * M + m) * N + n, v, n, N, tr.sync != nullptr);
                 }
             }
         } else if (epi.glu) {   // n-groups 0 / 1 hold the gate / up block of one output block (NG == 2, even nb_begin)
@@ -1045,6 +1283,7 @@ __global__ __launch_bounds__(512) void gemm_skinny3(const bf16_t* __restrict__ A
         }
     }
     SKT(3);
+    if (partial != nullptr && tr.sync != nullptr) tail_reduce(tr, partial, M, N, smem);
 }
 
 // out = epi(sum_s partial[s]) ; one thread per 4 output columns
@@ -1102,160 +1341,6 @@ __global__ __launch_bounds__(256) void splitk_reduce(const float* __restrict__ p
     }
 }
 
-// out = epi(sum_s partial[s]) AND norm_out = rmsnorm(out) / layernorm(out): one 512-thread block per output row
-// (N % 8 == 0, N <= 8192, no GLU, bf16 output). The statistics are taken over the bf16-ROUNDED outputs, i.e. exactly what
-// the separate norm kernel would read back, with that kernel's arithmetic.
-// block sum of a 512-thread block through LDS with an LDS-ONLY barrier: __syncthreads() would also wait for the stores
-// of C still in flight (their acknowledgement is ~1 us on the critical path of a kernel that lasts ~6). `red` is written
-// once per call: a second call in the same kernel takes a different slice.
-__device__ __forceinline__ float block_sum_lds(float v, float* red) {
-    v = wave_sum(v);
-    const int w = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) red[w] = v;
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    float t = 0.f;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) t += red[i];
-    return t;
-}
-
-#ifdef COVER_RN_DEBUG
-__device__ unsigned long long g_rn_dbg[512 * 8];   // per block (thread 0): start, slabs landed, epilogue done, before / after the block sum, end
-extern "C" int cover_rn_debug(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_rn_dbg), sizeof(g_rn_dbg)); }
-#define RNT(slot) do { if (threadIdx.x == 0) g_rn_dbg[(blockIdx.x & 511) * 8 + (slot)] = wall_clock64(); } while (0)
-#else
-#define RNT(slot) do { } while (0)
-#endif
-__global__ __launch_bounds__(512) void splitk_reduce_norm(const float* __restrict__ partial, int S, bf16_t* C, int ldc, int M,
-                                                          int N, EpiDev epi) {
-    __shared__ float red[16];
-    RNT(0);
-    const int m = blockIdx.x;
-    float vals[2][8];
-    float q = 0.f;
-    // the norm weights do not depend on anything: requested first, so their latency hides under the slab loads instead
-    // of following the block reduction (the stores to C in between keep the compiler from hoisting them itself)
-    float4 nw[2][2];
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-        const int n0 = (threadIdx.x + c * 512) * 8;
-        if (n0 < N) {
-            nw[c][0] = *(const float4*)(epi.norm_w + n0);
-            nw[c][1] = *(const float4*)(epi.norm_w + n0 + 4);
-        }
-    }
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-        const int n0 = (threadIdx.x + c * 512) * 8;
-        if (n0 < N) {
-            float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            const float* p0 = partial + (size_t)m * N + n0;
-            const size_t sstride = (size_t)M * N;
-            int s = 0;
-            for (; s + 4 <= S; s += 4) {  // four slices in flight
-                float4 a[4], b[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    a[j] = *(const float4*)(p0 + (s + j) * sstride);
-                    b[j] = *(const float4*)(p0 + (s + j) * sstride + 4);
-                }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    v[0] += a[j].x; v[1] += a[j].y; v[2] += a[j].z; v[3] += a[j].w;
-                    v[4] += b[j].x; v[5] += b[j].y; v[6] += b[j].z; v[7] += b[j].w;
-                }
-            }
-            for (; s < S; ++s) {
-                const float4 a = *(const float4*)(p0 + s * sstride), b = *(const float4*)(p0 + s * sstride + 4);
-                v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w; v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
-            }
-            if (c == 0) RNT(1);
-            // (the bf16 residual row is read in here, eight 2-byte loads BEHIND the slabs: 1.2 of the kernel's 3.5 us by the
-            // timeline -- yet requesting it as one 16-byte load ahead of the slabs made the decision 0.4 ms slower in a same-box
-            // A/B (35.0 vs 35.4 ms), so it stays)
-            epi_value4(epi, m, n0, N, v);
-            epi_value4(epi, m, n0 + 4, N, v + 4);
-            if (c == 0) RNT(2);
-            uint4 u;
-            u.x = pack_bf2(v[0], v[1]); u.y = pack_bf2(v[2], v[3]); u.z = pack_bf2(v[4], v[5]); u.w = pack_bf2(v[6], v[7]);
-            *(uint4*)(C + (size_t)m * ldc + n0) = u;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                vals[c][i] = bfround(v[i]);
-                q += vals[c][i] * vals[c][i];
-            }
-        }
-    }
-    float mean = 0.f, rstd;
-    if (epi.norm_style == 2) {   // LayerNorm (layernorm_bf16_k arithmetic: mean, then the centred second moment)
-        float sum = 0.f;
-#pragma unroll
-        for (int c = 0; c < 2; ++c)
-            if ((int)(threadIdx.x + c * 512) * 8 < N)
-#pragma unroll
-                for (int i = 0; i < 8; ++i) sum += vals[c][i];
-        mean = block_sum_lds(sum, red) / N;
-        float q2 = 0.f;
-#pragma unroll
-        for (int c = 0; c < 2; ++c)
-            if ((int)(threadIdx.x + c * 512) * 8 < N)
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const float d = vals[c][i] - mean;
-                    q2 += d * d;
-                }
-        rstd = rsqrtf(block_sum_lds(q2, red + 8) / N + epi.norm_eps);
-    } else {
-        RNT(3);
-        rstd = rsqrtf(block_sum_lds(q, red) / N + epi.norm_eps);
-        RNT(4);
-    }
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-        const int n0 = (threadIdx.x + c * 512) * 8;
-        if (n0 < N) {
-            float o[8];
-            const float wv[8] = {nw[c][0].x, nw[c][0].y, nw[c][0].z, nw[c][0].w, nw[c][1].x, nw[c][1].y, nw[c][1].z, nw[c][1].w};
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const float ww = wv[i];
-                if (epi.norm_style == 2) o[i] = (vals[c][i] - mean) * rstd * ww + (epi.norm_b ? epi.norm_b[n0 + i] : 0.f);
-                else o[i] = epi.norm_style == 1 ? ww * bfround(vals[c][i] * rstd) : vals[c][i] * rstd * (epi.norm_w_offset + ww);
-            }
-            uint4 u;
-            u.x = pack_bf2(o[0], o[1]); u.y = pack_bf2(o[2], o[3]); u.z = pack_bf2(o[4], o[5]); u.w = pack_bf2(o[6], o[7]);
-            *(uint4*)(epi.norm_out + (size_t)m * epi.ld_norm_out + n0) = u;
-            if (epi.nq8) {
-#pragma unroll
-                for (int i = 0; i < 8; ++i) vals[c][i] = bfround(o[i]);   // the stored bf16 row is what gets quantised
-            }
-        }
-    }
-    if (epi.nq8) {   // e4m3 twin of the norm_out row (cover_quantize_act_fp8's arithmetic on the stored bf16 values)
-        float mx = 0.f;
-#pragma unroll
-        for (int c = 0; c < 2; ++c)
-            if ((int)(threadIdx.x + c * 512) * 8 < N)
-#pragma unroll
-                for (int i = 0; i < 8; ++i) mx = fmaxf(mx, fabsf(vals[c][i]));
-        mx = wave_max(mx);
-        if ((threadIdx.x & 63) == 0) red[8 + (threadIdx.x >> 6)] = mx;     // (red[0..7] belong to the block sum above)
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        float t = 0.f;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) t = fmaxf(t, red[8 + i]);
-        const float sc = e4m3_pow2_scale(t), inv = 1.0f / sc;
-        if (threadIdx.x == 0) epi.nq8s[m] = sc;
-        uint8_t* qrow = epi.nq8 + (size_t)m * epi.ldnq8;
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            const int n0 = (threadIdx.x + c * 512) * 8;
-            if (n0 < N) store_q8_chunk(qrow, n0, vals[c], inv);
-        }
-        // zero padding up to the row pitch's 128-multiple is the caller's (N % 128 == 0 for the decoder widths this serves)
-    }
-    RNT(5);
-}
 
 // ---------------------------------------------------------------------------------------------------
 // Weight packing: W[N, ldw] row-major -> fragment-major. One thread per 16-B chunk of the packed image.
@@ -1464,11 +1549,16 @@ void gemm_plan_counts(long long* out, int n, int reset) {
     }
 }
 
+static TailReduce no_tail() {
+    TailReduce t;
+    ::memset(&t, 0, sizeof t);
+    return t;
+}
 static void launch_skinny2(const Skinny2Plan& p, const bf16_t* A, int lda, const bf16_t* Wp, float* ws, int M, int N, int K, int Kp,
-                           const uint8_t* w8, const float* w8s, hipStream_t st) {
+                           const uint8_t* w8, const float* w8s, hipStream_t st, const TailReduce& tr = no_tail()) {
     dim3 grid(p.gx, p.S), block(512);
     plan_hit(19);
-#define SK2(MF_, KS_, NBW_, W8_) launch_streaming(sk_class(N, K), (W8_ ? 1.0 : 2.0) * (double)N * (double)K, gemm_skinny2<MF_, KS_, NBW_, W8_>, grid, block, p.lds, st, A, lda, W8_ ? (const bf16_t*)w8 : Wp, ws, M, N, Kp, w8s)
+#define SK2(MF_, KS_, NBW_, W8_) launch_streaming(sk_class(N, K), (W8_ ? 1.0 : 2.0) * (double)N * (double)K, gemm_skinny2<MF_, KS_, NBW_, W8_>, grid, block, p.lds, st, A, lda, W8_ ? (const bf16_t*)w8 : Wp, ws, M, N, Kp, w8s, tr)
     if (w8 && w8s && p.MF <= 2) {
         if (p.MF == 1) { if (p.NBW == 6) SK2(1, 4, 6, true); else if (p.NBW == 4) SK2(1, 4, 4, true); else if (p.NBW == 3) SK2(1, 4, 3, true); else SK2(1, 4, 2, true); }
         else { if (p.NBW == 6) SK2(2, 4, 6, true); else if (p.NBW == 4) SK2(2, 4, 4, true); else if (p.NBW == 3) SK2(2, 4, 3, true); else SK2(2, 4, 2, true); }
@@ -1482,7 +1572,7 @@ static void launch_skinny2(const Skinny2Plan& p, const bf16_t* A, int lda, const
 }
 
 static hipError_t launch_skinny3(const Skinny3Plan& p, const bf16_t* A, int lda, const bf16_t* Wp, void* C, int ldc, int M, int N,
-                                 int Kp, const EpiDev& epi, float* partial, hipStream_t st) {
+                                 int Kp, const EpiDev& epi, float* partial, hipStream_t st, const TailReduce& tr = no_tail()) {
     hipError_t e = hipSuccess;
     dim3 grid(p.gx, p.S), block(512);
     plan_hit(20);
@@ -1495,7 +1585,7 @@ static hipError_t launch_skinny3(const Skinny3Plan& p, const bf16_t* A, int lda,
         }                                                                                                                   \
         if (e == hipSuccess)                                                                                                \
             launch_streaming(sk_class(N, Kp), (W8_ ? 1.0 : 2.0) * (double)N * (double)Kp, kfn, grid, block, p.lds, st, A, lda,  \
-                             W8_ ? (const bf16_t*)epi.w8 : Wp, C, ldc, M, N, Kp, epi, partial, p.kper, epi.w8s);             \
+                             W8_ ? (const bf16_t*)epi.w8 : Wp, C, ldc, M, N, Kp, epi, partial, p.kper, epi.w8s, tr);         \
     } while (0)
     if (epi.w8) {   // e4m3 weight stream
         if (p.MF == 1) { if (p.NBW == 4) SK3(1, 4, true); else if (p.NBW == 3) SK3(1, 3, true); else SK3(1, 2, true); }
@@ -1518,12 +1608,18 @@ static hipError_t run_norm(const EpiDev& epi, void* C, int ldc, int M, int Nout,
 }
 
 hipError_t launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* Wp, void* C, int ldc, int M, int N, int K,
-                            const cover_gemm_epi* epi_in, float* ws, size_t ws_bytes, int variant, hipStream_t st, int* splits_out) {
+                            const cover_gemm_epi* epi_in, float* ws, size_t ws_bytes, int variant, hipStream_t st, int* splits_out,
+                            unsigned* tail_sync) {
     if (splits_out) *splits_out = 0;
     if (M <= 0 || N <= 0) return hipSuccess;
     const int Kp = (K + 127) / 128 * 128;
     EpiDev epi = make_epi(epi_in);
     if (variant == 0) variant = (M <= 64 && ws != nullptr) ? 3 : 1;
+    // the split-K reduction + norm of a weight-streaming launch (M <= 64) can run at the tail of that launch (see "Tail reduction")
+    const bool norm_fusable = epi.norm_w != nullptr && epi.norm_out != nullptr && !epi.glu && !epi.out_f32 && (N % 8) == 0 && N <= 8192 && (ldc % 8) == 0 &&
+                              (epi.ld_norm_out % 8) == 0 && (((uintptr_t)epi.norm_w) & 15) == 0;
+    TailReduce tr = no_tail();
+    if (tail_sync != nullptr && norm_fusable && M <= 64) { tr.sync = tail_sync; tr.C = (bf16_t*)C; tr.ldc = ldc; tr.epi = epi; }
     // Third generation (full-K chunk loop per block, one block per CU): used whenever its plan fills the chip -- with the
     // epilogue fused when no grid split is needed (wide outputs), else leaving S (< the second generation's) partial slabs.
     int S3 = 0;   // > 0: the third generation has left S3 slabs in ws, fall through to the shared reduction
@@ -1538,8 +1634,10 @@ hipError_t launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* Wp, void* C,
         }
         if (p3.ok && p3.S > 1 && (ws == nullptr || ws_bytes < p3.ws_bytes)) p3.ok = false;
         if (p3.ok && (variant == 6 || !(g3 && g3[0] == '0'))) {
-            hipError_t e = launch_skinny3(p3, A, lda, Wp, C, ldc, M, N, Kp, epi, p3.S > 1 ? ws : nullptr, st);
+            tr.S = p3.S;
+            hipError_t e = launch_skinny3(p3, A, lda, Wp, C, ldc, M, N, Kp, epi, p3.S > 1 ? ws : nullptr, st, p3.S > 1 ? tr : no_tail());
             if (e != hipSuccess) return e;
+            if (p3.S > 1 && tr.sync != nullptr) return hipSuccess;   // the launch folded its own slabs
             if (p3.S == 1) {
                 if (epi.norm_w != nullptr && epi.norm_out != nullptr) e = run_norm(epi, C, ldc, M, epi.glu ? N / 2 : N, st);
                 return e;
@@ -1557,13 +1655,15 @@ hipError_t launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* Wp, void* C,
             Skinny2Plan p = plan_skinny2(M, N, Kp);
             if (ws == nullptr || ws_bytes < p.ws_bytes) return hipErrorInvalidValue;
             dim3 grid(p.gx, p.S), block(512);
-            launch_skinny2(p, A, lda, Wp, ws, M, N, K, Kp, epi.w8, epi.w8s, st);
+            tr.S = p.S;
+            launch_skinny2(p, A, lda, Wp, ws, M, N, K, Kp, epi.w8, epi.w8s, st, tr);
             S = p.S;
+            if (tr.sync != nullptr) return hipGetLastError();       // the launch folded its own slabs
         }
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
         const bool want_norm = epi.norm_w != nullptr && epi.norm_out != nullptr;
-        if (want_norm && !epi.glu && !epi.out_f32 && (N % 8) == 0 && N <= 8192 && (ldc % 8) == 0 && (epi.ld_norm_out % 8) == 0 && (((uintptr_t)epi.norm_w) & 15) == 0) {
+        if (norm_fusable) {
             launch_streaming(5, 0.0, splitk_reduce_norm, dim3(M), dim3(512), 0, st, (const float*)ws, S, (bf16_t*)C, ldc, M, N, epi);
             return hipGetLastError();
         }

@@ -11,7 +11,11 @@ typedef uint16_t bf16_t;
 // C[M,N] = epi(A[M,K] x W[N,K]^T); W pre-packed by cover_pack_weight_bf16 (fragment-major).
 hipError_t launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* Wp, void* C, int ldc, int M, int N, int K,
                             const cover_gemm_epi* epi, float* splitk_ws, size_t splitk_ws_bytes, int variant,
-                            hipStream_t st, int* splits_out = nullptr);
+                            hipStream_t st, int* splits_out = nullptr, unsigned* tail_sync = nullptr);
+// tail_sync (optional, two zeroed words of device memory owned by the caller's stream): a weight-streaming launch (M <= 64) whose split-K
+// slabs would be folded by splitk_reduce_norm folds them at its own tail instead (gemm_bf16.hip "Tail reduction": same code, same results,
+// one launch less). gemm_tail_status(): 0, or 1 once a bounded wait of that protocol gave up (synchronous read of a device word).
+int gemm_tail_status();
 // splits_out (optional): a split-K launch of the LDS-tiled kernels with a bias-only epilogue leaves its S raw fp32 slabs [S][M][N] in ws
 // and returns S here instead of folding them (the decoder folds them in rope_kv_write: one launch less per layer); 0 = C is written.
 hipError_t launch_gemm_skinny_partial(const bf16_t* A, int lda, const bf16_t* Wp, float* ws, size_t ws_bytes, int M, int N,

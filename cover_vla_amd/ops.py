@@ -143,6 +143,11 @@ def gemm(a: torch.Tensor, lin: PackedLinear, *, act: str = "none", residual: Opt
     return out
 
 
+def gemm_tail_status() -> None:
+    """Raises if a bounded wait of the weight-streaming kernels' tail reduction gave up (reads a device word: synchronise first)."""
+    L.check(L.lib().cover_gemm_tail_status(), "gemm_tail_status")
+
+
 def decode_chain_status() -> None:
     """Raises if a grid barrier of the persistent decode chain gave up since the last call (synchronises the device)."""
     L.check(L.lib().cover_decode_chain_status(), "decode_chain_status")
