@@ -516,13 +516,13 @@ int cover_decoder_forward(const cover_dec_desc* d, const cover_dec_pass* p, void
         e.a8 = q8; e.a8_scale = (const float*)q8s; e.ld_a8 = kp;
         return launch_quantize_act_fp8((const bf16_t*)src, K, rows, K, (uint8_t*)q8, kp, (float*)q8s, st);
     };
-    // weight-streaming passes (<= 64 rows): the split-K reductions of o_proj / down (+ residual + RMSNorm) run at the tail of the launch
-    // that wrote the slabs instead of as launches of their own (gemm_bf16.hip "Tail reduction": same code, bit-identical results).
-    // COVER_TAIL_REDUCE=0 keeps the reduction launches (read per call: the tests toggle it).
+    // weight-streaming passes (<= 64 rows), opt-in (COVER_TAIL_REDUCE=1, read per call: the tests toggle it): the split-K reductions of
+    // o_proj / down (+ residual + RMSNorm) run at the tail of the launch that wrote the slabs instead of as launches of their own
+    // (gemm_bf16.hip "Tail reduction": same code, bit-identical results; measured SLOWER than the reduction launches, so off by default)
     unsigned* tail_sync = nullptr;
     {
         const char* te = getenv("COVER_TAIL_REDUCE");
-        if (rows <= 64 && !(te && te[0] == '0') && (te && te[0] == '1')) {
+        if (rows <= 64 && te && te[0] == '1') {
             tail_sync = (unsigned*)tsync;
             HIPCHK(hipMemsetAsync(tail_sync, 0, 256, st), "memset tail-reduction tickets");
         }

@@ -485,8 +485,9 @@ int cover_decoder_forward(const cover_dec_desc* d, const cover_dec_pass* p, void
  * otherwise -- the outputs of that pass are then invalid; the barrier state is reset. */
 int cover_decode_chain_status(void);
 
-/* Tail reduction of the weight-streaming decoder passes (<= 64 rows; COVER_TAIL_REDUCE=0 disables): the split-K slabs of o_proj / down are
- * folded (+ residual + RMSNorm) by the last workgroups of the launch that wrote them instead of by a reduction launch. The wait of those
+/* Tail reduction of the weight-streaming decoder passes (<= 64 rows; opt-in, COVER_TAIL_REDUCE=1 -- measured slower than the reduction
+ * launches it replaces): the split-K slabs of o_proj / down are folded (+ residual + RMSNorm) by the last workgroups of the launch that
+ * wrote them instead of by a reduction launch. The wait of those
  * workgroups for the other slabs is bounded. Synchronises nothing by itself (reads one device word: call it after a stream / device
  * synchronise); COVER_OK, or COVER_EHIP (+ cover_last_error) once a wait has given up -- the outputs of that pass are then invalid. */
 int cover_gemm_tail_status(void);
