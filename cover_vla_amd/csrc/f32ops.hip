@@ -190,7 +190,11 @@ hipError_t launch_gemm_f32(const cover_gemm_f32_args* a, hipStream_t st) {
     const bool k_contig = a->a_k_stride == 1 && a->b_k_stride == 1 && (a->K & 15) == 0 && a->K >= 64 && (a->a_row_stride & 3) == 0 &&
                           (a->b_row_stride & 3) == 0 && (a->a_batch_stride & 3) == 0 && (a->b_batch_stride & 3) == 0 &&
                           (((uintptr_t)a->A | (uintptr_t)a->B) & 15) == 0;
-    if (k_contig && blocks64 < 1024) {
+    // (the direct MFMA kernel reads its operands straight from global: fine while the grid is small or the operands stay L2-resident;
+    //  COVER_F32_DIRECT_MAX overrides the block-count bound, read per call: A/B runs)
+    const char* dmax_env = getenv("COVER_F32_DIRECT_MAX");
+    const long long direct_max = dmax_env ? atoll(dmax_env) : 16384;   // (1024 until round 4: config 5's 5120-row trajectory GEMMs 235 -> 149 us, 292 -> 191 us)
+    if (k_contig && blocks64 < direct_max) {
         // experiment knob COVER_F32_UNR=8: eight steps in flight for K >= 512. Measured (round 4): the verifier tail got SLOWER, 0.563 vs 0.525 ms
         // -- the deeper window costs occupancy (126 registers: 3 waves per SIMD instead of 6) and these grids live off occupancy. Default 4.
         static const char* unr_env = getenv("COVER_F32_UNR");

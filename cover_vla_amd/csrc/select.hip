@@ -159,59 +159,52 @@ __device__ void group_argmax_dev(const float* scores, int N, int gs, int* result
     }
 }
 
-__global__ __launch_bounds__(1024) void score_select_k(cover_score_select_args a, float* fit_ws, float* fact_ws) {
+// One 1024-thread block per 16 candidates (one wave per candidate); every block recomputes the fused image-text embedding (dim x members
+// floats: nothing) with the arithmetic of the former single-block kernel, so scores and embeddings are what that kernel produced, bit for
+// bit, for every N -- that kernel took 36 us at N = 32 on the tail of every decision and 480 us at N = 512 (16 waves x 32 candidates in
+// series). The grouped arg-max is the launch behind it (group_argmax_k).
+__global__ __launch_bounds__(1024) void score_rows_k(cover_score_select_args a, float* fit_ws, float* fact_ws) {
     __shared__ float red[16];
-    __shared__ float sv[16];
-    __shared__ int si[16];
-    __shared__ float gmean[4096];
+    __shared__ float sfit[4096];
     const int dim = a.dim;
-    // fused image-text embedding
     {
         float q = 0.f;
         for (int d = threadIdx.x; d < dim; d += blockDim.x) {
             float s = 0.f;
             for (int m = 0; m < a.n_members; ++m) s += a.it[(size_t)m * dim + d];
             s /= (float)a.n_members;
-            fit_ws[d] = s;
+            sfit[d] = s;
             q += s * s;
         }
         const float nrm = sqrtf(block_sum(q, red));
-        for (int d = threadIdx.x; d < dim; d += blockDim.x) fit_ws[d] = fit_ws[d] / nrm;
+        for (int d = threadIdx.x; d < dim; d += blockDim.x) {
+            const float f = sfit[d] / nrm;
+            sfit[d] = f;
+            if (blockIdx.x == 0) fit_ws[d] = f;
+        }
     }
     __syncthreads();
-    // per candidate: fused action embedding + score (one wave per candidate)
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    for (int n = w; n < a.N; n += (int)(blockDim.x >> 6)) {   // one wave per candidate, 16 waves
-        float q = 0.f;
-        for (int d = lane; d < dim; d += 64) {
-            float s = 0.f;
-            for (int m = 0; m < a.n_members; ++m) s += a.act[((size_t)m * a.N + n) * dim + d];
-            s /= (float)a.n_members;
-            fact_ws[(size_t)n * dim + d] = s;
-            q += s * s;
-        }
-        const float nrm = sqrtf(wave_sum(q));
-        float dot = 0.f;
-        for (int d = lane; d < dim; d += 64) {
-            const float f = fact_ws[(size_t)n * dim + d] / nrm;
-            fact_ws[(size_t)n * dim + d] = f;
-            dot += fit_ws[d] * f;
-        }
-        dot = wave_sum(dot);
-        if (lane == 0) a.scores_out[n] = dot;
+    const int n = blockIdx.x * 16 + w;
+    if (n >= a.N) return;
+    float q = 0.f;
+    for (int d = lane; d < dim; d += 64) {
+        float s = 0.f;
+        for (int m = 0; m < a.n_members; ++m) s += a.act[((size_t)m * a.N + n) * dim + d];
+        s /= (float)a.n_members;
+        fact_ws[(size_t)n * dim + d] = s;
+        q += s * s;
     }
-    __syncthreads();
-    __threadfence_block();
-    group_argmax_dev(a.scores_out, a.N, a.group_size, a.result_out, a.best_out, gmean, sv, si);
+    const float nrm = sqrtf(wave_sum(q));
+    float dot = 0.f;
+    for (int d = lane; d < dim; d += 64) {
+        const float f = fact_ws[(size_t)n * dim + d] / nrm;
+        fact_ws[(size_t)n * dim + d] = f;
+        dot += sfit[d] * f;
+    }
+    dot = wave_sum(dot);
+    if (lane == 0) a.scores_out[n] = dot;
 }
-hipError_t launch_score_select(const cover_score_select_args* a, hipStream_t st) {
-    if (a->N <= 0 || a->group_size <= 0 || a->N % a->group_size != 0 || a->N / a->group_size > 4096)
-        return hipErrorInvalidValue;
-    if (!a->fused_it_out || !a->fused_act_out) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(score_select_k, dim3(1), dim3(1024), 0, st, *a, a->fused_it_out, a->fused_act_out);
-    return hipGetLastError();
-}
-
 __global__ __launch_bounds__(256) void group_argmax_k(const float* scores, int N, int gs, int* result, float* best) {
     __shared__ float sv[16];
     __shared__ int si[16];
@@ -221,6 +214,14 @@ __global__ __launch_bounds__(256) void group_argmax_k(const float* scores, int N
 hipError_t launch_group_argmax(const float* scores, int N, int gs, int* result, float* best, hipStream_t st) {
     if (N <= 0 || gs <= 0 || N % gs != 0 || N / gs > 4096) return hipErrorInvalidValue;
     hipLaunchKernelGGL(group_argmax_k, dim3(1), dim3(256), 0, st, scores, N, gs, result, best);
+    return hipGetLastError();
+}
+hipError_t launch_score_select(const cover_score_select_args* a, hipStream_t st) {
+    if (a->N <= 0 || a->group_size <= 0 || a->N % a->group_size != 0 || a->N / a->group_size > 4096 || a->dim <= 0 || a->dim > 4096)
+        return hipErrorInvalidValue;
+    if (!a->fused_it_out || !a->fused_act_out) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(score_rows_k, dim3((a->N + 15) / 16), dim3(1024), 0, st, *a, a->fused_it_out, a->fused_act_out);
+    hipLaunchKernelGGL(group_argmax_k, dim3(1), dim3(256), 0, st, (const float*)a->scores_out, a->N, a->group_size, a->result_out, a->best_out);
     return hipGetLastError();
 }
 

@@ -484,9 +484,11 @@ def test_token_select(dev):
     assert ops.token_select(wide.to(dev), 0, 257152)[0][1].item() == 7
 
 
-def test_score_select(dev):
+@pytest.mark.parametrize("N,gs", [(40, 5), (512, 16), (7, 7), (16, 1)])
+def test_score_select(dev, N, gs):
+    """score_rows_k (16 candidates per block: N = 40 / 7 leave a ragged last block, 512 = config 5) + group_argmax_k."""
     g = torch.Generator().manual_seed(4)
-    M, N, dim, gs = 3, 40, 512, 5
+    M, dim = 3, 512
     it = torch.nn.functional.normalize(torch.randn(M, dim, generator=g), dim=-1)
     act = torch.nn.functional.normalize(torch.randn(M, N, dim, generator=g), dim=-1)
     scores, result, best, fit, fact = ops.score_select(it.to(dev), act.to(dev), gs)
@@ -501,6 +503,7 @@ def test_score_select(dev):
     bi = ref.view(N // gs, gs)[bg].argmax().item()
     assert result.cpu().tolist()[:3] == [bg * gs + bi, bg, bi]
     assert abs(best[0].item() - ref[bg * gs + bi].item()) < 1e-6
+    assert torch.allclose(fit.cpu().view(-1), f_it, atol=1e-6) and torch.allclose(fact.cpu().view(N, dim), f_act, atol=1e-6)
     # ties: first maximum wins at both levels
     s = torch.zeros(12)
     r, _ = ops.group_argmax(s.to(dev), 3)

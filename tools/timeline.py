@@ -5,10 +5,12 @@ import re, sqlite3, sys
 db = sqlite3.connect(sys.argv[1])
 rows = db.execute("select name, stream_id, queue_id, start, end from kernels order by start").fetchall()
 # decisions are delimited by the patch-embedding kernel of the first vision tower ('patchify' appears twice+ per decision)
-idx = [i for i, r in enumerate(rows) if "score_select" in r[0]]
-print("score_select dispatches:", len(idx))
-lo = idx[-2] + 1 if len(idx) >= 2 else 0
-hi = idx[-1] + 1
+# a decision ends with the verifier's score kernel (score_rows_k, older traces: score_select_k) and the grouped arg-max behind it
+idx = [i for i, r in enumerate(rows) if "score_rows" in r[0] or "score_select" in r[0]]
+print("score dispatches:", len(idx))
+tail = lambda i: i + 2 if i + 1 < len(rows) and "group_argmax" in rows[i + 1][0] else i + 1
+lo = tail(idx[-2]) if len(idx) >= 2 else 0
+hi = tail(idx[-1])
 sel = rows[lo:hi]
 t0, t1 = sel[0][3], max(r[4] for r in sel)
 print(f"last decision: {len(sel)} dispatches, span {(t1 - t0) / 1e6:.3f} ms")
@@ -54,9 +56,9 @@ def last(pred, seq=main):
     return r
 
 
-print("markers (ms): first patchify %.3f | first decode_attn %.3f | last token_select end %.3f | score_select end %.3f" % (
+print("markers (ms): first patchify %.3f | first decode_attn %.3f | last token_select end %.3f | score / arg-max end %.3f" % (
     first(lambda n: "patchify" in n) or -1, first(lambda n: "decode_attn" in n) or -1,
-    last(lambda n: "token_select" in n) or -1, last(lambda n: "score_select" in n) or -1))
+    last(lambda n: "token_select" in n) or -1, last(lambda n: "score_rows" in n or "score_select" in n or "group_argmax" in n) or -1))
 tail0 = last(lambda n: "token_select" in n)
 tail = [(a, b, n) for a, b, n in main if (a - t0) / 1e6 >= tail0]
 agg = {}
