@@ -439,6 +439,9 @@ size_t cover_decoder_workspace_bytes(const cover_dec_desc* d, int rows) {
     return dec_ws(d, rows, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
 }
 
+__global__ void zero_words_k(unsigned* p, int n) {
+    if ((int)threadIdx.x < n) p[threadIdx.x] = 0u;
+}
 int cover_decoder_forward(const cover_dec_desc* d, const cover_dec_pass* p, void* x, cover_workspace ws, int variant,
                           void* stream) {
     if (!d || !p || !x || !d->layers_host) return fail(COVER_EINVAL, "cover_decoder_forward: null pointer");
@@ -524,7 +527,10 @@ int cover_decoder_forward(const cover_dec_desc* d, const cover_dec_pass* p, void
         const char* te = getenv("COVER_TAIL_REDUCE");
         if (rows <= 64 && te && te[0] == '1') {
             tail_sync = (unsigned*)tsync;
-            HIPCHK(hipMemsetAsync(tail_sync, 0, 256, st), "memset tail-reduction tickets");
+            // (a kernel, not hipMemsetAsync: as a memset node of the captured decode graph the latter gave wrong tokens on replay -- ROCm 7.2;
+            //  eager it was fine -- tests/test_fullsize_gpu.py::test_fullsize_config2_n16 under COVER_TAIL_REDUCE=1 caught it)
+            hipLaunchKernelGGL(zero_words_k, dim3(1), dim3(64), 0, st, tail_sync, 64);
+            HIPCHK(hipGetLastError(), "zero tail-reduction tickets");
         }
     }
     // h = in_norm_0(x); afterwards every norm is folded into the epilogue of the GEMM that produces its input

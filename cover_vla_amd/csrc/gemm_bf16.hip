@@ -741,6 +741,9 @@ int gemm_tail_status() {
 #ifndef COVER_TAIL_ACQUIRE
 #define COVER_TAIL_ACQUIRE 0
 #endif
+#ifndef COVER_TAIL_RELEASE
+#define COVER_TAIL_RELEASE 0
+#endif
 // slab store of 4 consecutive columns; WT = write-through (the tail reduction reads them from other XCDs inside the same launch)
 __device__ __forceinline__ void slab_store4(float* o, const float (&v)[4], int n, int N, bool wt) {
     if (n + 3 < N && ((((uintptr_t)o) & 15) == 0)) {
@@ -762,7 +765,11 @@ __device__ __forceinline__ void slab_store4(float* o, const float (&v)[4], int n
 // called by every thread of the block after its slab stores have been issued; smem = the block's LDS (>= 128 B, free by now)
 __device__ __forceinline__ void tail_reduce(const TailReduce& tr, const float* __restrict__ partial, int M, int N, char* smem) {
     unsigned* sh = (unsigned*)smem;        // [0] ticket ; floats [16..32) = reduce_norm_row's scratch
+#if COVER_TAIL_RELEASE
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // A/B build: the memory model's release (L2 write-back + wait) instead of the bare wait
+#else
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's slab stores have been acknowledged (written through)
+#endif
     __syncthreads();                                     // ... every wave's (and the LDS k-slice buffer is dead)
     const unsigned total = gridDim.x * gridDim.y;
     const unsigned nred = total < (unsigned)M ? total : (unsigned)M;
