@@ -335,6 +335,9 @@ size_t cover_vit_workspace_bytes(const cover_vit_desc* d, int n_seq, int T) {
     return vit_ws(d, n_seq, T, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, &tcap);
 }
 
+__global__ void zero_u32_k(unsigned* __restrict__ p, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = 0u;
+}
 int cover_vit_forward(const cover_vit_desc* d, void* x, int n_seq, int T, void* attn_out, cover_workspace ws, int variant,
                       void* stream) {
     if (!d || !x || !d->layers_host) return fail(COVER_EINVAL, "cover_vit_forward: null pointer");
@@ -348,7 +351,13 @@ int cover_vit_forward(const cover_vit_desc* d, void* x, int n_seq, int T, void* 
     if (!ws.ptr || ws.bytes < need) return fail(COVER_EWORKSPACE, "cover_vit_forward: workspace too small");
     const int R = n_seq * T, dim = d->dim, H = d->heads, Dp = d->head_dim_p, HD = H * Dp;
     // the transposed-V scratch must be finite where keys >= T are read under a zero probability
-    if (tcap != T) HIPCHK(hipMemsetAsync(vt, 0, (size_t)n_seq * HD * tcap * 2, st), "memset vt");
+    // (a kernel, not hipMemsetAsync: this forward is replayed inside hipGraphs, and a memset NODE was seen to run unordered with the kernel
+    //  nodes around it on ROCm 7.2 -- see the tail-reduction note in cover_decoder_forward)
+    if (tcap != T) {
+        const size_t words = (size_t)n_seq * HD * tcap / 2;   // bf16 elements / 2 (HD is even)
+        hipLaunchKernelGGL(zero_u32_k, dim3((unsigned)((words + 1023) / 1024 < 2048 ? (words + 1023) / 1024 : 2048)), dim3(256), 0, st, (unsigned*)vt, words);
+        HIPCHK(hipGetLastError(), "zero vt");
+    }
 
     // ln1 of layer 0 is its own launch; every later LayerNorm rides on the GEMM that produces its input (folded into the
     // split-K reduction whenever that GEMM splits K, which the dim-wide outputs of ViT-sized problems do)
