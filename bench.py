@@ -784,6 +784,7 @@ def main():
     dt = time.perf_counter() - t0
     from cover_vla_amd import ops as _ops
     _ops.decode_chain_status()      # a grid barrier of the persistent decode chain that gave up = invalid results: fail loudly, never report them
+    _ops.gemm_tail_status()         # same for the opt-in tail reduction of the weight-streaming kernels (COVER_TAIL_REDUCE=1)
     if world > 1:
         t = torch.tensor([dt], device=dev if a.backend == "nccl" else "cpu")
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
