@@ -195,6 +195,19 @@ def test_gemm_epilogues(dev, variant, M, act):
     assert rel_l2(out, ACT_REF[act](yy[:, :N]) * yy[:, N:]) < 1e-2
 
 
+def test_gemm_random_sweep(dev):
+    """300 random problems through cover_gemm_bf16's automatic plan selection (ragged M / N, K up to 11 008, weight streaming / 64..224-row
+    tiles / split-K; plain, bias + activation, in-place residual, GLU, residual + fused RMSNorm) against fp32 matmuls of the same bf16
+    operands (tools/dbg/fuzz_gemm.py: 6 400 cases over four seeds ran clean when this was added)."""
+    import importlib.util, os
+    spec = importlib.util.spec_from_file_location("fuzz_gemm", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "dbg", "fuzz_gemm.py"))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    fails, plans = fz.run(300, 7, dev, verbose=False)
+    assert not fails, fails[:5]
+    assert len(plans) >= 6, plans          # the sweep reached the streaming kernels and several tile families
+
+
 # ------------------------------------------------------------------------------------------------ attention
 def attn_ref(q, segs, scale):
     """q [B,Tq,Hq,D]; segs: list of (k [B,Tk,Hkv,D], v [B,Tk,Hkv,D], vis bool [B,Tq,Tk])."""
@@ -307,6 +320,18 @@ def test_attention_spike_forces_rescale(dev):
     ops.attention(q.to(dev), (Tq * H * D, H * D, D), out, (Tq * H * D, H * D, D), B, Tq, H, H, D, 1.0,
                   [ops.Segment(kc, vt, ks, vs, length=Tk)])
     assert torch.allclose(out.float().cpu(), ref, atol=3e-2, rtol=3e-2)
+
+
+def test_attention_random_sweep(dev):
+    """300 random problems through cover_attention_bf16 (head dims 64 / 96 / 128 / 256, GQA ratios 1-8, 1-3 key segments with shared slots,
+    slot maps, per-row lengths and causal offsets, Tq 1..300, keys 1..900) against an fp32 restatement (tools/dbg/fuzz_attn.py: 1 800 cases
+    over three seeds ran clean when this was added)."""
+    import importlib.util, os
+    spec = importlib.util.spec_from_file_location("fuzz_attn", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "dbg", "fuzz_attn.py"))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    fails = fz.run(300, 11, dev, verbose=False)
+    assert not fails, fails[:5]
 
 
 # ------------------------------------------------------------------------------------------------ row kernels
