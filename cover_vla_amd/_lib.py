@@ -149,7 +149,7 @@ class DecGroup(C.Structure):
                 ("write_slot_of_batch", c_p), ("write_t_offset_of_batch", c_p),
                 ("write_t_offset", c_i), ("seg0_shared", c_i),
                 ("own_kv_mode", c_i), ("seg1_group", c_i), ("seg1_slot_of_group", c_p), ("seg1_len_of_group", c_p),
-                ("own_region_elems", c_ll)]
+                ("own_region_elems", c_ll), ("write_scratch", c_i)]
 
 
 class DecPass(C.Structure):

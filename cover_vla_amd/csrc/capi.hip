@@ -677,6 +677,14 @@ int cover_decoder_forward(const cover_dec_desc* d, const cover_dec_pass* p, void
             }
             pending[g] = true;
             if (pair_ok) continue;   // both groups: launched together below
+            {   // scratch write segment + split-K slabs: fold and rotate inside the attention launch (no RoPE launch, nothing cached)
+                const char* fz_env = getenv("COVER_ROPE_ATTN_FUSE");   // read per call: the tests toggle it
+                // opt-in (=1): measured at parity with the separate RoPE launch on the pi0 profile (29.7 vs 29.4-30.1 ms per decision)
+                if (G.write_scratch && qkv_splits > 0 && fz_env && fz_env[0] == '1' && attention_rope_fusable(&aa, &ra, G.write_seg)) {
+                    HIPCHK(launch_attention_rope_fused(&aa, &ra, G.write_seg, st), "dec attention (qkv fold + RoPE inside)");
+                    continue;
+                }
+            }
             HIPCHK(launch_rope_kv_write(&ra, st), "dec rope/kv");
             if (G.seg0_shared && G.T == 1 && G.n_seg >= 2 && G.segs[0].mask_mode == COVER_MASK_LEN) {
                 // phase A: the shared segment, candidates as the query rows of one "sequence"

@@ -32,6 +32,10 @@ hipError_t launch_pack_weight_bf16(const bf16_t* W, int ldw, int N, int K, bf16_
 // ---- attention.hip -------------------------------------------------------------------------------
 hipError_t launch_attention_bf16(const cover_attn_args* a, hipStream_t st);
 hipError_t launch_attention_bf16_pair(const cover_attn_args* a0, const cover_attn_args* a1, hipStream_t st);
+// RoPE + split-K fold of the qkv projection inside the attention launch (attention.hip "FuseDev"): r describes the slabs / tables exactly as
+// launch_rope_kv_write would get them; wseg = the segment of a whose keys / values are this pass's own rows. Nothing is written to the caches.
+bool attention_rope_fusable(const cover_attn_args* a, const cover_rope_args* r, int wseg);
+hipError_t launch_attention_rope_fused(const cover_attn_args* a, const cover_rope_args* r, int wseg, hipStream_t st);
 hipError_t launch_decode_attention_fused(const cover_decode_attn_args* a, hipStream_t st);
 hipError_t launch_decode_own_attention(const cover_own_attn_args* a, hipStream_t st);   // decode_own.hip
 

@@ -258,10 +258,11 @@ class Decoder:
         self._ws = None
 
     def group(self, B, T, positions, segs, write_seg, write_slot=None, write_t_off_of_batch=None, write_t_off=0,
-              seg0_shared=False, own_kv=None, seg1_group=0, seg1_slot_of_group=None, seg1_len_of_group=None):
+              seg0_shared=False, own_kv=None, seg1_group=0, seg1_slot_of_group=None, seg1_len_of_group=None, write_scratch=False):
         """segs: list of dicts {region, length, len_of_batch, slot_of_batch, mask, causal_offset, vis_len}.
         own_kv "bf16" / "fp8" (large-N candidate decode, cover_dec_group.own_kv_mode): the write segment lives in the head-major
-        layout of cover_decode_own_attention; rows [i * seg1_group, (i + 1) * seg1_group) share segs[1]'s slot / length."""
+        layout of cover_decode_own_attention; rows [i * seg1_group, (i + 1) * seg1_group) share segs[1]'s slot / length.
+        write_scratch: nobody reads the write segment after this pass (pi0 denoise steps) -- the library may leave it unwritten."""
         g = L.DecGroup()
         g.B, g.T = B, T
         g.positions = positions.data_ptr()
@@ -285,6 +286,7 @@ class Decoder:
         g.write_t_offset_of_batch = write_t_off_of_batch.data_ptr() if write_t_off_of_batch is not None else None
         g.write_t_offset = write_t_off
         g.seg0_shared = 1 if seg0_shared else 0
+        g.write_scratch = 1 if write_scratch else 0
         if own_kv is not None:
             r = segs[write_seg]["region"]
             g.own_kv_mode = {"bf16": 1, "fp8": 2}[own_kv]

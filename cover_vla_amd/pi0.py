@@ -245,7 +245,7 @@ class PI0FlowMatching:
                       temb=torch.empty(B * self.chunk, W, dtype=BF, device=dev))
             st["g1"] = self.expert.group(B, S, st["spos"].view(-1),
                                          [dict(region=0, length=Tp, len_of_batch=st["row_plen"], slot_of_batch=st["row_prompt"]),
-                                          dict(region=1, length=S, mask=ops.MASK_VISLEN, vis_len=self.vis_len)], 1)
+                                          dict(region=1, length=S, mask=ops.MASK_VISLEN, vis_len=self.vis_len)], 1, write_scratch=True)   # suffix K/V: per-step temporaries
             self._den[B] = st
         st["calls"] += 1
         if st.get("Tp") != Tp:                      # the prefix width is baked into the group (and into a captured graph)

@@ -467,6 +467,10 @@ typedef struct cover_dec_group {
     int own_kv_mode; int seg1_group;
     const int* seg1_slot_of_group; const int* seg1_len_of_group;
     long long own_region_elems;
+    /* 1: nobody reads the write segment after this pass (pi0 denoise steps: the suffix K/V are per-step temporaries,
+     * paligemma_with_expert.py:305-308) -- the pass may then leave it unwritten: with few-token groups on the split-K path the qkv slabs
+     * can be folded and rotated INSIDE the attention launch (one launch per layer less; opt-in, COVER_ROPE_ATTN_FUSE=1: measured at parity) */
+    int write_scratch;
 } cover_dec_group;
 typedef struct cover_dec_pass {
     int n_groups; int final_norm;      /* final_norm: apply final_norm_w to x at the end */

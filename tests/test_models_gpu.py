@@ -545,6 +545,24 @@ def test_expert_layer_200_rows_qkv_slabs_folded_by_rope_equals_reduction_launch(
     assert torch.isfinite(outs[0][0].float()).all() and outs[0][0].float().abs().max() > 0
     for a, b in zip(outs[0], outs[1]):
         assert torch.equal(a, b)
+    # the same pass with the write segment declared scratch (what pi0.py's denoise steps do): the slabs are folded and rotated INSIDE the
+    # attention launch (attention.hip FuseDev), no RoPE launch, nothing written to the suffix caches -- bit-identical layer output, and the
+    # suffix regions keep what the previous pass left there; opt-in (COVER_ROPE_ATTN_FUSE=1), the RoPE launch is the default
+    g1s = ex.group(B, S, spos.view(-1), [dict(region=0, length=T, len_of_batch=row_plen, slot_of_batch=row_prompt),
+                                          dict(region=1, length=S, mask=ops.MASK_VISLEN, vis_len=vis_len)], 1, write_scratch=True)
+    o1 = geom.k_off[1]
+    for fz in ("1", "0"):
+        os.environ["COVER_ROPE_ATTN_FUSE"] = fz
+        try:
+            ex.k_cache[0][o1:].fill_(7.0)
+            xb = torch.empty(B * S, W, dtype=BF, device=dev)
+            ex.forward(xb, [g1s], final_norm=True, x_f32=suf.view(B * S, W).contiguous())
+            torch.cuda.synchronize()
+            assert torch.equal(xb, outs[1][0]), fz
+            untouched = bool((ex.k_cache[0][o1:].float() == 7.0).all())
+            assert untouched == (fz == "1"), (fz, untouched)      # "1": fused (cache not written); "0": the RoPE launch wrote the suffix keys
+        finally:
+            os.environ.pop("COVER_ROPE_ATTN_FUSE", None)
 
 
 # ------------------------------------------------------------------------------------------------ serving boundary on the device
