@@ -726,6 +726,23 @@ def test_decode_attention_fused_with_recurring_prompt_slots(dev, N, pattern):
     _decode_attention_case(dev, 128, 8, N, 3, 2, True, permute_slots=False, slot_pattern=pattern, check_fp32=True)
 
 
+def test_decode_attention_fused_random_sweep(dev):
+    """60 random shapes of the fused decode attention (head dim, heads, candidates 1..200, own keys 1..21, RoPE mode, qkv from split-K
+    slabs or rows, permuted own slots, prompt-slot patterns) against the RoPE launch + generic attention and, for the recurring-slot
+    patterns, fp32 torch; appended K / V^T bit-exact."""
+    import random
+    rnd = random.Random(5)
+    for _ in range(60):
+        D, H = rnd.choice([(128, 8), (128, 32), (64, 4), (128, 16), (64, 16)])
+        N = rnd.choice([rnd.randint(1, 16), rnd.randint(17, 64), rnd.randint(65, 200)])
+        if H * ((N + 15) // 16) > 1400:
+            N = 64
+        write_t = rnd.choice([0, 0, rnd.randint(1, 7), rnd.randint(8, 20)])
+        pattern = rnd.choice(["grouped", "interleaved", "scattered"])
+        _decode_attention_case(dev, D, H, N, write_t, rnd.randint(0, 2), rnd.random() < 0.5, permute_slots=rnd.random() < 0.3,
+                               slot_pattern=pattern, check_fp32=(pattern != "grouped" and N <= 48))
+
+
 def _rope_ref(x, pos, cos, sin, mode):
     """x fp32 [N, H, D] (bf16 values), the two RoPE arithmetics of rope_kv_write restated in torch (bf16 roundings where the kernel has them)."""
     half = x.shape[-1] // 2
