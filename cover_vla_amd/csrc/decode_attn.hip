@@ -273,15 +273,6 @@ __global__ __launch_bounds__(1024) void decode_attn_fused_k(DecAttnDev a) {
                 const float b1 = x[2] * cs - x[3] * sn, b2 = x[3] * cs + x[2] * sn;
                 x[0] = a1; x[1] = a2; x[2] = b1; x[3] = b2;
             }
-            {
-                bf16_t* kd = a.k2 + a.write_t * a.k2_t + h * a.k2_h;
-                const unsigned kof = (unsigned)pslot2 * (unsigned)a.k2_slot + pi;
-                if (blockIdx.z == 0) { kd[kof] = f2bf(x[2]); kd[kof + HALF] = f2bf(x[3]); }
-                bf16_t* vd = a.vt2 + h * a.vt2_h + a.write_t;
-                const unsigned vof = (unsigned)pslot2 * (unsigned)a.vt2_slot + pi * a.vt2_d;
-                if (pi >= dv0 && pi < dv0 + DV) vd[vof] = f2bf(x[4]);
-                if (pi + HALF >= dv0 && pi + HALF < dv0 + DV) vd[vof + HALF * a.vt2_d] = f2bf(x[5]);
-            }
         }
         qs[pc * D + pi] = f2bf(x[0]);
         qs[pc * D + pi + HALF] = f2bf(x[1]);
@@ -299,6 +290,19 @@ __global__ __launch_bounds__(1024) void decode_attn_fused_k(DecAttnDev a) {
     // still in flight are waited for here
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     DAT(1);
+    // k_new / v_new -> the candidate's own cache segment, BEHIND the barrier: the V^T stores touch one 128-byte line per lane (d-major rows),
+    // a block issues ~2 000 of them, and in front of the barrier their ISSUE time (per-block timelines: the last wave reached the barrier
+    // 2 us after the first) was on every wave's critical path; here it runs under the flight time of the first tiles' loads. Nobody reads
+    // these rows in this launch (pool C takes the new token from LDS).
+    if (p1_ok) {
+        bf16_t* kd = a.k2 + a.write_t * a.k2_t + h * a.k2_h;
+        const unsigned kof = (unsigned)pslot2 * (unsigned)a.k2_slot + pi;
+        if (blockIdx.z == 0) { kd[kof] = f2bf(x[2]); kd[kof + HALF] = f2bf(x[3]); }
+        bf16_t* vd = a.vt2 + h * a.vt2_h + a.write_t;
+        const unsigned vof = (unsigned)pslot2 * (unsigned)a.vt2_slot + pi * a.vt2_d;
+        if (pi >= dv0 && pi < dv0 + DV) vd[vof] = f2bf(x[4]);
+        if (pi + HALF >= dv0 && pi + HALF < dv0 + DV) vd[vof + HALF * a.vt2_d] = f2bf(x[5]);
+    }
 
     // ---------------- phase 2 ----------------
     // Every tile is computed as an independent softmax state (m, l, O) and parked in the wave's LDS slot; a further tile
