@@ -87,7 +87,9 @@ __global__ __launch_bounds__(1024) void decode_attn_fused_k(DecAttnDev a) {
         if (a.slot2) pslot2 = a.slot2[pcand];
     }
 
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef COVER_DA_DEBUG   // (timeline builds only: in the product the slab loads below go out BEHIND the index loads without waiting for them --
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   //  only cos / sin chain on the position -- one round trip less in front of phase 1b)
+#endif
     DAT(4);
     // ---------------- phase 1a: q / k / v elements (i, i + HALF) of one candidate, summed over the split-K partials ----------------
     float x[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};      // q1 q2 k1 k2 v1 v2
@@ -95,30 +97,47 @@ __global__ __launch_bounds__(1024) void decode_attn_fused_k(DecAttnDev a) {
     if (p1_ok) {
         unsigned col[6];
 #pragma unroll
-        for (int j = 0; j < 6; ++j) col[j] = (unsigned)(((j >> 1) * a.H + h) * D + pi + (j & 1) * HALF);
+        for (int j = 0; j < 3; ++j) {
+            col[2 * j] = (unsigned)((j * a.H + h) * D + pi);
+            col[2 * j + 1] = col[2 * j] + HALF;
+        }
+        // Order of issue = order of return: the index loads above are the oldest, the q / k / v loads below depend on nothing but the
+        // candidate number and go out BEHIND them without waiting, and only then the cos / sin entries, which chain on the position:
+        // two round trips in front of phase 1b (index -> cos / sin, with the slabs travelling underneath) instead of three
+        // (index -> cos / sin -> slabs, what the branches of the former layout made of it).
+        float pv[6][4], bs[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        const unsigned pstride = (unsigned)a.N * (unsigned)ncols;   // (N * ncols * n_splits < 2^31 is checked by the launcher)
+        if (a.n_splits <= 0) {
+            const unsigned ro = (unsigned)pcand * (unsigned)a.ld_qkv;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) x[j] = bf2f(a.qkv[ro + col[j]]);
+        } else {
+            // uniform base pointer per split + 32-bit lane offsets
+            const unsigned ro = (unsigned)pcand * (unsigned)ncols;
+#pragma unroll
+            for (int sidx = 0; sidx < 4; ++sidx) {   // (uniform test per slab: a block's 16 waves share one ~60 GB/s load path, and loads of
+                if (sidx < a.n_splits) {             //  slabs that are not there -- formerly re-reads of the last one -- cost as much as real ones)
+                    const float* ps = a.partial + (size_t)sidx * pstride;
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) pv[j][sidx] = ps[ro + col[j]];
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) pv[j][sidx] = 0.f;
+                }
+            }
+            if (a.bias) {
+#pragma unroll
+                for (int j = 0; j < 6; ++j) bs[j] = a.bias[col[j]];
+            }
+        }
         if (a.rope_mode != 0) {
             ppos = ppos < 0 ? 0 : (ppos >= a.n_pos ? a.n_pos - 1 : ppos);
             const unsigned po = (unsigned)(ppos * HALF + pi);
             cs = a.cos_t[po];
             sn = a.sin_t[po];
         }
-        if (a.n_splits <= 0) {
-            const unsigned ro = (unsigned)pcand * (unsigned)a.ld_qkv;
-#pragma unroll
-            for (int j = 0; j < 6; ++j) x[j] = bf2f(a.qkv[ro + col[j]]);
-        } else {
-            // uniform base pointer per split + 32-bit lane offsets (N * ncols * n_splits < 2^31 is checked by the launcher)
-            const unsigned pstride = (unsigned)a.N * (unsigned)ncols;
+        if (a.n_splits > 0) {
             const unsigned ro = (unsigned)pcand * (unsigned)ncols;
-            float pv[6][4], bs[6];
-#pragma unroll
-            for (int sidx = 0; sidx < 4; ++sidx) {   // splits beyond n_splits re-read the last one and are not added
-                const float* ps = a.partial + (size_t)(sidx < a.n_splits ? sidx : a.n_splits - 1) * pstride;
-#pragma unroll
-                for (int j = 0; j < 6; ++j) pv[j][sidx] = ps[ro + col[j]];
-            }
-#pragma unroll
-            for (int j = 0; j < 6; ++j) bs[j] = a.bias ? a.bias[col[j]] : 0.f;
 #pragma unroll
             for (int j = 0; j < 6; ++j) {
                 float v = 0.f;
