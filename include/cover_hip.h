@@ -493,7 +493,8 @@ int cover_decode_chain_status(void);
  * launches it replaces): the split-K slabs of o_proj / down are folded (+ residual + RMSNorm) by the last workgroups of the launch that
  * wrote them instead of by a reduction launch. The wait of those
  * workgroups for the other slabs is bounded. Synchronises nothing by itself (reads one device word: call it after a stream / device
- * synchronise); COVER_OK, or COVER_EHIP (+ cover_last_error) once a wait has given up -- the outputs of that pass are then invalid. */
+ * synchronise); COVER_OK, or COVER_EHIP (+ cover_last_error) once a wait has given up -- the outputs of that pass are then invalid (the
+ * word is sticky: it stays set for the rest of the process). */
 int cover_gemm_tail_status(void);
 
 /* hipGraph capture helpers: everything launched on `stream` between begin/end becomes one replayable graph */
