@@ -16,11 +16,15 @@
 //   * hand-off = MI355X guide, Guideline 16: payload stored write-through (agent-scope relaxed atomic stores -> `sc1`), every
 //     storing wave drains vmcnt, ONE lane arrives on a counter; ONE wave polls ONE word relaxed with s_sleep, ONE agent acquire,
 //     block barrier, then plain loads. The barrier is sense-reversing and hierarchical (8 group counters -> top counter ->
-//     per-group generation words), needs no per-launch reset, and every spin is BOUNDED: on a timeout the workgroup records an
-//     error code, stops waiting for the rest of the launch (the results are then garbage, the launch still ends) and the host
-//     reports it (cover_decode_chain_status).
-// Residency comes from the grid size alone: 256 workgroups of 512 threads with ~145 KiB of LDS each = one per CU; the launcher
-// refuses devices with fewer CUs.
+//     per-group generation words) and every spin is BOUNDED: on a timeout the workgroup records an error code, stops waiting for
+//     the rest of the launch (the results are then garbage, the launch still ends) and the host reports it
+//     (cover_decode_chain_status; the model classes check it at their next host sync when the chain is switched on).
+//     The barrier words belong to the PASS: they are carved from the decoder's pass workspace (one decoder, one stream) and zeroed
+//     by a kernel in front of the pass's first launch, so two decoders on two streams never count on the same words and a pass
+//     that gave up leaves nothing behind; only the sticky status word is per device.
+// Residency: 256 workgroups of 512 threads with ~112 KiB of LDS each = one per CU on every CU. The launcher asks the occupancy API
+// once per device (and refuses devices with fewer CUs), and serialises chain launches that arrive on DIFFERENT streams with an event
+// (two such grids in flight at once would share the CUs and both spin at their first barrier until the bound).
 //
 // A workgroup = 8 waves; wave w owns the 128-deep k-slice w of every 1024-deep activation chunk for ALL of the workgroup's
 // n-blocks; weights go HBM -> VGPR (non-temporal, 1 KiB per wave instruction, fragment-major packing) -> MFMA, activations through a
@@ -67,13 +71,14 @@ struct ChainPhase {
 struct ChainArgs {
     ChainPhase ph[4];
     int n_phases, M;
-    unsigned* sync;            // SYNC_WORDS words, zeroed once; persists across launches
+    unsigned* sync;            // BARRIER_WORDS words of the PASS workspace (one decoder, one stream), zeroed by a kernel at the start of every pass
+    unsigned* err;             // status word of the device (sticky give-up code; shared by every pass: it carries no barrier state)
 };
 
 constexpr int NWG = 256;                       // workgroups = CUs
 constexpr int NGRP = 8;                        // barrier groups (key = blockIdx & 7: the XCD a block is observed to land on)
 constexpr int LINE = 32;                       // words per 128-byte line
-constexpr int SYNC_WORDS = (2 * NGRP + 2) * LINE;
+constexpr int BARRIER_WORDS = (2 * NGRP + 1) * LINE;   // group counters, top counter, per-group generation words
 constexpr unsigned SPIN_LIMIT = 1u << 21;      // polls before a workgroup gives up (~1 s)
 constexpr int KC = 1024;                       // a wave owns one 128-deep slice of every 1024-deep chunk of K
 constexpr int LDS_RED = 6 * 16 * 1024;         // k-slice reduction buffer: [8 waves][NBW <= 6][2][4][64 lanes] fp32
@@ -100,6 +105,7 @@ __device__ __forceinline__ void stf_agent(float* p, float v) { st_agent((unsigne
 
 struct Sync {
     unsigned* w;
+    unsigned* e;       // the device's status word
     unsigned g0;       // generation at launch start
     int k;             // barriers passed in this launch
     int p;             // phase index of the launch (debug stamps)
@@ -107,7 +113,7 @@ struct Sync {
     __device__ __forceinline__ unsigned* cnt(int g) const { return w + g * LINE; }
     __device__ __forceinline__ unsigned* top() const { return w + NGRP * LINE; }
     __device__ __forceinline__ unsigned* gen(int g) const { return w + (NGRP + 1 + g) * LINE; }
-    __device__ __forceinline__ unsigned* err() const { return w + (2 * NGRP + 1) * LINE; }
+    __device__ __forceinline__ unsigned* err() const { return e; }
 };
 
 // ONE lane of the workgroup (wave 0, lane 0): arrive. Called after every storing wave has drained its stores and the block barrier.
@@ -462,6 +468,7 @@ __global__ __launch_bounds__(512) void decode_chain_k(ChainArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     Sync sy;
     sy.w = a.sync;
+    sy.e = a.err;
     sy.k = 0;
     sy.dead = false;
     {   // generation at launch start: it cannot advance before this workgroup has arrived at the first barrier
@@ -481,12 +488,40 @@ __global__ __launch_bounds__(512) void decode_chain_k(ChainArgs a) {
     }
 }
 
-unsigned* g_sync[16] = {};
+unsigned* g_err[16] = {};          // per device: ONE status word (sticky give-up code), never barrier state
+hipEvent_t g_last_ev[16] = {};     // per device: completion of the last chain launch, and the stream it went to (see chain_serialise)
+hipStream_t g_last_st[16] = {};
+bool g_have_last[16] = {};
+hipError_t g_attr[16];
+bool g_attr_done[16] = {};
+int g_resident[16] = {};           // 0 = not asked yet, 1 = 256 workgroups of decode_chain_k fit the device at once, -1 = they do not
 std::mutex g_mu;
+
+__global__ void chain_zero_k(unsigned* p, int n) {
+    for (int i = threadIdx.x; i < n; i += blockDim.x) p[i] = 0u;
+}
 
 }  // namespace
 
 // ---- host side ---------------------------------------------------------------------------------------------------------------
+// once per DEVICE: the LDS attribute of the kernel, and whether one workgroup per CU on every CU is what the hardware will admit (the
+// software grid barrier needs all 256 workgroups resident at once)
+static hipError_t chain_device_setup(int dev) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!g_attr_done[dev]) {
+        g_attr[dev] = hipFuncSetAttribute((const void*)decode_chain_k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        g_attr_done[dev] = true;
+        int per_cu = 0;
+        hipDeviceProp_t p;
+        if (g_attr[dev] == hipSuccess && hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, decode_chain_k, 512, LDS_TOTAL) == hipSuccess &&
+            hipGetDeviceProperties(&p, dev) == hipSuccess)
+            g_resident[dev] = (per_cu >= 1 && p.multiProcessorCount >= NWG) ? 1 : -1;
+        else
+            g_resident[dev] = -1;
+    }
+    return g_attr[dev];
+}
+
 bool decode_chain_supported(const cover_dec_desc* d, int rows) {
     // OPT-IN (COVER_DECODE_CHAIN=1; 2 = every phase its own launch). Measured on MI355X (docs/OPTIMISATION_LOG.md, round 4): the chain
     // runs a 7B decode layer in 114 us against 109.6 us for the separate kernels, the headline decision in 34.9-35.3 ms against 34.7:
@@ -500,41 +535,57 @@ bool decode_chain_supported(const cover_dec_desc* d, int rows) {
         if (d->layers_host[l].qkv_w8) return false;         // e4m3 weight stream: separate-launch path
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return false;
-    static int cus[16] = {};
-    if (cus[dev] == 0) {
-        hipDeviceProp_t p;
-        if (hipGetDeviceProperties(&p, dev) != hipSuccess) return false;
-        cus[dev] = p.multiProcessorCount;
-    }
-    return cus[dev] >= NWG;
+    if (chain_device_setup(dev) != hipSuccess) return false;
+    return g_resident[dev] == 1;
 }
-size_t decode_chain_ws_bytes() { return (size_t)2 * 32 * NWG * sizeof(float); }
+// [2][32][NWG] partial sums of squares, then the BARRIER_WORDS of this pass
+size_t decode_chain_ws_bytes() { return (size_t)2 * 32 * NWG * sizeof(float) + (size_t)BARRIER_WORDS * sizeof(unsigned); }
+static unsigned* chain_barrier_words(float* ssq) { return (unsigned*)(ssq + 2 * 32 * NWG); }
 
-static hipError_t chain_sync_words(unsigned** out) {
-    int dev = 0;
-    hipError_t e = hipGetDevice(&dev);
-    if (e != hipSuccess) return e;
+static hipError_t chain_err_word(int dev, unsigned** out) {
     std::lock_guard<std::mutex> lk(g_mu);
-    if (!g_sync[dev]) {
+    if (!g_err[dev]) {
         unsigned* p = nullptr;
-        e = hipMalloc((void**)&p, SYNC_WORDS * sizeof(unsigned));
+        hipError_t e = hipMalloc((void**)&p, LINE * sizeof(unsigned));
         if (e != hipSuccess) return e;
-        e = hipMemset(p, 0, SYNC_WORDS * sizeof(unsigned));
+        e = hipMemset(p, 0, LINE * sizeof(unsigned));
         if (e != hipSuccess) return e;
-        g_sync[dev] = p;
+        g_err[dev] = p;
     }
-    *out = g_sync[dev];
+    *out = g_err[dev];
     return hipSuccess;
 }
 
-// error word of the last launches on this device: 0 = every barrier completed; resets the word (and the barrier state after an error)
+// Two chain launches must never be in flight at once on one device: each wants every CU (112 KiB of LDS per workgroup), so workgroups of
+// two launches from different streams would share the CUs between them and both grids would spin at their first barrier until the bound.
+// A launch on another stream than the previous one therefore waits for the previous one's completion event (stream-ordered launches of
+// ONE stream already serialise). Capturing streams are left alone: an event wait across a capture boundary is not legal, and a captured
+// decode loop replays on the stream that owns it.
+static hipError_t chain_serialise_before(int dev, hipStream_t st) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return hipSuccess;
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (g_have_last[dev] && g_last_st[dev] != st) return hipStreamWaitEvent(st, g_last_ev[dev], 0);
+    return hipSuccess;
+}
+static void chain_serialise_after(int dev, hipStream_t st) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return;
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!g_last_ev[dev] && hipEventCreateWithFlags(&g_last_ev[dev], hipEventDisableTiming) != hipSuccess) return;
+    if (hipEventRecord(g_last_ev[dev], st) == hipSuccess) { g_last_st[dev] = st; g_have_last[dev] = true; }
+}
+
+// error word of the chain launches on this device since the last call: 0 = every barrier completed; resets the word. (The barrier words
+// themselves live in the pass workspace and are zeroed at the start of every pass, so a pass that gave up does not poison the next one.)
 int decode_chain_status() {
+    int dev = 0;
     unsigned* s = nullptr;
-    if (chain_sync_words(&s) != hipSuccess) return -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16 || chain_err_word(dev, &s) != hipSuccess) return -1;
     if (hipDeviceSynchronize() != hipSuccess) return -1;
     unsigned e = 0;
-    if (hipMemcpy(&e, s + (2 * NGRP + 1) * LINE, sizeof e, hipMemcpyDeviceToHost) != hipSuccess) return -1;
-    if (e != 0) (void)hipMemset(s, 0, SYNC_WORDS * sizeof(unsigned));
+    if (hipMemcpy(&e, s, sizeof e, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    if (e != 0) (void)hipMemset(s, 0, sizeof(unsigned));
     return (int)e;
 }
 
@@ -551,8 +602,19 @@ hipError_t launch_decode_chain(const cover_dec_desc* d, int stage, const cover_d
                                void* attn, void* mlp, float* ssq, int rows, bool split, hipStream_t st) {
     ChainArgs a;
     memset(&a, 0, sizeof a);
-    hipError_t e = chain_sync_words(&a.sync);
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= 16) return hipErrorInvalidDevice;
+    e = chain_device_setup(dev);
+    if (e != hipSuccess) return e;
+    e = chain_err_word(dev, &a.err);
+    if (e != hipSuccess) return e;
+    a.sync = chain_barrier_words(ssq);
+    e = chain_serialise_before(dev, st);
+    if (e != hipSuccess) return e;
+    if (stage == 0)   // first launch of a pass: this pass's barrier words start from zero (a kernel, not a memset node: see gemm_bf16.hip "Tail reduction")
+        hipLaunchKernelGGL(chain_zero_k, dim3(1), dim3(256), 0, st, a.sync, BARRIER_WORDS);
     a.M = rows;
     const int dim = d->dim, nqkv = (d->Hq + 2 * d->Hkv) * d->D;
     float* ssq_a = ssq;                 // behind o_proj
@@ -586,8 +648,6 @@ hipError_t launch_decode_chain(const cover_dec_desc* d, int stage, const cover_d
             norm_from(q, next->in_norm_w, ssq_b);
         }
     }
-    static hipError_t attr = hipFuncSetAttribute((const void*)decode_chain_k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (attr != hipSuccess) return attr;
     auto launch = [&](const ChainArgs& aa, double bytes) {
         hipEvent_t ea, eb;
         if (prof_enabled() && prof_reserve(0, bytes, &ea, &eb) >= 0)
@@ -609,5 +669,7 @@ hipError_t launch_decode_chain(const cover_dec_desc* d, int stage, const cover_d
             launch(one, wbytes(a.ph[i]));
         }
     }
-    return hipGetLastError();
+    e = hipGetLastError();
+    chain_serialise_after(dev, st);
+    return e;
 }

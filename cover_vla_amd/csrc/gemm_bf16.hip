@@ -719,9 +719,10 @@ __global__ __launch_bounds__(512) void splitk_reduce_norm(const float* __restric
 //   * who waits: only workgroups that have finished their own slab, for workgroups that are running or will be dispatched
 //     without their help -- no residency assumption, no deadlock; the wait is bounded (1 s of the 100 MHz clock), a give-up sets
 //     g_tail_error (cover_gemm_tail_status) and lets the launch finish
-//   * no acquire: nobody reads a slab in this launch before the count is complete, so no cache of this launch holds a stale line
-//     of one (the launch boundary invalidated what earlier launches left), and the slabs were written through
-//     (-DCOVER_TAIL_ACQUIRE=1 adds the agent-scope acquire for A/B runs)
+//   * one agent-scope acquire per reducing workgroup behind the complete count (adjacent workgroups write 64-byte halves of one
+//     128-byte slab line: a reducer whose own XCD L2 allocated that line on its partial write-through store must not rest on
+//     unspecified fill behaviour for the neighbour's half). 32 000 stress passes were clean without it on this chip
+//     (tools/dbg/tail_stress.py), the memory model still asks for it; -DCOVER_TAIL_ACQUIRE=0 builds without, for A/B runs
 //   * sync[0] = arrivals, sync[1] = reducers that have seen them all; the last of those zeroes both (the caller zeroes them once
 //     per decoder pass as well, so a give-up cannot poison later passes)
 // ---------------------------------------------------------------------------------------------------
@@ -739,7 +740,7 @@ int gemm_tail_status() {
     return (int)v;
 }
 #ifndef COVER_TAIL_ACQUIRE
-#define COVER_TAIL_ACQUIRE 0
+#define COVER_TAIL_ACQUIRE 1   // one buffer_inv per reducing workgroup: what the memory model asks for (the path is opt-in and slower anyway)
 #endif
 #ifndef COVER_TAIL_RELEASE
 #define COVER_TAIL_RELEASE 0
@@ -1717,7 +1718,7 @@ hipError_t launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* Wp, void* C,
     // ---- tile / split-K selection: fill >= ~1 block per CU when the problem allows it
     // tile configurations: {wave tile (WM, WN) in 16-row units, wave grid, stages}
     struct Cand { int wm, wn, wgm, wgn, nst; };
-    const Cand cands[19] = {
+    const Cand cands[27] = {
         {4, 4, 2, 2, 2},   // 0: 128x128, 4 waves of 64x64, 2 stages (64 KiB)
         {2, 4, 2, 2, 2},   // 1:  64x128, 4 waves of 32x64, 2 stages (48 KiB)
         {2, 2, 2, 2, 3},   // 2:  64x64,  4 waves of 32x32, 3 stages (48 KiB)
@@ -1739,6 +1740,12 @@ hipError_t launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* Wp, void* C,
         {7, 3, 2, 4, 3},   // g: 224x192, 8 MFMA waves of 112x48 + 4 loaders, 3 stages (156 KiB)
         {7, 2, 2, 3, 4},   // h: 224x96,  6 MFMA waves of 112x32 + 4 loaders, 4 stages (160 KiB)
         {4, 3, 2, 4, 3},   // i: 128x192, 8 MFMA waves of 64x48 + 4 loaders, 3 stages (120 KiB) -- fp8 instantiation only (gemm_fp8.hip)
+        {0, 0, 0, 0, 0}, {0, 0, 0, 0, 0}, {0, 0, 0, 0, 0}, {0, 0, 0, 0, 0},   // (19..22: plan-counter slots of the weight-streaming / fp8 kernels)
+        // self-loading 8-wave tiles (gemm_v3.hip): no loader waves, fragment reads and LDS-DMA pieces interleaved with the MFMAs
+        {7, 3, 2, 4, 3},   // n (23): 224x192, 8 waves of 112x48, 3 stages (156 KiB)
+        {7, 2, 2, 4, 3},   // o (24): 224x128, 8 waves of 112x32, 3 stages (132 KiB)
+        {8, 2, 2, 4, 3},   // p (25): 256x128, 8 waves of 128x32, 3 stages (144 KiB)
+        {4, 4, 2, 4, 3},   // q (26): 128x256, 8 waves of 64x64,  3 stages (144 KiB)
     };
     // Measured on MI355X (tools/bench_kernels.py, M = 441): this single-barrier-per-k-tile structure is latency-bound per
     // block, so residency beats tile size until the tile grid oversubscribes the chip several times over, while 64x64
@@ -1819,6 +1826,13 @@ hipError_t launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* Wp, void* C,
         static const char* force = getenv("COVER_TILE_PICK");  // experiment knob: index into cands
         if (force && force[0] >= '0' && force[0] <= '9') pick = force[0] - '0';
         if (force && force[0] >= 'a' && force[0] <= 'h') pick = 10 + (force[0] - 'a');
+        if (force && force[0] >= 'n' && force[0] <= 'q') pick = 10 + (force[0] - 'a');
+    }
+    {   // the loader-wave tiles' self-loading successors (gemm_v3.hip); COVER_V3=0 keeps the loader-wave kernels (A/B runs)
+        static const char* v3_env = getenv("COVER_V3");
+        const bool v3_on = !(v3_env && v3_env[0] == '0') && !f8_on && variant != 2 && (size_t)M * lda * 2 + 4096 < ((size_t)1 << 31);
+        if (v3_on) pick = pick == 16 ? 23 : pick == 15 ? 24 : pick == 12 ? 25 : pick == 13 ? 26 : pick;
+        else if (pick >= 23) pick = pick == 23 ? 16 : pick == 24 ? 15 : pick == 25 ? 12 : 13;
     }
     if (variant == 2 && pick > 2) pick = 0;
     if (pick == 18 && !(f8_on && gemm_fp8_tiled_supported(18))) return hipErrorInvalidValue;   // 128 x 192 exists as an fp8 kernel only
@@ -1845,7 +1859,7 @@ hipError_t launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* Wp, void* C,
     // the load latency (~12.8 TB/s chip-wide at 2 stages => 42.7 / 64 FLOP per byte).
     const int nst = variant == 2 ? 2 : cd.nst;
     const size_t lds = (size_t)nst * (bm + bn) * BK * 2;
-    const bool pc = pick >= 9;
+    const bool pc = pick >= 9 && pick <= 18;
     dim3 grid(tiles_m * tiles_n, S), block(pc ? 320 : 64 * cd.wgm * cd.wgn);
     // profiling: the GEMM kernel's own start / stop stamps; class 4 = LLM-sized weight matrix (prefill), 1 = ViT-sized
     const int tcls = (double)N * (double)Kp >= 16.0e6 ? 4 : 1;
@@ -1881,6 +1895,9 @@ hipError_t launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* Wp, void* C,
         partial = S > 1 ? ws : nullptr;
         e = launch_gemm_fp8_tiled(pick, epi.a8, epi.lda8, epi.a8s, epi.w8, epi.w8s, C, ldc, M, N, Kp, epi, tiles_m, tiles_n, kt8, S, partial, lds,
                                   7, 2.0 * (double)M * (double)N * (double)K, st);
+    } else if (pick >= 23) {
+        plan_hit(pick);
+        e = launch_gemm_v3(pick, A, lda, Wp, C, ldc, M, N, Kp, epi, tiles_m, tiles_n, kt_per, S, partial, tcls, twork, st);
     } else if (pc) {
         plan_hit(pick);
         // loader waves: one wave issues an LDS-DMA piece every ~60 cycles, four keep the CU's vector memory path busy

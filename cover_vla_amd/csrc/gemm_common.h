@@ -438,3 +438,6 @@ hipError_t launch_gemm_fp8_tiled(int pick, const uint8_t* A8, int lda8, const fl
                                  int M, int N, int Kp, const EpiDev& epi, int tiles_m, int tiles_n, int kt_per, int S, float* partial, size_t lds,
                                  int prof_cls, double prof_work, hipStream_t st);
 
+// gemm_v3.hip: the self-loading 8-wave tiled bf16 GEMM (picks 23..26 of launch_gemm_bf16's tile table)
+hipError_t launch_gemm_v3(int pick, const bf16_t* A, int lda, const bf16_t* Wp, void* C, int ldc, int M, int N, int Kp, const EpiDev& epi, int tiles_m,
+                          int tiles_n, int kt_per, int S, float* partial, int prof_cls, double prof_work, hipStream_t st);

@@ -1,0 +1,254 @@
+// Self-loading 8-wave tiled bf16 GEMM for gfx950 ("v3"): C[M,N] = epi(A[M,K] . W[N,K]^T), fp32 accumulate on v_mfma_f32_16x16x32_bf16.
+//
+// Same operand layouts, LDS images and epilogue as gemm_tiled_pc (gemm_bf16.hip): packed fragment-major weights, activation rows
+// staged with the XOR chunk swizzle on the SOURCE address of the LDS-DMA, accumulators acc[n-block][m-fragment]. What differs is who
+// does what, and when:
+//   * no loader waves. gemm_tiled_pc's 4 loader waves make the block 12 waves = 3 per SIMD = 168 registers per lane, which is what the
+//     84 accumulator + 80 fragment registers of a 112 x 48 wave tile just fit -- with nothing left to schedule with. Here the block is
+//     8 waves (2 x 4 wave tiles, two per SIMD, 256 registers) and every wave issues its share of the tile's LDS-DMA pieces itself.
+//   * nothing is issued as a burst. In gemm_tiled_pc every MFMA wave pushes the WM + WN fragment reads of the next 32-deep step at the
+//     LDS right behind the barrier, all eight waves at the same moment (80 KiB = 320 LDS cycles per step), and a wave cannot issue its
+//     first MFMA before its last read has been accepted; the in-kernel counters of round 4 had the matrix pipes idle 30 % of a k-tile
+//     with or without DMA. Here the WM + WN reads of the next step and the wave's DMA pieces are spread BETWEEN the MFMAs of the
+//     current step at compile-time positions (read j behind MFMA j NM / NR, piece p behind MFMA (2 p + 1) NM / PT of the two-step
+//     phase), so the LDS and the vector-memory address path see an even request stream and the matrix pipe always has the next MFMA.
+//   * one s_barrier per 64-deep k-tile, in the middle of the tile (between its two steps) as before: a wave reaching barrier kt + 1
+//     has every fragment of tile kt in registers, so that barrier releases the stage of tile kt for tile kt + NST.
+// Ordering of LDS-DMA data for the readers: every wave waits for ITS OWN pieces of tile kt + 1 with a counted vmcnt (the pieces of the
+// younger tiles stay in flight) before barrier kt + 1; the first fragment read of tile kt + 1 is issued behind that barrier.
+#include <stdlib.h>
+#include <type_traits>
+#include <hip/hip_ext.h>
+#include "common.h"
+#include "kernels.h"
+#include "gemm_common.h"
+
+// LDS-DMA of 16 B per lane with a scalar base: LDS destination = M0 (wave-uniform) + lane * 16, global source = sbase + voff (per lane)
+__device__ __forceinline__ void glds16_s(uint32_t voff, const void* sbase, uint32_t lds_wave_base_u32) {
+    uint32_t keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %3\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, %2\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voff), "s"(sbase), "s"(lds_wave_base_u32)
+        : "memory");
+}
+
+template <int V> using IC = std::integral_constant<int, V>;
+// position (MFMA index inside the two-step phase of 2 NM MFMAs that follows a barrier) behind which a wave issues its piece p of PT:
+// evenly spread in general; with a TWO-stage ring the refill of the stage the barrier has just released is the tile the NEXT barrier
+// needs, so its pieces go out at once
+constexpr int v3_pos(int p, int PT, int NM, int NST) { return NST == 2 ? p : ((2 * p + 1) * NM) / PT; }
+constexpr int v3_half_pieces(int PT, int NM, int NST) {   // pieces issued in the first step of the phase
+    int c = 0;
+    for (int p = 0; p < PT; ++p)
+        if (v3_pos(p, PT, NM, NST) < NM) ++c;
+    return c;
+}
+
+template <int WM, int WN, int NSTA, int NSTB>
+__global__ __launch_bounds__(512) void gemm_tiled_v3(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ Wp, void* C, int ldc, int M, int N,
+                                                     int Kp, EpiDev epi, int tiles_m, int tiles_n, int kt_per, float* __restrict__ partial) {
+    PCTL(0);
+    constexpr int CGM = 2, CGN = 4;                                       // wave grid: waves w and w + 4 (one SIMD) share the column block
+    constexpr int BM_ = CGM * WM * 16, BN_ = CGN * WN * 16;
+    constexpr int A_BYTES = BM_ * BK * 2, B_BYTES = BN_ * BK * 2;
+    constexpr int AT = A_BYTES / 1024, BT = B_BYTES / 1024;               // 1-KiB LDS-DMA pieces per k-tile
+    constexpr int PTA = AT / 4, PTB = BT / 4;                             // pieces per wave: waves 0-3 own the activation pieces, 4-7 the weight pieces
+    constexpr int NM = WM * WN, NR = WM + WN;                             // MFMAs / fragment reads per 32-deep step
+    static_assert(AT % 4 == 0 && BT % 4 == 0, "pieces must split evenly over the four waves of a role");
+    static_assert(NSTA >= 2 && NSTB >= 2, "a ring needs two stages");
+    static_assert((NSTA - 2) * PTA <= 63 && (NSTB - 2) * PTB <= 63, "counted vmcnt must fit its 6-bit field");
+    static_assert(NR <= NM && PTA <= NM && PTB <= NM, "at most one read and one piece behind an MFMA");
+    static_assert(NSTA * A_BYTES + NSTB * B_BYTES <= 160 * 1024, "LDS");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* As = smem;                   // [NSTA][A_BYTES]
+    char* Bs = smem + NSTA * A_BYTES;  // [NSTB][B_BYTES]
+    const int nwg = tiles_m * tiles_n;
+    int bid = blockIdx.x;
+    {   // XCD-aware bijective remap: the row tiles of one column of tiles (one weight panel) land on one L2
+        const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+        const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+        bid = base + (bid >> 3);
+    }
+    const int tn = bid / tiles_m, tm = bid % tiles_m;
+    const int m0 = tm * BM_, n0 = tn * BN_;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int K32 = Kp >> 5;
+    const int N16 = (N + 15) >> 4;
+    const int nk_total = Kp / BK;
+    const int kt0 = blockIdx.y * kt_per;
+    const int nk = min(kt_per, nk_total - kt0);
+    const uint32_t as_u32 = __builtin_amdgcn_readfirstlane(lds_addr_u32(As));
+    const uint32_t bs_u32 = __builtin_amdgcn_readfirstlane(lds_addr_u32(Bs));
+
+    // ---- MFMA side (every wave) ----
+    const int wm = w / CGN, wn = w % CGN;
+    const int r = lane & 15, g = lane >> 4;
+    f32x4 acc[WN][WM];  // [n-block b][m-frag f]
+#pragma unroll
+    for (int b = 0; b < WN; ++b)
+#pragma unroll
+        for (int f = 0; f < WM; ++f) acc[b][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const uint32_t a_addr0 = lds_addr_u32(As) + ((wm * (WM * 16) + r) * 8 + ((0 * 4 + g) ^ (r & 7))) * 16;
+    const uint32_t a_addr1 = lds_addr_u32(As) + ((wm * (WM * 16) + r) * 8 + ((1 * 4 + g) ^ (r & 7))) * 16;
+    const uint32_t b_addr = lds_addr_u32(Bs) + (wn * WN * 2 * 64 + lane) * 16;
+    // fragment read j of a step, in the order of first use by the MFMA loop below: w0, x0 .. x(WM-1), w1 .. w(WN-1)
+    auto read_nth = [&](uint32_t aa, uint32_t ba, int j, u32x4(&xf)[WM], u32x4(&wf)[WN]) {
+        if (j == 0) asm volatile("ds_read_b128 %0, %1" : "=v"(wf[0]) : "v"(ba));
+        else if (j <= WM) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(xf[j - 1]) : "v"(aa), "n"((j - 1) * 2048));
+        else asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(wf[j - WM]) : "v"(ba), "n"((j - WM) * 2048));
+    };
+    auto landed = [&](u32x4(&xf)[WM], u32x4(&wf)[WN]) {   // ties the fragments to the wait that precedes this call
+#pragma unroll
+        for (int f = 0; f < WM; ++f) asm volatile("" : "+v"(xf[f]));
+#pragma unroll
+        for (int b = 0; b < WN; ++b) asm volatile("" : "+v"(wf[b]));
+    };
+
+    // ---- the whole pipeline, once per DMA role (ROLE 0: this wave owns activation pieces, 1: weight pieces). Each role runs its own ring
+    // depth: a wave's vmcnt retires in issue order, so one wave cannot keep a deep weight ring (HBM latency) in flight behind a shallow
+    // activation ring (L2 latency) -- two kinds of wave can.
+    auto run = [&](auto ROLE) {
+        constexpr int role = decltype(ROLE)::value;
+        constexpr int PT = role ? PTB : PTA, NST = role ? NSTB : NSTA, SB = role ? B_BYTES : A_BYTES, KSH = role ? 11 : 7;
+        constexpr int HALF = v3_half_pieces(PT, NM, NST);
+        const int wl = w & 3;
+        uint32_t voff[PT];          // per lane: byte offset from the piece's scalar base
+        const char* sbase[PT];      // wave-uniform: source of the piece in the slice's first k-tile
+        uint32_t dst0[PT];          // wave-uniform: LDS byte address of the piece in stage 0
+#pragma unroll
+        for (int i = 0; i < PT; ++i) {
+            const int j = wl + 4 * i;
+            if constexpr (role == 0) {   // A: LDS chunk position p = j*64 + lane: row = p>>3, c = p&7 holds global chunk c ^ (row&7)
+                const int row = j * 8 + (lane >> 3), c = lane & 7;
+                int gr = m0 + row;
+                gr = gr < M ? gr : M - 1;
+                voff[i] = (uint32_t)(((size_t)gr * lda + ((c ^ (row & 7)) << 3)) * 2);
+                sbase[i] = (const char*)(A + (size_t)kt0 * BK);
+                dst0[i] = as_u32 + j * 1024;
+            } else {
+                const int nbi = j >> 1, kbi = j & 1;
+                int nb = (n0 >> 4) + nbi;
+                nb = nb < N16 ? nb : N16 - 1;
+                voff[i] = lane * 16;
+                sbase[i] = (const char*)(Wp + ((size_t)nb * K32 + (size_t)kt0 * 2 + kbi) * 512);
+                dst0[i] = bs_u32 + j * 1024;
+            }
+        }
+        // issue piece i of tile t into stage `stage` of this role's ring. t is clamped to the last tile by the caller: the surplus issues at
+        // the end of the K range re-load the last tile into a stage nobody reads any more, which keeps every vmcnt count of the steady state exact.
+        auto issue = [&](int i, int stage, int t) { glds16_s(voff[i], sbase[i] + ((size_t)(uint32_t)t << KSH), dst0[i] + stage * SB); };
+        // one 32-deep step: NM MFMAs on (xf, wf) with -- behind them -- the reads of step RKS of stages (rsa, rsb) into (xn, wn_) and this wave's DMA
+        // pieces of phase half DH (0: first step behind a barrier, 1: second) of tile dt into stage ds
+        auto group = [&](const u32x4(&xf)[WM], const u32x4(&wf)[WN], u32x4(&xn)[WM], u32x4(&wn_)[WN], int rsa, int rsb, auto RKS, auto DH, int ds, auto RD,
+                         auto DMA, int dt) {
+            constexpr int rks = decltype(RKS)::value, dh = decltype(DH)::value;
+            constexpr bool rd = decltype(RD)::value != 0, dma = decltype(DMA)::value != 0;
+            const uint32_t aa = (rks ? a_addr1 : a_addr0) + rsa * A_BYTES;
+            const uint32_t ba = b_addr + rsb * B_BYTES + rks * 1024;
+#pragma unroll
+            for (int b = 0; b < WN; ++b)
+#pragma unroll
+                for (int f = 0; f < WM; ++f) {
+                    const int i = b * WM + f;
+                    acc[b][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[b]), __builtin_bit_cast(bf16x8, xf[f]), acc[b][f], 0, 0, 0);
+                    if (rd) {
+#pragma unroll
+                        for (int j = 0; j < NR; ++j)
+                            if ((j * NM) / NR == i) read_nth(aa, ba, j, xn, wn_);
+                    }
+                    if (dma) {
+#pragma unroll
+                        for (int p = 0; p < PT; ++p)
+                            if (v3_pos(p, PT, NM, NST) == dh * NM + i) issue(p, ds, dt);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+        };
+        // ---- prologue: tiles 0 .. NST-2 and the first-step pieces of tile NST-1 ----
+#pragma unroll
+        for (int s = 0; s < NST - 1; ++s)
+#pragma unroll
+            for (int p = 0; p < PT; ++p) issue(p, s, min(s, nk - 1));
+#pragma unroll
+        for (int p = 0; p < PT; ++p)
+            if (v3_pos(p, PT, NM, NST) < NM) issue(p, NST - 1, min(NST - 1, nk - 1));
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * PT + HALF) : "memory");   // tile 0: everything but the younger tiles and the half tile
+        __builtin_amdgcn_s_barrier();
+        PCTL(1);
+        u32x4 xa[WM], wa[WN], xb[WM], wb[WN];
+#pragma unroll
+        for (int j = 0; j < NR; ++j) read_nth(a_addr0, b_addr, j, xa, wa);
+        asm volatile("s_waitcnt lgkmcnt(0)");
+        landed(xa, wa);
+        // ---- main loop (stage indices are wave-uniform run-time values: they only enter scalar address arithmetic) ----
+        // tile kt:  first its step 0 | reads of its step 1 | second-step pieces of tile kt + NST - 1 -> the stage of tile kt - 1
+        //           own pieces of tile kt + 1 landed, fragments of tile kt complete -> barrier kt + 1
+        //           then its step 1 | reads of step 0 of tile kt + 1 | first-step pieces of tile kt + NST -> the stage of tile kt
+        int ca = 0, cb = 0, cr = 0, pr = NST - 1;      // read stages of the activation / weight ring; this role's DMA ring (current / previous tile)
+        for (int kt = 0; kt < nk - 1; ++kt) {
+            const int na = ca == NSTA - 1 ? 0 : ca + 1, nb_ = cb == NSTB - 1 ? 0 : cb + 1, nr = cr == NST - 1 ? 0 : cr + 1;
+            group(xa, wa, xb, wb, ca, cb, IC<1>{}, IC<1>{}, pr, IC<1>{}, IC<1>{}, min(kt + NST - 1, nk - 1));
+            asm volatile("s_waitcnt lgkmcnt(0)");
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * PT) : "memory");
+            __builtin_amdgcn_s_barrier();
+            landed(xb, wb);
+            group(xb, wb, xa, wa, na, nb_, IC<0>{}, IC<0>{}, cr, IC<1>{}, IC<1>{}, min(kt + NST, nk - 1));
+            asm volatile("s_waitcnt lgkmcnt(0)");
+            landed(xa, wa);
+            ca = na; cb = nb_; pr = cr; cr = nr;
+        }
+        // last tile of the slice: no barrier, no DMA, no reads of a next tile
+        group(xa, wa, xb, wb, ca, cb, IC<1>{}, IC<1>{}, pr, IC<1>{}, IC<0>{}, 0);
+        asm volatile("s_waitcnt lgkmcnt(0)");
+        landed(xb, wb);
+        group(xb, wb, xa, wa, ca, cb, IC<0>{}, IC<0>{}, cr, IC<0>{}, IC<0>{}, 0);
+    };
+    if (w < 4) run(IC<0>{});
+    else run(IC<1>{});
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the surplus pieces of the clamped tail must not land in the epilogue's staging area
+    PCTL(2);
+    tiled_epilogue_staged<WM, WN, BM_, BN_>(acc, epi, C, ldc, M, N, m0, n0, m0 + wm * (WM * 16), n0 + wn * (WN * 16), r, g, partial, smem,
+                                            NSTA * A_BYTES + NSTB * B_BYTES, tid, 512);
+    PCTL(3);
+}
+
+// pick -> instantiation (the tile table of launch_gemm_bf16 continues with these indices). COVER_V3_RING=<a><b> (two digits) selects another
+// instantiated ring-depth pair for A/B runs.
+hipError_t launch_gemm_v3(int pick, const bf16_t* A, int lda, const bf16_t* Wp, void* C, int ldc, int M, int N, int Kp, const EpiDev& epi, int tiles_m,
+                          int tiles_n, int kt_per, int S, float* partial, int prof_cls, double prof_work, hipStream_t st) {
+    hipError_t e = hipSuccess;
+    if ((size_t)M * lda * 2 + 4096 >= ((size_t)1 << 31)) return hipErrorInvalidValue;   // 32-bit lane offsets of the activation pieces
+    dim3 grid(tiles_m * tiles_n, S), block(512);
+    static const char* ring_env = getenv("COVER_V3_RING");
+    const int ring = ring_env ? atoi(ring_env) : 0;
+#define LAUNCH_V3(WM_, WN_, NA_, NB_)                                                                                        \
+    do {                                                                                                                     \
+        auto kfn = gemm_tiled_v3<WM_, WN_, NA_, NB_>;                                                                        \
+        const size_t lds = ((size_t)NA_ * 2 * WM_ * 16 + (size_t)NB_ * 4 * WN_ * 16) * BK * 2;                               \
+        static hipError_t attr = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+        e = attr;                                                                                                            \
+        if (e == hipSuccess) {                                                                                               \
+            hipEvent_t ea, eb;                                                                                               \
+            if (prof_enabled() && prof_reserve(prof_cls, prof_work, &ea, &eb) >= 0)                                          \
+                hipExtLaunchKernelGGL(kfn, grid, block, (uint32_t)lds, st, ea, eb, 0, A, lda, Wp, C, ldc, M, N, Kp, epi, tiles_m, tiles_n, kt_per, partial); \
+            else                                                                                                             \
+                hipLaunchKernelGGL(kfn, grid, block, lds, st, A, lda, Wp, C, ldc, M, N, Kp, epi, tiles_m, tiles_n, kt_per, partial); \
+        }                                                                                                                    \
+    } while (0)
+    switch (pick) {
+        case 23: if (ring == 24) LAUNCH_V3(7, 3, 2, 4); else if (ring == 23) LAUNCH_V3(7, 3, 2, 3); else LAUNCH_V3(7, 3, 3, 3); break;
+        case 24: if (ring == 34) LAUNCH_V3(7, 2, 3, 4); else if (ring == 26) LAUNCH_V3(7, 2, 2, 6); else if (ring == 25) LAUNCH_V3(7, 2, 2, 5); else LAUNCH_V3(7, 2, 3, 3); break;
+        case 25: if (ring == 34) LAUNCH_V3(8, 2, 3, 4); else if (ring == 26) LAUNCH_V3(8, 2, 2, 6); else LAUNCH_V3(8, 2, 3, 3); break;
+        case 26: if (ring == 24) LAUNCH_V3(4, 4, 2, 4); else if (ring == 43) LAUNCH_V3(4, 4, 4, 3); else LAUNCH_V3(4, 4, 3, 3); break;
+        default: return hipErrorInvalidValue;
+    }
+#undef LAUNCH_V3
+    if (e == hipSuccess) e = hipGetLastError();
+    return e;
+}

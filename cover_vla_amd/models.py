@@ -102,6 +102,7 @@ class VitTower:
         self._arr = arr
         self.n_layers = nl
         self._ws = None
+        self.ws_gen = 0          # bumped whenever the workspace is re-allocated: a hipGraph captured over the old pointer must be re-captured
 
     def _desc(self, n_layers, last_attn_only):
         d = L.VitDesc()
@@ -161,6 +162,7 @@ class VitTower:
         need = h.cover_vit_workspace_bytes(C.byref(d), n, T)
         if self._ws is None or self._ws.numel() < need:
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.dev)
+            self.ws_gen += 1
         attn_out = torch.empty_like(x) if last_attn_only else None
         ws = L.Workspace(self._ws.data_ptr(), self._ws.numel())
         L.check(h.cover_vit_forward(C.byref(d), x.data_ptr(), n, T, attn_out.data_ptr() if last_attn_only else None, ws,
@@ -256,6 +258,16 @@ class Decoder:
         d.layers_host = C.cast(self._arr, C.POINTER(L.DecLayer))
         self.desc = d
         self._ws = None
+        self.ws_gen = 0          # bumped whenever the workspace is re-allocated (see reserve)
+
+    def reserve(self, rows: int) -> None:
+        """Sizes the pass workspace for up to `rows` input rows once. A captured hipGraph holds the workspace's device pointer; a later
+        pass with more rows would otherwise re-allocate it under the graphs captured for smaller passes (their replay would then write
+        through a freed pointer). Owners that capture graphs call this with their largest pass and compare ws_gen before a replay."""
+        need = L.lib().cover_decoder_workspace_bytes(C.byref(self.desc), rows)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.dev)
+            self.ws_gen += 1
 
     def group(self, B, T, positions, segs, write_seg, write_slot=None, write_t_off_of_batch=None, write_t_off=0,
               seg0_shared=False, own_kv=None, seg1_group=0, seg1_slot_of_group=None, seg1_len_of_group=None, write_scratch=False):
@@ -310,6 +322,7 @@ class Decoder:
         need = h.cover_decoder_workspace_bytes(C.byref(self.desc), rows)
         if self._ws is None or self._ws.numel() < need:
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.dev)
+            self.ws_gen += 1
         ws = L.Workspace(self._ws.data_ptr(), self._ws.numel())
         L.check(h.cover_decoder_forward(C.byref(self.desc), C.byref(p), x.data_ptr(), ws, gemm_variant,
                                         torch.cuda.current_stream().cuda_stream), "decoder_forward")

@@ -78,6 +78,9 @@ class OpenVLA:
                            mlp=c["llm_mlp"], act="silu", norm="llama", eps=1e-5, rope="hf", n_pos=self.T0 + max_text + self.n_gen + 8,
                            device=device, cache=geom, fp8_weights=fp8)
         self.max_prompts, self.max_candidates, self.max_text = max_prompts, max_candidates, max_text
+        # the largest pass this model can run (patch rows + every prompt's text rows): sized once, so that the decode graphs captured for
+        # one (P, Lt) never see the workspace move when a later decision has more prompt rows
+        self.llm.reserve(self.T0 + max_prompts * max_text)
         D = c["llm_dim"]
         self.action_lo = c["tok_vocab"] - c["n_bins"]
         self.action_hi = c["tok_vocab"]
@@ -168,6 +171,9 @@ class OpenVLA:
         n, H, W, _ = frame_u8.shape
         st = self._vision_static(n, H, W)
         st["frame"].copy_(frame_u8)
+        gen = (self.dino.ws_gen, self.siglip.ws_gen)
+        if st["graph"] is not None and st.get("ws_gen") != gen:
+            st["graph"] = None                                           # a tower workspace moved (a larger frame batch ran since): re-capture
         if st["graph"] is not None and self.vision_graph:
             st["graph"].launch()
             return st["h"][2]
@@ -181,6 +187,7 @@ class OpenVLA:
                 with ops.Graph() as g:
                     self._encode_static(st)
             st["graph"] = g
+            st["ws_gen"] = (self.dino.ws_gen, self.siglip.ws_gen)
             cur.wait_stream(self._cap)
         return out
 
@@ -252,6 +259,8 @@ class OpenVLA:
                 st["u"].copy_(u_t)
             body = lambda: self._decode_body(x, N, n_samples, Lt, st["prompt_of_cand"], st["cand_len"], st["last_row"], st["pos_all"], st["u"], temperature,
                                              st["tokens"], st["sel"], st["tokens"], None, st["prompt_slots"], st["prompt_lens"])
+            if st["graph"] is not None and st.get("ws_gen") != self.llm.ws_gen:
+                st["graph"] = None                                      # the decoder workspace moved under the captured pointer: re-capture
             if st["graph"] is None:
                 body()                                                  # eager once (also sizes every workspace), then recorded
                 cur = torch.cuda.current_stream()
@@ -262,9 +271,11 @@ class OpenVLA:
                     with ops.Graph() as g:
                         body()
                 st["graph"] = g
+                st["ws_gen"] = self.llm.ws_gen
                 cur.wait_stream(self._cap)
             else:
                 st["graph"].launch()
+            self._check_opt_in_protocols()
             return st["tokens"].t().contiguous(), st["sel"].t().contiguous()
         # step-major buffers: row i of each is contiguous, so the kernels of step i read / write them in place (no per-step slice copies)
         tokens = torch.empty(self.n_gen, N, dtype=torch.int64, device=dev)
@@ -272,7 +283,17 @@ class OpenVLA:
         fed = tokens if force_tokens is None else force_tokens.t().contiguous()
         self._decode_body(x, N, n_samples, Lt, prompt_of_cand, cand_len, last_row, pos_all, u_t, temperature, tokens, sel, fed, trace,
                           torch.arange(P, dtype=torch.int32, device=dev), prompt_lens.to(torch.int32).contiguous(), mark)
+        self._check_opt_in_protocols()
         return tokens.t().contiguous(), sel.t().contiguous()
+
+    def _check_opt_in_protocols(self):
+        """The opt-in in-kernel synchronisation protocols (COVER_DECODE_CHAIN, COVER_TAIL_REDUCE) end a bounded wait that times out with
+        a status word instead of a hang; their results are then garbage. When either is switched on, every decision checks the words
+        before its tokens are handed back (this synchronises the device: the opt-in paths are measurement paths)."""
+        if os.environ.get("COVER_DECODE_CHAIN", "0") in ("1", "2"):
+            ops.decode_chain_status()
+        if os.environ.get("COVER_TAIL_REDUCE", "0") == "1":
+            ops.gemm_tail_status()
 
     def _decode_body(self, x, N, n_samples, Lt, prompt_of_cand, cand_len, last_row, pos_all, uniforms, temperature, tokens, sel, fed, trace,
                      prompt_slots, prompt_lens_i32, mark=lambda name: None):

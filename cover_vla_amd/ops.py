@@ -155,8 +155,9 @@ def decode_chain_status() -> None:
 
 def gemm_plan_counts(reset: bool = False) -> list:
     """Launch counters per GEMM kernel plan since the last reset (cover_gemm_plan_counts): [0..18] tiled picks (14..17 = 224-row
-    tiles), [19] / [20] / [22] weight-streaming generations 2 / 3 / 1, [21] fp8 MFMA tiles."""
-    n = 23
+    tiles), [19] / [20] / [22] weight-streaming generations 2 / 3 / 1, [21] fp8 MFMA tiles, [23..26] self-loading 8-wave tiles
+    (gemm_v3.hip: 224x192, 224x128, 256x128, 128x256)."""
+    n = 27
     buf = (C.c_longlong * n)()
     L.lib().cover_gemm_plan_counts(buf, n, 1 if reset else 0)
     return list(buf)

@@ -25,7 +25,10 @@ def shard_prompts(prompts: Sequence, rank: int, world: int) -> List:
 
 
 def _select(g: torch.Tensor, S: int) -> dict:
-    """g fp32 [G, S] in global prompt order -> first-maximum-wins grouped arg-max (torch.max semantics)."""
+    """g fp32 [G, S] in global prompt order -> first-maximum-wins grouped arg-max (torch.max semantics).
+    Device tensors -- every production caller: the gathered buffer lives where the scores were computed -- go to the library's
+    group_argmax kernel. The torch branch below is TEST-ONLY: it is what the world_size-2 `gloo` tests on CPU tensors reach (there is
+    no GPU in the CPU test tier); it is not a fallback of the product path, which never holds its scores on the host."""
     if g.is_cuda:
         from . import ops
         res, best = ops.group_argmax(g.reshape(-1).contiguous(), S)
@@ -38,19 +41,38 @@ def _select(g: torch.Tensor, S: int) -> dict:
 
 
 def gather_records_and_select(local_scores: torch.Tensor, samples_per_prompt: int, rank: int, world: int,
-                              n_prompts_total: int, local_payload: Optional[torch.Tensor] = None) -> dict:
-    """local_scores fp32 [n_local_prompts * S] in this rank's prompt order; local_payload [n_local * S, P] (any dtype
-    exactly representable in fp32: token ids < 2^24, fp32 action chunks) or None.
+                              n_prompts_total: int, local_payload: Optional[torch.Tensor] = None,
+                              payload_width: Optional[int] = None) -> dict:
+    """local_scores fp32 [n_local_prompts * S] in this rank's prompt order; local_payload [n_local * S, P...] (any dtype
+    exactly representable in fp32: token ids < 2^24, fp32 action chunks) or None -- the SAME choice on every rank.
+    payload_width: P, when it cannot be read off local_payload -- a rank that owns no prompt group (world > n_prompts_total) holds an
+    empty payload tensor; its trailing dimensions give P when it was built as [0, P...], otherwise pass the width every rank agrees on.
     ONE all-gather of [n_local * S, 1 + P] fp32 records. Returns, identically on every rank:
     dict(global_idx, group, in_group, max_score, group_mean, scores [N], payload [N, P] | None,
          winner_payload [P] | None, group_payload [S, P] | None)."""
     S = samples_per_prompt
     n_loc = local_scores.numel()
     n_local_prompts = n_loc // S
-    P = 0 if local_payload is None else int(local_payload.reshape(n_loc, -1).shape[1])
+    if local_payload is None:
+        P = 0 if payload_width is None else int(payload_width)
+        if P and n_loc:
+            raise ValueError("payload_width without a payload is only meaningful on a rank that owns no prompt group")
+    elif n_loc > 0:
+        P = int(local_payload.reshape(n_loc, -1).shape[1])
+    elif payload_width is not None:
+        P = int(payload_width)
+    elif local_payload.dim() >= 2:
+        P = 1
+        for d in local_payload.shape[1:]:
+            P *= int(d)
+    else:
+        raise ValueError("a rank without prompt groups must pass its payload as [0, P] or give payload_width (the record width of the all-gather)")
+    if payload_width is not None and P != int(payload_width):
+        raise ValueError(f"payload width {P} differs from payload_width={payload_width}")
     rec = local_scores.reshape(n_loc, 1).to(torch.float32)
     if P:
-        rec = torch.cat([rec, local_payload.reshape(n_loc, P).to(torch.float32)], dim=1)
+        pl = local_payload.reshape(n_loc, P).to(torch.float32) if local_payload is not None else torch.zeros(0, P, dtype=torch.float32, device=rec.device)
+        rec = torch.cat([rec, pl], dim=1)
     rec = rec.contiguous()
     if world > 1:
         # rank r owns global prompts r, r + W, ...: ceil((G - r) / W) of them. Shards may be ragged (8 prompts on 3 or 5 GPUs): every
@@ -75,7 +97,7 @@ def gather_records_and_select(local_scores: torch.Tensor, samples_per_prompt: in
     sel["scores"] = scores
     if P:
         pay = allrec[:, 1:]
-        if local_payload.dtype != torch.float32:
+        if local_payload is not None and local_payload.dtype != torch.float32:
             pay = pay.round().to(local_payload.dtype)
         gi, gg = sel["global_idx"], sel["group"]
         sel["payload"] = pay

@@ -122,7 +122,7 @@ def _worker(rank, world, port, q, n_prompts=8):
     S = 4
     gidx = [prompts.index(p) * S + s for p in mine for s in range(S)]
     scores = torch.tensor([((g * 37) % 101) / 101.0 for g in gidx], dtype=torch.float32)
-    tokens = torch.tensor([[31744 + (g * 13 + j * 7) % 256 for j in range(7)] for g in gidx], dtype=torch.int64)
+    tokens = torch.tensor([[31744 + (g * 13 + j * 7) % 256 for j in range(7)] for g in gidx], dtype=torch.int64).reshape(len(gidx), 7)
     res = gather_records_and_select(scores, S, rank, world, n_prompts_total=len(prompts), local_payload=tokens)
     res = {k: (v.tolist() if torch.is_tensor(v) else v) for k, v in res.items()}
     q.put((rank, res))
@@ -180,6 +180,30 @@ def test_candidate_sharding_gloo_world2_ragged_shards():
         assert outs[r]["winner_payload"] == tok(bg * S + bi)
         assert outs[r]["payload"] == [tok(g) for g in range(28)]
         assert np.allclose(outs[r]["scores"], all_scores.view(-1).numpy(), atol=0)
+    assert outs[0] == outs[1]
+
+
+def test_candidate_sharding_gloo_world2_idle_rank():
+    """More ranks than prompt groups (1 group on 2 ranks): the idle rank contributes an empty [0, 7] payload -- its record width comes
+    from the trailing dimension -- pads for the equal-size all-gather, and still ends up with the winner and its group's tokens."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + (os.getpid() % 2000)
+    ps = [ctx.Process(target=_worker, args=(r, 2, port, q, 1)) for r in range(2)]
+    for p in ps:
+        p.start()
+    outs = dict(q.get(timeout=120) for _ in ps)
+    for p in ps:
+        p.join(60)
+    S = 4
+    all_scores = torch.tensor([((g * 37) % 101) / 101.0 for g in range(4)]).view(1, S)
+    bi = int(all_scores[0].argmax())
+    tok = lambda g: [31744 + (g * 13 + j * 7) % 256 for j in range(7)]
+    for r in range(2):
+        assert outs[r]["global_idx"] == bi and outs[r]["group"] == 0
+        assert outs[r]["winner_payload"] == tok(bi)
+        assert outs[r]["payload"] == [tok(g) for g in range(4)]
     assert outs[0] == outs[1]
 
 

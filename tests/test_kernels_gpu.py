@@ -98,7 +98,7 @@ def test_gemm_headline_prefill_tiles_m448_bf16(dev, N, K, kind):
         ops.gemm(a, ops.pack_linear(w), residual=out, out=out, norm_w=nw, norm_out=h, norm_style=1, norm_w_offset=0.0, norm_eps=1e-5)
         ref = res.float() + y
     counts = ops.gemm_plan_counts()
-    assert sum(counts[14:18]) == 1 and sum(counts) == 1, counts
+    assert sum(counts[14:18]) + sum(counts[23:25]) == 1 and sum(counts) == 1, counts   # a 224-row tile (loader-wave or self-loading kernel)
     assert rel_l2(out, ref) < 6e-3
     d = (out.float() - ref).abs()
     assert (d <= 0.06 + 2e-2 * ref.abs()).all()

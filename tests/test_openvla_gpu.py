@@ -211,6 +211,32 @@ def test_openvla_decode_graph_replay_equals_eager_loop(dev, own_kv, horizon):
     assert all(st["graph"] is not None for st in model._dec.values()) and len(model._dec) == 2      # sampled and greedy shapes
 
 
+def test_openvla_decode_graph_survives_a_larger_prompt_batch(dev):
+    """A decode graph captured for a small (P, Lt) holds the decoder workspace's device pointer. A later decision with more prompt rows
+    (larger P x Lt prefill) must not move that workspace under it: the workspace is sized once for T0 + max_prompts x max_text rows
+    (Decoder.reserve) and its generation is compared before every replay. Small -> small (replay) -> large -> large (replay) -> small
+    (replay of the FIRST graph after the larger pass), each against the eager loop, bit for bit."""
+    from cover_vla_amd.openvla import OpenVLA
+    c, sd, frame, toks, lens, u = _case(seed=17)
+    Lt = toks.shape[1]
+    kw = dict(device="cuda:0", max_prompts=4, max_candidates=8, max_text=Lt + 8)
+    eager = OpenVLA(sd, c, **kw)
+    eager.decode_graph = False
+    model = OpenVLA(sd, c, **kw)
+    gen0 = model.llm.ws_gen
+    f = frame.to(dev)
+    small = (toks[:2].contiguous().to(dev), lens[:2].contiguous().to(dev), u[:4].contiguous().to(dev))
+    wide = torch.zeros(3, Lt + 8, dtype=torch.long)
+    wide[:, :Lt] = toks
+    large = (wide.to(dev), lens.to(dev), u.to(dev))
+    for tk, ln, uu in (small, small, large, large, small, large):
+        a_t, a_l = model.sample(f, tk, ln, 2, uu, 1.0)
+        b_t, b_l = eager.sample(f, tk, ln, 2, uu, 1.0)
+        assert torch.equal(a_t, b_t) and torch.equal(a_l, b_l)
+    assert model.llm.ws_gen == gen0, "the decoder workspace was re-allocated after __init__ sized it"
+    assert len(model._dec) == 2 and all(st["graph"] is not None and st["ws_gen"] == gen0 for st in model._dec.values())
+
+
 def test_openvla_end_to_end_matches_hf_composition(dev):
     """END-TO-END pin of the headline profile at a public implementation: the HIP path (vision towers -> projector -> shared
     prefix + per-prompt prefill -> 6 decode passes -> lm_head -> greedy pick) against HF Dinov2WithRegisters + SiglipVision +
@@ -295,7 +321,7 @@ def test_full_width_llama7b_layer_matches_hf_g3(dev):
     ops.gemm_plan_counts(reset=True)
     llm.forward(x, [g0, g1], final_norm=True)
     counts = ops.gemm_plan_counts()
-    assert sum(counts[14:18]) == 4 and sum(counts) == 4, counts          # qkv, o_proj, gate_up, down: all on the 224-row tiles
+    assert sum(counts[14:18]) + sum(counts[23:25]) == 4 and sum(counts) == 4, counts          # qkv, o_proj, gate_up, down: all on the 224-row tiles
     lens = i["lens"]
     pre = x[:N_PATCH]
     text = x[N_PATCH:].view(P, LT, Dm)
