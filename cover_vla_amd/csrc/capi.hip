@@ -78,6 +78,11 @@ int cover_gemm_tail_status(void) {
     if (v != 0) return fail(COVER_EHIP, "a bounded wait of the tail reduction gave up (gemm_bf16.hip): results of that pass are invalid");
     return COVER_OK;
 }
+int cover_gemm_probe(unsigned long long* out) {
+    if (!out) return fail(COVER_EINVAL, "cover_gemm_probe: null pointer");
+    if (gemm_v3_probe(out) != 0) return fail(COVER_EHIP, "cover_gemm_probe: could not read the probe words");
+    return COVER_OK;
+}
 int cover_gemm_plan_counts(long long* counts, int n, int reset) {
     if (n < 0 || (n > 0 && !counts)) return fail(COVER_EINVAL, "cover_gemm_plan_counts: bad arguments");
     gemm_plan_counts(counts, n, reset);
@@ -412,7 +417,7 @@ int cover_vit_forward(const cover_vit_desc* d, void* x, int n_seq, int T, void* 
 
 static size_t dec_ws(const cover_dec_desc* d, int rows, Carver* c, void** h, void** qkv, void** attn, void** mlp, void** sk,
                      size_t* sk_bytes, void** st_o = nullptr, void** st_ml = nullptr, void** q8 = nullptr, void** q8s = nullptr, void** ssq = nullptr,
-                     void** tsync = nullptr) {
+                     void** tsync = nullptr, void** dn_ssq = nullptr) {
     Carver tmp{nullptr, 0, 0};
     Carver& cc = c ? *c : tmp;
     const int nqkv = (d->Hq + 2 * d->Hkv) * d->D;
@@ -438,10 +443,12 @@ static size_t dec_ws(const cover_dec_desc* d, int rows, Carver* c, void** h, voi
             skb = b > skb ? b : skb;
         }
     }
+    if (skb < (size_t)rows * nqkv * 4) skb = (size_t)rows * nqkv * 4;      // deferred-norm passes: the qkv projection as ONE fp32 slab
     p = cc.take(skb); if (sk) *sk = p;
     if (sk_bytes) *sk_bytes = skb;
     p = cc.take(decode_chain_ws_bytes()); if (ssq) *ssq = p;   // partial sums of squares of the persistent decode chain (rows <= 32)
     p = cc.take(256); if (tsync) *tsync = p;                   // ticket words of the tail reduction (gemm_bf16.hip), zeroed per pass
+    p = cc.take((size_t)2 * rows * ((d->dim + 31) / 32) * 4); if (dn_ssq) *dn_ssq = p;   // deferred RMSNorm: [2][rows][dim / 32] partial sums of squares
     return cc.off + 256;
 }
 size_t cover_decoder_workspace_bytes(const cover_dec_desc* d, int rows) {
@@ -465,9 +472,9 @@ int cover_decoder_forward(const cover_dec_desc* d, const cover_dec_pass* p, void
         rows += G.B * G.T;
     }
     Carver c{(char*)ws.ptr, ws.bytes, 0};
-    void *h, *qkv, *attn, *mlp, *sk, *st_o, *st_ml, *q8, *q8s, *ssq, *tsync;
+    void *h, *qkv, *attn, *mlp, *sk, *st_o, *st_ml, *q8, *q8s, *ssq, *tsync, *dn_ssq;
     size_t skb;
-    const size_t need = dec_ws(d, rows, &c, &h, &qkv, &attn, &mlp, &sk, &skb, &st_o, &st_ml, &q8, &q8s, &ssq, &tsync);
+    const size_t need = dec_ws(d, rows, &c, &h, &qkv, &attn, &mlp, &sk, &skb, &st_o, &st_ml, &q8, &q8s, &ssq, &tsync, &dn_ssq);
     if (!ws.ptr || ws.bytes < need) return fail(COVER_EWORKSPACE, "cover_decoder_forward: workspace too small");
     const int dim = d->dim, Hq = d->Hq, Hkv = d->Hkv, D = d->D, nqkv = (Hq + 2 * Hkv) * D, HD = Hq * D;
 
@@ -540,6 +547,88 @@ int cover_decoder_forward(const cover_dec_desc* d, const cover_dec_pass* p, void
             //  eager it was fine -- tests/test_fullsize_gpu.py::test_fullsize_config2_n16 under COVER_TAIL_REDUCE=1 caught it)
             hipLaunchKernelGGL(zero_words_k, dim3(1), dim3(64), 0, st, tail_sync, 64);
             HIPCHK(hipGetLastError(), "zero tail-reduction tickets");
+        }
+    }
+    // ---- deferred RMSNorm pass (cover_dec_layer.qkv_wf / gate_up_wf; the pi0 denoise steps: 200 rows = 40 candidates x 5 suffix tokens, 18 layers,
+    //      10 Euler steps per decision). Five launches per layer instead of eight:
+    //        qkv'      x (raw rows) . Wqkv'^T, rows scaled by rsqrt(mean square) from the partial sums of squares down(l-1) left, ONE fp32 slab
+    //        attention the qkv fold + RoPE inside the launch (nothing is written to the scratch suffix cache)
+    //        o_proj    UNSPLIT on 32 x 32 tiles with a sixteen-stage ring: x += attn . Wo^T in the epilogue, partial sums of squares of the new x beside it
+    //        gate_up'  x (raw rows) . Wgu'^T, row scale, GLU
+    //        down      as o_proj; its partial sums of squares feed the next layer's qkv'
+    //      No split-K slabs, no reduction / norm launches, no RoPE launch. Layer 0 takes its input norm as a launch (its input may be fp32).
+    //      COVER_DEFER_NORM=0 keeps the eight-launch path (A/B runs; read per call).
+    {
+        bool dn = p->n_groups == 1 && rows > 64 && rows <= 1024 && !f8 && variant == 0 && (dim % 32) == 0 && !d->layers_host[0].qkv_b;
+        for (int l = 0; l < d->n_layers && dn; ++l) dn = d->layers_host[l].qkv_wf != nullptr && d->layers_host[l].gate_up_wf != nullptr;
+        const char* dn_env = getenv("COVER_DEFER_NORM");
+        if (dn && dn_env && dn_env[0] == '0') dn = false;
+        if (dn) {
+            const cover_dec_group& G = p->groups[0];
+            dn = G.write_scratch && G.T < 16 && G.own_kv_mode == 0 && !(G.seg0_shared && G.T == 1) && G.B * G.T == rows;
+        }
+        if (dn) {
+            const cover_dec_group& G = p->groups[0];
+            const cover_kv_segment& W = G.segs[G.write_seg];
+            const int parts = dim / 32;
+            float* ssq_a = (float*)dn_ssq;                      // behind o_proj
+            float* ssq_b = ssq_a + (size_t)rows * parts;        // behind down
+            const bool f32in = p->x_f32 != nullptr;
+            HIPCHK(launch_rmsnorm(f32in ? (const void*)p->x_f32 : (const void*)x, f32in ? 1 : 0, dim, d->layers_host[0].in_norm_w, d->norm_w_offset,
+                                  d->norm_style, (bf16_t*)h, dim, rows, dim, d->norm_eps, st), "dec in_norm (layer 0)");
+            for (int l = 0; l < d->n_layers; ++l) {
+                const cover_dec_layer& L = d->layers_host[l];
+                const bool first_f32 = (l == 0 && f32in);
+                cover_gemm_epi e;
+                memset(&e, 0, sizeof e);
+                e.out_scale = 1.0f; e.out_f32 = 1;
+                if (l > 0) { e.rs_in = ssq_b; e.rs_ld = parts; e.rs_parts = parts; e.rs_n = dim; e.rs_eps = d->norm_eps; }
+                HIPCHK(launch_gemm_bf16(l == 0 ? (const bf16_t*)h : (const bf16_t*)x, dim, (const bf16_t*)(l == 0 ? L.qkv_w : L.qkv_wf), sk, nqkv, rows, nqkv, dim, &e,
+                                        nullptr, 0, 0, st), "dec qkv (deferred norm, one fp32 slab)");
+                cover_rope_args ra;
+                memset(&ra, 0, sizeof ra);
+                ra.qkv = (bf16_t*)qkv; ra.ld_qkv = nqkv; ra.B = G.B; ra.T = G.T; ra.Hq = Hq; ra.Hkv = Hkv; ra.D = D;
+                ra.positions = G.positions; ra.cos_table = d->cos_table; ra.sin_table = d->sin_table; ra.n_pos = d->n_pos; ra.rope_mode = d->rope_mode;
+                ra.k_cache = (bf16_t*)L.k_cache + G.seg_k_offset[G.write_seg];
+                ra.k_slot_stride = W.k_slot_stride; ra.k_t_stride = W.k_t_stride; ra.k_h_stride = W.k_h_stride;
+                ra.vt_cache = (bf16_t*)L.vt_cache + G.seg_vt_offset[G.write_seg];
+                ra.vt_slot_stride = W.vt_slot_stride; ra.vt_h_stride = W.vt_h_stride; ra.vt_d_stride = W.vt_d_stride;
+                ra.slot_of_batch = G.write_slot_of_batch; ra.t_offset_of_batch = G.write_t_offset_of_batch; ra.t_offset = G.write_t_offset;
+                ra.n_splits = 1; ra.partial = (const float*)sk; ra.bias = nullptr;
+                cover_attn_args aa;
+                memset(&aa, 0, sizeof aa);
+                aa.q = (bf16_t*)qkv; aa.q_b_stride = (long long)G.T * nqkv; aa.q_t_stride = nqkv; aa.q_h_stride = D;
+                aa.out = (bf16_t*)attn; aa.o_b_stride = (long long)G.T * HD; aa.o_t_stride = HD; aa.o_h_stride = D;
+                aa.B = G.B; aa.Tq = G.T; aa.Hq = Hq; aa.Hkv = Hkv; aa.D = D; aa.scale = d->attn_scale; aa.n_seg = G.n_seg;
+                for (int s2 = 0; s2 < G.n_seg; ++s2) {
+                    aa.seg[s2] = G.segs[s2];
+                    aa.seg[s2].k = (const bf16_t*)L.k_cache + G.seg_k_offset[s2];
+                    aa.seg[s2].vt = (const bf16_t*)L.vt_cache + G.seg_vt_offset[s2];
+                }
+                if (attention_rope_fusable(&aa, &ra, G.write_seg)) {
+                    HIPCHK(launch_attention_rope_fused(&aa, &ra, G.write_seg, st), "dec attention (qkv fold + RoPE inside)");
+                } else {
+                    HIPCHK(launch_rope_kv_write(&ra, st), "dec rope/kv");
+                    HIPCHK(launch_attention_bf16(&aa, st), "dec attention");
+                }
+                memset(&e, 0, sizeof e);
+                e.out_scale = 1.0f;
+                e.residual = first_f32 ? (const void*)p->x_f32 : (const void*)x; e.residual_f32 = first_f32 ? 1 : 0; e.ld_residual = dim;
+                e.ssq_out = ssq_a; e.ssq_ld = parts;
+                HIPCHK(launch_gemm_bf16((const bf16_t*)attn, HD, (const bf16_t*)L.o_w, x, dim, rows, dim, HD, &e, nullptr, 0, 0, st), "dec o_proj (unsplit, residual + sums of squares)");
+                memset(&e, 0, sizeof e);
+                e.out_scale = 1.0f; e.act = d->act; e.glu = 1;
+                e.rs_in = ssq_a; e.rs_ld = parts; e.rs_parts = parts; e.rs_n = dim; e.rs_eps = d->norm_eps;
+                HIPCHK(launch_gemm_bf16((const bf16_t*)x, dim, (const bf16_t*)L.gate_up_wf, mlp, d->mlp, rows, 2 * d->mlp, dim, &e, nullptr, 0, 0, st), "dec gate_up (deferred norm)");
+                memset(&e, 0, sizeof e);
+                e.out_scale = 1.0f;
+                e.residual = x; e.ld_residual = dim;
+                e.ssq_out = ssq_b; e.ssq_ld = parts;
+                HIPCHK(launch_gemm_bf16((const bf16_t*)mlp, d->mlp, (const bf16_t*)L.down_w, x, dim, rows, dim, d->mlp, &e, nullptr, 0, 0, st), "dec down (unsplit, residual + sums of squares)");
+            }
+            if (p->final_norm)
+                HIPCHK(launch_rmsnorm(x, 0, dim, d->final_norm_w, d->norm_w_offset, d->norm_style, (bf16_t*)x, dim, rows, dim, d->norm_eps, st), "dec final_norm");
+            return COVER_OK;
         }
     }
     // h = in_norm_0(x); afterwards every norm is folded into the epilogue of the GEMM that produces its input

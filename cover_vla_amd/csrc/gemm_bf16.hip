@@ -1412,6 +1412,10 @@ static EpiDev make_epi(const cover_gemm_epi* e) {
     d.nq8s = e ? e->norm_out8_scale : nullptr;
     d.ldnq8 = e ? e->ld_norm_out8 : 0;
     if (!d.nq8 || !d.nq8s || !d.norm_out || d.norm_style == 2) { d.nq8 = nullptr; d.nq8s = nullptr; }
+    d.ssq_out = e ? e->ssq_out : nullptr;
+    d.rs_in = e ? e->rs_in : nullptr;
+    d.ssq_ld = e ? e->ssq_ld : 0; d.rs_ld = e ? e->rs_ld : 0; d.rs_parts = e ? e->rs_parts : 0; d.rs_n = e ? e->rs_n : 0;
+    d.rs_eps = e ? e->rs_eps : 0.f;
     return d;
 }
 
@@ -1718,7 +1722,7 @@ hipError_t launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* Wp, void* C,
     // ---- tile / split-K selection: fill >= ~1 block per CU when the problem allows it
     // tile configurations: {wave tile (WM, WN) in 16-row units, wave grid, stages}
     struct Cand { int wm, wn, wgm, wgn, nst; };
-    const Cand cands[27] = {
+    const Cand cands[32] = {
         {4, 4, 2, 2, 2},   // 0: 128x128, 4 waves of 64x64, 2 stages (64 KiB)
         {2, 4, 2, 2, 2},   // 1:  64x128, 4 waves of 32x64, 2 stages (48 KiB)
         {2, 2, 2, 2, 3},   // 2:  64x64,  4 waves of 32x32, 3 stages (48 KiB)
@@ -1746,6 +1750,11 @@ hipError_t launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* Wp, void* C,
         {7, 2, 2, 4, 3},   // o (24): 224x128, 8 waves of 112x32, 3 stages (132 KiB)
         {8, 2, 2, 4, 3},   // p (25): 256x128, 8 waves of 128x32, 3 stages (144 KiB)
         {4, 4, 2, 4, 3},   // q (26): 128x256, 8 waves of 64x64,  3 stages (144 KiB)
+        {7, 3, 2, 2, 4},   // r (27): 224x96,  4 waves of 112x48 (one per SIMD), 4 stages (160 KiB)
+        {7, 6, 2, 2, 3},   // s (28): 224x192, 4 waves of 112x96, 3 stages (156 KiB)
+        {7, 4, 2, 2, 3},   // t (29): 224x128, 4 waves of 112x64, 3 stages (132 KiB)
+        {2, 2, 2, 2, 3},   // u (30): 64x64, 4 waves of 32x32, 3 stages (48 KiB, three blocks per CU): few-hundred-row GEMMs with a deferred-norm row scale
+        {1, 1, 2, 2, 16},  // v (31): 32x32, 4 waves of 16x16, 16 stages (128 KiB): UNSPLIT narrow outputs on a long K (fifteen 8-KiB k-tiles in flight)
     };
     // Measured on MI355X (tools/bench_kernels.py, M = 441): this single-barrier-per-k-tile structure is latency-bound per
     // block, so residency beats tile size until the tile grid oversubscribes the chip several times over, while 64x64
@@ -1800,12 +1809,17 @@ hipError_t launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* Wp, void* C,
     // per block; split-K reduction ~4 us + slab bytes at 3 TB/s). Cold weights, M = 448, kernel timestamps, before -> after:
     // qkv 81.5 -> 52 us (224x96/128), gate_up 138 -> 78.5 us (224x192, 1.03 PFLOP/s), down 72.6 + norm -> 43 + 10 us (224x128, 4 slices).
     int S_forced = 0;
+    static const char* v3_env = getenv("COVER_V3");   // 0 keeps the loader-wave kernels where the self-loading ones (gemm_v3.hip) are the default (A/B runs)
+    const bool v3_on = !(v3_env && v3_env[0] == '0') && !f8_on && variant != 2 && (size_t)M * lda * 2 + 4096 < ((size_t)1 << 31);
     {
         static const char* no224 = getenv("COVER_TILES_224");   // experiment knob: 0 disables
         const int t224 = (M + 223) / 224, waste224 = t224 * 224 - M;
         if (variant != 2 && Kp >= 2048 && M >= 400 && waste224 * 10 <= M && !(no224 && no224[0] == '0')) {
-            const int bns[3] = {96, 128, 192}, idx[3] = {17, 15, 16};
-            const double ktile_us[3] = {0.67, 0.70, 1.05};
+            // loader-wave kernels (gemm_tiled_pc): 224x96 (6 MFMA waves) / 224x128 / 224x192; self-loading kernels (gemm_v3.hip, round 5,
+            // in-kernel probe of workgroup 0 at M = 448 / 2232): 224x96 with one wave of 112x48 per SIMD 0.62 us per k-tile, 224x128
+            // 0.69-0.78, 224x192 0.91-1.02; prologue + epilogue 6 / 7 / 10 us
+            const int bns[3] = {96, 128, 192}, idx_pc[3] = {17, 15, 16}, idx_v3[3] = {27, 24, 23};
+            const double kt_pc[3] = {0.67, 0.70, 1.05}, kt_v3[3] = {0.62, 0.72, 0.93}, fix_v3[3] = {6.0, 7.0, 10.0};
             double best = 1e30;
             for (int c = 0; c < 3; ++c) {
                 if (epi.glu && (bns[c] % 32)) continue;
@@ -1814,10 +1828,10 @@ hipError_t launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* Wp, void* C,
                     if (S > 1 && (ws == nullptr || (size_t)S * M * N * sizeof(float) > ws_bytes || epi.glu || (Kp / BK) / S < 8)) break;
                     const long long blocks = (long long)t224 * ((N + bns[c] - 1) / bns[c]) * S;
                     const long long rounds = (blocks + 255) / 256;
-                    double us = rounds * (ktile_us[c] * ((Kp / BK + S - 1) / S) + 5.0);
+                    double us = rounds * ((v3_on ? kt_v3[c] : kt_pc[c]) * ((Kp / BK + S - 1) / S) + (v3_on ? fix_v3[c] : 5.0));
                     if (S > 1) us += 4.0 + (double)S * M * N * 4.0 / 3.0e6;
                     else if (epi.norm_w != nullptr && epi.norm_out != nullptr) us += 6.0;   // the norm is its own launch without a reduction to ride on
-                    if (us < best) { best = us; pick = idx[c]; S_forced = S; }
+                    if (us < best) { best = us; pick = v3_on ? idx_v3[c] : idx_pc[c]; S_forced = S; }
                 }
             }
         }
@@ -1826,14 +1840,27 @@ hipError_t launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* Wp, void* C,
         static const char* force = getenv("COVER_TILE_PICK");  // experiment knob: index into cands
         if (force && force[0] >= '0' && force[0] <= '9') pick = force[0] - '0';
         if (force && force[0] >= 'a' && force[0] <= 'h') pick = 10 + (force[0] - 'a');
-        if (force && force[0] >= 'n' && force[0] <= 'q') pick = 10 + (force[0] - 'a');
+        if (force && force[0] >= 'n' && force[0] <= 'v') pick = 10 + (force[0] - 'a');
     }
-    {   // the loader-wave tiles' self-loading successors (gemm_v3.hip); COVER_V3=0 keeps the loader-wave kernels (A/B runs)
-        static const char* v3_env = getenv("COVER_V3");
-        const bool v3_on = !(v3_env && v3_env[0] == '0') && !f8_on && variant != 2 && (size_t)M * lda * 2 + 4096 < ((size_t)1 << 31);
-        if (v3_on) pick = pick == 16 ? 23 : pick == 15 ? 24 : pick == 12 ? 25 : pick == 13 ? 26 : pick;
-        else if (pick >= 23) pick = pick == 23 ? 16 : pick == 24 ? 15 : pick == 25 ? 12 : 13;
+    // deferred RMSNorm (cover_gemm_epi.ssq_out / rs_in): only the self-loading kernels carry it. The producer of a residual stream runs UNSPLIT on
+    // 32 x 32 tiles with a sixteen-stage ring (M = 200, N = 1024: 224 workgroups, the whole K in one block, no slabs and no reduction
+    // launch); the consumer of the raw rows runs on 64 x 64 tiles.
+    const bool dn_prod = epi.ssq_out != nullptr, dn_cons = epi.rs_in != nullptr;
+    if (dn_prod || dn_cons) {
+        if (!v3_on || M <= 64 || (dn_prod && (epi.glu || epi.out_f32 || (N % 32) != 0 || epi.ssq_ld < N / 32 || epi.norm_out)) ||
+            (dn_cons && (epi.rs_parts <= 0 || epi.rs_n <= 0 || epi.rs_ld < epi.rs_parts)))
+            return hipErrorInvalidValue;
+        pick = dn_prod ? 31 : (pick >= 23 && pick <= 29 ? pick : 30);
+        S_forced = 1;
     }
+    // a forced self-loading pick with COVER_V3=0 (or on a problem the self-loading kernels do not take) falls back to its loader-wave twin
+    {
+        // the 256 x 128 / 128 x 256 tiles (M >= 512 with more than 10 % of 224-row padding: config 4's 704-row prefill) on the self-loading kernel
+        // as well: layer 426 -> 416 us at M = 704 (gate_up 164 -> 157). COVER_V3_BIG=0 keeps the loader-wave kernels.
+        static const char* big3 = getenv("COVER_V3_BIG");
+        if (v3_on && !(big3 && big3[0] == '0')) pick = pick == 12 ? 25 : pick == 13 ? 26 : pick;
+    }
+    if (!v3_on && pick >= 23) pick = (pick == 23 || pick == 28) ? 16 : (pick == 24 || pick == 29) ? 15 : pick == 25 ? 12 : pick == 26 ? 13 : pick == 27 ? 17 : 2;
     if (variant == 2 && pick > 2) pick = 0;
     if (pick == 18 && !(f8_on && gemm_fp8_tiled_supported(18))) return hipErrorInvalidValue;   // 128 x 192 exists as an fp8 kernel only
     const Cand cd = cands[pick];
@@ -1842,7 +1869,9 @@ hipError_t launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* Wp, void* C,
     const int nk_total = Kp / BK;
     int S = 1;
     static const char* force_pick = getenv("COVER_TILE_PICK");
-    if (S_forced > 0 && !force_pick) {
+    if (dn_prod || dn_cons) {
+        S = 1;                                   // (the deferred-norm epilogues exist in the unsplit form only)
+    } else if (S_forced > 0 && !force_pick) {
         S = S_forced;
     } else if (ws != nullptr) {
         while ((long long)tiles_m * tiles_n * S < 192 && S < 8 && nk_total / (S * 2) >= 8 &&
@@ -1897,7 +1926,13 @@ hipError_t launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* Wp, void* C,
                                   7, 2.0 * (double)M * (double)N * (double)K, st);
     } else if (pick >= 23) {
         plan_hit(pick);
-        e = launch_gemm_v3(pick, A, lda, Wp, C, ldc, M, N, Kp, epi, tiles_m, tiles_n, kt_per, S, partial, tcls, twork, st);
+        // an unsplit launch with a plain fp32 output IS one split-K slab: take the raw-slab epilogue (LDS-staged 16-byte stores of the fp32 sums;
+        // the consumer -- the qkv fold of the attention launch -- rounds them exactly as it rounds a sum of slabs)
+        float* part3 = partial;
+        if (S == 1 && epi.out_f32 && !epi.bias && !epi.residual && !epi.lscale && epi.act == ACT_NONE && epi.out_scale == 1.0f && !epi.glu && !epi.norm_out &&
+            ldc == N)
+            part3 = (float*)C;
+        e = launch_gemm_v3(pick, A, lda, Wp, C, ldc, M, N, Kp, epi, tiles_m, tiles_n, kt_per, S, part3, tcls, twork, st);
     } else if (pc) {
         plan_hit(pick);
         // loader waves: one wave issues an LDS-DMA piece every ~60 cycles, four keep the CU's vector memory path busy

@@ -28,6 +28,12 @@ struct EpiDev {
     uint8_t* nq8;           // optional e4m3 twin of norm_out (+ row scales), written by the norm that writes norm_out
     float* nq8s;
     int ldnq8;
+    // deferred RMSNorm (cover_gemm_epi.ssq_out / rs_in): producer side = partial sums of squares per (row, 32-column group) of the stored bf16
+    // output; consumer side = per-row rsqrt(mean square) applied to the fp32 sums (gemm_v3.hip does both)
+    float* ssq_out;
+    const float* rs_in;
+    int ssq_ld, rs_ld, rs_parts, rs_n;
+    float rs_eps;
 };
 
 // e4m3 quantisation of 8 consecutive bf16-valued elements k..k+7 of an activation row into the MX MFMA operand order
@@ -337,6 +343,7 @@ __device__ __forceinline__ void tiled_epilogue_staged(f32x4 (&acc)[WN][WM], cons
             for (int c0 = t; c0 < total; c0 += 2 * nthr) {
                 int rowi[2], chi[2], mi[2];
                 bool ok[2];
+                float sq[2] = {0.f, 0.f};
                 float4 bb[2][2] = {}, ll[2][2] = {}, rf[2][2] = {};
                 uint4 rb[2] = {};
 #pragma unroll
@@ -389,6 +396,21 @@ __device__ __forceinline__ void tiled_epilogue_staged(f32x4 (&acc)[WN][WM], cons
                     }
                     char* dst = base + (size_t)mi[u] * ld_bytes + (size_t)oc0 * esz_out + chi[u] * 16;
                     *(uint4*)dst = make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
+                    if (epi.ssq_out) {
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) { const float b = bfround(v[i]); sq[u] += b * b; }
+                    }
+                }
+                if (epi.ssq_out) {
+                    // the four 16-byte chunks of a 32-column group sit in four consecutive lanes (cpr % 4 == 0, chunk index = lane mod cpr):
+                    // fixed-order sum over the quad, lane 0 of the quad stores
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        float q = sq[u];
+                        q += __shfl_xor(q, 1);
+                        q += __shfl_xor(q, 2);
+                        if (ok[u] && (chi[u] & 3) == 0) epi.ssq_out[(size_t)mi[u] * epi.ssq_ld + ((n0 + chi[u] * 8) >> 5)] = q;
+                    }
                 }
             }
             return;

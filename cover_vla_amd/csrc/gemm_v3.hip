@@ -37,6 +37,14 @@ __device__ __forceinline__ void glds16_s(uint32_t voff, const void* sbase, uint3
         : "memory");
 }
 
+// In-kernel probe of the LAST launch (always on: six stores by one thread of workgroup (0, 0)): wall-clock stamps (100 MHz) at kernel start,
+// loop start, loop end and kernel end, and the shader cycle counter at loop start / end -- the clock the loop really ran at (the matrix
+// peak the rooflines are priced against assumes 2.4 GHz; under MFMA + LDS + HBM load the chip sustains 1.6-1.9) and the split of a
+// launch into prologue / k-loop / epilogue. cover_gemm_probe() reads it.
+__device__ unsigned long long g_v3_probe[8];
+#define V3P(slot, val) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_v3_probe[slot] = (val); } while (0)
+int gemm_v3_probe(unsigned long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_v3_probe), sizeof(g_v3_probe)) == hipSuccess ? 0 : -1; }
+
 template <int V> using IC = std::integral_constant<int, V>;
 // position (MFMA index inside the two-step phase of 2 NM MFMAs that follows a barrier) behind which a wave issues its piece p of PT:
 // evenly spread in general; with a TWO-stage ring the refill of the stage the barrier has just released is the tile the NEXT barrier
@@ -49,20 +57,22 @@ constexpr int v3_half_pieces(int PT, int NM, int NST) {   // pieces issued in th
     return c;
 }
 
-template <int WM, int WN, int NSTA, int NSTB>
-__global__ __launch_bounds__(512) void gemm_tiled_v3(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ Wp, void* C, int ldc, int M, int N,
+template <int WM, int WN, int CGM, int CGN, int NSTA, int NSTB>
+__global__ __launch_bounds__(64 * CGM * CGN) void gemm_tiled_v3(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ Wp, void* C, int ldc, int M, int N,
                                                      int Kp, EpiDev epi, int tiles_m, int tiles_n, int kt_per, float* __restrict__ partial) {
     PCTL(0);
-    constexpr int CGM = 2, CGN = 4;                                       // wave grid: waves w and w + 4 (one SIMD) share the column block
+    V3P(0, wall_clock64());
+    constexpr int NW = CGM * CGN, NH = NW / 2;                            // waves: a CGM x CGN grid of wave tiles (2 x 4: two waves per SIMD, 2 x 2: one)
     constexpr int BM_ = CGM * WM * 16, BN_ = CGN * WN * 16;
     constexpr int A_BYTES = BM_ * BK * 2, B_BYTES = BN_ * BK * 2;
     constexpr int AT = A_BYTES / 1024, BT = B_BYTES / 1024;               // 1-KiB LDS-DMA pieces per k-tile
-    constexpr int PTA = AT / 4, PTB = BT / 4;                             // pieces per wave: waves 0-3 own the activation pieces, 4-7 the weight pieces
+    constexpr int PTA = AT / NH, PTB = BT / NH;                           // pieces per wave: the first half of the waves owns the activation pieces, the second the weight pieces
     constexpr int NM = WM * WN, NR = WM + WN;                             // MFMAs / fragment reads per 32-deep step
-    static_assert(AT % 4 == 0 && BT % 4 == 0, "pieces must split evenly over the four waves of a role");
+    static_assert(NW == 4 || NW == 8, "one or two waves per SIMD");
+    static_assert(AT % NH == 0 && BT % NH == 0, "pieces must split evenly over the waves of a role");
     static_assert(NSTA >= 2 && NSTB >= 2, "a ring needs two stages");
     static_assert((NSTA - 2) * PTA <= 63 && (NSTB - 2) * PTB <= 63, "counted vmcnt must fit its 6-bit field");
-    static_assert(NR <= NM && PTA <= NM && PTB <= NM, "at most one read and one piece behind an MFMA");
+    static_assert(PTA <= 2 * NM && PTB <= 2 * NM, "at most one piece behind an MFMA");
     static_assert(NSTA * A_BYTES + NSTB * B_BYTES <= 160 * 1024, "LDS");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* As = smem;                   // [NSTA][A_BYTES]
@@ -117,13 +127,13 @@ __global__ __launch_bounds__(512) void gemm_tiled_v3(const bf16_t* __restrict__ 
         constexpr int role = decltype(ROLE)::value;
         constexpr int PT = role ? PTB : PTA, NST = role ? NSTB : NSTA, SB = role ? B_BYTES : A_BYTES, KSH = role ? 11 : 7;
         constexpr int HALF = v3_half_pieces(PT, NM, NST);
-        const int wl = w & 3;
+        const int wl = w % NH;
         uint32_t voff[PT];          // per lane: byte offset from the piece's scalar base
         const char* sbase[PT];      // wave-uniform: source of the piece in the slice's first k-tile
         uint32_t dst0[PT];          // wave-uniform: LDS byte address of the piece in stage 0
 #pragma unroll
         for (int i = 0; i < PT; ++i) {
-            const int j = wl + 4 * i;
+            const int j = wl + NH * i;
             if constexpr (role == 0) {   // A: LDS chunk position p = j*64 + lane: row = p>>3, c = p&7 holds global chunk c ^ (row&7)
                 const int row = j * 8 + (lane >> 3), c = lane & 7;
                 int gr = m0 + row;
@@ -181,6 +191,8 @@ __global__ __launch_bounds__(512) void gemm_tiled_v3(const bf16_t* __restrict__ 
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * PT + HALF) : "memory");   // tile 0: everything but the younger tiles and the half tile
         __builtin_amdgcn_s_barrier();
         PCTL(1);
+        V3P(1, wall_clock64());
+        V3P(4, __builtin_readcyclecounter());
         u32x4 xa[WM], wa[WN], xb[WM], wb[WN];
 #pragma unroll
         for (int j = 0; j < NR; ++j) read_nth(a_addr0, b_addr, j, xa, wa);
@@ -209,13 +221,36 @@ __global__ __launch_bounds__(512) void gemm_tiled_v3(const bf16_t* __restrict__ 
         landed(xb, wb);
         group(xb, wb, xa, wa, ca, cb, IC<0>{}, IC<0>{}, cr, IC<0>{}, IC<0>{}, 0);
     };
-    if (w < 4) run(IC<0>{});
+    if (w < NH) run(IC<0>{});
     else run(IC<1>{});
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the surplus pieces of the clamped tail must not land in the epilogue's staging area
+    if (epi.rs_in) {
+        // deferred RMSNorm: the A rows were the RAW residual stream (the norm weight sits in the packed weight): row m of the fp32 sums is
+        // multiplied by rsqrt(mean square of row m), summed in a fixed order from the producer's partial sums of squares
+#pragma unroll
+        for (int f = 0; f < WM; ++f) {
+            int m = m0 + wm * (WM * 16) + f * 16 + r;
+            m = m < M ? m : M - 1;
+            const float* sp = epi.rs_in + (size_t)m * epi.rs_ld;
+            float q = 0.f;
+            for (int p4 = 0; p4 + 4 <= epi.rs_parts; p4 += 4) {
+                const float4 v = *(const float4*)(sp + p4);
+                q += v.x; q += v.y; q += v.z; q += v.w;
+            }
+            for (int p1 = epi.rs_parts & ~3; p1 < epi.rs_parts; ++p1) q += sp[p1];
+            const float rstd = rsqrtf(q / (float)epi.rs_n + epi.rs_eps);
+#pragma unroll
+            for (int b = 0; b < WN; ++b) acc[b][f] *= rstd;
+        }
+    }
     PCTL(2);
+    V3P(5, __builtin_readcyclecounter());
+    V3P(2, wall_clock64());
+    V3P(6, (unsigned long long)nk);
     tiled_epilogue_staged<WM, WN, BM_, BN_>(acc, epi, C, ldc, M, N, m0, n0, m0 + wm * (WM * 16), n0 + wn * (WN * 16), r, g, partial, smem,
-                                            NSTA * A_BYTES + NSTB * B_BYTES, tid, 512);
+                                            NSTA * A_BYTES + NSTB * B_BYTES, tid, 64 * NW);
     PCTL(3);
+    V3P(3, wall_clock64());
 }
 
 // pick -> instantiation (the tile table of launch_gemm_bf16 continues with these indices). COVER_V3_RING=<a><b> (two digits) selects another
@@ -224,13 +259,14 @@ hipError_t launch_gemm_v3(int pick, const bf16_t* A, int lda, const bf16_t* Wp, 
                           int tiles_n, int kt_per, int S, float* partial, int prof_cls, double prof_work, hipStream_t st) {
     hipError_t e = hipSuccess;
     if ((size_t)M * lda * 2 + 4096 >= ((size_t)1 << 31)) return hipErrorInvalidValue;   // 32-bit lane offsets of the activation pieces
-    dim3 grid(tiles_m * tiles_n, S), block(512);
+    dim3 grid(tiles_m * tiles_n, S);
     static const char* ring_env = getenv("COVER_V3_RING");
     const int ring = ring_env ? atoi(ring_env) : 0;
-#define LAUNCH_V3(WM_, WN_, NA_, NB_)                                                                                        \
+#define LAUNCH_V3(WM_, WN_, CGM_, CGN_, NA_, NB_)                                                                            \
     do {                                                                                                                     \
-        auto kfn = gemm_tiled_v3<WM_, WN_, NA_, NB_>;                                                                        \
-        const size_t lds = ((size_t)NA_ * 2 * WM_ * 16 + (size_t)NB_ * 4 * WN_ * 16) * BK * 2;                               \
+        auto kfn = gemm_tiled_v3<WM_, WN_, CGM_, CGN_, NA_, NB_>;                                                            \
+        const size_t lds = ((size_t)NA_ * CGM_ * WM_ * 16 + (size_t)NB_ * CGN_ * WN_ * 16) * BK * 2;                         \
+        dim3 block(64 * CGM_ * CGN_);                                                                                        \
         static hipError_t attr = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
         e = attr;                                                                                                            \
         if (e == hipSuccess) {                                                                                               \
@@ -242,10 +278,15 @@ hipError_t launch_gemm_v3(int pick, const bf16_t* A, int lda, const bf16_t* Wp, 
         }                                                                                                                    \
     } while (0)
     switch (pick) {
-        case 23: if (ring == 24) LAUNCH_V3(7, 3, 2, 4); else if (ring == 23) LAUNCH_V3(7, 3, 2, 3); else LAUNCH_V3(7, 3, 3, 3); break;
-        case 24: if (ring == 34) LAUNCH_V3(7, 2, 3, 4); else if (ring == 26) LAUNCH_V3(7, 2, 2, 6); else if (ring == 25) LAUNCH_V3(7, 2, 2, 5); else LAUNCH_V3(7, 2, 3, 3); break;
-        case 25: if (ring == 34) LAUNCH_V3(8, 2, 3, 4); else if (ring == 26) LAUNCH_V3(8, 2, 2, 6); else LAUNCH_V3(8, 2, 3, 3); break;
-        case 26: if (ring == 24) LAUNCH_V3(4, 4, 2, 4); else if (ring == 43) LAUNCH_V3(4, 4, 4, 3); else LAUNCH_V3(4, 4, 3, 3); break;
+        case 23: if (ring == 23) LAUNCH_V3(7, 3, 2, 4, 2, 3); else LAUNCH_V3(7, 3, 2, 4, 3, 3); break;          // 224x192, 8 waves of 112x48
+        case 24: if (ring == 34) LAUNCH_V3(7, 2, 2, 4, 3, 4); else LAUNCH_V3(7, 2, 2, 4, 3, 3); break;          // 224x128, 8 waves of 112x32
+        case 25: LAUNCH_V3(8, 2, 2, 4, 3, 3); break;                                                            // 256x128, 8 waves of 128x32
+        case 26: LAUNCH_V3(4, 4, 2, 4, 3, 3); break;                                                            // 128x256, 8 waves of 64x64
+        case 27: if (ring == 34) LAUNCH_V3(7, 3, 2, 2, 3, 4); else LAUNCH_V3(7, 3, 2, 2, 4, 4); break;          // 224x96,  4 waves of 112x48 (one per SIMD)
+        case 28: LAUNCH_V3(7, 6, 2, 2, 3, 3); break;                                                            // 224x192, 4 waves of 112x96
+        case 29: if (ring == 34) LAUNCH_V3(7, 4, 2, 2, 3, 4); else LAUNCH_V3(7, 4, 2, 2, 3, 3); break;          // 224x128, 4 waves of 112x64
+        case 30: LAUNCH_V3(2, 2, 2, 2, 3, 3); break;                                                            // 64x64,   4 waves of 32x32 (three blocks per CU)
+        case 31: if (ring == 8) LAUNCH_V3(1, 1, 2, 2, 8, 8); else LAUNCH_V3(1, 1, 2, 2, 16, 16); break;         // 32x32,   4 waves of 16x16, 16-stage ring
         default: return hipErrorInvalidValue;
     }
 #undef LAUNCH_V3

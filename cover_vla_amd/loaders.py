@@ -202,3 +202,83 @@ def load_pi0fast_pretrained(path: str, head_dim: int = 256, vit_heads: int = 16)
              vit_layers=1 + max(int(k.split(".")[2]) for k in n if k.startswith("vision.blocks.")), patch=patch,
              image=int(round(n["vision.pos"].shape[0] ** 0.5)) * patch, D=head_dim, Hkv=kD // head_dim, Hq=qD // head_dim, vit_heads=vit_heads)
     return n, c, cfg
+
+
+# ------------------------------------------------------------------------------------------------ verifier checkpoint
+# The merged verifier checkpoint is a pickled .pt (efficient_ensemble_merged.py:37-53: {"ensemble_components": [ {sub-module name ->
+# state dict | scalar} ... ], optionally backbone / use_transformer / history_length / action_dim / num_models}). Unpickling arbitrary
+# files is code execution, so the serving side never does it: the .pt is converted ONCE, where it was produced or downloaded and is
+# trusted, into tensors in safetensors + the non-tensor fields in JSON, and EfficientEnsembleMerged loads that pair. A .pt
+# path is still accepted, through torch.load(weights_only=True) (tensors, dicts, lists and plain scalars only).
+_VER_META = "cover_verifier.json"
+_VER_TENSORS = "cover_verifier.safetensors"
+
+
+def _flatten_verifier(ck: dict):
+    tensors, meta = {}, {"format": "cover-verifier-1", "top": {}, "components": []}
+    for k, v in ck.items():
+        if k != "ensemble_components":
+            meta["top"][k] = v if isinstance(v, (str, int, float, bool)) or v is None else str(v)
+    for i, comp in enumerate(ck["ensemble_components"]):
+        cm = {"subs": {}, "scalars": {}}
+        for name, val in comp.items():
+            if isinstance(val, dict):
+                keys = []
+                for kk, t in val.items():
+                    if not torch.is_tensor(t):
+                        t = torch.as_tensor(t)
+                    tensors[f"components.{i}.{name}.{kk}"] = t.detach().cpu().contiguous()
+                    keys.append(kk)
+                cm["subs"][name] = keys
+            elif val is None:
+                cm["scalars"][name] = None
+            elif torch.is_tensor(val):
+                tensors[f"components.{i}.{name}"] = val.detach().cpu().contiguous()
+                cm["subs"][name] = None                      # a bare tensor
+            else:
+                cm["scalars"][name] = float(val) if isinstance(val, (int, float)) else val
+        meta["components"].append(cm)
+    return tensors, meta
+
+
+def verifier_pt_to_safetensors(pt_path: str, out_dir: str) -> str:
+    """ONE-OFF, on a machine where the .pt is trusted: unpickles the merged verifier checkpoint and writes out_dir/cover_verifier.safetensors
+    (every tensor, named components.<i>.<sub-module>.<key>) + out_dir/cover_verifier.json (structure and scalars). Returns out_dir."""
+    from safetensors.torch import save_file
+    ck = torch.load(pt_path, map_location="cpu", weights_only=False)
+    return save_verifier_checkpoint(ck, out_dir)
+
+
+def save_verifier_checkpoint(ck: dict, out_dir: str) -> str:
+    from safetensors.torch import save_file
+    tensors, meta = _flatten_verifier(ck)
+    os.makedirs(out_dir, exist_ok=True)
+    save_file(tensors, os.path.join(out_dir, _VER_TENSORS))
+    with open(os.path.join(out_dir, _VER_META), "w") as f:
+        json.dump(meta, f, indent=1)
+    return out_dir
+
+
+def load_verifier_checkpoint(path: str) -> dict:
+    """Directory written by verifier_pt_to_safetensors -> the reference's checkpoint dict (no unpickling). A .pt / .pth file is read with
+    torch.load(weights_only=True); if that refuses it (custom classes inside), convert it once with verifier_pt_to_safetensors."""
+    if os.path.isdir(path):
+        from safetensors.torch import load_file
+        with open(os.path.join(path, _VER_META)) as f:
+            meta = json.load(f)
+        if meta.get("format") != "cover-verifier-1":
+            raise ValueError(f"{path}: not a converted verifier checkpoint")
+        tensors = load_file(os.path.join(path, _VER_TENSORS))
+        comps = []
+        for i, cm in enumerate(meta["components"]):
+            comp = dict(cm["scalars"])
+            for name, keys in cm["subs"].items():
+                comp[name] = tensors[f"components.{i}.{name}"] if keys is None else {kk: tensors[f"components.{i}.{name}.{kk}"] for kk in keys}
+            comps.append(comp)
+        return dict(meta["top"], ensemble_components=comps)
+    try:
+        return torch.load(path, map_location="cpu", weights_only=True)
+    except Exception as e:   # noqa: BLE001 -- whatever the restricted unpickler refuses
+        raise ValueError(f"{path}: torch.load(weights_only=True) refused this checkpoint ({type(e).__name__}: {e}). Convert it once, on a machine where "
+                         "the file is trusted, with cover_vla_amd.loaders.verifier_pt_to_safetensors(pt_path, out_dir) and pass out_dir instead") from e
+

@@ -103,9 +103,13 @@ def gemm(a: torch.Tensor, lin: PackedLinear, *, act: str = "none", residual: Opt
          layer_scale: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, out_f32: bool = False,
          out_scale: float = 1.0, variant: int = 0, ws: Optional[torch.Tensor] = None, norm_w: Optional[torch.Tensor] = None,
          norm_out: Optional[torch.Tensor] = None, norm_style: int = 0, norm_w_offset: float = 0.0, norm_eps: float = 1e-6,
-         norm_b: Optional[torch.Tensor] = None, a8: Optional[tuple] = None
+         norm_b: Optional[torch.Tensor] = None, a8: Optional[tuple] = None, ssq_out: Optional[torch.Tensor] = None,
+         rs_in: Optional[torch.Tensor] = None, rs_n: int = 0, rs_eps: float = 1e-6
          ) -> torch.Tensor:
     """out[M, n_out] = epi(a[M, K] @ W^T). `a` is bf16 with row stride >= padded K (zero padded).
+    Deferred RMSNorm (cover_gemm_epi.ssq_out / rs_in, M > 64): ssq_out fp32 [M, N / 32] receives the partial sums of squares of the stored bf16
+    output rows (producer of a residual stream: unsplit, bf16 output); rs_in fp32 [M, parts] are such partials of the INPUT rows: row m of the
+    fp32 sums is multiplied by rsqrt(sum(rs_in[m]) / rs_n + rs_eps) before the epilogue (the norm weight folded into `lin` by the caller).
     a8 = (q uint8 [M, >= padded K], scales fp32 [M]) from quantize_act_fp8: with an fp8 weight twin and M > 64 the GEMM runs on the
     MX-scaled fp8 matrix instruction (config 5) on those operands."""
     _chk_dev(a, residual, out)
@@ -135,6 +139,14 @@ def gemm(a: torch.Tensor, lin: PackedLinear, *, act: str = "none", residual: Opt
         e.norm_w, e.norm_out, e.ld_norm_out = norm_w.data_ptr(), norm_out.data_ptr(), norm_out.stride(0)
         e.norm_style, e.norm_w_offset, e.norm_eps = norm_style, norm_w_offset, norm_eps
         e.norm_b = _ptr(norm_b)
+    if ssq_out is not None:
+        _chk_dev(ssq_out)
+        assert ssq_out.dtype == torch.float32 and ssq_out.shape[0] == M and ssq_out.stride(1) == 1
+        e.ssq_out, e.ssq_ld = ssq_out.data_ptr(), ssq_out.stride(0)
+    if rs_in is not None:
+        _chk_dev(rs_in)
+        assert rs_in.dtype == torch.float32 and rs_in.shape[0] == M and rs_in.stride(1) == 1 and rs_n > 0
+        e.rs_in, e.rs_ld, e.rs_parts, e.rs_n, e.rs_eps = rs_in.data_ptr(), rs_in.stride(0), rs_in.shape[1], rs_n, rs_eps
     if ws is None:
         ws = gemm_workspace(M, lin.N, lin.K, a.device)   # None when this shape needs no split-K scratch
     L.check(h.cover_gemm_bf16(a.data_ptr(), a.stride(0), lin.wp.data_ptr(), out.data_ptr(), out.stride(0), M, lin.N,
@@ -153,11 +165,23 @@ def decode_chain_status() -> None:
     L.check(L.lib().cover_decode_chain_status(), "decode_chain_status")
 
 
+def gemm_probe() -> dict:
+    """In-kernel probe of the most recent self-loading tiled GEMM launch (cover_gemm_probe): microseconds of prologue / k-loop / epilogue of
+    its first workgroup, k-tiles, shader cycles per k-tile and the clock (GHz) the loop ran at. Synchronises the device."""
+    torch.cuda.synchronize()
+    buf = (C.c_ulonglong * 8)()
+    L.check(L.lib().cover_gemm_probe(buf), "gemm_probe")
+    w0, w1, w2, w3, c0, c1, nk = (int(buf[i]) for i in range(7))
+    loop_us = (w2 - w1) * 0.01
+    return dict(prologue_us=(w1 - w0) * 0.01, loop_us=loop_us, epilogue_us=(w3 - w2) * 0.01, k_tiles=nk,
+                cycles_per_k_tile=(c1 - c0) / max(nk, 1), clock_ghz=(c1 - c0) / max(loop_us, 1e-9) / 1e3)
+
+
 def gemm_plan_counts(reset: bool = False) -> list:
     """Launch counters per GEMM kernel plan since the last reset (cover_gemm_plan_counts): [0..18] tiled picks (14..17 = 224-row
-    tiles), [19] / [20] / [22] weight-streaming generations 2 / 3 / 1, [21] fp8 MFMA tiles, [23..26] self-loading 8-wave tiles
-    (gemm_v3.hip: 224x192, 224x128, 256x128, 128x256)."""
-    n = 27
+    tiles), [19] / [20] / [22] weight-streaming generations 2 / 3 / 1, [21] fp8 MFMA tiles, [23..29] self-loading tiles
+    (gemm_v3.hip: 8 waves 224x192, 224x128, 256x128, 128x256; 4 waves 224x96, 224x192, 224x128, 64x64, 32x32 with a 16-stage ring)."""
+    n = 32
     buf = (C.c_longlong * n)()
     L.lib().cover_gemm_plan_counts(buf, n, 1 if reset else 0)
     return list(buf)

@@ -264,10 +264,24 @@ OPENVLA_SMALL = dict(dino_dim=128, dino_layers=3, dino_heads=4, dino_mlp=256, di
 
 
 def openvla_state(c: dict, seed: int = 1234, nontrivial: bool = True, std: float = 0.02, device="cpu",
-                  wdtype=torch.float32) -> Dict[str, Tensor]:
+                  wdtype=torch.float32, peaked: bool = False) -> Dict[str, Tensor]:
     """Prismatic / OpenVLA-7B shaped checkpoint (no such model exists in the reference):
     dino.* and siglip.* (vit_state layout), projector.fc{1,2,3}.{weight,bias}, llm.* (decoder_state layout, Llama),
-    lm_head.weight."""
+    lm_head.weight.
+
+    peaked=True: the SAME draws (same seeds, same order), re-scaled so that the checkpoint behaves like a trained one where it matters
+    for parity checks -- decisions with a margin. An i.i.d. N(0, std) decoder is chaotic (every layer's update is as large as the
+    stream: two bf16 evaluation paths of the 7B shapes end ~8-10 % apart) and its logits are flat (256 Gaussian bins: top-1 / top-2
+    margins of a fraction of that noise), so "bit-exact arg-max" can hardly ever be decided on it. Three changes, all standard:
+      * depth-scaled residual projections: o_proj / down_proj x (2 L)^-1/2 / 4 (the GPT-2 / Llama initialisation rule, and a further 1/4:
+        the 64 sub-layer updates of the 7B stack then add up to a third of the embedding's magnitude instead of all of it);
+      * token embeddings at unit scale (x 1 / std), as large as the sum of the layer updates, so the stream has a clean component;
+      * a peaked action head: the n_bins action rows of lm_head are multiplied by log-normal gains exp(1.5 z) (normalised to unit RMS,
+        seed + 7): a few bins carry most of the probability mass, as after training.
+    Measured at the 7B shapes on the GPU (tools/dbg/r05/peaked_sweep.py, greedy M = 1 vs M = 8 decode rows, i.e. two tilings of the same bf16
+    arithmetic, 8 prompts x 7 steps): steps whose top-1 / top-2 margin exceeds twice the logit difference 24 of 56 on the flat checkpoint,
+    44 with (2 L)^-1/2 alone, 55 of 56 with this setting (30 of them by more than 10 x); the 32 sampled candidates of a decision stay
+    distinct (31 different token rows of 32) and greedy decoding picks action tokens 98 % of the time."""
     g = _G(seed, nontrivial, std, device, wdtype)
     n_patches = (c["image"] // c["patch"]) ** 2
     sd = {}
@@ -286,6 +300,19 @@ def openvla_state(c: dict, seed: int = 1234, nontrivial: bool = True, std: float
                               mlp=c["llm_mlp"], rms_base=1.0, vocab=c["vocab"]).items():
         sd["llm." + k] = v
     sd["lm_head.weight"] = g.w(c["vocab"], c["llm_dim"])
+    if peaked:
+        import os
+        L = c["llm_layers"]
+        rs = (2.0 * L) ** -0.5 * float(os.environ.get("COVER_SYNTH_RES", "0.25"))         # (experiment knobs: tools/dbg/r05/peaked_sweep.py)
+        for l in range(L):
+            sd[f"llm.layers.{l}.self_attn.o_proj.weight"] *= rs
+            sd[f"llm.layers.{l}.mlp.down_proj.weight"] *= rs
+        sd["llm.embed_tokens.weight"] *= (float(os.environ.get("COVER_SYNTH_EMBED", "1.0")) / std)
+        z = torch.randn(c["n_bins"], generator=torch.Generator().manual_seed(seed + 7))
+        gain = torch.exp(float(os.environ.get("COVER_SYNTH_SIGMA", "1.5")) * z)
+        gain = (gain / gain.pow(2).mean().sqrt()).to(sd["lm_head.weight"].device, sd["lm_head.weight"].dtype)
+        lo, hi = c["tok_vocab"] - c["n_bins"], c["tok_vocab"]
+        sd["lm_head.weight"][lo:hi] *= gain[:, None]
     return sd
 
 

@@ -359,13 +359,16 @@ class SigLIP2Encoder:
 class EfficientEnsembleMerged:
     def __init__(self, merged_checkpoint, device="cuda:0", encoder: Optional[SigLIP2Encoder] = None,
                  preprocess: Optional[Callable] = None, tokenizer: Optional[Callable] = None):
-        """merged_checkpoint: path to the merged .pt (torch.load) or the already-loaded dict
-        (efficient_ensemble_merged.py:37-53). encoder/preprocess/tokenizer: the SigLIP2 towers and the open_clip
+        """merged_checkpoint: the already-loaded dict, or a path -- the directory written once by loaders.verifier_pt_to_safetensors, or the
+        merged .pt itself, read with torch.load(weights_only=True) (efficient_ensemble_merged.py:37-53 unpickles it; this side never does). encoder/preprocess/tokenizer: the SigLIP2 towers and the open_clip
         CPU transforms are injected (they are un-vendored pip dependencies of the reference, :57,69)."""
         self.device = device
         dev = torch.device(device)
-        ck = torch.load(merged_checkpoint, map_location="cpu", weights_only=False) if isinstance(merged_checkpoint, str) \
-            else merged_checkpoint
+        if isinstance(merged_checkpoint, str):   # a converted directory (safetensors + JSON) or a .pt read WITHOUT arbitrary unpickling
+            from .loaders import load_verifier_checkpoint
+            ck = load_verifier_checkpoint(merged_checkpoint)
+        else:
+            ck = merged_checkpoint
         if "ensemble_components" in ck and "backbone" not in ck:
             self.backbone, self.use_transformer, self.history_length, self.action_dim = \
                 "hf-hub:timm/ViT-L-16-SigLIP2-384", True, 10, 7

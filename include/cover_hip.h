@@ -87,6 +87,19 @@ typedef struct cover_gemm_epi {
      * would make of the stored bf16 norm_out rows -- the next GEMM's fp8 operand without another launch. */
     void* norm_out8;
     float* norm_out8_scale;
+    /* Deferred RMSNorm (round 5; LDS-tiled launches with more than 64 rows only). A PRODUCER GEMM that writes a residual stream x
+     * leaves, beside it, the rows' partial sums of squares: ssq_out[m * ssq_ld + n / 32] = sum over the 32-column group of the stored
+     * bf16 values squared (what a norm kernel reading x back would sum; unsplit launch, bf16 output, N % 32 == 0, ssq_ld >= N / 32).
+     * The CONSUMER GEMM takes x itself as its A operand, with the norm weight folded into its packed weight along k at load time
+     * (W'[n, k] = W[n, k] * (norm_w_offset + norm_w[k])), and multiplies row m of its fp32 sums by
+     * rsqrt(sum_{p < rs_parts} rs_in[m * rs_ld + p] / rs_n + rs_eps) before its own epilogue: norm(x) W^T without the norm launch and
+     * without the reduction launch the norm used to ride on. One rounding point moves: norm(x) is no longer rounded to bf16 before
+     * the product (the weight product W' is). NULL = off. */
+    float* ssq_out;
+    const float* rs_in;
+    int ssq_ld, rs_ld, rs_parts, rs_n;
+    float rs_eps;
+    int _pad_epi;
 } cover_gemm_epi;
 
 /* bytes needed for the packed form of an [N, K] weight (K padded to a multiple of 128, N to 16) */
@@ -126,8 +139,15 @@ int cover_gemm_bf16(const void* A, int lda, const void* Wp, void* C, int ldc, in
 /* Which kernel plan every GEMM launch of this process took since the last reset (test / audit hook: a parity test can assert
  * that a shape really ran on the tile it means to cover). counts[0..18] = LDS-tiled configurations (14..17 = the 224-row
  * loader-wave tiles of the M = 448 prefill pass, 12/13 = 256x128 / 128x256), [19] = second-generation weight streaming,
- * [20] = third generation, [21] = fp8 MFMA tiles, [22] = first generation. Copies min(n, 23) counters, returns 23. */
+ * [20] = third generation, [21] = fp8 MFMA tiles, [22] = first generation, [23..29] = the self-loading tiles of gemm_v3.hip
+ * (8 waves: 224x192, 224x128, 256x128, 128x256; 4 waves: 224x96, 224x192, 224x128, 64x64, 32x32 / 16 stages). Copies min(n, 32) counters,
+ * returns 32. */
 int cover_gemm_plan_counts(long long* counts, int n, int reset);
+/* In-kernel probe of the most recent launch of the self-loading tiled GEMM (gemm_v3.hip; plan counters 23..31), written by one thread of
+ * its first workgroup: out[0..3] = 100 MHz wall-clock stamps at kernel start / k-loop start / k-loop end / kernel end, out[4..5] = shader
+ * cycle counter at k-loop start / end, out[6] = k-tiles of the loop. (out[5] - out[4]) / (out[2] - out[1]) / 10 ns = the clock the loop ran
+ * at. Synchronous read of 8 device words (synchronise the stream first). Measurement hook: nothing on the product path reads it. */
+int cover_gemm_probe(unsigned long long* out);
 
 /* ------------------------------------------------------------------------------------------------
  * Flash-style attention on MFMA, fp32 softmax, over up to 3 KV segments per query row.
@@ -429,6 +449,12 @@ typedef struct cover_dec_layer {
     /* optional e4m3 twins (cover_pack_weight_fp8) + packed-order scales of the four projections; NULL = bf16 only */
     const void* qkv_w8; const float* qkv_s; const void* o_w8; const float* o_s;
     const void* gate_up_w8; const float* gate_up_s; const void* down_w8; const float* down_s;
+    /* optional (deferred RMSNorm, cover_gemm_epi.rs_in): the qkv / gate_up weights with this layer's input / post-attention norm weight
+     * folded in along k (W * (norm_w_offset + norm_w)[None, :], packed like qkv_w / gate_up_w). When every layer carries both, passes of
+     * 65 .. 1024 rows over ONE few-token group whose write segment is scratch (the pi0 denoise steps) run five launches per layer --
+     * qkv', attention with the qkv fold + RoPE inside, o_proj (unsplit, residual + partial sums of squares), gate_up', down (the
+     * same) -- instead of eight. NULL = the norms stay where they are. */
+    const void* qkv_wf; const void* gate_up_wf;
 } cover_dec_layer;
 typedef struct cover_dec_desc {
     int dim, Hq, Hkv, D, mlp, n_layers, act;  /* act: COVER_ACT_GELU_TANH (Gemma) / COVER_ACT_SILU (Llama) */

@@ -90,25 +90,30 @@ def _decision_properties(pipe, dev, P, S):
         perm = torch.tensor([3, 0, 7, 1, 6, 2, 5, 4], device=dev)
         tokp, _ = pipe.policy.sample(i["frame"], i["toks"][perm], i["lens"][perm], S, u.view(P, S, 7)[perm].reshape(P * S, 7).contiguous(), 1.0)
         assert torch.equal(tokp.view(P, S, 7), tv[perm])
-    # (d) greedy decoding of a single prompt vs the first row of a batched greedy run (M = 1 vs M = 8 decode rows; the prefill passes
-    # have 280 vs 448 rows and run on other GEMM tiles, so the two runs' logits differ by bf16-level noise: measured max |diff| 0.14
-    # against top-1 / top-2 margins of 0.03 .. 1.7 on these random-init weights). Data-decided criterion: a step whose margin exceeds twice
-    # the logit difference must pick the same token.
-    t8, t1 = {}, {}
+    # (d) greedy decoding of every prompt ALONE vs its row of the batched greedy run (M = 1 vs M = P decode rows; the prefill passes have
+    # ~280 vs 448 rows and run on other GEMM tiles, so the two runs' logits differ by bf16-level noise). Data-decided criterion: a step whose
+    # top-1 / top-2 margin exceeds twice the logit difference must pick the same token, bit for bit. On the checkpoint with decision margins
+    # (bench.Pipeline(peaked=True), the default) at least 6 of 7 steps must be decided on average over the prompts; the flat i.i.d. checkpoint
+    # of rounds 1-4 (logit noise 0.14 against margins of 0.03 .. 1.7) decided 3 of 7.
+    t8 = {}
     g8, _ = pipe.policy.sample(i["frame"], i["toks"], i["lens"], 1, trace=t8)
-    # the M = 1 run is teacher-forced on the M = 8 run's tokens (it still returns its own picks), so that every step compares like with like
-    g1, _ = pipe.policy.sample(i["frame"], i["toks"][:1], i["lens"][:1], 1, trace=t1, force_tokens=g8[:1].contiguous())
     V = pipe.c["tok_vocab"]
-    decided = 0
-    for s_ in range(7):
-        a8, a1 = t8["logits"][s_][0, :V].float(), t1["logits"][s_][0, :V].float()
-        err = float((a8 - a1).abs().max())
-        top = a8.topk(2).values
-        assert err < 0.5, (s_, err)
-        if float(top[0] - top[1]) > 2 * err:
-            assert int(g1[0, s_]) == int(g8[0, s_]), (s_, err, float(top[0] - top[1]))
-            decided += 1
-    assert decided >= 3, decided
+    decided, worst_err = 0, 0.0
+    for p_ in range(P):
+        t1 = {}
+        # the M = 1 run is teacher-forced on the batched run's tokens (it still returns its own picks), so that every step compares like with like
+        g1, _ = pipe.policy.sample(i["frame"], i["toks"][p_:p_ + 1], i["lens"][p_:p_ + 1], 1, trace=t1, force_tokens=g8[p_:p_ + 1].contiguous())
+        for s_ in range(7):
+            a8, a1 = t8["logits"][s_][p_, :V].float(), t1["logits"][s_][0, :V].float()
+            err = float((a8 - a1).abs().max())
+            top = a8.topk(2).values
+            worst_err = max(worst_err, err / max(float(a8.std()), 1e-6))
+            if float(top[0] - top[1]) > 2 * err:
+                assert int(g1[0, s_]) == int(g8[p_, s_]), (p_, s_, err, float(top[0] - top[1]))
+                decided += 1
+    print(f"greedy M = 1 vs M = {P}: {decided} of {7 * P} steps data-decided (all equal), worst logit difference {worst_err:.3f} of the logit spread")
+    assert worst_err < 0.5, worst_err
+    assert decided >= (6 if getattr(pipe, "peaked", False) else 3) * P, decided
     # (e) the serialised decision bench.py profiles (one stream, no hipGraph replay, both towers on one stream) selects the same
     idx3, tok3, _ = pipe.decision(serial=True)
     assert idx3 == idx1 and torch.equal(tok3, tok1)

@@ -221,6 +221,49 @@ def test_gather_records_world1_fp32_payload():
 
 
 # ------------------------------------------------------------------------------------------------ checkpoint format
+def test_verifier_checkpoint_converts_once_and_loads_without_pickle(tmp_path):
+    """SURVEY 8c: the merged verifier .pt (efficient_ensemble_merged.py:37-53) -> safetensors + JSON once, then loaded with no unpickling;
+    the .pt itself is only ever read through the restricted unpickler. Both routes give back the reference's dict, tensor for tensor,
+    for the transformer and the MLP action encoder and with the optional top-level fields."""
+    from cover_vla_amd import loaders, synth
+    for kw in (dict(), dict(use_transformer=False)):
+        try:
+            ck = synth.verifier_checkpoint(2, seed=3, **kw)
+        except TypeError:
+            if kw:
+                continue
+            raise
+        ck = dict(ck, backbone="hf-hub:timm/ViT-L-16-SigLIP2-384", use_transformer=not kw, history_length=10, action_dim=7, num_models=2)
+        pt = tmp_path / f"merged{len(kw)}.pt"
+        torch.save(ck, str(pt))
+        out = loaders.verifier_pt_to_safetensors(str(pt), str(tmp_path / f"conv{len(kw)}"))
+        for got in (loaders.load_verifier_checkpoint(out), loaders.load_verifier_checkpoint(str(pt))):
+            assert {k: v for k, v in got.items() if k != "ensemble_components"} == {k: v for k, v in ck.items() if k != "ensemble_components"}
+            assert len(got["ensemble_components"]) == 2
+            for a, b in zip(got["ensemble_components"], ck["ensemble_components"]):
+                assert set(a) == set(b)
+                for name, val in b.items():
+                    if isinstance(val, dict):
+                        assert set(a[name]) == set(val)
+                        assert all(torch.equal(a[name][kk], torch.as_tensor(val[kk])) for kk in val)
+                    elif torch.is_tensor(val):
+                        assert torch.equal(a[name], val)
+                    else:
+                        assert a[name] == val
+    # a pickle with code in it is refused, with the conversion named in the message
+    import pickle
+
+    class Evil:
+        def __reduce__(self):
+            return (print, ("unpickled",))
+    bad = tmp_path / "bad.pt"
+    with open(bad, "wb") as f:
+        pickle.dump({"ensemble_components": [Evil()]}, f)
+    with pytest.raises(ValueError, match="verifier_pt_to_safetensors"):
+        loaders.load_verifier_checkpoint(str(bad))
+
+
+
 def test_pi0_checkpoint_key_layout_round_trip(tmp_path):
     """neutral -> the reference's safetensors key layout (convert_pi0_to_hf_lerobot.py:67-245,384-390) -> neutral."""
     import json

@@ -70,6 +70,48 @@ def test_gemm_long_panel_tiles(dev, M, N, K, glu):
     assert (d <= 0.06 + 2e-2 * ref.abs()).all()
 
 
+@pytest.mark.parametrize("M,dim,mlp,style", [(200, 1024, 4096, 0), (130, 512, 1536, 1), (200, 1024, 4096, 1)])
+def test_gemm_deferred_rmsnorm_producer_and_consumer(dev, M, dim, mlp, style):
+    """Deferred RMSNorm (cover_gemm_epi.ssq_out / rs_in; the pi0 expert's M = 200 rows): a producer GEMM (down: [M, mlp] -> x += ., unsplit on
+    the 32 x 32 sixteen-stage tiles) leaves the partial sums of squares of the stored bf16 rows -- bit-exact against sums over the stored x in
+    the kernel's order -- and the consumer (gate_up with the norm weight folded into the packed weight, GLU epilogue) scales its fp32 sums by
+    rsqrt(mean square): against norm-then-GEMM in fp32 on the same bf16 operands rel-L2 < 6e-3, and against the library's own
+    GEMM-with-fused-norm + GEMM two-launch path within bf16 rounding of the normalised rows (< 8e-3)."""
+    g = torch.Generator(device=dev).manual_seed(M + dim + style)
+    a = torch.randn(M, mlp, device=dev, generator=g).bfloat16()
+    wd = (torch.randn(dim, mlp, device=dev, generator=g) * 0.03).bfloat16()
+    res = torch.randn(M, dim, device=dev, generator=g).bfloat16()
+    nw = (torch.randn(dim, device=dev, generator=g) * 0.2 + (1.0 if style == 1 else 0.0)).bfloat16().float()
+    off = 0.0 if style == 1 else 1.0
+    wgu = (torch.randn(2 * mlp, dim, device=dev, generator=g) * 0.03).bfloat16()
+    # producer
+    x = res.clone()
+    ssq = torch.full((M, dim // 32), -1.0, device=dev)
+    ops.gemm_plan_counts(reset=True)
+    ops.gemm(a, ops.pack_linear(wd), residual=x, out=x, ssq_out=ssq)
+    assert ops.gemm_plan_counts()[31] == 1
+    ref_x = res.float() + a.float() @ wd.float().T
+    assert rel_l2(x, ref_x) < 6e-3
+    xs = x.float().view(M, dim // 32, 4, 8).pow(2).sum(-1)                       # per 16-byte chunk: eight squares in element order
+    exp = (xs[:, :, 0] + xs[:, :, 1]) + (xs[:, :, 2] + xs[:, :, 3])              # quad: xor-1 then xor-2 butterfly
+    assert torch.allclose(ssq, exp, rtol=2e-6, atol=0) and (ssq >= 0).all()
+    # consumer: folded weight + row scale vs norm-then-GEMM
+    lin_f = ops.pack_linear(wgu.float() * (off + nw)[None, :], glu=True)
+    ops.gemm_plan_counts(reset=True)
+    y = ops.gemm(x, lin_f, act="gelu_tanh", rs_in=ssq, rs_n=dim, rs_eps=1e-6)
+    assert ops.gemm_plan_counts()[30] == 1
+    xf = x.float()
+    hn = xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-6) * (off + nw)
+    yy = hn @ wgu.float().T
+    ref = torch.nn.functional.gelu(yy[:, :mlp], approximate="tanh") * yy[:, mlp:]
+    assert rel_l2(y, ref) < 6e-3
+    # the two-launch path of the library on the same operands: GEMM with the fused norm epilogue, then the GLU GEMM on the bf16 normalised rows
+    x2, h2 = res.clone(), torch.empty(M, dim, dtype=torch.bfloat16, device=dev)
+    ops.gemm(a, ops.pack_linear(wd), residual=x2, out=x2, norm_w=nw, norm_out=h2, norm_style=style, norm_w_offset=off, norm_eps=1e-6)
+    y2 = ops.gemm(h2, ops.pack_linear(wgu, glu=True), act="gelu_tanh")
+    assert rel_l2(x, x2.float()) < 4e-3 and rel_l2(y, y2.float()) < 8e-3
+
+
 @pytest.mark.parametrize("N,K,kind", [(12288, 4096, "bias_residual"), (22016, 4096, "glu"), (4096, 4096, "norm"), (4096, 11008, "norm")])
 def test_gemm_headline_prefill_tiles_m448_bf16(dev, N, K, kind):
     """The headline decision's prefill pass is M = 448 rows (256 patch rows + 8 prompts x 24 text rows) on the Llama-2-7B shapes:
@@ -98,7 +140,7 @@ def test_gemm_headline_prefill_tiles_m448_bf16(dev, N, K, kind):
         ops.gemm(a, ops.pack_linear(w), residual=out, out=out, norm_w=nw, norm_out=h, norm_style=1, norm_w_offset=0.0, norm_eps=1e-5)
         ref = res.float() + y
     counts = ops.gemm_plan_counts()
-    assert sum(counts[14:18]) + sum(counts[23:25]) == 1 and sum(counts) == 1, counts   # a 224-row tile (loader-wave or self-loading kernel)
+    assert sum(counts[14:18]) + sum(counts[23:30]) == 1 and sum(counts) == 1, counts   # a 224-row tile (loader-wave or self-loading kernel)
     assert rel_l2(out, ref) < 6e-3
     d = (out.float() - ref).abs()
     assert (d <= 0.06 + 2e-2 * ref.abs()).all()

@@ -341,6 +341,30 @@ def test_oracle_openvla_end_to_end_matches_hf_composition(prec):
     assert n_dec >= 10
 
 
+def test_oracle_openvla_batched_execution_equals_per_candidate():
+    """OR.sample_batched (ONE left-padded batched forward over N un-deduplicated rows, the way the reference executes a policy call --
+    what bench.py times as `cpu_baseline.as_executed_batched`) is the same function as OR.sample (one candidate at a time): in fp32 the
+    per-step logits agree to 2e-3 and every token is identical, greedy and sampled, with ragged prompt lengths and samples > 1; the same
+    structure through HF's fixture: tokens of the HF composition reproduced exactly."""
+    from cover_ref import openvla as OR
+    from gen_golden_hf import openvla_e2e_weights
+    z = np.load(os.path.join(GOLD, "hf_openvla_e2e_tiny.npz"))
+    c, sd = openvla_e2e_weights(int(z["weight_seed"]))
+    frame, toks, lens = torch.from_numpy(z["frame"]), torch.from_numpy(z["toks"]), torch.from_numpy(z["lens"])
+    with _fp32_blocks(), torch.no_grad():
+        tr = {}
+        tb = OR.sample_batched(c, sd, frame, toks, lens, 1, None, trace=tr)
+        assert torch.equal(tb, torch.from_numpy(z["tokens_fp32"]))
+        assert torch.allclose(tr["logits"], torch.from_numpy(z["logits_fp32"]), atol=2e-3)
+        g = torch.Generator().manual_seed(5)
+        u = torch.rand(toks.shape[0] * 2, 7, generator=g)
+        ta, tbb = {}, {}
+        a = OR.sample(c, sd, frame, toks, lens, 2, u, 1.0, trace=ta)
+        b = OR.sample_batched(c, sd, frame, toks, lens, 2, u, 1.0, trace=tbb)
+        assert torch.equal(a, b)
+        assert torch.allclose(ta["logits"], tbb["logits"], atol=2e-3)
+
+
 # ------------------------------------------------------------------------------------------------ pi0-FAST token path (SURVEY 8 f4)
 def _fast_case(name):
     from gen_golden_pi0fast import fast_inputs
