@@ -862,6 +862,18 @@ def main():
         # ---- rooflines: kernel start/stop stamps of every GEMM / attention launch of one extra (serialised) decision
         ms, cnt, work = profile_decision(pipe, world, rank, cpu_gather)
         out.update(roofline_objects(ms, cnt, work, ms_per_step, out["config"]["lib_sha16"]))
+        try:   # context for roofline_mfma (never its denominator): the clock the prefill tiles really run at, read inside the kernel
+            pr = _ops.gemm_probe()
+            if isinstance(out.get("roofline_mfma"), dict) and pr["k_tiles"] > 0:
+                out["roofline_mfma"]["in_kernel_clock"] = {
+                    "ghz": round(pr["clock_ghz"], 3), "cycles_per_k_tile": round(pr["cycles_per_k_tile"], 1), "k_tiles": pr["k_tiles"],
+                    "prologue_us": round(pr["prologue_us"], 2), "loop_us": round(pr["loop_us"], 2), "epilogue_us": round(pr["epilogue_us"], 2),
+                    "kernel": "last self-loading tiled GEMM launch of the profiled decision (gemm_v3.hip, workgroup 0: the prefill pass's last down projection, 224 x 128 "
+                              "tile): shader cycle counter over the 100 MHz wall clock across its k-loop",
+                    "note": "context only: the fractions above stay priced against 2.5 PFLOP/s = the matrix peak at 2.4 GHz; under MFMA + LDS + HBM load the chip "
+                            "sustains the clock reported here (power limit), so the same kernel time is a larger share of the peak actually available"}
+        except Exception as e:   # noqa: BLE001 -- a measurement hook must never take the bench line down
+            out.setdefault("notes", []).append(f"in-kernel clock probe unavailable: {e}")
     if a.dtype == "fp8" and world == 1 and not a.no_agreement:
         out["fp8_vs_bf16"] = fp8_agreement(pipe, dev, a, n_prompts_global, prompt_ids)
     if rank == 0 and world == 1 and not a.no_cpu_baseline and not a.small:

@@ -557,12 +557,16 @@ int cover_decoder_forward(const cover_dec_desc* d, const cover_dec_pass* p, void
     //        gate_up'  x (raw rows) . Wgu'^T, row scale, GLU
     //        down      as o_proj; its partial sums of squares feed the next layer's qkv'
     //      No split-K slabs, no reduction / norm launches, no RoPE launch. Layer 0 takes its input norm as a launch (its input may be fp32).
-    //      COVER_DEFER_NORM=0 keeps the eight-launch path (A/B runs; read per call).
+    //      OPT-IN (COVER_DEFER_NORM=1, read per call): measured on MI355X at the pi0 expert's shapes (tools/dbg/r05/bench_expert.py, 18 layers x
+    //      200 rows, eager and as a replayed graph): 74.5 us per layer-step against 67.8 us for the eight launches -- the unsplit producers save
+    //      what their reduction launch cost (o_proj 12.8 -> 10.2-11.1 us, down 13.4 -> 13.2-13.6) and no more, the consumers pay ~1-4 us for
+    //      summing the partials behind their k-loop, and the kernel boundaries saved were nearly free (the launches of a stream overlap at
+    //      their edges: eight kernels of 69.2 us of kernel time take 67.8 us). docs/OPTIMISATION_LOG.md round 5.
     {
         bool dn = p->n_groups == 1 && rows > 64 && rows <= 1024 && !f8 && variant == 0 && (dim % 32) == 0 && !d->layers_host[0].qkv_b;
         for (int l = 0; l < d->n_layers && dn; ++l) dn = d->layers_host[l].qkv_wf != nullptr && d->layers_host[l].gate_up_wf != nullptr;
         const char* dn_env = getenv("COVER_DEFER_NORM");
-        if (dn && dn_env && dn_env[0] == '0') dn = false;
+        if (dn && !(dn_env && dn_env[0] == '1')) dn = false;
         if (dn) {
             const cover_dec_group& G = p->groups[0];
             dn = G.write_scratch && G.T < 16 && G.own_kv_mode == 0 && !(G.seg0_shared && G.T == 1) && G.B * G.T == rows;

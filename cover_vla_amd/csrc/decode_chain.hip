@@ -397,7 +397,7 @@ __device__ __forceinline__ void gemm_phase(const ChainPhase& ph, int M, char* sm
                     for (int e = 0; e < 4; ++e) {           // epi_store4_glu's arithmetic
                         float gg = bfround(gv[e]);
                         const float uu = bfround(uv[e]);
-                        gg = bfround(act_apply(gg, ph.act));
+                        gg = bfround(act_apply_bf16(gg, ph.act));
                         o[e] = bfround(gg * uu);
                     }
                     st8_agent(ph.C + (size_t)m * ph.ldc + (nb >> 1) * 16 + 4 * g, pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3]));

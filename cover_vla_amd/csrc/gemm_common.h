@@ -1,6 +1,7 @@
 // Shared device code of the GEMM kernels (gemm_bf16.hip, gemm_fp8.hip): the epilogue description, the per-group epilogue
 // arithmetic with its bf16 rounding points, and the direct / LDS-staged tile epilogues.
 #pragma once
+#include <type_traits>
 #include "common.h"
 #include "kernels.h"
 
@@ -88,7 +89,7 @@ __device__ __forceinline__ void epi_value4(const EpiDev& e, int m, int n0, int N
             float x = v[i];
             if (e.bias) x += b[i];
             x = bfround(x);
-            if (e.act != ACT_NONE) x = bfround(act_apply(x, e.act));
+            if (e.act != ACT_NONE) x = bfround(act_apply_bf16(x, e.act));
             if (e.lscale) x = bfround(x * ls[i]);
             if (e.residual) x = x + r[i];
             if (e.out_scale != 1.0f) x *= e.out_scale;
@@ -101,7 +102,7 @@ __device__ __forceinline__ void epi_value4(const EpiDev& e, int m, int n0, int N
         float x = v[i];
         if (e.bias && (full || n0 + i < N)) x += e.bias[n0 + i];
         x = bfround(x);                       // nn.Linear output rounding point
-        if (e.act != ACT_NONE) x = bfround(act_apply(x, e.act));
+        if (e.act != ACT_NONE) x = bfround(act_apply_bf16(x, e.act));
         v[i] = x;
     }
     if (e.lscale) {
@@ -192,7 +193,7 @@ __device__ __forceinline__ void epi_store4_glu(const EpiDev& e, void* C, int ldc
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         float gg = bfround(g[i]), uu = bfround(u[i]);
-        gg = bfround(act_apply(gg, e.act));
+        gg = bfround(act_apply_bf16(gg, e.act));
         v[i] = bfround(gg * uu);
     }
     if (e.out_f32) {
@@ -280,9 +281,12 @@ __device__ __forceinline__ void tiled_epilogue(f32x4 (&acc)[WN][WM], const EpiDe
 // mode 1: plain / GLU -- the accumulators rounded to bf16 (the nn.Linear output rounding point), nothing else.
 template <int WM, int WN, int F>
 __device__ __forceinline__ void staged_fill_row(f32x4 (&acc)[WN][WM], char* st, int pitch, int m0, int n0, int mw, int nw, int r, int g,
-                                                int mode) {
-    char* row = st + (size_t)(mw + F * 16 + r - m0) * pitch;
-    if (mode == 0) {
+                                                int mode, int r0, int rpp) {
+    // rows [r0, r0 + rpp) of the tile are staged in this pass (a 16-row fragment lies inside one pass: rpp % 16 == 0)
+    const int lr = mw + F * 16 - m0 - r0;
+    char* row = st + (size_t)(lr + r) * pitch;
+    if (lr < 0 || lr >= rpp) {
+    } else if (mode == 0) {
 #pragma unroll
         for (int b = 0; b < WN; ++b)
             *(float4*)(row + (nw - n0 + b * 16 + 4 * g) * 4) = make_float4(acc[b][F][0], acc[b][F][1], acc[b][F][2], acc[b][F][3]);
@@ -295,7 +299,7 @@ __device__ __forceinline__ void staged_fill_row(f32x4 (&acc)[WN][WM], char* st, 
             *(uint2*)(row + (nw - n0 + b * 16 + 4 * g) * 2) = p;
         }
     }
-    if constexpr (F + 1 < WM) staged_fill_row<WM, WN, F + 1>(acc, st, pitch, m0, n0, mw, nw, r, g, mode);
+    if constexpr (F + 1 < WM) staged_fill_row<WM, WN, F + 1>(acc, st, pitch, m0, n0, mw, nw, r, g, mode, r0, rpp);
 }
 
 // BM x BN tile of the block at (m0, n0); the calling threads are `nthr` consecutive threads with index `t` (every one of them
@@ -318,20 +322,28 @@ __device__ __forceinline__ void tiled_epilogue_staged(f32x4 (&acc)[WN][WM], cons
     char* base = raw ? (char*)(partial + (size_t)blockIdx.y * M * N) : (char*)C;
     const size_t ld_bytes = (size_t)(raw ? N : ldc) * esz_out;
     const int cvalid = min(ocols, Nout - oc0);                         // ragged last column tile: whole 16-byte chunks only
-    const bool ok = (size_t)BM * pitch <= (size_t)st_bytes && cvalid > 0 && ((cvalid * esz_out) & 15) == 0 && (ld_bytes & 15) == 0 &&
+    // rows per staging pass: the whole tile when it fits the (dead) pipeline stages, else half of it (a 224 x 192 tile of fp32 slab values is
+    // 172 KiB: its direct, un-staged epilogue -- 16 rows x 16 bytes per store instruction -- took 14.7 us of a 53 us launch at M = 2 232)
+    const int rpp = ((size_t)BM * pitch <= (size_t)st_bytes || (BM % 32) != 0) ? BM : BM / 2;
+    const int npass = BM / rpp;
+    const bool ok = (size_t)rpp * pitch <= (size_t)st_bytes && cvalid > 0 && ((cvalid * esz_out) & 15) == 0 && (ld_bytes & 15) == 0 &&
                     ((((uintptr_t)base) + (size_t)oc0 * esz_out) & 15) == 0 && !((glu || plain) && epi.out_f32);
     if (!ok) {   // uniform over the block
         tiled_epilogue<WM, WN>(acc, epi, C, ldc, M, N, mw, nw, r, g, partial);
         return;
     }
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");       // every wave is done reading the pipeline stages
+    const int cpr = (cvalid * esz_out) >> 4;                           // 16-byte chunks per output row
+    const int total = rpp * cpr;
+    const unsigned magic = 0xFFFFFFFFu / (unsigned)cpr + 1u;            // c / cpr == umulhi(c, magic) for every c < 2^32 / cpr (c < 16 K here) ...
+    auto div_cpr = [&](int c) -> int { return cpr == 1 ? c : (int)__umulhi((unsigned)c, magic); };   // ... except cpr == 1, whose magic is 2^32
+    for (int pass = 0; pass < npass; ++pass) {
+    const int r0 = pass * rpp;
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");       // every wave is done reading the pipeline stages / the previous pass's tile
     PCTL(4);
-    staged_fill_row<WM, WN, 0>(acc, st, pitch, m0, n0, mw, nw, r, g, mode);
+    staged_fill_row<WM, WN, 0>(acc, st, pitch, m0, n0, mw, nw, r, g, mode, r0, rpp);
     PCTL(5);
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     PCTL(6);
-    const int cpr = (cvalid * esz_out) >> 4;                           // 16-byte chunks per output row
-    const int total = BM * cpr;
     if (generic && !epi.out_f32) {
         // Generic epilogue, bf16 output, with the operand loads HOISTED: per-block timelines of the 64 x 64 tile at ViT sizes showed 4.0 of
         // the 4.5 us epilogue in this store loop -- bias / layer-scale / residual were read element by element BEHIND the LDS reads, two
@@ -349,7 +361,7 @@ __device__ __forceinline__ void tiled_epilogue_staged(f32x4 (&acc)[WN][WM], cons
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
                     const int c = c0 + u * nthr;
-                    rowi[u] = c / cpr; chi[u] = c - rowi[u] * cpr; mi[u] = m0 + rowi[u];
+                    rowi[u] = div_cpr(c); chi[u] = c - rowi[u] * cpr; mi[u] = m0 + r0 + rowi[u];
                     ok[u] = c < total && mi[u] < M;
                     const int mm = ok[u] ? mi[u] : (M - 1), cc = ok[u] ? chi[u] : 0;        // clamped: loads stay unconditional
                     const int n = n0 + cc * 8;
@@ -388,7 +400,7 @@ __device__ __forceinline__ void tiled_epilogue_staged(f32x4 (&acc)[WN][WM], cons
                         float x = v[i];
                         if (epi.bias) x += bv[i];
                         x = bfround(x);
-                        if (epi.act != ACT_NONE) x = bfround(act_apply(x, epi.act));
+                        if (epi.act != ACT_NONE) x = bfround(act_apply_bf16(x, epi.act));
                         if (epi.lscale) x = bfround(x * lv[i]);
                         if (epi.residual) x = x + rv[i];
                         if (epi.out_scale != 1.0f) x *= epi.out_scale;
@@ -413,12 +425,38 @@ __device__ __forceinline__ void tiled_epilogue_staged(f32x4 (&acc)[WN][WM], cons
                     }
                 }
             }
-            return;
+            continue;
         }
     }
+    if (glu && (epi.act == ACT_SILU || epi.act == ACT_GELU_TANH)) {
+        // GLU store loop with the activation selected ONCE (the per-element switch of act_apply inside an 8-wide body was a scalar branch per
+        // element): output columns 8 ch .. 8 ch + 7 = pair ch / 2, half ch % 2: gate at tile column 32 (ch / 2) + 8 (ch % 2), up 16 further.
+        // epi_store4_glu's arithmetic on the already bf16-rounded gate / up values.
+        auto body = [&](auto ACT) {
+            constexpr int act = decltype(ACT)::value;
+            for (int c = t; c < total; c += nthr) {
+                const int row = div_cpr(c), ch = c - row * cpr;
+                const int m = m0 + r0 + row;
+                if (m >= M) continue;
+                const char* gp = st + (size_t)row * pitch + ((ch >> 1) * 32 + (ch & 1) * 8) * 2;
+                const uint4 gq = *(const uint4*)gp, uq = *(const uint4*)(gp + 32);
+                const uint32_t gw[4] = {gq.x, gq.y, gq.z, gq.w}, uw[4] = {uq.x, uq.y, uq.z, uq.w};
+                uint32_t ow[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float g0 = bfround(act_apply_bf16(bf2f((bf16_t)(gw[i] & 0xffffu)), act)), g1 = bfround(act_apply_bf16(bf2f((bf16_t)(gw[i] >> 16)), act));
+                    ow[i] = pack_bf2(g0 * bf2f((bf16_t)(uw[i] & 0xffffu)), g1 * bf2f((bf16_t)(uw[i] >> 16)));
+                }
+                *(uint4*)(base + (size_t)m * ld_bytes + (size_t)oc0 * esz_out + ch * 16) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+            }
+        };
+        if (epi.act == ACT_SILU) body(std::integral_constant<int, ACT_SILU>{});
+        else body(std::integral_constant<int, ACT_GELU_TANH>{});
+        continue;
+    }
     for (int c = t; c < total; c += nthr) {
-        const int row = c / cpr, ch = c - row * cpr;
-        const int m = m0 + row;
+        const int row = div_cpr(c), ch = c - row * cpr;
+        const int m = m0 + r0 + row;
         if (m >= M) continue;
         const char* lrow = st + (size_t)row * pitch;
         char* dst = base + (size_t)m * ld_bytes + (size_t)oc0 * esz_out + ch * 16;
@@ -431,7 +469,7 @@ __device__ __forceinline__ void tiled_epilogue_staged(f32x4 (&acc)[WN][WM], cons
             uint32_t ow[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {   // epi_store4_glu's arithmetic on the already bf16-rounded gate / up values
-                const float g0 = bfround(act_apply(bf2f((bf16_t)(gw[i] & 0xffffu)), epi.act)), g1 = bfround(act_apply(bf2f((bf16_t)(gw[i] >> 16)), epi.act));
+                const float g0 = bfround(act_apply_bf16(bf2f((bf16_t)(gw[i] & 0xffffu)), epi.act)), g1 = bfround(act_apply_bf16(bf2f((bf16_t)(gw[i] >> 16)), epi.act));
                 ow[i] = pack_bf2(g0 * bf2f((bf16_t)(uw[i] & 0xffffu)), g1 * bf2f((bf16_t)(uw[i] >> 16)));
             }
             *(uint4*)dst = make_uint4(ow[0], ow[1], ow[2], ow[3]);
@@ -452,6 +490,21 @@ __device__ __forceinline__ void tiled_epilogue_staged(f32x4 (&acc)[WN][WM], cons
             }
         }
     }
+    }   // passes
+}
+
+// LDS-DMA of 16 B per lane with a scalar base: LDS destination = M0 (wave-uniform) + lane * 16, global source = sbase + voff (per lane)
+__device__ __forceinline__ void glds16_s(uint32_t voff, const void* sbase, uint32_t lds_wave_base_u32) {
+    uint32_t keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %3\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, %2\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voff), "s"(sbase), "s"(lds_wave_base_u32)
+        : "memory");
 }
 
 // gemm_fp8.hip: the LDS-tiled GEMM on the MX-scaled fp8 matrix instruction, for the tile configurations listed there

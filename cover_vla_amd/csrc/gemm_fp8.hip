@@ -24,6 +24,7 @@
 // LDS latency hides behind the MFMAs without a second fragment set (which would not fit the register budget of a 12-wave block).
 // (First version: all fragment reads right after the barrier, then the MFMAs behind counted waits -- qkv at M = 512 1478 TFLOP/s.)
 #include <stdlib.h>
+#include <type_traits>
 #include <hip/hip_ext.h>
 #include "gemm_common.h"
 
@@ -289,6 +290,203 @@ __global__ __launch_bounds__(64 * (CGM * CGN + NL)) void gemm_tiled_pc_f8(const 
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Self-loading form of the kernel above (round 5; the fp8 twin of gemm_v3.hip): 8 waves, NO loader waves -- 256 registers per lane instead of the
+// 168 of a 12-wave block -- every wave issues LDS-DMA pieces itself, spread between its MFMAs at compile-time slots: the first half of the waves
+// owns the activation pieces, the second half the weight pieces (one DMA role per wave: a wave's vmcnt retires in order, and each role keeps
+// its own ring depth NSTA / NSTB). The consumer side is the in-place-refill pipeline of gemm_tiled_pc_f8 unchanged (phase 0 | barrier |
+// middle phases | last phase); the barrier behind phase 0 of tile kt publishes tile kt + 1 and releases the stage of tile kt, which the
+// pieces issued during the middle and last phases refill with tile kt + NST. Every wave waits for ITS OWN pieces of tile kt + 1 with a counted
+// vmcnt in front of that barrier; the surplus issues at the end of the K range re-load the last tile (clamped), so every count stays exact.
+// ---------------------------------------------------------------------------------------------------
+template <int V> using IC8 = std::integral_constant<int, V>;
+// DMA slot s of a tile = behind the MFMAs of middle phase s + 1 (s < WN - 2), then behind MFMA s - (WN - 2) of the last phase
+template <int B, int WM, int WN, bool REFILL, typename DMA>
+__device__ __forceinline__ void mid_phases_dma(f32x4 (&acc)[WN][WM], u32x4 (&xlo)[WM], u32x4 (&xhi)[WM], u32x4 (&wlo)[WN], u32x4 (&whi)[WN], uint32_t ba, DMA& dma) {
+    if constexpr (B < WN - 1) {
+#pragma unroll
+        for (int f = 0; f < WM; ++f) acc[B][f] = mfma_f8(wlo[B], whi[B], xlo[f], xhi[f], acc[B][f]);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (REFILL) {
+            ds_read128<B * 2048>(wlo[B], ba);
+            ds_read128<B * 2048 + 1024>(whi[B], ba);
+            dma(IC8<B - 1>{});
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        mid_phases_dma<B + 1, WM, WN, REFILL>(acc, xlo, xhi, wlo, whi, ba, dma);
+    }
+}
+template <int F, int WM, int WN, bool REFILL, typename DMA>
+__device__ __forceinline__ void last_phase_dma(f32x4 (&acc)[WN][WM], u32x4 (&xlo)[WM], u32x4 (&xhi)[WM], u32x4 (&wlo)[WN], u32x4 (&whi)[WN], uint32_t a0, uint32_t a1,
+                                               uint32_t ba, DMA& dma) {
+    if constexpr (F < WM) {
+        acc[WN - 1][F] = mfma_f8(wlo[WN - 1], whi[WN - 1], xlo[F], xhi[F], acc[WN - 1][F]);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (REFILL) {
+            ds_read128<F * 2048>(xlo[F], a0);
+            ds_read128<F * 2048>(xhi[F], a1);
+            dma(IC8<WN - 2 + F>{});
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        last_phase_dma<F + 1, WM, WN, REFILL>(acc, xlo, xhi, wlo, whi, a0, a1, ba, dma);
+    } else if constexpr (REFILL) {
+        ds_read128<(WN - 1) * 2048>(wlo[WN - 1], ba);
+        ds_read128<(WN - 1) * 2048 + 1024>(whi[WN - 1], ba);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+template <int WM, int WN, int CGM, int CGN, int NSTA, int NSTB>
+__global__ __launch_bounds__(64 * CGM * CGN) void gemm_tiled_v3_f8(const uint8_t* __restrict__ A8, int lda8, const uint8_t* __restrict__ W8, void* C, int ldc, int M,
+                                                                   int N, int Kp, EpiDev epi, int tiles_m, int tiles_n, int kt_per, float* __restrict__ partial,
+                                                                   const float* __restrict__ a_scale, const float* __restrict__ w_scale) {
+    constexpr int NW = CGM * CGN, NH = NW / 2;
+    constexpr int BM_ = CGM * WM * 16, BN_ = CGN * WN * 16;
+    constexpr int A_BYTES = BM_ * 128, B_BYTES = BN_ * 128;   // one 128-deep k-tile: 128 B per row
+    constexpr int AT = A_BYTES / 1024, BT = B_BYTES / 1024;
+    constexpr int PTA = AT / NH, PTB = BT / NH;
+    constexpr int NSLOT = WN - 2 + WM;                        // DMA slots per tile (see mid_phases_dma / last_phase_dma)
+    static_assert(NW == 8, "two waves per SIMD");
+    static_assert(AT % NH == 0 && BT % NH == 0, "pieces must split evenly over the waves of a role");
+    static_assert(WN >= 2, "the pipelined consumer refills w[0] while w[WN-1] is still needed");
+    static_assert(NSTA >= 2 && NSTB >= 2 && (NSTA - 1) * PTA <= 63 && (NSTB - 1) * PTB <= 63, "ring depths / counted vmcnt field");
+    static_assert(NSTA * A_BYTES + NSTB * B_BYTES <= 160 * 1024, "LDS");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* As = smem;                    // [NSTA][A_BYTES]
+    char* Bs = smem + NSTA * A_BYTES;   // [NSTB][B_BYTES]
+    const int nwg = tiles_m * tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+        const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+        bid = base + (bid >> 3);
+    }
+    const int tn = bid / tiles_m, tm = bid % tiles_m;
+    const int m0 = tm * BM_, n0 = tn * BN_;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int K64 = Kp >> 6;
+    const int N16 = (N + 15) >> 4;
+    const int nk_total = Kp >> 7;
+    const int kt0 = blockIdx.y * kt_per;
+    const int nk = min(kt_per, nk_total - kt0);
+    const uint32_t as_u32 = __builtin_amdgcn_readfirstlane(lds_addr_u32(As));
+    const uint32_t bs_u32 = __builtin_amdgcn_readfirstlane(lds_addr_u32(Bs));
+    const int wm = w / CGN, wn = w % CGN;
+    const int r = lane & 15, g = lane >> 4;
+    f32x4 acc[WN][WM];  // [n-block b][m-frag f]
+#pragma unroll
+    for (int b = 0; b < WN; ++b)
+#pragma unroll
+        for (int f = 0; f < WM; ++f) acc[b][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const uint32_t a_addr0 = lds_addr_u32(As) + ((wm * (WM * 16) + r) * 8 + ((0 * 4 + g) ^ (r & 7))) * 16;
+    const uint32_t a_addr1 = lds_addr_u32(As) + ((wm * (WM * 16) + r) * 8 + ((1 * 4 + g) ^ (r & 7))) * 16;
+    const uint32_t b_addr = lds_addr_u32(Bs) + (wn * WN * 2 * 64 + lane) * 16;
+
+    auto run = [&](auto ROLE) {
+        constexpr int role = decltype(ROLE)::value;
+        constexpr int PT = role ? PTB : PTA, NST = role ? NSTB : NSTA, SB = role ? B_BYTES : A_BYTES, KSH = role ? 11 : 7;
+        const int wl = w % NH;
+        uint32_t voff[PT];
+        const char* sbase[PT];
+        uint32_t dst0[PT];
+#pragma unroll
+        for (int i = 0; i < PT; ++i) {
+            const int j = wl + NH * i;
+            if constexpr (role == 0) {   // A: LDS chunk position p = j*64 + lane: row = p>>3, c = p&7 holds global chunk c ^ (row&7)
+                const int row = j * 8 + (lane >> 3), c = lane & 7;
+                int gr = m0 + row;
+                gr = gr < M ? gr : M - 1;
+                voff[i] = (uint32_t)((size_t)gr * lda8 + ((c ^ (row & 7)) << 4));
+                sbase[i] = (const char*)(A8 + (size_t)kt0 * 128);
+                dst0[i] = as_u32 + j * 1024;
+            } else {
+                const int nbi = j >> 1, kbi = j & 1;
+                int nb = (n0 >> 4) + nbi;
+                nb = nb < N16 ? nb : N16 - 1;
+                voff[i] = lane * 16;
+                sbase[i] = (const char*)(W8 + ((size_t)nb * K64 + (size_t)kt0 * 2 + kbi) * 1024);
+                dst0[i] = bs_u32 + j * 1024;
+            }
+        }
+        auto issue = [&](int i, int stage, int t) { glds16_s(voff[i], sbase[i] + ((size_t)(uint32_t)t << KSH), dst0[i] + stage * SB); };
+        // ---- prologue: this wave's pieces of tiles 0 .. NST-1 (every stage), then tile 0 landed -> barrier -> all of its fragments requested
+#pragma unroll
+        for (int s2 = 0; s2 < NST; ++s2)
+#pragma unroll
+            for (int p = 0; p < PT; ++p) issue(p, s2, min(s2, nk - 1));
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 1) * PT) : "memory");
+        asm volatile("s_barrier" ::: "memory");
+        u32x4 xlo[WM], xhi[WM], wlo[WN], whi[WN];
+        {
+            const uint32_t ba = b_addr;
+            read_w_frags_range<0, WN - 1, WN>(wlo, whi, ba);
+            read_x_frags<0, WM>(xlo, xhi, a_addr0, a_addr1);
+            ds_read128<(WN - 1) * 2048>(wlo[WN - 1], ba);
+            ds_read128<(WN - 1) * 2048 + 1024>(whi[WN - 1], ba);
+        }
+        int na = NSTA > 1 ? 1 : 0, nb_ = NSTB > 1 ? 1 : 0;    // read stages of tile kt + 1 in the activation / weight ring
+        int cr = 0;                                           // this role's ring: stage of tile kt (released by the barrier behind phase 0)
+        for (int kt = 0; kt + 1 < nk; ++kt) {
+            phase0<0, WM, WN>(acc, xlo, xhi, wlo, whi);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * PT) : "memory");   // own pieces of tile kt + 1 landed; NST - 2 younger tiles in flight
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");          // w[WN-1] landed too: stage kt is free; tile kt+1 is published
+            asm volatile("" : "+v"(wlo[WN - 1]), "+v"(whi[WN - 1]));
+            __builtin_amdgcn_sched_barrier(0);
+            const uint32_t a0 = a_addr0 + na * A_BYTES, a1 = a_addr1 + na * A_BYTES, ba = b_addr + nb_ * B_BYTES;
+            ds_read128<0>(wlo[0], ba);
+            ds_read128<1024>(whi[0], ba);
+            __builtin_amdgcn_sched_barrier(0);
+            const int dt = min(kt + NST, nk - 1), ds = cr;
+            auto dma = [&](auto SLOT) {
+                constexpr int slot = decltype(SLOT)::value;
+#pragma unroll
+                for (int p = 0; p < PT; ++p)
+                    if ((p * NSLOT) / PT == slot) issue(p, ds, dt);
+            };
+            mid_phases_dma<1, WM, WN, true>(acc, xlo, xhi, wlo, whi, ba, dma);
+            last_phase_dma<0, WM, WN, true>(acc, xlo, xhi, wlo, whi, a0, a1, ba, dma);
+            na = na == NSTA - 1 ? 0 : na + 1;
+            nb_ = nb_ == NSTB - 1 ? 0 : nb_ + 1;
+            cr = cr == NST - 1 ? 0 : cr + 1;
+        }
+        {   // last tile: no refills, no DMA
+            phase0<0, WM, WN>(acc, xlo, xhi, wlo, whi);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            asm volatile("" : "+v"(wlo[WN - 1]), "+v"(whi[WN - 1]));
+            __builtin_amdgcn_sched_barrier(0);
+            mid_phases<1, WM, WN, false>(acc, xlo, xhi, wlo, whi, 0u);
+            last_phase<0, WM, WN, false>(acc, xlo, xhi, wlo, whi, 0u, 0u, 0u);
+        }
+    };
+    if (w < NH) run(IC8<0>{});
+    else run(IC8<1>{});
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the surplus pieces of the clamped tail must not land in the epilogue's staging area
+    // quantisation scales (constant along k): row scale of A x channel scale of W, on the fp32 sums
+    {
+        const int mw = m0 + wm * (WM * 16), nw = n0 + wn * (WN * 16);
+        float as[WM];
+#pragma unroll
+        for (int f = 0; f < WM; ++f) {
+            int m = mw + f * 16 + r;
+            m = m < M ? m : M - 1;
+            as[f] = a_scale[m];
+        }
+#pragma unroll
+        for (int b = 0; b < WN; ++b) {
+            int nb = (nw >> 4) + b;
+            nb = nb < N16 ? nb : N16 - 1;
+            const float4 ws = *(const float4*)(w_scale + (size_t)nb * 16 + 4 * g);
+#pragma unroll
+            for (int f = 0; f < WM; ++f) {
+                acc[b][f][0] *= as[f] * ws.x; acc[b][f][1] *= as[f] * ws.y; acc[b][f][2] *= as[f] * ws.z; acc[b][f][3] *= as[f] * ws.w;
+            }
+        }
+    }
+    tiled_epilogue_staged<WM, WN, BM_, BN_>(acc, epi, C, ldc, M, N, m0, n0, m0 + wm * (WM * 16), n0 + wn * (WN * 16), r, g, partial, smem,
+                                            NSTA * A_BYTES + NSTB * B_BYTES, tid, 64 * NW);
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Dynamic per-row e4m3 quantisation of activation rows, written in the k order the MFMA operands want (see the header):
 //   s_m = smallest power of two with max_k |x[m,k]| / s_m <= 448,  q = RNE_e4m3(x / s_m)   (division exact)
 //   out[m][64 c + 16 g + 8 h + e] = q[m][64 c + 32 h + 8 g + e],  zero beyond K up to Kp (multiple of 128).
@@ -380,6 +578,34 @@ hipError_t launch_gemm_fp8_tiled(int pick, const uint8_t* A8, int lda8, const fl
                 hipLaunchKernelGGL(kfn, grid, block, lds, st, A8, lda8, W8, C, ldc, M, N, Kp, epi, tiles_m, tiles_n, kt_per, partial, a_scale, w_scale); \
         }                                                                                                                    \
     } while (0)
+#define LAUNCH_F8V3(WM_, WN_, CGM_, CGN_, NA_, NB_)                                                                          \
+    do {                                                                                                                     \
+        auto kfn = gemm_tiled_v3_f8<WM_, WN_, CGM_, CGN_, NA_, NB_>;                                                         \
+        const size_t lds3 = ((size_t)NA_ * CGM_ * WM_ * 16 + (size_t)NB_ * CGN_ * WN_ * 16) * 128;                           \
+        static hipError_t attr = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+        e = attr;                                                                                                            \
+        if (e == hipSuccess) {                                                                                               \
+            dim3 block(64 * CGM_ * CGN_);                                                                                    \
+            hipEvent_t ea, eb;                                                                                               \
+            if (prof_enabled() && prof_reserve(prof_cls, prof_work, &ea, &eb) >= 0)                                          \
+                hipExtLaunchKernelGGL(kfn, grid, block, (uint32_t)lds3, st, ea, eb, 0, A8, lda8, W8, C, ldc, M, N, Kp, epi, tiles_m, tiles_n, kt_per, partial, a_scale, w_scale); \
+            else                                                                                                             \
+                hipLaunchKernelGGL(kfn, grid, block, lds3, st, A8, lda8, W8, C, ldc, M, N, Kp, epi, tiles_m, tiles_n, kt_per, partial, a_scale, w_scale); \
+        }                                                                                                                    \
+    } while (0)
+    // the self-loading form (gemm_tiled_v3_f8) for the tiles whose eight MFMA waves split into two DMA roles; COVER_V3_F8=0 keeps the loader-wave form
+    static const char* v3f8_env = getenv("COVER_V3_F8");
+    const bool v3f8 = !(v3f8_env && v3f8_env[0] == '0') && (size_t)M * lda8 + 4096 < ((size_t)1 << 31);
+    if (v3f8 && (pick == 12 || pick == 13 || pick == 15 || pick == 18)) {
+        switch (pick) {
+            case 12: LAUNCH_F8V3(4, 4, 4, 2, 3, 3); break;
+            case 13: LAUNCH_F8V3(4, 4, 2, 4, 3, 3); break;
+            case 15: LAUNCH_F8V3(7, 2, 2, 4, 3, 3); break;
+            default: LAUNCH_F8V3(4, 3, 2, 4, 3, 3); break;
+        }
+        if (e == hipSuccess) e = hipGetLastError();
+        return e;
+    }
     switch (pick) {
         case 10: LAUNCH_F8(2, 4, 4, 4, 2, 2); break;
         case 12: LAUNCH_F8(4, 4, 3, 4, 4, 2); break;

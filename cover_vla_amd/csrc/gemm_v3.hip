@@ -21,28 +21,16 @@
 #include <hip/hip_ext.h>
 #include "common.h"
 #include "kernels.h"
+// the epilogue's own stamps (gemm_common.h PCTL(4..6): stages released / LDS tile filled / tile published) go to the probe words as well
+__device__ unsigned long long g_v3_probe[16];
+#define V3P(slot, val) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_v3_probe[slot] = (val); } while (0)
+#define PCTL(slot) V3P(8 + (slot), wall_clock64())
 #include "gemm_common.h"
-
-// LDS-DMA of 16 B per lane with a scalar base: LDS destination = M0 (wave-uniform) + lane * 16, global source = sbase + voff (per lane)
-__device__ __forceinline__ void glds16_s(uint32_t voff, const void* sbase, uint32_t lds_wave_base_u32) {
-    uint32_t keep;
-    asm volatile(
-        "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %3\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, %2\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep)
-        : "v"(voff), "s"(sbase), "s"(lds_wave_base_u32)
-        : "memory");
-}
 
 // In-kernel probe of the LAST launch (always on: six stores by one thread of workgroup (0, 0)): wall-clock stamps (100 MHz) at kernel start,
 // loop start, loop end and kernel end, and the shader cycle counter at loop start / end -- the clock the loop really ran at (the matrix
 // peak the rooflines are priced against assumes 2.4 GHz; under MFMA + LDS + HBM load the chip sustains 1.6-1.9) and the split of a
 // launch into prologue / k-loop / epilogue. cover_gemm_probe() reads it.
-__device__ unsigned long long g_v3_probe[8];
-#define V3P(slot, val) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_v3_probe[slot] = (val); } while (0)
 int gemm_v3_probe(unsigned long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_v3_probe), sizeof(g_v3_probe)) == hipSuccess ? 0 : -1; }
 
 template <int V> using IC = std::integral_constant<int, V>;

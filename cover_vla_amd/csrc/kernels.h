@@ -22,7 +22,7 @@ hipError_t launch_gemm_skinny_partial(const bf16_t* A, int lda, const bf16_t* Wp
                                       int K, int* S_out, hipStream_t st, const void* w8 = nullptr, const float* w8s = nullptr);
 #define COVER_GEMM_PLANS 32
 void gemm_plan_counts(long long* out, int n, int reset);   // per-plan launch counters (tests): see gemm_bf16.hip
-int gemm_v3_probe(unsigned long long* out);                  // 8 words: in-kernel probe of the last gemm_v3.hip launch (g_v3_probe)
+int gemm_v3_probe(unsigned long long* out);                  // 16 words: in-kernel probe of the last gemm_v3.hip launch (g_v3_probe)
 hipError_t launch_quantize_rows_fp8(const bf16_t* W, int ldw, int N, int K, float* scales, bf16_t* Wdq, hipStream_t st);
 hipError_t launch_pack_weight_fp8(const bf16_t* Wdq, int ldw, const float* scales, int N, int K, uint8_t* Wq, float* scales_packed,
                                   int Kpad, int glu, hipStream_t st);

@@ -169,12 +169,15 @@ def gemm_probe() -> dict:
     """In-kernel probe of the most recent self-loading tiled GEMM launch (cover_gemm_probe): microseconds of prologue / k-loop / epilogue of
     its first workgroup, k-tiles, shader cycles per k-tile and the clock (GHz) the loop ran at. Synchronises the device."""
     torch.cuda.synchronize()
-    buf = (C.c_ulonglong * 8)()
+    buf = (C.c_ulonglong * 16)()
     L.check(L.lib().cover_gemm_probe(buf), "gemm_probe")
     w0, w1, w2, w3, c0, c1, nk = (int(buf[i]) for i in range(7))
+    e4, e5, e6 = (int(buf[i]) for i in (12, 13, 14))
     loop_us = (w2 - w1) * 0.01
+    staged = w2 <= e4 <= e5 <= e6 <= w3          # (the direct epilogue of a ragged tile leaves older stamps there)
     return dict(prologue_us=(w1 - w0) * 0.01, loop_us=loop_us, epilogue_us=(w3 - w2) * 0.01, k_tiles=nk,
-                cycles_per_k_tile=(c1 - c0) / max(nk, 1), clock_ghz=(c1 - c0) / max(loop_us, 1e-9) / 1e3)
+                cycles_per_k_tile=(c1 - c0) / max(nk, 1), clock_ghz=(c1 - c0) / max(loop_us, 1e-9) / 1e3,
+                epilogue_split_us=[(e4 - w2) * 0.01, (e5 - e4) * 0.01, (e6 - e5) * 0.01, (w3 - e6) * 0.01] if staged else None)
 
 
 def gemm_plan_counts(reset: bool = False) -> list:

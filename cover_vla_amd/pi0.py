@@ -51,7 +51,7 @@ class PI0FlowMatching:
                           act="gelu_tanh", norm="gemma", eps=1e-6, rope="pi0", n_pos=n_pos, device=device, cache=geom)
         self.expert = Decoder(sub("expert."), dim=c["ex_dim"], layers=c["layers"], Hq=c["Hq"], Hkv=c["Hkv"], D=c["D"],
                               mlp=c["ex_mlp"], act="gelu_tanh", norm="gemma", eps=1e-6, rope="pi0", n_pos=n_pos, device=device,
-                              share_cache_with=self.lm, final_norm_bf16=False, fold_norm=os.environ.get("COVER_PI0_FOLD_NORM", "1") != "0")
+                              share_cache_with=self.lm, final_norm_bf16=False, fold_norm=os.environ.get("COVER_DEFER_NORM", "0") == "1")   # (the folded weight copies are only packed when the opt-in path is on)
         # pi0's own projections stay fp32 (modeling_pi0.py:488-494)
         self.p = {n: (_f32(sd[n + ".weight"], dev), _f32(sd[n + ".bias"], dev))
                   for n in ("state_proj", "action_in_proj", "action_out_proj", "action_time_mlp_in", "action_time_mlp_out")}

@@ -146,7 +146,9 @@ int cover_gemm_plan_counts(long long* counts, int n, int reset);
 /* In-kernel probe of the most recent launch of the self-loading tiled GEMM (gemm_v3.hip; plan counters 23..31), written by one thread of
  * its first workgroup: out[0..3] = 100 MHz wall-clock stamps at kernel start / k-loop start / k-loop end / kernel end, out[4..5] = shader
  * cycle counter at k-loop start / end, out[6] = k-tiles of the loop. (out[5] - out[4]) / (out[2] - out[1]) / 10 ns = the clock the loop ran
- * at. Synchronous read of 8 device words (synchronise the stream first). Measurement hook: nothing on the product path reads it. */
+ * at; out[12..14] = stamps inside the LDS-staged epilogue (pipeline stages released / LDS tile filled / tile published, the store loop runs
+ * from out[14] to out[3]). Synchronous read of 16 device words (synchronise the stream first). Measurement hook: nothing on the product
+ * path reads it. */
 int cover_gemm_probe(unsigned long long* out);
 
 /* ------------------------------------------------------------------------------------------------

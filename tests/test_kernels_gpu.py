@@ -70,6 +70,35 @@ def test_gemm_long_panel_tiles(dev, M, N, K, glu):
     assert (d <= 0.06 + 2e-2 * ref.abs()).all()
 
 
+@pytest.mark.parametrize("act", ["silu", "gelu_tanh"])
+@pytest.mark.parametrize("glu", [False, True])
+def test_gemm_epilogue_fast_activation_on_every_bf16_input(dev, act, glu):
+    """The store loops of the staged epilogue evaluate SiLU / tanh-GELU with v_exp_f32 + v_rcp_f32 (common.h act_apply_bf16) on values that are
+    rounded to bf16 right after. Every finite bf16 bit pattern goes through an identity GEMM (x * 1 + zeros: exact) into the epilogue; the
+    result must sit within one bf16 ulp of torch's fp32 activation rounded to bf16 (2e-6 absolute in tanh-GELU's cancelling tail, where
+    0.5 x (1 + tanh u) is quantised to 2^-24 x in the fp32 reference as well)."""
+    bits = torch.arange(65536, dtype=torch.int32).to(torch.int16)
+    x = bits.view(torch.bfloat16)
+    x = x[torch.isfinite(x.float())]
+    x = torch.cat([x, torch.zeros((-len(x)) % 128, dtype=torch.bfloat16)]).reshape(-1, 128)          # [M, 128], one value per GEMM output
+    M = x.shape[0]
+    eye = torch.eye(128, dtype=torch.bfloat16)
+    if glu:   # gate = x through the identity, up = 1: out = act(x) * 1 (pack_linear(glu=True): rows [gate; up])
+        a = torch.cat([x, torch.ones(M, 128, dtype=torch.bfloat16)], 1)
+        w = torch.zeros(256, 256, dtype=torch.bfloat16)
+        w[:128, :128] = eye
+        w[128:, 128] = 1.0
+        out = ops.gemm(a.to(dev), ops.pack_linear(w.to(dev), glu=True), act=act)
+    else:
+        out = ops.gemm(x.to(dev), ops.pack_linear(eye.to(dev)), act=act)
+    ref = ACT_REF[act](x.float()).bfloat16().float()
+    got = out.float().cpu()
+    assert got.shape == ref.shape and bool(torch.isfinite(got).all())
+    err = (got - ref).abs()
+    assert bool((err <= ref.abs() * 2.0 ** -7 + 2e-6).all()), (err - ref.abs() * 2.0 ** -7).max()
+    assert (got != ref).float().mean().item() < 0.02            # and all but a few rounding-boundary cases are bit-identical
+
+
 @pytest.mark.parametrize("M,dim,mlp,style", [(200, 1024, 4096, 0), (130, 512, 1536, 1), (200, 1024, 4096, 1)])
 def test_gemm_deferred_rmsnorm_producer_and_consumer(dev, M, dim, mlp, style):
     """Deferred RMSNorm (cover_gemm_epi.ssq_out / rs_in; the pi0 expert's M = 200 rows): a producer GEMM (down: [M, mlp] -> x += ., unsplit on

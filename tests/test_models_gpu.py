@@ -563,6 +563,26 @@ def test_expert_layer_200_rows_qkv_slabs_folded_by_rope_equals_reduction_launch(
             assert untouched == (fz == "1"), (fz, untouched)      # "1": fused (cache not written); "0": the RoPE launch wrote the suffix keys
         finally:
             os.environ.pop("COVER_ROPE_ATTN_FUSE", None)
+    # the same pass on the deferred-RMSNorm path (COVER_DEFER_NORM=1 + a decoder packed with fold_norm=True): qkv (layer 0: unfolded, behind the
+    # input-norm launch) as ONE fp32 slab folded inside the attention launch, o_proj / down UNSPLIT on the 32 x 32 sixteen-stage tiles with the
+    # residual and the partial sums of squares in the epilogue, gate_up on the norm-folded weight with the row scale. Two bf16 rounding points
+    # move (the normalised rows are not rounded, the folded weight is): one layer's output within 6e-3 of the eight-launch path.
+    exf = Decoder(sub("expert."), dim=g2["ex_dim"], layers=1, Hq=g2["Hq"], Hkv=g2["Hkv"], D=g2["D"], mlp=g2["ex_mlp"], act="gelu_tanh",
+                  norm="gemma", eps=1e-6, rope="pi0", n_pos=n_pos, device="cuda:0", share_cache_with=lm, final_norm_bf16=False, fold_norm=True)
+    g1f = exf.group(B, S, spos.view(-1), [dict(region=0, length=T, len_of_batch=row_plen, slot_of_batch=row_prompt),
+                                           dict(region=1, length=S, mask=ops.MASK_VISLEN, vis_len=vis_len)], 1, write_scratch=True)
+    os.environ["COVER_DEFER_NORM"] = "1"
+    try:
+        ops.gemm_plan_counts(reset=True)
+        xb = torch.empty(B * S, W, dtype=BF, device=dev)
+        exf.forward(xb, [g1f], final_norm=True, x_f32=suf.view(B * S, W).contiguous())
+        torch.cuda.synchronize()
+        counts = ops.gemm_plan_counts()
+    finally:
+        os.environ.pop("COVER_DEFER_NORM", None)
+    assert counts[31] == 2 and counts[30] == 1 and sum(counts) == 4, counts         # o_proj + down | gate_up | + layer 0's qkv on its usual tile
+    ref = outs[1][0].float()
+    assert ((xb.float() - ref).norm() / ref.norm()).item() < 6e-3
 
 
 # ------------------------------------------------------------------------------------------------ serving boundary on the device

@@ -3,7 +3,7 @@
 # leg, the P1 line with its own kernel table, and the secondary configurations. Everything lands in gpurun_out/ (merged back); copy what is
 # to be judged into profiles/.
 set -x
-TAG=${1:-r04}
+TAG=${1:-r05}
 SHA=$(sha256sum cover_vla_amd/libcover_hip.so | cut -c1-16)
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
@@ -16,6 +16,9 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace -d gpurun_out/${TAG}_pmc -o pmc -- pyt
 python tools/pmc_stats.py gpurun_out/${TAG}_pmc/pmc_results.db profiles/${TAG}_pmc_traffic.json $SHA > gpurun_out/${TAG}_pmc_fetch_size.txt 2>&1
 cp profiles/${TAG}_pmc_traffic.json gpurun_out/${TAG}_pmc_traffic.json
 tail -1 gpurun_out/${TAG}_pmc_fetch_size.txt
+# matrix-pipe utilisation (own PMC pass, kernel trace only) through the COMMITTED tool
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --kernel-trace -d gpurun_out/${TAG}_mf -o mf -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-profile > /dev/null 2>&1
+python tools/pmc_mfma.py gpurun_out/${TAG}_mf/mf_results.db > gpurun_out/${TAG}_pmc_mfma.txt 2>&1; head -12 gpurun_out/${TAG}_pmc_mfma.txt
 python bench.py > gpurun_out/${TAG}_bench_line.json 2> gpurun_out/${TAG}_bench_stderr.log
 cut -c1-400 gpurun_out/${TAG}_bench_line.json
 python tools/phases.py > gpurun_out/${TAG}_phases.txt 2>/dev/null; cat gpurun_out/${TAG}_phases.txt
@@ -30,4 +33,4 @@ python bench.py --samples 8 --cams 2 --members 2 --steps 10 --warmup 2 --no-cpu-
 python tools/bench_pi0fast.py 2>/dev/null | tail -1 > gpurun_out/${TAG}_pi0fast_line.json
 for f in config3_w1_line fp8_n32_bench_line config5_fp8_n512_h8_bench_line config2_n16_bench_line config4_2cam_n64_bench_line pi0_bench_line; do python -c "import json,sys; d=json.load(open('gpurun_out/${TAG}_'+sys.argv[1]+'.json')); print(sys.argv[1], d['ms_per_step'], d['value'])" $f; done
 cat gpurun_out/${TAG}_pi0fast_line.json
-rm -rf gpurun_out/${TAG}_pmc/*.db gpurun_out/${TAG}/*.db gpurun_out/${TAG}_pi0/*.db
+rm -rf gpurun_out/${TAG}_pmc/*.db gpurun_out/${TAG}/*.db gpurun_out/${TAG}_pi0/*.db gpurun_out/${TAG}_mf/*.db

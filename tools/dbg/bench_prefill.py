@@ -43,7 +43,7 @@ for name, N, K, glu, norm in shapes:
     tot_fl += fl
     pr = ops.gemm_probe()
     print(f"M={M} {name:8s} {us:7.1f} us  {fl / us / 1e6:6.0f} TF  (incl. its split-K reduction / norm launch)   [last v3 launch, workgroup 0: prologue {pr['prologue_us']:.1f} "
-          f"loop {pr['loop_us']:.1f} epilogue {pr['epilogue_us']:.1f} us, {pr['k_tiles']} k-tiles x {pr['cycles_per_k_tile']:.0f} cycles at {pr['clock_ghz']:.2f} GHz]", flush=True)
+          f"loop {pr['loop_us']:.1f} epilogue {pr['epilogue_us']:.1f} us {[round(x, 1) for x in pr['epilogue_split_us']] if pr['epilogue_split_us'] else ''}, {pr['k_tiles']} k-tiles x {pr['cycles_per_k_tile']:.0f} cycles at {pr['clock_ghz']:.2f} GHz]", flush=True)
     del lins
     torch.cuda.empty_cache()
 print(f"layer: {tot_us:7.1f} us  {tot_fl / tot_us / 1e6:6.0f} TF = {tot_fl / tot_us / 1e6 / 2500:.3f} of 2.5 PF; x32 layers = {tot_us * 32 / 1e3:.2f} ms")
