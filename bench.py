@@ -426,7 +426,7 @@ def main_pi0(a):
         fp = work_p[1] + work_p[4]
         if tp > 0:
             tf = fp / (tp * 1e-3) / 1e12
-            out["roofline_mfma"] = {"bound": "mfma", "kernel": "gemm_tiled / gemm_tiled_pc: SigLIP-So400m tower + projector + the 18-layer Gemma-2B prefix pass "
+            out["roofline_mfma"] = {"bound": "mfma", "kernel": "gemm_tiled_v3 (self-loading, prefix pass) / gemm_tiled: SigLIP-So400m tower + projector + the 18-layer Gemma-2B prefix pass "
                                                                f"(M = {pipe.P} x (256 + longest real prompt) rows), split-K reductions included",
                                     "achieved": round(tf, 1), "peak": MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": round(tf / MFMA_PEAK_TF, 4),
                                     "launches": int(cnt_p[1] + cnt_p[4]), "kernel_ms_per_decision": round(tp, 3), "flop_per_decision": fp}
@@ -684,7 +684,7 @@ def roofline_objects(ms, cnt, work, ms_per_step, lib_sha):
     t_mfma = ms[1] + ms[4] + ms[6]
     if cnt[1] + cnt[4] > 0 and t_mfma > 0:
         tf_all = (work[1] + work[4]) / (t_mfma * 1e-3) / 1e12
-        obj = {"bound": "mfma", "kernel": "gemm_tiled / gemm_tiled_pc (LLM prefill + DINOv2 / SigLIP / SigLIP2 towers + projector), split-K reductions included",
+        obj = {"bound": "mfma", "kernel": "gemm_tiled_v3 (self-loading 224-row tiles: LLM prefill) / gemm_tiled (64-row tiles: towers) (LLM prefill + DINOv2 / SigLIP / SigLIP2 towers + projector), split-K reductions included",
                "achieved": round(tf_all, 1), "peak": MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": round(tf_all / MFMA_PEAK_TF, 4),
                "launches": int(cnt[1] + cnt[4]), "kernel_ms_per_decision": round(t_mfma, 3), "flop_per_decision": work[1] + work[4]}
         if cnt[4] > 0 and ms[4] > 0:
@@ -702,7 +702,7 @@ def roofline_objects(ms, cnt, work, ms_per_step, lib_sha):
     if len(cnt) > 7 and cnt[7] > 0 and ms[7] > 0:
         # config 5: the decoder's projections on the MX-scaled fp8 matrix instruction -- priced against the 5 PFLOP/s fp8 peak
         tf8 = work[7] / (ms[7] * 1e-3) / 1e12
-        obj = {"bound": "mfma", "kernel": "gemm_tiled_pc_f8 (v_mfma_scale_f32_16x16x128_f8f6f4: e4m3 activations per row x e4m3 weights per channel; the decoder's "
+        obj = {"bound": "mfma", "kernel": "gemm_tiled_v3_f8 / gemm_tiled_pc_f8 (v_mfma_scale_f32_16x16x128_f8f6f4: e4m3 activations per row x e4m3 weights per channel; the decoder's "
                                           "projections in every pass with more than 64 rows)",
                "achieved": round(tf8, 1), "peak": FP8_PEAK_TF, "unit": "TFLOP/s", "frac": round(tf8 / FP8_PEAK_TF, 4), "traffic": None,
                "launches": int(cnt[7]), "avg_launch_us": round(1e3 * ms[7] / cnt[7], 2), "kernel_ms_per_decision": round(ms[7], 3), "flop_per_decision": work[7]}
