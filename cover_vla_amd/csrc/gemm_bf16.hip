@@ -1751,7 +1751,7 @@ hipError_t launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* Wp, void* C,
         {8, 2, 2, 4, 3},   // p (25): 256x128, 8 waves of 128x32, 3 stages (144 KiB)
         {4, 4, 2, 4, 3},   // q (26): 128x256, 8 waves of 64x64,  3 stages (144 KiB)
         {7, 3, 2, 2, 4},   // r (27): 224x96,  4 waves of 112x48 (one per SIMD), 4 stages (160 KiB)
-        {7, 6, 2, 2, 3},   // s (28): 224x192, 4 waves of 112x96, 3 stages (156 KiB)
+        {7, 2, 1, 4, 4},   // s (28): 112x128, 4 waves of 112x32 (one per SIMD), 4 stages (120 KiB): narrow outputs at M = 448 with HALF the K slices of the 224-row tile
         {7, 4, 2, 2, 3},   // t (29): 224x128, 4 waves of 112x64, 3 stages (132 KiB)
         {2, 2, 2, 2, 3},   // u (30): 64x64, 4 waves of 32x32, 3 stages (48 KiB, three blocks per CU): few-hundred-row GEMMs with a deferred-norm row scale
         {1, 1, 2, 2, 16},  // v (31): 32x32, 4 waves of 16x16, 16 stages (128 KiB): UNSPLIT narrow outputs on a long K (fifteen 8-KiB k-tiles in flight)
@@ -1842,6 +1842,11 @@ hipError_t launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* Wp, void* C,
         if (force && force[0] >= 'a' && force[0] <= 'h') pick = 10 + (force[0] - 'a');
         if (force && force[0] >= 'n' && force[0] <= 'v') pick = 10 + (force[0] - 'a');
     }
+    {
+        // experiment knob: the 64 x 64 tile of ViT-sized problems on the self-loading kernel (pick 30) instead of gemm_tiled<2, 2, .., 3 stages>
+        static const char* small3 = getenv("COVER_V3_SMALL");
+        if (small3 && small3[0] == '1' && v3_on && pick == 2) pick = 30;
+    }
     // deferred RMSNorm (cover_gemm_epi.ssq_out / rs_in): only the self-loading kernels carry it. The producer of a residual stream runs UNSPLIT on
     // 32 x 32 tiles with a sixteen-stage ring (M = 200, N = 1024: 224 workgroups, the whole K in one block, no slabs and no reduction
     // launch); the consumer of the raw rows runs on 64 x 64 tiles.
@@ -1860,7 +1865,7 @@ hipError_t launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* Wp, void* C,
         static const char* big3 = getenv("COVER_V3_BIG");
         if (v3_on && !(big3 && big3[0] == '0')) pick = pick == 12 ? 25 : pick == 13 ? 26 : pick;
     }
-    if (!v3_on && pick >= 23) pick = (pick == 23 || pick == 28) ? 16 : (pick == 24 || pick == 29) ? 15 : pick == 25 ? 12 : pick == 26 ? 13 : pick == 27 ? 17 : 2;
+    if (!v3_on && pick >= 23) pick = pick == 23 ? 16 : (pick == 24 || pick == 29 || pick == 28) ? 15 : pick == 25 ? 12 : pick == 26 ? 13 : pick == 27 ? 17 : 2;
     if (variant == 2 && pick > 2) pick = 0;
     if (pick == 18 && !(f8_on && gemm_fp8_tiled_supported(18))) return hipErrorInvalidValue;   // 128 x 192 exists as an fp8 kernel only
     const Cand cd = cands[pick];

@@ -352,14 +352,16 @@ __device__ __forceinline__ void tiled_epilogue_staged(f32x4 (&acc)[WN][WM], cons
         const bool al = (!epi.bias || (((uintptr_t)epi.bias) & 15) == 0) && (!epi.lscale || (((uintptr_t)epi.lscale) & 15) == 0) && (n0 & 7) == 0 &&
                         (!epi.residual || ((((uintptr_t)epi.residual) & 15) == 0 && ((epi.ldr * (epi.res_f32 ? 4 : 2)) & 15) == 0));
         if (al) {
-            for (int c0 = t; c0 < total; c0 += 2 * nthr) {
-                int rowi[2], chi[2], mi[2];
-                bool ok[2];
-                float sq[2] = {0.f, 0.f};
-                float4 bb[2][2] = {}, ll[2][2] = {}, rf[2][2] = {};
-                uint4 rb[2] = {};
+            constexpr int NU = 2;   // chunks per thread in flight (four were measured on the one-wave-per-SIMD kernels: the 13 us store loop of the pi0 prefix
+            // o_proj -- 224 x 96 tiles with an in-place residual at M = 2 232 -- did not move, so it is not this loop's round trips; four spill the 224 x 192 tile)
+            for (int c0 = t; c0 < total; c0 += NU * nthr) {
+                int rowi[NU], chi[NU], mi[NU];
+                bool ok[NU];
+                float sq[NU] = {};
+                float4 bb[NU][2] = {}, ll[NU][2] = {}, rf[NU][2] = {};
+                uint4 rb[NU] = {};
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
+                for (int u = 0; u < NU; ++u) {
                     const int c = c0 + u * nthr;
                     rowi[u] = div_cpr(c); chi[u] = c - rowi[u] * cpr; mi[u] = m0 + r0 + rowi[u];
                     ok[u] = c < total && mi[u] < M;
@@ -377,7 +379,7 @@ __device__ __forceinline__ void tiled_epilogue_staged(f32x4 (&acc)[WN][WM], cons
                     }
                 }
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
+                for (int u = 0; u < NU; ++u) {
                     if (!ok[u]) continue;
                     const char* lrow = st + (size_t)rowi[u] * pitch;
                     const float4 a4 = *(const float4*)(lrow + chi[u] * 32), b4 = *(const float4*)(lrow + chi[u] * 32 + 16);
@@ -417,7 +419,7 @@ __device__ __forceinline__ void tiled_epilogue_staged(f32x4 (&acc)[WN][WM], cons
                     // the four 16-byte chunks of a 32-column group sit in four consecutive lanes (cpr % 4 == 0, chunk index = lane mod cpr):
                     // fixed-order sum over the quad, lane 0 of the quad stores
 #pragma unroll
-                    for (int u = 0; u < 2; ++u) {
+                    for (int u = 0; u < NU; ++u) {
                         float q = sq[u];
                         q += __shfl_xor(q, 1);
                         q += __shfl_xor(q, 2);

@@ -271,7 +271,7 @@ hipError_t launch_gemm_v3(int pick, const bf16_t* A, int lda, const bf16_t* Wp, 
         case 25: LAUNCH_V3(8, 2, 2, 4, 3, 3); break;                                                            // 256x128, 8 waves of 128x32
         case 26: LAUNCH_V3(4, 4, 2, 4, 3, 3); break;                                                            // 128x256, 8 waves of 64x64
         case 27: if (ring == 34) LAUNCH_V3(7, 3, 2, 2, 3, 4); else LAUNCH_V3(7, 3, 2, 2, 4, 4); break;          // 224x96,  4 waves of 112x48 (one per SIMD)
-        case 28: LAUNCH_V3(7, 6, 2, 2, 3, 3); break;                                                            // 224x192, 4 waves of 112x96
+        case 28: LAUNCH_V3(7, 2, 1, 4, 4, 4); break;                                                            // 112x128, 4 waves of 112x32 (one per SIMD), 4 stages
         case 29: if (ring == 34) LAUNCH_V3(7, 4, 2, 2, 3, 4); else LAUNCH_V3(7, 4, 2, 2, 3, 3); break;          // 224x128, 4 waves of 112x64
         case 30: LAUNCH_V3(2, 2, 2, 2, 3, 3); break;                                                            // 64x64,   4 waves of 32x32 (three blocks per CU)
         case 31: if (ring == 8) LAUNCH_V3(1, 1, 2, 2, 8, 8); else LAUNCH_V3(1, 1, 2, 2, 16, 16); break;         // 32x32,   4 waves of 16x16, 16-stage ring

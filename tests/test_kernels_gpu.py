@@ -99,6 +99,34 @@ def test_gemm_epilogue_fast_activation_on_every_bf16_input(dev, act, glu):
     assert (got != ref).float().mean().item() < 0.02            # and all but a few rounding-boundary cases are bit-identical
 
 
+def test_gemm_loader_wave_and_self_loading_forms_agree(dev, tmp_path):
+    """The loader-wave kernels (gemm_tiled_pc, gemm_tiled_pc_f8) stay in the library behind COVER_V3=0 / COVER_V3_F8=0 (A/B runs, fallback for
+    problems the self-loading kernels do not take). Both knobs are read once per process, so each form runs in a child; the parent compares:
+    fp8 -- same tile, same K slices, same k order per accumulator: BIT-IDENTICAL; bf16 -- the planner may pick another tile / slice count for the
+    other kernel family: rel-L2 <= 2e-3 (fp32 sums in another order, one bf16 rounding). The plan counters prove which family ran."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for tag, env in (("self", {}), ("loader", {"COVER_V3": "0", "COVER_V3_F8": "0"})):
+        path = str(tmp_path / f"{tag}.pt")
+        e = dict(os.environ, **env)
+        e["PYTHONPATH"] = root + os.pathsep + e.get("PYTHONPATH", "")
+        r = subprocess.run([sys.executable, os.path.join(root, "tests", "_gemm_forms_child.py"), path], env=e, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[tag] = torch.load(path)
+    ps, pl = res["self"]["plans"], res["loader"]["plans"]
+    assert sum(ps[23:30]) >= 4 and sum(pl[23:30]) == 0 and sum(pl[12:18]) >= 4, (ps, pl)   # bf16: self-loading picks 23-29 vs loader-wave picks 12-17
+    assert ps[21] == 4 and pl[21] == 4                                                      # fp8: the same four launches in both
+    from tests._gemm_forms_child import CASES
+    for i, (M, N, K, glu, f8) in enumerate(CASES):
+        a, b = res["self"][i], res["loader"][i]
+        assert bool(torch.isfinite(a.float()).all())
+        if f8:
+            assert torch.equal(a.view(torch.int16), b.view(torch.int16)), (i, M, N, K)
+        else:
+            assert rel_l2(a, b) < 2e-3, (i, M, N, K, rel_l2(a, b))
+
+
 @pytest.mark.parametrize("M,dim,mlp,style", [(200, 1024, 4096, 0), (130, 512, 1536, 1), (200, 1024, 4096, 1)])
 def test_gemm_deferred_rmsnorm_producer_and_consumer(dev, M, dim, mlp, style):
     """Deferred RMSNorm (cover_gemm_epi.ssq_out / rs_in; the pi0 expert's M = 200 rows): a producer GEMM (down: [M, mlp] -> x += ., unsplit on
