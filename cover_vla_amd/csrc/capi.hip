@@ -447,7 +447,7 @@ static size_t dec_ws(const cover_dec_desc* d, int rows, Carver* c, void** h, voi
     p = cc.take(skb); if (sk) *sk = p;
     if (sk_bytes) *sk_bytes = skb;
     p = cc.take(decode_chain_ws_bytes()); if (ssq) *ssq = p;   // partial sums of squares of the persistent decode chain (rows <= 32)
-    p = cc.take(256); if (tsync) *tsync = p;                   // ticket words of the tail reduction (gemm_bf16.hip), zeroed per pass
+    p = cc.take(256 + (size_t)64 * gemm_head_words() * 4); if (tsync) *tsync = p;   // ticket words of the tail reduction / hand-off areas of the head reduction (gemm_bf16.hip), zeroed per pass
     p = cc.take((size_t)2 * rows * ((d->dim + 31) / 32) * 4); if (dn_ssq) *dn_ssq = p;   // deferred RMSNorm: [2][rows][dim / 32] partial sums of squares
     return cc.off + 256;
 }
@@ -456,7 +456,8 @@ size_t cover_decoder_workspace_bytes(const cover_dec_desc* d, int rows) {
 }
 
 __global__ void zero_words_k(unsigned* p, int n) {
-    if ((int)threadIdx.x < n) p[threadIdx.x] = 0u;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = 0u;
 }
 int cover_decoder_forward(const cover_dec_desc* d, const cover_dec_pass* p, void* x, cover_workspace ws, int variant,
                           void* stream) {
@@ -549,6 +550,24 @@ int cover_decoder_forward(const cover_dec_desc* d, const cover_dec_pass* p, void
             HIPCHK(hipGetLastError(), "zero tail-reduction tickets");
         }
     }
+    // weight-streaming passes of <= 32 rows (candidate decode), opt-in (COVER_HEAD_REDUCE=1, read per call: the tests toggle it): HEAD reduction
+    // (kernels.h GemmDeferred, gemm_bf16.hip "Head reduction") -- the split-K reduction + residual + RMSNorm of o_proj rides in the first
+    // workgroups of the gate_up launch, that of down in the next layer's qkv launch: two launches per layer less, bit-identical results.
+    // Measured SLOWER than the reduction launches (decode pass 3.72 against 3.555 ms: the release / acquire pair and three dependent
+    // cross-XCD round trips of the hand-off cost more than the 5.5 us launch + boundary they replace), so off by default. One zeroed hand-off
+    // area per reduction, behind the ticket words of the tail reduction (which is mutually exclusive with this).
+    unsigned* head_flags = nullptr;
+    {
+        const char* he = getenv("COVER_HEAD_REDUCE");
+        if (rows <= 32 && p->n_groups == 1 && variant == 0 && tail_sync == nullptr && d->n_layers <= 32 && he && he[0] == '1') {
+            head_flags = (unsigned*)tsync + 64;
+            const int nw = 2 * d->n_layers * gemm_head_words();
+            hipLaunchKernelGGL(zero_words_k, dim3((nw + 255) / 256), dim3(256), 0, st, head_flags, nw);
+            HIPCHK(hipGetLastError(), "zero head-reduction counters");
+        }
+    }
+    GemmDeferred pend;          // the hand-off in flight: armed by o_proj / down, consumed by the very next GEMM launch
+    pend.armed = false; pend.flag = nullptr;
     // ---- deferred RMSNorm pass (cover_dec_layer.qkv_wf / gate_up_wf; the pi0 denoise steps: 200 rows = 40 candidates x 5 suffix tokens, 18 layers,
     //      10 Euler steps per decision). Five launches per layer instead of eight:
     //        qkv'      x (raw rows) . Wqkv'^T, rows scaled by rsqrt(mean square) from the partial sums of squares down(l-1) left, ONE fp32 slab
@@ -656,7 +675,7 @@ int cover_decoder_forward(const cover_dec_desc* d, const cover_dec_pass* p, void
         int qkv_splits = 0;
         if (rows <= 64 && p->n_groups == 1 && (variant == 0 || variant == 3) && p->groups[0].own_kv_mode == 0)
             HIPCHK(launch_gemm_skinny_partial((const bf16_t*)h, dim, (const bf16_t*)L.qkv_w, (float*)sk, skb, rows, nqkv, dim, &qkv_splits, st,
-                                              L.qkv_w8, L.qkv_s), "dec qkv (partials)");
+                                              L.qkv_w8, L.qkv_s, &pend), "dec qkv (partials)");
         else {
             // few-token groups on the LDS tiles (the pi0 action expert: 200 rows, T = 5): a split-K launch leaves its slabs for
             // rope_kv_write to fold as well (same sums, same order, same rounding as the reduction launch it replaces)
@@ -664,8 +683,9 @@ int cover_decoder_forward(const cover_dec_desc* d, const cover_dec_pass* p, void
             const bool fold = rows > 64 && p->n_groups == 1 && p->groups[0].own_kv_mode == 0 && p->groups[0].T < 16 && !f8 &&
                               !(p->groups[0].seg0_shared && p->groups[0].T == 1) && !(fold_env && fold_env[0] == '0');
             HIPCHK(launch_gemm_bf16((const bf16_t*)h, dim, (const bf16_t*)L.qkv_w, qkv, nqkv, rows, nqkv, dim, &e, (float*)sk, skb, variant, st,
-                                    fold ? &qkv_splits : nullptr), "dec qkv");
+                                    fold ? &qkv_splits : nullptr, nullptr, nullptr, &pend), "dec qkv");
         }
+        pend.armed = false;
         cover_rope_args ras[2];
         cover_attn_args aas[2];
         bool pending[2] = {false, false};
@@ -816,14 +836,18 @@ int cover_decoder_forward(const cover_dec_desc* d, const cover_dec_pass* p, void
         e.w8 = L.o_w8; e.w8_scale = L.o_s;
         if (f8) HIPCHK(quant(attn, HD, e), "dec quantise (o_proj input)");
         norm_q8(e);
-        HIPCHK(launch_gemm_bf16((const bf16_t*)attn, HD, (const bf16_t*)L.o_w, x, dim, rows, dim, HD, &e, (float*)sk, skb, variant, st, nullptr, tail_sync), "dec o_proj (+post_norm)");
+        if (head_flags) pend.flag = head_flags + (size_t)(2 * l) * gemm_head_words();
+        HIPCHK(launch_gemm_bf16((const bf16_t*)attn, HD, (const bf16_t*)L.o_w, x, dim, rows, dim, HD, &e, (float*)sk, skb, variant, st, nullptr, tail_sync,
+                                head_flags ? &pend : nullptr), "dec o_proj (+post_norm)");
         memset(&e, 0, sizeof e);
         e.out_scale = 1.0f;
         e.act = d->act; e.glu = 1;
         e.w8 = L.gate_up_w8; e.w8_scale = L.gate_up_s;
         if (f8q) use_q8(dim, e);
         else if (f8) HIPCHK(quant(h, dim, e), "dec quantise (gate_up input)");
-        HIPCHK(launch_gemm_bf16((const bf16_t*)h, dim, (const bf16_t*)L.gate_up_w, mlp, d->mlp, rows, 2 * d->mlp, dim, &e, (float*)sk, skb, variant, st), "dec gate_up");
+        HIPCHK(launch_gemm_bf16((const bf16_t*)h, dim, (const bf16_t*)L.gate_up_w, mlp, d->mlp, rows, 2 * d->mlp, dim, &e, (float*)sk, skb, variant, st, nullptr, nullptr,
+                                nullptr, &pend), "dec gate_up");
+        pend.armed = false;
         memset(&e, 0, sizeof e);
         e.out_scale = 1.0f;
         e.residual = x; e.ld_residual = dim;
@@ -834,7 +858,10 @@ int cover_decoder_forward(const cover_dec_desc* d, const cover_dec_pass* p, void
         e.w8 = L.down_w8; e.w8_scale = L.down_s;
         if (f8) HIPCHK(quant(mlp, d->mlp, e), "dec quantise (down input)");
         if (l + 1 < d->n_layers) norm_q8(e);
-        HIPCHK(launch_gemm_bf16((const bf16_t*)mlp, d->mlp, (const bf16_t*)L.down_w, x, dim, rows, dim, d->mlp, &e, (float*)sk, skb, variant, st, nullptr, tail_sync), "dec down (+next in_norm)");
+        const bool hand_on = head_flags && l + 1 < d->n_layers;   // (the last layer's sums have no streaming launch behind them in this pass)
+        if (hand_on) pend.flag = head_flags + (size_t)(2 * l + 1) * gemm_head_words();
+        HIPCHK(launch_gemm_bf16((const bf16_t*)mlp, d->mlp, (const bf16_t*)L.down_w, x, dim, rows, dim, d->mlp, &e, (float*)sk, skb, variant, st, nullptr, tail_sync,
+                                hand_on ? &pend : nullptr), "dec down (+next in_norm)");
     }
     if (p->final_norm)
         HIPCHK(launch_rmsnorm(x, 0, dim, d->final_norm_w, d->norm_w_offset, d->norm_style, (bf16_t*)x, dim, rows, dim, d->norm_eps, st), "dec final_norm");

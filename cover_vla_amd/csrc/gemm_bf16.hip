@@ -739,6 +739,63 @@ int gemm_tail_status() {
     if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_tail_error), sizeof v) != hipSuccess) return -1;
     return (int)v;
 }
+
+// ---------------------------------------------------------------------------------------------------
+// Head reduction (kernels.h GemmDeferred; opt-in, measured 0.17 ms per decode pass SLOWER than the launches it replaces -- see capi.hip and
+// docs/OPTIMISATION_LOG.md round 5). The mirror image of the tail reduction above: the slabs of the PREVIOUS
+// GEMM are complete when this launch starts (the kernel boundary is the synchronisation), so no ticket chain is needed -- workgroups
+// 0 .. M-1 run reduce_norm_row for one row each and arrive at the hand-off's counter (one release per workgroup); every workgroup waits for
+// the release word the last arrival writes (bounded wait: g_tail_error; one acquire per workgroup: the rows were written by workgroups on
+// other XCDs) and only then runs the streaming kernel's prologue. What it removes per hand-off: one launch of 32 workgroups and its boundary
+// (~5.5 + 1.5 us); what it adds: an L2 write-back, three dependent cross-XCD round trips (arrive -> release word -> poll) and an L2
+// invalidate in front of every workgroup's first activation load -- measured +2.5 us per hand-off net. Versions on the way there: every
+// workgroup polling the counter itself every 128 cycles (+17 us per hand-off), release / acquire fences by all eight waves of a workgroup
+// (+5 us), and the head code inside the DEFAULT kernel (its branchy prologue made the compiler's counted waits in the straight-line part
+// conservative: +1.6 us per streaming launch with the feature OFF) -- hence a template instantiation of its own.
+// ---------------------------------------------------------------------------------------------------
+struct HeadReduce {
+    unsigned* flag;   // nullptr: none
+    const float* partial;
+    int S;
+    bf16_t* C;
+    int ldc, M, N;
+    EpiDev epi;
+};
+static_assert(sizeof(HeadReduce) <= sizeof(((GemmDeferred*)nullptr)->blob), "GemmDeferred::blob too small");
+static HeadReduce no_head() {
+    HeadReduce h;
+    ::memset(&h, 0, sizeof h);
+    return h;
+}
+// One hand-off = HEAD_WORDS words: the arrival counter on its own 128-byte line, then HEAD_GROUPS release words on lines of their own. The
+// LAST producer (its fetch-add returns M - 1) writes every release word; a consumer polls the word of its group (blockIdx mod 8 -- roughly
+// its XCD) with a 512-cycle sleep. (First version: every workgroup polled the counter itself every 128 cycles -- 256 pollers on one line,
+// the producers' own slab loads queued behind them on that channel: decode pass 3.74 -> 4.99 ms.)
+constexpr int HEAD_GROUPS = 8, HEAD_LINE = 32, HEAD_WORDS = (1 + HEAD_GROUPS) * HEAD_LINE;
+int gemm_head_words() { return HEAD_WORDS; }
+__device__ __forceinline__ void head_arrive(unsigned* flag, unsigned producers) {   // one lane, after the block's release fence + barrier
+    const unsigned old = __hip_atomic_fetch_add(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (old == producers - 1) {
+#pragma unroll
+        for (int g = 0; g < HEAD_GROUPS; ++g) __hip_atomic_store(flag + (1 + g) * HEAD_LINE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+__device__ __forceinline__ void head_wait(const unsigned* flag, int bid) {
+    if (threadIdx.x == 0) {
+        const unsigned* rel = flag + (1 + (bid & (HEAD_GROUPS - 1))) * HEAD_LINE;
+        const unsigned long long t0 = wall_clock64();
+        while (__hip_atomic_load(rel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+            if (wall_clock64() - t0 > 2000000ull) {   // 20 ms
+                __hip_atomic_store(&g_tail_error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(8);
+        }
+    }
+    // ONE wave's acquire invalidates the XCD's L2 for everybody in the block (first version: all eight waves of all 256 workgroups issued it)
+    if (threadIdx.x < 64) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
 #ifndef COVER_TAIL_ACQUIRE
 #define COVER_TAIL_ACQUIRE 1   // one buffer_inv per reducing workgroup: what the memory model asks for (the path is opt-in and slower anyway)
 #endif
@@ -1007,11 +1064,11 @@ extern "C" int cover_sk_debug(unsigned long long* out) {
 #else
 #define SKT(slot) do { } while (0)
 #endif
-template <int MF, int KS, int NBW, int NBUF, bool W8 = false>
+template <int MF, int KS, int NBW, int NBUF, bool W8 = false, bool HEAD = false>
 __global__ __launch_bounds__(512) void gemm_skinny3(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ Wp,
                                                     void* C, int ldc, int M, int N, int Kp, EpiDev epi,
                                                     float* __restrict__ partial, int kper, const float* __restrict__ wscale,
-                                                    TailReduce tr) {
+                                                    TailReduce tr, HeadReduce hd) {
     SKT(0);
     constexpr int NG = 8 / KS, KC = 256 * KS, NBPB = NG * NBW;
     constexpr int XB = MF * 16 * KC * 2;          // bytes of one activation chunk (fragment-major)
@@ -1108,6 +1165,23 @@ __global__ __launch_bounds__(512) void gemm_skinny3(const bf16_t* __restrict__ A
     // prologue. The activation chunk is requested BEFORE the first NBUF weight items: loads return in order, so with the
     // weights first the chunk (and with it the first MFMA, and with that the first REFILL of a weight buffer) would wait for
     // all NBUF x 8 KiB per wave to land -- the stream would drain its whole initial window before issuing anything new.
+    // head reduction (HEAD instantiations only: the default kernel's code is untouched -- a branchy prologue made the compiler's counted waits
+    // in the straight-line part conservative and cost the plain path 6 us per layer): the first hd.M workgroups fold the previous GEMM's slabs,
+    // one row each, before anything else of theirs; everybody then meets at the hand-off's release word and starts its own prologue
+    if constexpr (HEAD) {
+        const int bid = blockIdx.y * gridDim.x + blockIdx.x;
+        if (bid < hd.M) {
+            const float* pl = hd.partial;
+            asm volatile("" : "+s"(pl)::"memory");
+            reduce_norm_row(pl, hd.S, hd.C, hd.ldc, hd.M, hd.N, hd.epi, bid, (float*)smem);
+            __syncthreads();   // every wave's row stores are in the XCD's L2 (the barrier drains vmcnt) ...
+            if (tid < 64) {    // ... ONE wave writes the L2 back (a release per wave was eight L2 sweeps per workgroup), one lane arrives
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                if (tid == 0) head_arrive(hd.flag, (unsigned)hd.M);
+            }
+        }
+        head_wait(hd.flag, bid);
+    }
     if (items >= NBUF && min(KC, ke - kb) == KC) {   // straight-line: the compiler counts the weight loads behind the chunk's
         {   // whole first chunk: no per-element conditions (rows beyond M re-read row M-1; their outputs are never stored)
 #pragma unroll
@@ -1584,20 +1658,22 @@ static void launch_skinny2(const Skinny2Plan& p, const bf16_t* A, int lda, const
 }
 
 static hipError_t launch_skinny3(const Skinny3Plan& p, const bf16_t* A, int lda, const bf16_t* Wp, void* C, int ldc, int M, int N,
-                                 int Kp, const EpiDev& epi, float* partial, hipStream_t st, const TailReduce& tr = no_tail()) {
+                                 int Kp, const EpiDev& epi, float* partial, hipStream_t st, const TailReduce& tr = no_tail(),
+                                 const HeadReduce& hd = no_head()) {
     hipError_t e = hipSuccess;
     dim3 grid(p.gx, p.S), block(512);
     plan_hit(20);
 #define SK3(MF_, NBW_, W8_)                                                                                                  \
     do {                                                                                                                    \
-        auto kfn = gemm_skinny3<MF_, 4, NBW_, NBW_, W8_>;                                                                   \
+        auto kfn = hd.flag ? gemm_skinny3<MF_, 4, NBW_, NBW_, W8_, true> : gemm_skinny3<MF_, 4, NBW_, NBW_, W8_, false>;  \
         if (p.lds > 64 * 1024) {                                                                                            \
-            static hipError_t attr = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-            e = attr;                                                                                                       \
+            static hipError_t attr0 = hipFuncSetAttribute((const void*)gemm_skinny3<MF_, 4, NBW_, NBW_, W8_, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+            static hipError_t attr1 = hipFuncSetAttribute((const void*)gemm_skinny3<MF_, 4, NBW_, NBW_, W8_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+            e = attr0 != hipSuccess ? attr0 : attr1;                                                                        \
         }                                                                                                                   \
         if (e == hipSuccess)                                                                                                \
             launch_streaming(sk_class(N, Kp), (W8_ ? 1.0 : 2.0) * (double)N * (double)Kp, kfn, grid, block, p.lds, st, A, lda,  \
-                             W8_ ? (const bf16_t*)epi.w8 : Wp, C, ldc, M, N, Kp, epi, partial, p.kper, epi.w8s, tr);         \
+                             W8_ ? (const bf16_t*)epi.w8 : Wp, C, ldc, M, N, Kp, epi, partial, p.kper, epi.w8s, tr, hd);     \
     } while (0)
     if (epi.w8) {   // e4m3 weight stream
         if (p.MF == 1) { if (p.NBW == 4) SK3(1, 4, true); else if (p.NBW == 3) SK3(1, 3, true); else SK3(1, 2, true); }
@@ -1619,14 +1695,39 @@ static hipError_t run_norm(const EpiDev& epi, void* C, int ldc, int M, int Nout,
                           epi.nq8, epi.ldnq8, epi.nq8s);
 }
 
+// the ordinary reduction launch for an armed hand-off that the next launch cannot carry
+static hipError_t launch_deferred_reduce(const GemmDeferred* d, hipStream_t st) {
+    const HeadReduce* hp = (const HeadReduce*)d->blob;
+    launch_streaming(5, 0.0, splitk_reduce_norm, dim3(hp->M), dim3(512), 0, st, hp->partial, hp->S, hp->C, hp->ldc, hp->M, hp->N, hp->epi);
+    return hipGetLastError();
+}
+
 hipError_t launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* Wp, void* C, int ldc, int M, int N, int K,
                             const cover_gemm_epi* epi_in, float* ws, size_t ws_bytes, int variant, hipStream_t st, int* splits_out,
-                            unsigned* tail_sync) {
+                            unsigned* tail_sync, GemmDeferred* defer_out, const GemmDeferred* head_in) {
     if (splits_out) *splits_out = 0;
-    if (M <= 0 || N <= 0) return hipSuccess;
+    if (defer_out) defer_out->armed = false;
+    if (M <= 0 || N <= 0) return head_in && head_in->armed ? launch_deferred_reduce(head_in, st) : hipSuccess;
     const int Kp = (K + 127) / 128 * 128;
     EpiDev epi = make_epi(epi_in);
     if (variant == 0) variant = (M <= 64 && ws != nullptr) ? 3 : 1;
+    // head reduction: an armed hand-off rides in this launch's first workgroups when this launch is the unsplit third-generation streaming
+    // kernel with at least as many workgroups as rows to fold; anything else folds the slabs with the ordinary reduction launch first
+    HeadReduce hd = no_head();
+    if (head_in && head_in->armed) {
+        const HeadReduce* hp = (const HeadReduce*)head_in->blob;
+        bool ride = false;
+        if (variant == 3 && M <= 32) {
+            static const char* g3e = getenv("COVER_SKINNY3");
+            const Skinny3Plan q3 = plan_skinny3(M, N, Kp);
+            ride = q3.ok && q3.S == 1 && !(g3e && g3e[0] == '0') && (long long)q3.gx >= hp->M && tail_sync == nullptr;
+        }
+        if (ride) hd = *hp;
+        else {
+            hipError_t e0 = launch_deferred_reduce(head_in, st);
+            if (e0 != hipSuccess) return e0;
+        }
+    }
     // the split-K reduction + norm of a weight-streaming launch (M <= 64) can run at the tail of that launch (see "Tail reduction")
     const bool norm_fusable = epi.norm_w != nullptr && epi.norm_out != nullptr && !epi.glu && !epi.out_f32 && (N % 8) == 0 && N <= 8192 && (ldc % 8) == 0 &&
                               (epi.ld_norm_out % 8) == 0 && (((uintptr_t)epi.norm_w) & 15) == 0;
@@ -1647,7 +1748,7 @@ hipError_t launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* Wp, void* C,
         if (p3.ok && p3.S > 1 && (ws == nullptr || ws_bytes < p3.ws_bytes)) p3.ok = false;
         if (p3.ok && (variant == 6 || !(g3 && g3[0] == '0'))) {
             tr.S = p3.S;
-            hipError_t e = launch_skinny3(p3, A, lda, Wp, C, ldc, M, N, Kp, epi, p3.S > 1 ? ws : nullptr, st, p3.S > 1 ? tr : no_tail());
+            hipError_t e = launch_skinny3(p3, A, lda, Wp, C, ldc, M, N, Kp, epi, p3.S > 1 ? ws : nullptr, st, p3.S > 1 ? tr : no_tail(), hd);
             if (e != hipSuccess) return e;
             if (p3.S > 1 && tr.sync != nullptr) return hipSuccess;   // the launch folded its own slabs
             if (p3.S == 1) {
@@ -1676,6 +1777,12 @@ hipError_t launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* Wp, void* C,
         if (e != hipSuccess) return e;
         const bool want_norm = epi.norm_w != nullptr && epi.norm_out != nullptr;
         if (norm_fusable) {
+            if (defer_out && defer_out->flag && M <= 32) {   // head reduction: the NEXT streaming launch folds these slabs in its first M workgroups
+                HeadReduce* hp = (HeadReduce*)defer_out->blob;
+                hp->flag = defer_out->flag; hp->partial = ws; hp->S = S; hp->C = (bf16_t*)C; hp->ldc = ldc; hp->M = M; hp->N = N; hp->epi = epi;
+                defer_out->armed = true;
+                return hipSuccess;
+            }
             launch_streaming(5, 0.0, splitk_reduce_norm, dim3(M), dim3(512), 0, st, (const float*)ws, S, (bf16_t*)C, ldc, M, N, epi);
             return hipGetLastError();
         }
@@ -2003,9 +2110,10 @@ hipError_t launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* Wp, void* C,
 // Weight-streaming GEMM WITHOUT its reduction: leaves fp32 partials [S][M][N] in ws for a consumer that folds them
 // (the decoder fuses the QKV reduction into rope_kv_write). Returns the number of K slices through *S_out.
 hipError_t launch_gemm_skinny_partial(const bf16_t* A, int lda, const bf16_t* Wp, float* ws, size_t ws_bytes, int M, int N,
-                                      int K, int* S_out, hipStream_t st, const void* w8, const float* w8s) {
+                                      int K, int* S_out, hipStream_t st, const void* w8, const float* w8s, const GemmDeferred* head_in) {
     if (M <= 0 || M > 64 || N <= 0) return hipErrorInvalidValue;
     const int Kp = (K + 127) / 128 * 128;
+    const bool armed = head_in && head_in->armed;
     {
         static const char* g3 = getenv("COVER_SKINNY3");
         Skinny3Plan p3 = plan_skinny3(M, N, Kp);
@@ -2013,10 +2121,25 @@ hipError_t launch_gemm_skinny_partial(const bf16_t* A, int lda, const bf16_t* Wp
         if (p3.ok && !(g3 && g3[0] == '0') && ws != nullptr && ws_bytes >= need) {
             EpiDev none = make_epi(nullptr);
             if (w8 && w8s) { none.w8 = (const uint8_t*)w8; none.w8s = w8s; }
-            hipError_t e = launch_skinny3(p3, A, lda, Wp, nullptr, 0, M, N, Kp, none, ws, st);
+            HeadReduce hd = no_head();
+            if (armed) {
+                // the head rows are folded out of the SAME workspace this launch writes its own slabs to: every workgroup stores at its very end,
+                // behind the counter that says all rows have been read and folded
+                const HeadReduce* hp = (const HeadReduce*)head_in->blob;
+                if (M <= 32 && (long long)p3.gx * p3.S >= hp->M) hd = *hp;
+                else {
+                    hipError_t e0 = launch_deferred_reduce(head_in, st);
+                    if (e0 != hipSuccess) return e0;
+                }
+            }
+            hipError_t e = launch_skinny3(p3, A, lda, Wp, nullptr, 0, M, N, Kp, none, ws, st, no_tail(), hd);
             *S_out = p3.S;
             return e;
         }
+    }
+    if (armed) {
+        hipError_t e0 = launch_deferred_reduce(head_in, st);
+        if (e0 != hipSuccess) return e0;
     }
     Skinny2Plan p = plan_skinny2(M, N, Kp);
     if (ws == nullptr || ws_bytes < p.ws_bytes) return hipErrorInvalidValue;

@@ -70,10 +70,10 @@ def _group(m, dev, N, write_t=0):
                                dict(region=2, length=write_t + 1)], 2, write_t_off=write_t, seg0_shared=True)
 
 
-def _run(m, dev, x0, mode, N, write_t=0, tail="0"):
-    """One decode pass of the two layers from hidden rows x0; mode = COVER_DECODE_CHAIN value, tail = COVER_TAIL_REDUCE value.
-    Returns (x, own K region, own V^T region, plan counters)."""
-    with _Env(COVER_DECODE_CHAIN=mode, COVER_TAIL_REDUCE=tail):
+def _run(m, dev, x0, mode, N, write_t=0, tail="0", head="0"):
+    """One decode pass of the two layers from hidden rows x0; mode = COVER_DECODE_CHAIN value, tail = COVER_TAIL_REDUCE value, head =
+    COVER_HEAD_REDUCE value. Returns (x, own K region, own V^T region, plan counters)."""
+    with _Env(COVER_DECODE_CHAIN=mode, COVER_TAIL_REDUCE=tail, COVER_HEAD_REDUCE=head):
         x = x0.clone()
         g = _group(m, dev, N, write_t)
         ops.gemm_plan_counts(reset=True)
@@ -222,6 +222,35 @@ def test_tail_reduction_equals_the_reduction_launches(llm, dev, M):
                     a = (a @ a).tanh()
                     big.add_(1)
         xt, kt, vt, c1 = _run(m, dev, x0, "0", M, tail="1")
+        assert c1 == c0, (c0, c1)                                       # the same GEMM plans ran
+        assert torch.equal(xt, xr), it
+        assert all(torch.equal(p, q) for p, q in zip(kt, kr)) and all(torch.equal(p, q) for p, q in zip(vt, vr)), it
+    side.synchronize()
+    torch.cuda.synchronize()
+    ops.gemm_tail_status()
+
+
+@pytest.mark.parametrize("M", [32, 20, 8, 1])
+def test_head_reduction_equals_the_reduction_launches(llm, dev, M):
+    """COVER_HEAD_REDUCE=1 (gemm_bf16.hip "Head reduction", opt-in): the split-K slabs of o_proj / down are folded (+ residual + RMSNorm) by
+    the FIRST M workgroups of the next weight-streaming launch (gate_up / the next layer's qkv), every workgroup of that launch waiting at the
+    hand-off's release word before it loads activation rows. Default = the reduction launches. Same code on the
+    same slabs: hidden rows and the K / V^T rows bit-identical, over repeated passes with other kernels co-running (which workgroups reach
+    the counter first changes from pass to pass), fewer launches, and the bounded wait never gives up."""
+    m, _ = llm
+    g = torch.Generator(device=dev).manual_seed(13)
+    x0 = torch.randn(M, L7["dim"], device=dev, generator=g).to(BF)
+    xr, kr, vr, c0 = _run(m, dev, x0, "0", M, head="0")
+    side = torch.cuda.Stream(device=dev)
+    a = torch.randn(2048, 2048, device=dev)
+    big = torch.empty(64 << 20, dtype=torch.uint8, device=dev)
+    for it in range(8):
+        if it >= 2:
+            with torch.cuda.stream(side):
+                for _ in range(6):
+                    a = (a @ a).tanh()
+                    big.add_(1)
+        xt, kt, vt, c1 = _run(m, dev, x0, "0", M, head="1", write_t=0)
         assert c1 == c0, (c0, c1)                                       # the same GEMM plans ran
         assert torch.equal(xt, xr), it
         assert all(torch.equal(p, q) for p, q in zip(kt, kr)) and all(torch.equal(p, q) for p, q in zip(vt, vr)), it
