@@ -287,12 +287,12 @@ class OpenVLA:
         return tokens.t().contiguous(), sel.t().contiguous()
 
     def _check_opt_in_protocols(self):
-        """The opt-in in-kernel synchronisation protocols (COVER_DECODE_CHAIN, COVER_TAIL_REDUCE) end a bounded wait that times out with
-        a status word instead of a hang; their results are then garbage. When either is switched on, every decision checks the words
-        before its tokens are handed back (this synchronises the device: the opt-in paths are measurement paths)."""
+        """The opt-in in-kernel synchronisation protocols (COVER_DECODE_CHAIN, COVER_TAIL_REDUCE, COVER_HEAD_REDUCE) end a bounded wait that
+        times out with a status word instead of a hang; their results are then garbage. When one is switched on, every decision checks the
+        words before its tokens are handed back (this synchronises the device: the opt-in paths are measurement paths)."""
         if os.environ.get("COVER_DECODE_CHAIN", "0") in ("1", "2"):
             ops.decode_chain_status()
-        if os.environ.get("COVER_TAIL_REDUCE", "0") == "1":
+        if os.environ.get("COVER_TAIL_REDUCE", "0") == "1" or os.environ.get("COVER_HEAD_REDUCE", "0") == "1":
             ops.gemm_tail_status()
 
     def _decode_body(self, x, N, n_samples, Lt, prompt_of_cand, cand_len, last_row, pos_all, uniforms, temperature, tokens, sel, fed, trace,
