@@ -50,6 +50,7 @@ N_PROMPTS, N_SAMPLES, LT = 8, 4, 24
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_PEAK_TF = 2500.0      # bf16 dense
 FP8_PEAK_TF = 5000.0       # MX-scaled fp8 dense (MI355X_MICROARCH.md chip table; measured 4.65 PF)
+N_PROF = 10                # include/cover_hip.h COVER_PROF_CLASSES: 6 / 8 / 9 = the split-K reductions behind the ViT-sized / LLM-sized / fp8 tiled GEMMs
 BASE_METRIC = "candidate actions scored/sec (whole node), OpenVLA-7B N=32, 224^2 RGB"
 
 
@@ -300,7 +301,7 @@ def _profile_phases(pipe):
     import ctypes as C
     from cover_vla_amd import _lib as L
     h = L.lib()
-    n = 8
+    n = N_PROF
     out = {}
 
     def begin():
@@ -422,7 +423,7 @@ def main_pi0(a):
                            "algorithmic_bytes_per_launch": round(exp_bytes / max(cnt_d[1], 1)), "algorithmic_bytes_per_decision": exp_bytes,
                            "kernel_ms_per_decision": round(ms_d[1], 3), "splitk_reduce_ms_per_decision": round(ms_d[6], 3),
                            "attention_ms_per_decision": round(ms_d[2], 3), "attention_launches": int(cnt_d[2])}
-        tp = ms_p[1] + ms_p[4] + ms_p[6]
+        tp = ms_p[1] + ms_p[4] + ms_p[6] + ms_p[8]
         fp = work_p[1] + work_p[4]
         if tp > 0:
             tf = fp / (tp * 1e-3) / 1e12
@@ -430,15 +431,16 @@ def main_pi0(a):
                                                                f"(M = {pipe.P} x (256 + longest real prompt) rows), split-K reductions included",
                                     "achieved": round(tf, 1), "peak": MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": round(tf / MFMA_PEAK_TF, 4),
                                     "launches": int(cnt_p[1] + cnt_p[4]), "kernel_ms_per_decision": round(tp, 3), "flop_per_decision": fp}
-            if ms_p[4] > 0:
-                t4 = work_p[4] / (ms_p[4] * 1e-3) / 1e12
+            if ms_p[4] > 0:   # the LLM-sized GEMMs of the prefix pass WITH the split-K reductions that complete them (profiler class 8)
+                t4 = work_p[4] / ((ms_p[4] + ms_p[8]) * 1e-3) / 1e12
                 out["roofline_mfma"]["prefix_mlp"] = {"achieved": round(t4, 1), "frac": round(t4 / MFMA_PEAK_TF, 4), "launches": int(cnt_p[4]),
-                                                      "kernel_ms_per_decision": round(ms_p[4], 3)}
+                                                      "kernel_ms_per_decision": round(ms_p[4] + ms_p[8], 3), "splitk_reduce_ms": round(ms_p[8], 3),
+                                                      "gemm_kernels_only_frac": round(work_p[4] / (ms_p[4] * 1e-3) / 1e12 / MFMA_PEAK_TF, 4)}
         fv = work_v[1] + work_v[4]
         floor_ms = 1e3 * (exp_bytes / (HBM_PEAK_GBS * 1e9) + (fp + fv) / (MFMA_PEAK_TF * 1e12))
         out["end_to_end"] = {"floor_ms": round(floor_ms, 3), "measured_ms": round(ms_per_step, 3), "frac": round(floor_ms / ms_per_step, 4),
                              "floor": "expert weight bytes (10 steps) / 8 TB/s + (tower + prefix + verifier-tower tiled FLOPs) / 2.5 PFLOP/s (attention, norms, fp32 heads: 0)"}
-        out["phase_kernel_ms"] = {k: {"gemm_tiled_small": round(v[0][1], 3), "gemm_tiled_llm": round(v[0][4], 3), "splitk_reduce": round(v[0][6] + v[0][5], 3),
+        out["phase_kernel_ms"] = {k: {"gemm_tiled_small": round(v[0][1], 3), "gemm_tiled_llm": round(v[0][4], 3), "splitk_reduce": round(v[0][6] + v[0][5] + v[0][8], 3),
                                       "attention": round(v[0][2], 3), "weight_streaming": round(v[0][0] + v[0][3], 3),
                                       "launches": int(sum(v[1]))} for k, v in ph.items()}
         for k in ("roofline", "roofline_mfma"):
@@ -463,7 +465,112 @@ def _cpu_info():
     return model, {"amx_bf16": "amx_bf16" in flags, "avx512_bf16": "avx512_bf16" in flags, "avx512f": "avx512f" in flags}
 
 
-def cpu_baseline(pipe, timed=1, batched=True):
+def oracle_agreement(pipe, tok_o, logits_o, sel_o, n_prompts, free=None):
+    """Full-size agreement of the HIP path with the CPU oracle on the SAME decision (checkpoint, frame, prompts, uniforms): what
+    run_simpler_eval_with_openpi.py:305-326 (one batched policy call) and :346-365 (verifier scores -> grouped arg-max) produce.
+      tokens : the HIP sampler TEACHER-FORCED on the oracle's tokens (every step then compares like with like; the returned tokens are the
+               HIP path's own picks), per (row, step): err = max |logit difference| over the action bins; the oracle's inverse-CDF pick
+               of bin t on uniform u is DATA-DECIDED when no logit perturbation of magnitude <= err can move either CDF edge of bin t
+               across u -- exactly: an edge at cumulative mass c moves at most to c e^(a) / (c e^(a) + (1 - c) e^(-a)), a = err / T
+               (the mass below the edge up-weighted, the rest down-weighted). This is the worst case the relative bound
+               exp(4 err / T) - 1 of tests/test_openvla_gpu.py over-estimates; a pick that is decided must be equal bit for bit.
+      scores : the HIP verifier on the ORACLE's tokens (same histories) against the oracle's scores; the winner must be the same
+               whenever the oracle's own margins (best group mean vs runner-up, best candidate in that group vs runner-up) exceed
+               twice the largest score difference.
+    free = (winner index, tokens) of the free-running HIP decision: reported (token agreement, same winner), not asserted -- after
+    the first undecided pick two free-running histories are different sequences."""
+    from cover_vla_amd import ops
+    i, S, dev, c = pipe.inp, pipe.n_samples, pipe.dev, pipe.c
+    N_ = n_prompts * S
+    lo, hi = c["tok_vocab"] - c["n_bins"], c["tok_vocab"]
+    n_gen = tok_o.shape[1]
+    tr = {}
+    tok_g, _ = pipe.policy.sample(i["frame"], i["toks"][:n_prompts].contiguous(), i["lens"][:n_prompts].contiguous(), S,
+                                  i["u"][:N_].contiguous(), 1.0, trace=tr, force_tokens=tok_o.to(dev))
+    tok_g = tok_g.cpu()
+    lg = torch.stack([l[:N_, lo:hi].float().cpu() for l in tr["logits"][:n_gen]], 1).double()      # [N, n_gen, bins]
+    lo_ = logits_o[:, :n_gen, lo:hi].double()
+    u = i["u"][:N_, :n_gen].cpu().double()
+    err = (lg - lo_).abs().amax(dim=2)                                                                # [N, n_gen]
+    p = torch.exp(lo_ - lo_.amax(dim=2, keepdim=True))
+    cs = torch.cumsum(p, 2) / p.sum(2, keepdim=True)
+    t = (tok_o[:, :n_gen] - lo).clamp(0, hi - lo - 1)
+    hi_edge = torch.gather(cs, 2, t[..., None])[..., 0]
+    lo_edge = torch.where(t > 0, torch.gather(cs, 2, (t - 1).clamp(min=0)[..., None])[..., 0], torch.zeros_like(hi_edge))
+    ea = torch.exp(err)
+    moved = lambda cc, up: (cc * (ea if up else 1 / ea)) / (cc * (ea if up else 1 / ea) + (1 - cc) * ((1 / ea) if up else ea))
+    eps = 1e-5                                                                                        # the fp32 cumsum of both selectors
+    decided = (moved(lo_edge, True) < u - eps) & ((moved(hi_edge, False) > u + eps) | (t == hi - lo - 1))
+    same = tok_g[:, :n_gen] == tok_o[:, :n_gen]
+    n_dec = int(decided.sum())
+    rel = ((lg - lo_).flatten(1).norm(dim=1) / lo_.flatten(1).norm(dim=1))
+    # verifier on the oracle's tokens
+    hb, pad = ops.tokens_to_histories(tok_o.to(dev), c["tok_vocab"], pipe.centers, pipe.past_dev, n_use=1)
+    pf, tf = pipe.ver.extract_shared_features(i["img384"], i["text"])
+    r = pipe.ver.score_histories(pipe.ver.image_text_embeddings(pf, tf), hb, S, pad=pad)
+    sc_g, sc_o = r["scores"].float().cpu().double(), torch.as_tensor(np.asarray(sel_o["scores"])).double().flatten()
+    s_err = float((sc_g - sc_o).abs().max())
+    gm = sc_o.view(n_prompts, S).mean(1)
+    g_best = int(sel_o["group"])
+    m_group = float(gm[g_best] - gm[torch.arange(n_prompts) != g_best].max()) if n_prompts > 1 else float("inf")
+    in_g = sc_o.view(n_prompts, S)[g_best]
+    m_cand = float(in_g.max() - in_g[torch.arange(S) != int(in_g.argmax())].max()) if S > 1 else float("inf")
+    w_decided = min(m_group, m_cand) > 2 * s_err
+    out = {"rows": N_, "steps": n_gen, "decided": n_dec, "of": int(decided.numel()),
+           "agree_on_decided": round(float(same[decided].double().mean()), 6) if n_dec else None,
+           "agree_all_teacher_forced": round(float(same.double().mean()), 4),
+           "logit_max_abs": round(float(err.max()), 4), "logit_rel_l2_max": round(float(rel.max()), 4),
+           "score_max_abs": round(s_err, 6), "winner_same": bool(int(r["result"][0]) == int(sel_o["global_idx"])), "winner_decided": bool(w_decided),
+           "oracle_winner": int(sel_o["global_idx"]), "oracle_margins": {"group_mean": round(m_group, 5), "within_group": round(m_cand, 5)},
+           "criterion": "HIP sampler teacher-forced on the oracle's tokens; a pick is decided when no logit perturbation <= the measured max |logit difference| of that "
+                        "(row, step) can move a CDF edge of the picked bin across the uniform (exact worst case); HIP verifier on the oracle's tokens vs the oracle's scores"}
+    if free is not None:
+        gi_f, tok_f = free
+        tok_f = tok_f[:N_, :n_gen].cpu()
+        first = (tok_f != tok_o[:, :n_gen]).int().argmax(1)
+        out["free_running"] = {"token_agreement": round(float((tok_f == tok_o[:, :n_gen]).double().mean()), 4), "winner_same": bool(int(gi_f) == int(sel_o["global_idx"])),
+                               "rows_identical": int((tok_f == tok_o[:, :n_gen]).all(1).sum())}
+    return out
+
+
+def oracle_state(pipe):
+    """The CPU oracle's copy of the SAME synthetic checkpoints the pipeline holds (drawn on the device with the same seeds, copied to the host)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    from cover_ref import blocks as Bk
+    from cover_vla_amd import synth
+    c, sc, dev = pipe.c, pipe.sc, pipe.dev
+    sd = {k: v.cpu() for k, v in synth.openvla_state(c, seed=1234, nontrivial=False, device=dev, wdtype=torch.bfloat16, peaked=pipe.peaked).items()}
+    sd = Bk.to_bf16(sd)
+    ssd = Bk.to_bf16({k: v.cpu() for k, v in synth.siglip2_state(sc, seed=4321, nontrivial=False, device=dev, wdtype=torch.bfloat16).items()})
+    torch.cuda.empty_cache()
+    ck = synth.verifier_checkpoint(len(pipe.ver.trainable_models), seed=1234, num_patches=(sc["image"] // sc["patch"]) ** 2, vision_dim=sc["dim"], text_dim=sc["dim"])
+    return sd, ssd, ck
+
+
+def oracle_batched_decision(pipe, sd, ssd, ck, n_prompts):
+    """ONE decision of the CPU oracle on the pipeline's first n_prompts prompt groups, executed the way the reference executes it
+    (oracle/cover_ref/openvla.py::sample_batched + the verifier). Returns (tokens, trace with logits / seconds, selection, policy s, towers s, heads s)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    from cover_ref import openvla as OR, verifier as V
+    c, sc, i, S = pipe.c, pipe.sc, pipe.inp, pipe.n_samples
+    N_ = n_prompts * S
+    trb = {"seconds": {}}
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        tok_b = OR.sample_batched(c, sd, i["frame"][:1].cpu(), i["toks"][:n_prompts].cpu(), i["lens"][:n_prompts].cpu(), S, i["u"][:N_].cpu(), 1.0, trace=trb)
+        t_pol = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        pf, tf = OR.siglip2_features(sc, ssd, i["img384"].cpu(), i["text"].cpu())
+        t_tow = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        acts = OR.tokens_to_actions(c, tok_b.numpy())                            # [N, 7]
+        hists = [np.concatenate([i["past"], acts[n:n + 1].astype(np.float64)], 0) for n in range(N_)]
+        sel_b = V.compute_max_similarity_scores(ck["ensemble_components"], pf, tf, hists, S)
+        t_heads = time.perf_counter() - t0
+    return tok_b, trb, sel_b, t_pol, t_tow, t_heads
+
+
+def cpu_baseline(pipe, timed=1, batched=True, free=None):
     """BASELINE.md 4 protocol, bounded: the CPU oracle (oracle/cover_ref, PyTorch-CPU eager bf16) executes FULL candidates exactly as
     an eager, un-deduplicated implementation does -- both vision towers at full depth, the 3-layer projector, all 32 Llama layers for
     the T ~ 280 prefill and six single-token decode steps with a concatenated KV cache, lm_head x 7, then the verifier (SigLIP2-L
@@ -476,16 +583,11 @@ def cpu_baseline(pipe, timed=1, batched=True):
     towers once + 8 prefills + 32 x (decode + heads) -- what a CPU run of this repo's schedule would cost; reported beside it so
     the part of the GPU/CPU ratio that is dedup rather than kernels is visible."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    from cover_ref import blocks as Bk, openvla as OR, verifier as V
-    from cover_vla_amd import synth
-    c, sc, dev = pipe.c, pipe.sc, pipe.dev
+    from cover_ref import openvla as OR, verifier as V
+    c, sc = pipe.c, pipe.sc
     t_all = time.time()
-    sd = {k: v.cpu() for k, v in synth.openvla_state(c, seed=1234, nontrivial=False, device=dev, wdtype=torch.bfloat16, peaked=pipe.peaked).items()}
-    sd = Bk.to_bf16(sd)
-    ssd = Bk.to_bf16({k: v.cpu() for k, v in synth.siglip2_state(sc, seed=4321, nontrivial=False, device=dev, wdtype=torch.bfloat16).items()})
-    torch.cuda.empty_cache()
+    sd, ssd, ck = oracle_state(pipe)
     i = pipe.inp
-    ck = synth.verifier_checkpoint(3, seed=1234, num_patches=(sc["image"] // sc["patch"]) ** 2, vision_dim=sc["dim"], text_dim=sc["dim"])
     frame, img384, text = i["frame"][:1].cpu(), i["img384"].cpu(), i["text"].cpu()
     S = pipe.n_samples
 
@@ -518,22 +620,14 @@ def cpu_baseline(pipe, timed=1, batched=True):
     asx = None
     if batched:
         P_, N_ = n_local, n_local * S
-        trb = {"seconds": {}}
-        with torch.no_grad():
-            t0 = time.perf_counter()
-            tok_b = OR.sample_batched(c, sd, frame, i["toks"][:P_].cpu(), i["lens"][:P_].cpu(), S, i["u"][:N_].cpu(), 1.0, trace=trb)
-            t_pol = time.perf_counter() - t0
-            t0 = time.perf_counter()
-            pf, tf = OR.siglip2_features(sc, ssd, img384, text)
-            t_tow = time.perf_counter() - t0
-            t0 = time.perf_counter()
-            acts = OR.tokens_to_actions(c, tok_b.numpy())                            # [N, 7]
-            hists = [np.concatenate([i["past"], acts[n:n + 1].astype(np.float64)], 0) for n in range(N_)]
-            V.compute_max_similarity_scores(ck["ensemble_components"], pf, tf, hists, S)
-            t_heads = time.perf_counter() - t0
+        tok_b, trb, sel_b, t_pol, t_tow, t_heads = oracle_batched_decision(pipe, sd, ssd, ck, P_)
         dec_s = t_pol + t_tow + t_heads
+        # the oracle's decision is the CHECKER of the GPU decision on the same checkpoint, frame, prompts and uniforms (never the other way round)
+        # (bf16 profile only: the fp8 profile's oracle runs on the de-quantised weights, tests/test_openvla_gpu.py)
+        agreement = oracle_agreement(pipe, tok_b, trb["logits"], sel_b, P_, free=free) if (pipe.weight_dtype == "bf16" and pipe.horizon == 1) else None
         asx = {"decision_seconds": round(dec_s, 2), "candidates_per_s": round(N_ / dec_s, 4), "rows": N_, "measured": True,
                "phase_seconds": {**{k: round(v, 3) for k, v in trb["seconds"].items()}, "verifier_towers": round(t_tow, 3), "verifier_heads": round(t_heads, 3)},
+               "agreement": agreement,
                "note": "ONE decision: policy = one batched forward over the N un-deduplicated rows (both vision towers + projector on N copies of the frame, "
                        "left-padded batched prefill of N full sequences, 6 batched decode steps over a concatenated KV cache, lm_head on N rows x 7: "
                        "oracle/cover_ref/openvla.py::sample_batched), verifier = SigLIP2 towers on one image + P instructions, 3-member heads on N histories; "
@@ -547,7 +641,7 @@ def cpu_baseline(pipe, timed=1, batched=True):
     return {"value": asx["candidates_per_s"] if asx else round(1.0 / per_cand, 4), "unit": "candidates/s", "cores": torch.get_num_threads(), "kind": "port",
             "value_is": ("as_executed_batched: N / the measured seconds of ONE batched, un-deduplicated N-row decision (the way the reference executes a decision)" if asx
                          else "per_candidate_unbatched: 1 / the median seconds of one batch-1 candidate (pessimistic: see extrapolation)"),
-            "as_executed_batched": asx,
+            "as_executed_batched": asx, "agreement": asx["agreement"] if asx else None,
             "per_candidate_unbatched": {"candidates_per_s": round(1.0 / per_cand, 4), "seconds_per_candidate": r2(per_cand),
                                         "note": "secondary figure: one full candidate at batch 1 (no weight re-use across rows); N x this is an upper bound of the decision time"},
             "extrapolation": f"per_candidate_unbatched only: N={N} x ONE timed single-candidate forward (batch 1) = {N * per_cand:.0f} s would be a pessimistic bound of the "
@@ -635,7 +729,7 @@ def profile_decision(pipe, world, rank, cpu_gather):
     import ctypes as C
     from cover_vla_amd import _lib as L
     h = L.lib()
-    n = 8
+    n = N_PROF
     ms, cnt, work = (C.c_double * n)(), (C.c_longlong * n)(), (C.c_double * n)()
     L.check(h.cover_profile_begin(32768), "profile_begin")
     try:
@@ -681,31 +775,33 @@ def roofline_objects(ms, cnt, work, ms_per_step, lib_sha):
                            "kernel_ms_per_decision": round(ms[0] + ms[5], 3), "streaming_kernels_only": {"ms": round(ms[0], 3), "achieved": round(ach_k, 1),
                                                                                                          "frac": round(ach_k / HBM_PEAK_GBS, 4)},
                            "splitk_reduce_ms_per_decision": round(ms[5], 3)})
-    t_mfma = ms[1] + ms[4] + ms[6]
+    t_mfma = ms[1] + ms[4] + ms[6] + ms[8]
     if cnt[1] + cnt[4] > 0 and t_mfma > 0:
         tf_all = (work[1] + work[4]) / (t_mfma * 1e-3) / 1e12
         obj = {"bound": "mfma", "kernel": "gemm_tiled_v3 (self-loading 224-row tiles: LLM prefill) / gemm_tiled (64-row tiles: towers) (LLM prefill + DINOv2 / SigLIP / SigLIP2 towers + projector), split-K reductions included",
                "achieved": round(tf_all, 1), "peak": MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": round(tf_all / MFMA_PEAK_TF, 4),
                "launches": int(cnt[1] + cnt[4]), "kernel_ms_per_decision": round(t_mfma, 3), "flop_per_decision": work[1] + work[4]}
-        if cnt[4] > 0 and ms[4] > 0:
-            tf_p = work[4] / (ms[4] * 1e-3) / 1e12
+        if cnt[4] > 0 and ms[4] > 0:   # every sub-object carries the split-K reductions of ITS OWN GEMMs (profiler classes 8 / 6)
+            tf_p = work[4] / ((ms[4] + ms[8]) * 1e-3) / 1e12
             obj["prefill"] = {"achieved": round(tf_p, 1), "frac": round(tf_p / MFMA_PEAK_TF, 4), "launches": int(cnt[4]),
-                              "kernel_ms_per_decision": round(ms[4], 3)}
+                              "kernel_ms_per_decision": round(ms[4] + ms[8], 3), "splitk_reduce_ms": round(ms[8], 3), "splitk_reduce_launches": int(cnt[8]),
+                              "gemm_kernels_only_frac": round(work[4] / (ms[4] * 1e-3) / 1e12 / MFMA_PEAK_TF, 4)}
         if cnt[1] > 0 and ms[1] > 0:
             tf_v = work[1] / ((ms[1] + ms[6]) * 1e-3) / 1e12
             obj["vit"] = {"achieved": round(tf_v, 1), "frac": round(tf_v / MFMA_PEAK_TF, 4), "launches": int(cnt[1]),
-                          "kernel_ms_per_decision": round(ms[1] + ms[6], 3)}
+                          "kernel_ms_per_decision": round(ms[1] + ms[6], 3), "splitk_reduce_ms": round(ms[6], 3)}
         if any(o.get("frac", 0) > 1.0 for o in (obj, obj.get("prefill", {}), obj.get("vit", {}))):
             out["roofline_mfma"] = {"invalid": "a fraction > 1: refused"}
         else:
             out["roofline_mfma"] = obj
     if len(cnt) > 7 and cnt[7] > 0 and ms[7] > 0:
         # config 5: the decoder's projections on the MX-scaled fp8 matrix instruction -- priced against the 5 PFLOP/s fp8 peak
-        tf8 = work[7] / (ms[7] * 1e-3) / 1e12
+        tf8 = work[7] / ((ms[7] + ms[9]) * 1e-3) / 1e12     # with the split-K reductions behind the fp8 GEMMs (class 9)
         obj = {"bound": "mfma", "kernel": "gemm_tiled_v3_f8 / gemm_tiled_pc_f8 (v_mfma_scale_f32_16x16x128_f8f6f4: e4m3 activations per row x e4m3 weights per channel; the decoder's "
                                           "projections in every pass with more than 64 rows)",
                "achieved": round(tf8, 1), "peak": FP8_PEAK_TF, "unit": "TFLOP/s", "frac": round(tf8 / FP8_PEAK_TF, 4), "traffic": None,
-               "launches": int(cnt[7]), "avg_launch_us": round(1e3 * ms[7] / cnt[7], 2), "kernel_ms_per_decision": round(ms[7], 3), "flop_per_decision": work[7]}
+               "launches": int(cnt[7]), "avg_launch_us": round(1e3 * ms[7] / cnt[7], 2), "kernel_ms_per_decision": round(ms[7] + ms[9], 3),
+               "splitk_reduce_ms": round(ms[9], 3), "gemm_kernels_only_frac": round(work[7] / (ms[7] * 1e-3) / 1e12 / FP8_PEAK_TF, 4), "flop_per_decision": work[7]}
         guard("roofline_fp8_mfma", obj)
         if "roofline" not in out and "frac" in out.get("roofline_fp8_mfma", {}):
             out["roofline"] = dict(out["roofline_fp8_mfma"])
@@ -877,7 +973,12 @@ def main():
     if a.dtype == "fp8" and world == 1 and not a.no_agreement:
         out["fp8_vs_bf16"] = fp8_agreement(pipe, dev, a, n_prompts_global, prompt_ids)
     if rank == 0 and world == 1 and not a.no_cpu_baseline and not a.small:
-        out["cpu_baseline"] = cpu_baseline(pipe, batched=not a.no_cpu_batched)
+        out["cpu_baseline"] = cpu_baseline(pipe, batched=not a.no_cpu_batched, free=(last[0], last[1]))
+        ag = out["cpu_baseline"].get("agreement")
+        if ag is not None and ag["decided"] > 0 and ag["agree_on_decided"] < 1.0:
+            # a data-decided pick that differs from the oracle's is a wrong result, not a slow one: no bench line
+            print(json.dumps({"error": "HIP path disagrees with the CPU oracle on a data-decided pick: bench line refused", "agreement": ag}), flush=True)
+            sys.exit(3)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -2089,16 +2089,18 @@ hipError_t launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* Wp, void* C,
         return e;
     }
     if (e == hipSuccess && S > 1) {
+        // the reduction is charged to the class of the GEMM it completes: 6 behind a ViT-sized tiled GEMM, 8 behind an LLM-sized one, 9 behind an fp8 one
+        const int rcls = (f8_on && gemm_fp8_tiled_supported(pick)) ? 9 : (tcls == 4 ? 8 : 6);
         const bool want_norm = epi.norm_w != nullptr && epi.norm_out != nullptr;
         if (want_norm && !epi.glu && !epi.out_f32 && (N % 8) == 0 && N <= 8192 && (ldc % 8) == 0 && (epi.ld_norm_out % 8) == 0 && (((uintptr_t)epi.norm_w) & 15) == 0) {
-            launch_streaming(6, 0.0, splitk_reduce_norm, dim3(M), dim3(512), 0, st, (const float*)ws, S, (bf16_t*)C, ldc, M, N, epi);
+            launch_streaming(rcls, 0.0, splitk_reduce_norm, dim3(M), dim3(512), 0, st, (const float*)ws, S, (bf16_t*)C, ldc, M, N, epi);
             norm_done = true;
         } else {
             const int Nout = epi.glu ? N / 2 : N;
             const long long total = (long long)M * ((Nout + 3) / 4);
             int rb = (int)((total + 255) / 256);
             if (rb > 2048) rb = 2048;
-            launch_streaming(6, 0.0, splitk_reduce, dim3(rb), dim3(256), 0, st, (const float*)ws, S, C, ldc, M, N, epi);
+            launch_streaming(rcls, 0.0, splitk_reduce, dim3(rb), dim3(256), 0, st, (const float*)ws, S, C, ldc, M, N, epi);
         }
         e = hipGetLastError();
     }

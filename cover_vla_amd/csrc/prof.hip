@@ -4,7 +4,8 @@
 // bracket several kernels (attention pairs) record the pair around them instead.
 // Classes: 0 = weight-streaming GEMM with >= 16 MB of weights (work = weight bytes), 1 = LDS-tiled GEMM of a ViT-sized
 // problem (work = FLOPs), 2 = attention (work = 0), 3 = small weight-streaming GEMMs (work = weight bytes),
-// 4 = LDS-tiled GEMM of an LLM-sized problem (N*K >= 16 M: prefill; work = FLOPs), 5 / 6 = split-K reductions behind a weight-streaming / an LDS-tiled GEMM (work = 0).
+// 4 = LDS-tiled GEMM of an LLM-sized problem (N*K >= 16 M: prefill; work = FLOPs), 5 = split-K reductions behind a weight-streaming GEMM,
+// 6 / 8 / 9 = split-K reductions behind a ViT-sized (class 1) / an LLM-sized (class 4) / an fp8 (class 7) LDS-tiled GEMM (work = 0), 7 = fp8 LDS-tiled GEMM (work = FLOPs).
 // Thread safety: records are claimed with one atomic fetch_add (bench.py may queue launches from two host threads); a
 // record is written only by the thread that claimed it, and cover_profile_end runs after every launcher has returned.
 // Launches replayed from a hipGraph never reach the launchers: they carry neither events nor work (both sides of the

@@ -570,12 +570,13 @@ int cover_resize_bilinear_pad_f32(const float* in, float* out, int NC, int Hin, 
  * this library carries a hipEvent pair stamped with the kernel's own start / stop on its stream. Classes:
  *   0 weight-streaming GEMM with >= 16 MB of weights (work = weight bytes)   1 LDS-tiled GEMM, ViT-sized (work = FLOPs)
  *   2 attention (work = 0)   3 small weight-streaming GEMMs (work = weight bytes)
- *   4 LDS-tiled GEMM, LLM-sized (N*K >= 16 M; work = FLOPs)   5 / 6 split-K reductions behind a weight-streaming / an LDS-tiled GEMM (work = 0)
+ *   4 LDS-tiled GEMM, LLM-sized (N*K >= 16 M; work = FLOPs)   5 split-K reductions behind a weight-streaming GEMM (work = 0)
  *   7 LDS-tiled GEMM on the MX-scaled fp8 matrix instruction (work = FLOPs; priced against the 5 PFLOP/s fp8 peak)
+ *   6 / 8 / 9 split-K reductions behind a class-1 / class-4 / class-7 GEMM (work = 0): every reduction is charged to the GEMM class it completes
  * Thread-safe (records are claimed atomically). Launches replayed from a hipGraph are not seen (neither time nor work).
  * end_n() synchronises the device and fills ms[n], count[n], work[n] (n <= COVER_PROF_CLASSES); it returns
  * COVER_EWORKSPACE when more launches were issued than max_events (sums incomplete). end() = end_n(.., 4). */
-#define COVER_PROF_CLASSES 8
+#define COVER_PROF_CLASSES 10
 int cover_profile_begin(int max_events);
 int cover_profile_end(double* ms, long long* count, double* work);
 int cover_profile_end_n(double* ms, long long* count, double* work, int n_classes);

@@ -291,3 +291,37 @@ def test_fullsize_config5_fp8_n512_horizon8(pipe, dev):
     assert torch.equal(tokp.view(P, S, G), tv[perm])
     del p5
     torch.cuda.empty_cache()
+
+
+def _oracle_agreement(pipe, n_prompts):
+    """The bench's own full-size check (bench.oracle_agreement, emitted as cpu_baseline.agreement): the CPU oracle executes ONE batched
+    decision on the pipeline's first `n_prompts` prompt groups (same checkpoint, frame, prompts, uniforms), the HIP sampler runs
+    teacher-forced on the oracle's tokens and the HIP verifier scores the oracle's tokens."""
+    import bench
+    sd, ssd, ck = bench.oracle_state(pipe)
+    tok_o, tr, sel, *_ = bench.oracle_batched_decision(pipe, sd, ssd, ck, n_prompts)
+    del sd, ssd
+    ag = bench.oracle_agreement(pipe, tok_o, tr["logits"], sel, n_prompts)
+    print(ag)
+    return ag
+
+
+def test_small_config_oracle_agreement(dev):
+    """Plumbing of the agreement record at the small config (seconds of CPU): every data-decided pick equals the oracle's, scores 2e-2."""
+    import bench
+    p = bench.Pipeline(dev, small=True)
+    ag = _oracle_agreement(p, 8)
+    assert ag["of"] == 32 * 7 and ag["decided"] >= 0.5 * ag["of"], ag
+    assert ag["agree_on_decided"] == 1.0, ag
+    assert ag["score_max_abs"] < 2e-2 and (ag["winner_same"] or not ag["winner_decided"]), ag
+
+
+def test_fullsize_oracle_agreement_one_prompt_group(pipe, dev):
+    """OpenVLA-7B against the CPU oracle at full size: one prompt group x 4 samples, all 7 steps (run_simpler_eval_with_openpi.py:305-326,
+    346-365). Every pick the data decide must be the oracle's pick bit for bit; logits within the bf16 bars of the small-config test;
+    verifier scores on the oracle's tokens within 2e-2; same winner whenever the oracle's margins exceed twice the score difference."""
+    ag = _oracle_agreement(pipe, 1)
+    assert ag["of"] == 4 * 7 and ag["decided"] >= 14, ag
+    assert ag["agree_on_decided"] == 1.0, ag
+    assert ag["logit_rel_l2_max"] < 3.5e-2, ag
+    assert ag["score_max_abs"] < 2e-2 and (ag["winner_same"] or not ag["winner_decided"]), ag
