@@ -34,6 +34,22 @@ __device__ unsigned long long g_v3_probe[16];
 int gemm_v3_probe(unsigned long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_v3_probe), sizeof(g_v3_probe)) == hipSuccess ? 0 : -1; }
 
 template <int V> using IC = std::integral_constant<int, V>;
+// Experiment knobs (compile time; tools/ab_build.sh builds the variants):
+//   COVER_V3_RDSPAN_NUM / _DEN  the NR fragment reads of the next step sit behind the first NM * NUM / DEN MFMAs of a step (1 / 1 = spread over all of them)
+//   COVER_V3_PRIO               1: the weight-role waves (second half) run at s_setprio 1 inside the loop, 2: the activation-role waves
+//   COVER_V3_DEPHASE_NUM / _DEN the weight-role waves pass the mid-tile barrier NM * NUM / DEN MFMAs into the tile's second step, so that the two waves of a
+//                               SIMD do not reach their `s_waitcnt lgkmcnt(0)` at the same moment
+#ifndef COVER_V3_RDSPAN_NUM
+#define COVER_V3_RDSPAN_NUM 1
+#define COVER_V3_RDSPAN_DEN 1
+#endif
+#ifndef COVER_V3_PRIO
+#define COVER_V3_PRIO 0
+#endif
+#ifndef COVER_V3_DEPHASE_NUM
+#define COVER_V3_DEPHASE_NUM 0
+#define COVER_V3_DEPHASE_DEN 1
+#endif
 // position (MFMA index inside the two-step phase of 2 NM MFMAs that follows a barrier) behind which a wave issues its piece p of PT:
 // evenly spread in general; with a TWO-stage ring the refill of the stage the barrier has just released is the tile the NEXT barrier
 // needs, so its pieces go out at once
@@ -143,10 +159,14 @@ __global__ __launch_bounds__(64 * CGM * CGN) void gemm_tiled_v3(const bf16_t* __
         auto issue = [&](int i, int stage, int t) { glds16_s(voff[i], sbase[i] + ((size_t)(uint32_t)t << KSH), dst0[i] + stage * SB); };
         // one 32-deep step: NM MFMAs on (xf, wf) with -- behind them -- the reads of step RKS of stages (rsa, rsb) into (xn, wn_) and this wave's DMA
         // pieces of phase half DH (0: first step behind a barrier, 1: second) of tile dt into stage ds
+        // MFMAs [I0, I1) of the step only (the de-phased waves split the step that holds the barrier); the reads sit behind the first SPAN of them
         auto group = [&](const u32x4(&xf)[WM], const u32x4(&wf)[WN], u32x4(&xn)[WM], u32x4(&wn_)[WN], int rsa, int rsb, auto RKS, auto DH, int ds, auto RD,
-                         auto DMA, int dt) {
+                         auto DMA, int dt, auto I0_, auto I1_) {
             constexpr int rks = decltype(RKS)::value, dh = decltype(DH)::value;
             constexpr bool rd = decltype(RD)::value != 0, dma = decltype(DMA)::value != 0;
+            constexpr int I0 = decltype(I0_)::value, I1 = decltype(I1_)::value;
+            constexpr int SPAN0 = (NM * COVER_V3_RDSPAN_NUM) / COVER_V3_RDSPAN_DEN;
+            constexpr int SPAN = SPAN0 < 1 ? 1 : (SPAN0 > I1 - I0 ? I1 - I0 : SPAN0);
             const uint32_t aa = (rks ? a_addr1 : a_addr0) + rsa * A_BYTES;
             const uint32_t ba = b_addr + rsb * B_BYTES + rks * 1024;
 #pragma unroll
@@ -154,16 +174,19 @@ __global__ __launch_bounds__(64 * CGM * CGN) void gemm_tiled_v3(const bf16_t* __
 #pragma unroll
                 for (int f = 0; f < WM; ++f) {
                     const int i = b * WM + f;
+                    if (i < I0 || i >= I1) continue;
                     acc[b][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[b]), __builtin_bit_cast(bf16x8, xf[f]), acc[b][f], 0, 0, 0);
                     if (rd) {
 #pragma unroll
                         for (int j = 0; j < NR; ++j)
-                            if ((j * NM) / NR == i) read_nth(aa, ba, j, xn, wn_);
+                            if (I0 + (j * SPAN) / NR == i) read_nth(aa, ba, j, xn, wn_);
                     }
                     if (dma) {
 #pragma unroll
-                        for (int p = 0; p < PT; ++p)
-                            if (v3_pos(p, PT, NM, NST) == dh * NM + i) issue(p, ds, dt);
+                        for (int p = 0; p < PT; ++p) {
+                            const int pos = v3_pos(p, PT, NM, NST) - dh * NM;                 // position inside this step, < 0 or >= NM: the other step's piece
+                            if (pos >= 0 && pos < NM && (pos == i || (i == I0 && pos < I0))) issue(p, ds, dt);
+                        }
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -191,23 +214,31 @@ __global__ __launch_bounds__(64 * CGM * CGN) void gemm_tiled_v3(const bf16_t* __
         //           own pieces of tile kt + 1 landed, fragments of tile kt complete -> barrier kt + 1
         //           then its step 1 | reads of step 0 of tile kt + 1 | first-step pieces of tile kt + NST -> the stage of tile kt
         int ca = 0, cb = 0, cr = 0, pr = NST - 1;      // read stages of the activation / weight ring; this role's DMA ring (current / previous tile)
+        constexpr int DPH = role == 1 ? (NM * COVER_V3_DEPHASE_NUM) / COVER_V3_DEPHASE_DEN : 0;   // MFMAs of the second step in front of the barrier
+        static_assert(DPH >= 0 && DPH < NM, "the barrier stays inside the step");
+        if (COVER_V3_PRIO == 1 + (1 - role)) __builtin_amdgcn_s_setprio(1);
         for (int kt = 0; kt < nk - 1; ++kt) {
             const int na = ca == NSTA - 1 ? 0 : ca + 1, nb_ = cb == NSTB - 1 ? 0 : cb + 1, nr = cr == NST - 1 ? 0 : cr + 1;
-            group(xa, wa, xb, wb, ca, cb, IC<1>{}, IC<1>{}, pr, IC<1>{}, IC<1>{}, min(kt + NST - 1, nk - 1));
+            group(xa, wa, xb, wb, ca, cb, IC<1>{}, IC<1>{}, pr, IC<1>{}, IC<1>{}, min(kt + NST - 1, nk - 1), IC<0>{}, IC<NM>{});
             asm volatile("s_waitcnt lgkmcnt(0)");
+            if constexpr (DPH > 0) {
+                landed(xb, wb);
+                group(xb, wb, xa, wa, na, nb_, IC<0>{}, IC<0>{}, cr, IC<0>{}, IC<0>{}, 0, IC<0>{}, IC<DPH>{});
+            }
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * PT) : "memory");
             __builtin_amdgcn_s_barrier();
             landed(xb, wb);
-            group(xb, wb, xa, wa, na, nb_, IC<0>{}, IC<0>{}, cr, IC<1>{}, IC<1>{}, min(kt + NST, nk - 1));
+            group(xb, wb, xa, wa, na, nb_, IC<0>{}, IC<0>{}, cr, IC<1>{}, IC<1>{}, min(kt + NST, nk - 1), IC<DPH>{}, IC<NM>{});
             asm volatile("s_waitcnt lgkmcnt(0)");
             landed(xa, wa);
             ca = na; cb = nb_; pr = cr; cr = nr;
         }
+        if (COVER_V3_PRIO) __builtin_amdgcn_s_setprio(0);
         // last tile of the slice: no barrier, no DMA, no reads of a next tile
-        group(xa, wa, xb, wb, ca, cb, IC<1>{}, IC<1>{}, pr, IC<1>{}, IC<0>{}, 0);
+        group(xa, wa, xb, wb, ca, cb, IC<1>{}, IC<1>{}, pr, IC<1>{}, IC<0>{}, 0, IC<0>{}, IC<NM>{});
         asm volatile("s_waitcnt lgkmcnt(0)");
         landed(xb, wb);
-        group(xb, wb, xa, wa, ca, cb, IC<0>{}, IC<0>{}, cr, IC<0>{}, IC<0>{}, 0);
+        group(xb, wb, xa, wa, ca, cb, IC<0>{}, IC<0>{}, cr, IC<0>{}, IC<0>{}, 0, IC<0>{}, IC<NM>{});
     };
     if (w < NH) run(IC<0>{});
     else run(IC<1>{});
