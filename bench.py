@@ -153,6 +153,15 @@ class Pipeline:
                 tokens, _ = self.policy.sample(i["frame"], i["toks"], i["lens"], S, i["u"], 1.0)
             finally:
                 self.policy.vision_graph, self.policy.vision_overlap, self.policy.decode_graph = keep
+        elif os.environ.get("COVER_SIDE_GRAPH", "1") != "0":
+            # round 6: the verifier's two towers + image-text heads as ONE replayed hipGraph (image tower and text tower as parallel branches),
+            # launched on the side stream by THIS thread before the policy: one host call instead of ~600 from a second thread
+            ev = torch.cuda.Event()
+            ev.record(main)
+            self.side.wait_event(ev)
+            with torch.cuda.stream(self.side):
+                its = self.ver.shared_embeddings_graph(i["img384"], i["text"])
+            tokens, _ = self.policy.sample(i["frame"], i["toks"], i["lens"], S, i["u"], 1.0)
         elif os.environ.get("COVER_SIDE_THREAD", "1") != "0":
             if self.pool is None:
                 import concurrent.futures
@@ -269,8 +278,13 @@ class Pi0Pipeline:
             its = self._side_work()
             if on_phase:
                 on_phase("verifier_towers")
-            x = self.model.sample_actions([i["img"]], [self.all_valid], i["toks"], i["masks"], i["state"], noise=noise,
-                                          on_prefix_enqueued=(lambda: on_phase("prefix")) if on_phase else None)
+            keep = (self.model.n_chains, self.model.denoise_graph)
+            self.model.n_chains, self.model.denoise_graph = 1, False     # ONE eager chain: launches replayed from a graph carry no timers
+            try:
+                x = self.model.sample_actions([i["img"]], [self.all_valid], i["toks"], i["masks"], i["state"], noise=noise,
+                                              on_prefix_enqueued=(lambda: on_phase("prefix")) if on_phase else None)
+            finally:
+                self.model.n_chains, self.model.denoise_graph = keep
             if on_phase:
                 on_phase("denoise")
         else:
@@ -286,9 +300,15 @@ class Pi0Pipeline:
                 with torch.cuda.stream(self.side):
                     return self._side_work()
 
-            fut = self.pool.submit(threaded)
-            x = self.model.sample_actions([i["img"]], [self.all_valid], i["toks"], i["masks"], i["state"], noise=noise)
-            its = fut.result()
+            if os.environ.get("COVER_SIDE_GRAPH", "1") != "0":   # the verifier's towers as one replayed graph on the side stream (see Pipeline.decision)
+                self.side.wait_event(ev)
+                with torch.cuda.stream(self.side):
+                    its = self.ver.shared_embeddings_graph(i["img384"], i["text"])
+                x = self.model.sample_actions([i["img"]], [self.all_valid], i["toks"], i["masks"], i["state"], noise=noise)
+            else:
+                fut = self.pool.submit(threaded)
+                x = self.model.sample_actions([i["img"]], [self.all_valid], i["toks"], i["masks"], i["state"], noise=noise)
+                its = fut.result()
             main.wait_stream(self.side)
         hists, pad = ops.actions_to_histories(x, self.c["chunk"], self.past_dev, self.lo_hi)
         r = self.ver.score_histories(its, hists, self.S, pad=pad)
@@ -407,7 +427,8 @@ def main_pi0(a):
            "data": "synthetic",
            "config": {"workload": f"pi0 (SigLIP-So400m + Gemma-2B prefix + 300M expert) B={B} = {pipe.P} prompts x {pipe.S} samples, chunk {c['chunk']}, 10 Euler steps, "
                                   f"tokenizer max_length {pipe.L}, one 224x224 RGB frame; CoVer verifier SigLIP2-L/16-384 + 3-member ensemble; random-init weights",
-                      "candidates_total": B, "parallelism": "one GPU", "lib_sha16": lib_hash(), "selected": idx}}
+                      "candidates_total": B, "parallelism": "one GPU", "lib_sha16": lib_hash(), "selected": idx,
+                      "denoise_chains": pipe.model.n_chains, "denoise_graph": pipe.model.denoise_graph}}
     if not a.no_profile:
         ph = _profile_phases(pipe)
         M_exp = B * (1 + c["chunk"])
@@ -914,8 +935,6 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     from cover_vla_amd import ops as _ops
-    _ops.decode_chain_status()      # a grid barrier of the persistent decode chain that gave up = invalid results: fail loudly, never report them
-    _ops.gemm_tail_status()         # same for the opt-in tail reduction of the weight-streaming kernels (COVER_TAIL_REDUCE=1)
     if world > 1:
         t = torch.tensor([dt], device=dev if a.backend == "nccl" else "cpu")
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)

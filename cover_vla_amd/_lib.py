@@ -32,8 +32,7 @@ class GemmEpi(C.Structure):
                 ("act", c_i), ("glu", c_i), ("out_f32", c_i), ("out_scale", c_f),
                 ("norm_w", c_p), ("norm_out", c_p), ("ld_norm_out", c_i), ("norm_style", c_i), ("norm_w_offset", c_f),
                 ("norm_eps", c_f), ("norm_b", c_p), ("w8", c_p), ("w8_scale", c_p), ("a8", c_p), ("a8_scale", c_p), ("ld_a8", c_i), ("ld_norm_out8", c_i),
-                ("norm_out8", c_p), ("norm_out8_scale", c_p),
-                ("ssq_out", c_p), ("rs_in", c_p), ("ssq_ld", c_i), ("rs_ld", c_i), ("rs_parts", c_i), ("rs_n", c_i), ("rs_eps", c_f), ("_pad_epi", c_i)]
+                ("norm_out8", c_p), ("norm_out8_scale", c_p)]
 
 
 class KvSegment(C.Structure):
@@ -133,7 +132,7 @@ class DecLayer(C.Structure):
     _fields_ = [("in_norm_w", c_p), ("post_norm_w", c_p), ("qkv_w", c_p), ("qkv_b", c_p), ("o_w", c_p),
                 ("gate_up_w", c_p), ("down_w", c_p), ("k_cache", c_p), ("vt_cache", c_p),
                 ("qkv_w8", c_p), ("qkv_s", c_p), ("o_w8", c_p), ("o_s", c_p), ("gate_up_w8", c_p), ("gate_up_s", c_p),
-                ("down_w8", c_p), ("down_s", c_p), ("qkv_wf", c_p), ("gate_up_wf", c_p)]
+                ("down_w8", c_p), ("down_s", c_p)]
 
 
 class DecDesc(C.Structure):
@@ -183,8 +182,6 @@ SYMBOLS = {
     "cover_gemm_bf16": (c_i, [c_p, c_i, c_p, c_p, c_i, c_i, c_i, c_i, _P(GemmEpi), c_p, C.c_size_t, c_i, c_p]),
     "cover_gemm_plan_counts": (c_i, [C.POINTER(C.c_longlong), c_i, c_i]),
     "cover_gemm_probe": (c_i, [C.POINTER(C.c_ulonglong)]),
-    "cover_decode_chain_status": (c_i, []),
-    "cover_gemm_tail_status": (c_i, []),
     "cover_attention_bf16": (c_i, [_P(AttnArgs), c_p]),
     "cover_decode_attention_fused": (c_i, [_P(DecodeAttnArgs), c_p]),
     "cover_decode_own_attention": (c_i, [_P(OwnAttnArgs), c_p]),

@@ -31,22 +31,7 @@ struct SegDev {
     const int* vis_len;
     int len, mode, causal_off;
 };
-// RoPE + split-K fold of the qkv projection INSIDE the attention launch (FUSED instantiation; pi0 denoise steps): the query rows and the
-// keys / values of segment `wseg` are this pass's own rows, read as the fp32 split-K slabs the qkv GEMM left ([S][rows][ncols], + bias),
-// rounded to bf16 and rotated with rope_kv_body's arithmetic (rowops.hip) by the whole block into LDS images (Q tile, K rows, V^T rows)
-// before the key loop; the loop then takes those operands from LDS instead of the caches. Nothing is written to the K / V^T caches:
-// the caller says (cover_dec_group.write_scratch) that nobody reads the segment after this pass.
-struct FuseDev {
-    const float* partial;      // nullptr: not fused
-    const float* bias;
-    const int* positions;
-    const float* cos_t;
-    const float* sin_t;
-    unsigned pstride;          // rows * ncols (elements; < 2^31)
-    int S, ncols, n_pos, rope_mode, wseg;
-};
 struct AttnDev {
-    FuseDev fz;
     const bf16_t* q;
     bf16_t* out;
     long long q_b, q_t, q_h, o_b, o_t, o_h;
@@ -65,67 +50,8 @@ extern "C" int cover_at_debug(unsigned long long* out) { return (int)hipMemcpyFr
 #else
 #define ATT(slot) do { } while (0)
 #endif
-// NV consecutive columns col .. of qkv row `row`: the slabs summed in slab order, + bias, rounded to bf16 (rope_kv_body's ld()), as
-// 16-byte loads -- every load of a call is independent of the others (one round trip)
-template <int NV>
-__device__ __forceinline__ void fz_fold(const FuseDev& z, unsigned row, int col, float (&x)[NV]) {
-    static_assert(NV == 4 || NV == 8, "");
-    unsigned o = row * (unsigned)z.ncols + (unsigned)col;
-#pragma unroll
-    for (int e = 0; e < NV; ++e) x[e] = 0.f;
-    for (int s = 0; s < z.S; ++s, o += z.pstride) {
-#pragma unroll
-        for (int q = 0; q < NV / 4; ++q) {
-            const float4 v = *(const float4*)(z.partial + o + 4 * q);
-            x[4 * q] += v.x; x[4 * q + 1] += v.y; x[4 * q + 2] += v.z; x[4 * q + 3] += v.w;
-        }
-    }
-    if (z.bias) {
-#pragma unroll
-        for (int q = 0; q < NV / 4; ++q) {
-            const float4 v = *(const float4*)(z.bias + col + 4 * q);
-            x[4 * q] += v.x; x[4 * q + 1] += v.y; x[4 * q + 2] += v.z; x[4 * q + 3] += v.w;
-        }
-    }
-#pragma unroll
-    for (int e = 0; e < NV; ++e) x[e] = bfround(x[e]);
-}
-// rotation pairs (i0 + e, i0 + e + D/2), e = 0..7, of the head at column `colbase` of row `row` -> dst (bf16, two 16-byte stores)
-template <int D>
-__device__ __forceinline__ void fz_rot8(const FuseDev& z, unsigned row, int colbase, int pos, int i0, bf16_t* dst) {
-    constexpr int half = D / 2;
-    float x1[8], x2[8], o1[8], o2[8];
-    fz_fold<8>(z, row, colbase + i0, x1);
-    fz_fold<8>(z, row, colbase + half + i0, x2);
-    if (z.rope_mode == 0) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { o1[e] = x1[e]; o2[e] = x2[e]; }
-    } else {
-        pos = pos < 0 ? 0 : (pos >= z.n_pos ? z.n_pos - 1 : pos);
-        const float* ct = z.cos_t + (size_t)pos * half + i0;
-        const float* sn = z.sin_t + (size_t)pos * half + i0;
-        const float4 c0 = *(const float4*)ct, c1 = *(const float4*)(ct + 4), s0 = *(const float4*)sn, s1 = *(const float4*)(sn + 4);
-        const float cv[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w}, sv[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            float cc = cv[e], ss = sv[e];
-            if (z.rope_mode == 2) {  // HF rotate_half in bf16 arithmetic
-                cc = bfround(cc); ss = bfround(ss);
-                o1[e] = bfround(bfround(x1[e] * cc) + bfround(-x2[e] * ss));
-                o2[e] = bfround(bfround(x2[e] * cc) + bfround(x1[e] * ss));
-            } else {  // apply_rope (paligemma_with_expert.py:34-57): fp32, one rounding
-#pragma clang fp contract(off)   // torch rounds each product: no FMA here
-                o1[e] = x1[e] * cc - x2[e] * ss;
-                o2[e] = x2[e] * cc + x1[e] * ss;
-            }
-        }
-    }
-    *(uint4*)(dst + i0) = make_uint4(pack_bf2(o1[0], o1[1]), pack_bf2(o1[2], o1[3]), pack_bf2(o1[4], o1[5]), pack_bf2(o1[6], o1[7]));
-    *(uint4*)(dst + half + i0) = make_uint4(pack_bf2(o2[0], o2[1]), pack_bf2(o2[2], o2[3]), pack_bf2(o2[4], o2[5]), pack_bf2(o2[6], o2[7]));
-}
-
 // NWS: waves per block in key-split mode (4 or 8), a compile-time constant there so that the merge below is straight-line code
-template <int D, bool KSPLIT, int NWS = 4, bool FUSED = false>
+template <int D, bool KSPLIT, int NWS = 4>
 __device__ __forceinline__ void attn_body(const AttnDev& a, int bx, int kvh, int b) {
     ATT(0);
     constexpr int KS = D / 32;  // k-steps of QK^T
@@ -146,46 +72,7 @@ __device__ __forceinline__ void attn_body(const AttnDev& a, int bx, int kvh, int
 
     // Q fragments
     bf16x8 qf[KS];
-    // FUSED: LDS images behind the key-split merge buffer -- Q tile [16][D], K rows [32][D], V^T rows [D][32] (bf16)
-    bf16_t* const fq = (bf16_t*)(smem + (size_t)(NWS * DB * 4 * 64 + 2 * NWS * 16) * sizeof(float));
-    bf16_t* const fk = fq + 16 * D;
-    bf16_t* const fv = fk + 32 * D;
-    if constexpr (FUSED) {
-        static_assert(KSPLIT, "the fused form is a key-split block");
-        const FuseDev& z = a.fz;
-        const int tid = threadIdx.x, nthr = 64 * NWS, half = D / 2;
-        const int own_len = a.seg[z.wseg].len;                       // = Tq (<= 32): one key tile
-        constexpr int CH = (D / 2) / 8;                                // 8-wide chunks of a half head
-        for (int i = tid; i < D * 32 / 8; i += nthr) ((uint4*)fv)[i] = make_uint4(0, 0, 0, 0);   // keys beyond the segment: finite (p = 0)
-        for (int it = tid; it < 16 * CH; it += nthr) {               // the tile's 16 query rows (D = 256: one item per thread)
-            const int rr = it / CH, i0 = (it - rr * CH) * 8;
-            const int qq = tile * 16 + rr;
-            if (qq < a.R) {
-                const int tq = qq / a.G, hq = kvh * a.G + (qq - tq * a.G);
-                const unsigned row = (unsigned)(b * a.Tq + tq);
-                fz_rot8<D>(z, row, hq * D, z.positions ? z.positions[row] : tq, i0, fq + rr * D);
-            } else {
-                *(uint4*)(fq + rr * D + i0) = make_uint4(0, 0, 0, 0);
-                *(uint4*)(fq + rr * D + half + i0) = make_uint4(0, 0, 0, 0);
-            }
-        }
-        for (int it = tid; it < own_len * CH; it += nthr) {          // the pass's own keys
-            const int key = it / CH, i0 = (it - key * CH) * 8;
-            const unsigned row = (unsigned)(b * a.Tq + key);
-            fz_rot8<D>(z, row, (a.Hq + kvh) * D, z.positions ? z.positions[row] : key, i0, fk + key * D);
-        }
-        __syncthreads();                                             // (the zero fill of fv above, before the values land in it)
-        for (int it = tid; it < own_len * (D / 4); it += nthr) {     // ... and values, transposed
-            const int key = it / (D / 4), d0 = (it - key * (D / 4)) * 4;
-            float v[4];
-            fz_fold<4>(z, (unsigned)(b * a.Tq + key), (a.Hq + a.Hkv + kvh) * D + d0, v);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) fv[(d0 + j) * 32 + key] = f2bf(v[j]);
-        }
-        __syncthreads();
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) qf[ks] = as_bf16x8(*(const uint4*)(fq + r * D + ks * 32 + g * 8));
-    } else {
+    {
         const bf16_t* qp = a.q + (long long)b * a.q_b + (long long)t * a.q_t + (long long)h * a.q_h + g * 8;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) qf[ks] = as_bf16x8(*(const uint4*)(qp + ks * 32));
@@ -240,31 +127,17 @@ __device__ __forceinline__ void attn_body(const AttnDev& a, int bx, int kvh, int
             const bf16_t* k1p = kb + (long long)key1 * sg.k_t;
             const bf16_t* vp = vb + t0;
             uint4 kr0[KS], kr1[KS];
-            const bool own = FUSED && si == a.fz.wseg;   // this segment = the pass's own rows: operands from the LDS images
-            if (own) {
 #pragma unroll
-                for (int ks = 0; ks < KS; ++ks) {
-                    kr0[ks] = *(const uint4*)(fk + key0 * D + ks * 32 + g * 8);
-                    kr1[ks] = *(const uint4*)(fk + key1 * D + ks * 32 + g * 8);
-                }
-            } else {
-#pragma unroll
-                for (int ks = 0; ks < KS; ++ks) {
-                    kr0[ks] = *(const uint4*)(k0p + ks * 32);
-                    kr1[ks] = *(const uint4*)(k1p + ks * 32);
-                }
+            for (int ks = 0; ks < KS; ++ks) {
+                kr0[ks] = *(const uint4*)(k0p + ks * 32);
+                kr1[ks] = *(const uint4*)(k1p + ks * 32);
             }
             // D = 256: 64 registers of V^T fragments beside 64 of K, 64 of O and 32 of Q only fit when the block is the 4-wave key-split
             // one (launch bounds 256 below: one wave per SIMD). Without them a tile is TWO dependent round trips (K, softmax, then V):
             // six per wave over the ~330 keys of a pi0 denoise step instead of three.
             constexpr bool V_EARLY = (D <= 128) || KSPLIT;
             uint4 vr[V_EARLY ? DB : 1];
-            if (own) {
-                if constexpr (V_EARLY) {
-#pragma unroll
-                    for (int db = 0; db < DB; ++db) vr[db] = *(const uint4*)(fv + (db * 16 + r) * 32 + g * 8);   // t0 = 0: one tile
-                }
-            } else if (V_EARLY) {
+            if (V_EARLY) {
 #pragma unroll
                 for (int db = 0; db < DB; ++db) vr[db] = *(const uint4*)(vp + (long long)(db * 16) * sg.vt_d);
             }
@@ -418,12 +291,6 @@ template <int D, bool KSPLIT, int NWS = 4>
 __global__ __launch_bounds__((KSPLIT && D > 128) ? 64 * NWS : 512) void attn_kernel(AttnDev a) {
     attn_body<D, KSPLIT, NWS>(a, blockIdx.x, blockIdx.y, blockIdx.z);
 }
-// key-split mode with the qkv fold + RoPE inside (FuseDev above)
-template <int D>
-__global__ __launch_bounds__(256) void attn_rope_fused_kernel(AttnDev a) {
-    attn_body<D, true, 4, true>(a, blockIdx.x, blockIdx.y, blockIdx.z);
-}
-
 // Two independent attention problems (the two row groups of a prefill pass: shared-prefix rows and the prompts' text rows)
 // in ONE launch: both are far too small to fill the chip, so back to back they cost two latency floors. Key-split mode
 // only; blockIdx.x enumerates (tile, batch) of problem 0, then of problem 1.
@@ -480,7 +347,6 @@ static hipError_t launch_d(const AttnDev& a, hipStream_t st) {
 
 static hipError_t build_attn_dev(const cover_attn_args* x, AttnDev& a) {
     if (x->n_seg < 1 || x->n_seg > 3 || x->Hq % x->Hkv != 0) return hipErrorInvalidValue;
-    memset(&a.fz, 0, sizeof a.fz);
     a.q = (const bf16_t*)x->q;
     a.out = (bf16_t*)x->out;
     a.q_b = x->q_b_stride; a.q_t = x->q_t_stride; a.q_h = x->q_h_stride;
@@ -518,47 +384,6 @@ hipError_t launch_attention_bf16(const cover_attn_args* x, hipStream_t st) {
         case 256: e = launch_d<256>(a, st); break;
         default: e = hipErrorInvalidValue;
     }
-    prof_close(st, pid);
-    return e;
-}
-
-// RoPE + split-K fold inside the attention launch (pi0 denoise steps: one launch per layer-step less). Supported: D = 128 / 256, a pass whose
-// own rows are the LAST segment (T keys written at offset 0, T <= 32), few enough query tiles for the key-split form, no state chaining.
-bool attention_rope_fusable(const cover_attn_args* x, const cover_rope_args* r, int wseg) {
-    if (!(x->D == 128 || x->D == 256) || r->n_splits <= 0 || !r->partial || wseg != x->n_seg - 1 || x->Tq > 32 || x->seg[wseg].len != x->Tq) return false;
-    if (x->seg[wseg].len_of_batch || x->state_in_o || x->state_out_o || r->t_offset != 0 || r->t_offset_of_batch || (x->Hq % x->Hkv) != 0) return false;
-    if (r->B != x->B || r->T != x->Tq || r->Hq != x->Hq || r->Hkv != x->Hkv || r->D != x->D) return false;
-    if ((((uintptr_t)r->partial) & 15) || (r->bias && (((uintptr_t)r->bias) & 15))) return false;                       // 16-byte loads
-    if (r->rope_mode != 0 && (((uintptr_t)r->cos_table | (uintptr_t)r->sin_table) & 15)) return false;
-    const long long elems = (long long)r->n_splits * r->B * r->T * (r->Hq + 2 * r->Hkv) * r->D;
-    if (elems >= (1ll << 31)) return false;
-    const long long qtiles = (long long)((x->Tq * (x->Hq / x->Hkv) + 15) / 16) * x->Hkv * x->B;
-    return qtiles <= 1023;
-}
-hipError_t launch_attention_rope_fused(const cover_attn_args* x, const cover_rope_args* r, int wseg, hipStream_t st) {
-    if (!attention_rope_fusable(x, r, wseg)) return hipErrorInvalidValue;
-    AttnDev a;
-    hipError_t e = build_attn_dev(x, a);
-    if (e != hipSuccess) return e;
-    if (a.B <= 0 || a.R <= 0) return hipSuccess;
-    FuseDev& z = a.fz;
-    z.partial = r->partial; z.bias = r->bias; z.positions = r->positions; z.cos_t = r->cos_table; z.sin_t = r->sin_table;
-    z.S = r->n_splits; z.ncols = (r->Hq + 2 * r->Hkv) * r->D; z.pstride = (unsigned)((long long)r->B * r->T * z.ncols);
-    z.n_pos = r->n_pos; z.rope_mode = r->rope_mode; z.wseg = wseg;
-    const int tiles = (a.R + 15) / 16;
-    const int pid = prof_enabled() ? prof_open(st, 2, 0.0) : -1;
-    dim3 grid(tiles, a.Hkv, a.B), block(256);
-#define FZ_LAUNCH(D_)                                                                                                              \
-    do {                                                                                                                           \
-        const size_t lds = (size_t)(4 * (D_ / 16) * 4 * 64 + 2 * 4 * 16) * sizeof(float) + (size_t)(16 + 32 + 32) * D_ * 2;          \
-        auto kfn = attn_rope_fused_kernel<D_>;                                                                                     \
-        static hipError_t attr = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);   \
-        e = attr;                                                                                                                  \
-        if (e == hipSuccess) hipLaunchKernelGGL(kfn, grid, block, lds, st, a);                                                     \
-    } while (0)
-    if (x->D == 256) FZ_LAUNCH(256); else FZ_LAUNCH(128);
-#undef FZ_LAUNCH
-    if (e == hipSuccess) e = hipGetLastError();
     prof_close(st, pid);
     return e;
 }

@@ -6,7 +6,6 @@
 #include <string.h>
 #include <string>
 #include "kernels.h"
-#include "decode_chain.h"
 
 static thread_local std::string g_err;
 static int fail(int code, const char* what, hipError_t e = hipSuccess) {
@@ -72,12 +71,6 @@ int cover_quantize_act_fp8(const void* X, int ldx, int M, int K, void* out8, int
     return COVER_OK;
 }
 size_t cover_gemm_workspace_bytes(int M, int N, int K) { return gemm_workspace_bytes(M, N, K); }
-int cover_gemm_tail_status(void) {
-    const int v = gemm_tail_status();
-    if (v < 0) return fail(COVER_EHIP, "cover_gemm_tail_status: could not read the status word");
-    if (v != 0) return fail(COVER_EHIP, "a bounded wait of the tail reduction gave up (gemm_bf16.hip): results of that pass are invalid");
-    return COVER_OK;
-}
 int cover_gemm_probe(unsigned long long* out) {
     if (!out) return fail(COVER_EINVAL, "cover_gemm_probe: null pointer");
     if (gemm_v3_probe(out) != 0) return fail(COVER_EHIP, "cover_gemm_probe: could not read the probe words");
@@ -110,13 +103,6 @@ int cover_decode_attention_fused(const cover_decode_attn_args* a, void* stream) 
     if (!a || !a->out || (a->n_splits <= 0 && !a->qkv) || (a->n_splits > 0 && !a->partial))
         return fail(COVER_EINVAL, "cover_decode_attention_fused: null pointer");
     HIPCHK(launch_decode_attention_fused(a, ST(stream)), "decode_attention_fused (D in {64,128}, COVER_MASK_LEN segments, 0 <= write_t < seg[2].len)");
-    return COVER_OK;
-}
-
-int cover_decode_chain_status(void) {
-    const int e = decode_chain_status();
-    if (e != 0) return fail(COVER_EHIP, e < 0 ? "cover_decode_chain_status: could not read the status word" :
-                                               "cover_decode_chain_status: a grid barrier of the persistent decode chain ran into its spin bound (results of that pass are invalid)");
     return COVER_OK;
 }
 
@@ -416,8 +402,7 @@ int cover_vit_forward(const cover_vit_desc* d, void* x, int n_seq, int T, void* 
 }
 
 static size_t dec_ws(const cover_dec_desc* d, int rows, Carver* c, void** h, void** qkv, void** attn, void** mlp, void** sk,
-                     size_t* sk_bytes, void** st_o = nullptr, void** st_ml = nullptr, void** q8 = nullptr, void** q8s = nullptr, void** ssq = nullptr,
-                     void** tsync = nullptr, void** dn_ssq = nullptr) {
+                     size_t* sk_bytes, void** st_o = nullptr, void** st_ml = nullptr, void** q8 = nullptr, void** q8s = nullptr) {
     Carver tmp{nullptr, 0, 0};
     Carver& cc = c ? *c : tmp;
     const int nqkv = (d->Hq + 2 * d->Hkv) * d->D;
@@ -443,22 +428,14 @@ static size_t dec_ws(const cover_dec_desc* d, int rows, Carver* c, void** h, voi
             skb = b > skb ? b : skb;
         }
     }
-    if (skb < (size_t)rows * nqkv * 4) skb = (size_t)rows * nqkv * 4;      // deferred-norm passes: the qkv projection as ONE fp32 slab
     p = cc.take(skb); if (sk) *sk = p;
     if (sk_bytes) *sk_bytes = skb;
-    p = cc.take(decode_chain_ws_bytes()); if (ssq) *ssq = p;   // partial sums of squares of the persistent decode chain (rows <= 32)
-    p = cc.take(256 + (size_t)64 * gemm_head_words() * 4); if (tsync) *tsync = p;   // ticket words of the tail reduction / hand-off areas of the head reduction (gemm_bf16.hip), zeroed per pass
-    p = cc.take((size_t)2 * rows * ((d->dim + 31) / 32) * 4); if (dn_ssq) *dn_ssq = p;   // deferred RMSNorm: [2][rows][dim / 32] partial sums of squares
     return cc.off + 256;
 }
 size_t cover_decoder_workspace_bytes(const cover_dec_desc* d, int rows) {
     return dec_ws(d, rows, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
 }
 
-__global__ void zero_words_k(unsigned* p, int n) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) p[i] = 0u;
-}
 int cover_decoder_forward(const cover_dec_desc* d, const cover_dec_pass* p, void* x, cover_workspace ws, int variant,
                           void* stream) {
     if (!d || !p || !x || !d->layers_host) return fail(COVER_EINVAL, "cover_decoder_forward: null pointer");
@@ -473,53 +450,11 @@ int cover_decoder_forward(const cover_dec_desc* d, const cover_dec_pass* p, void
         rows += G.B * G.T;
     }
     Carver c{(char*)ws.ptr, ws.bytes, 0};
-    void *h, *qkv, *attn, *mlp, *sk, *st_o, *st_ml, *q8, *q8s, *ssq, *tsync, *dn_ssq;
+    void *h, *qkv, *attn, *mlp, *sk, *st_o, *st_ml, *q8, *q8s;
     size_t skb;
-    const size_t need = dec_ws(d, rows, &c, &h, &qkv, &attn, &mlp, &sk, &skb, &st_o, &st_ml, &q8, &q8s, &ssq, &tsync, &dn_ssq);
+    const size_t need = dec_ws(d, rows, &c, &h, &qkv, &attn, &mlp, &sk, &skb, &st_o, &st_ml, &q8, &q8s);
     if (!ws.ptr || ws.bytes < need) return fail(COVER_EWORKSPACE, "cover_decoder_forward: workspace too small");
     const int dim = d->dim, Hq = d->Hq, Hkv = d->Hkv, D = d->D, nqkv = (Hq + 2 * Hkv) * D, HD = Hq * D;
-
-    // ---- persistent decode chain (decode_chain.hip): a single-token candidate pass of <= 32 rows at the 7B decoder shapes runs as
-    //      [ssq + qkv(0)]  then per layer  [fused decode attention] + [o_proj -> gate_up -> down -> qkv(next)]  = 2 launches per layer
-    //      instead of 7. Opt-in (COVER_DECODE_CHAIN=1: measured at parity with the separate launches, which stay the default); =2 launches
-    //      every phase of the chain on its own (no in-kernel barrier: bit-identical to the fused form, the A/B that isolates the hand-offs
-    //      from the arithmetic).
-    if (p->n_groups == 1 && !p->x_f32 && variant == 0) {
-        const cover_dec_group& G = p->groups[0];
-        const bool da_long = ((G.B + 15) / 16) * Hq >= 768 && G.segs[2].len > 16;
-        const bool fused_attn_ok = G.T == 1 && G.seg0_shared && G.n_seg == 3 && G.write_seg == 2 && Hq == Hkv && (D == 64 || D == 128) && !da_long &&
-                                   G.own_kv_mode == 0 && G.segs[0].mask_mode == COVER_MASK_LEN && G.segs[1].mask_mode == COVER_MASK_LEN &&
-                                   G.segs[2].mask_mode == COVER_MASK_LEN && G.write_t_offset_of_batch == nullptr && G.segs[2].len_of_batch == nullptr &&
-                                   G.segs[0].len_of_batch == nullptr;
-        if (fused_attn_ok && rows == G.B && decode_chain_supported(d, rows)) {
-            const char* ce = getenv("COVER_DECODE_CHAIN");
-            const bool split = ce && ce[0] == '2';
-            HIPCHK(launch_decode_chain(d, 0, &d->layers_host[0], nullptr, x, qkv, attn, mlp, (float*)ssq, rows, split, st), "decode chain (ssq + qkv)");
-            for (int l = 0; l < d->n_layers; ++l) {
-                const cover_dec_layer& L = d->layers_host[l];
-                cover_decode_attn_args da;
-                memset(&da, 0, sizeof da);
-                da.qkv = (bf16_t*)qkv; da.ld_qkv = nqkv;       // complete bf16 rows (bias included): no split-K partials on this path
-                da.N = G.B; da.H = Hq; da.D = D; da.scale = d->attn_scale;
-                da.positions = G.positions; da.cos_table = d->cos_table; da.sin_table = d->sin_table; da.n_pos = d->n_pos;
-                da.rope_mode = d->rope_mode;
-                for (int s = 0; s < 3; ++s) {
-                    da.seg[s] = G.segs[s];
-                    da.seg[s].k = (const bf16_t*)L.k_cache + G.seg_k_offset[s];
-                    da.seg[s].vt = (const bf16_t*)L.vt_cache + G.seg_vt_offset[s];
-                }
-                da.seg[2].slot_of_batch = G.write_slot_of_batch ? G.write_slot_of_batch : G.segs[2].slot_of_batch;
-                da.write_t = G.write_t_offset;
-                da.out = (bf16_t*)attn; da.out_row_stride = HD;
-                HIPCHK(launch_decode_attention_fused(&da, st), "decode chain: fused decode attention");
-                HIPCHK(launch_decode_chain(d, 1, &L, l + 1 < d->n_layers ? &d->layers_host[l + 1] : nullptr, x, qkv, attn, mlp, (float*)ssq, rows, split, st),
-                       "decode chain (o_proj -> gate_up -> down -> qkv)");
-            }
-            if (p->final_norm)
-                HIPCHK(launch_rmsnorm(x, 0, dim, d->final_norm_w, d->norm_w_offset, d->norm_style, (bf16_t*)x, dim, rows, dim, d->norm_eps, st), "dec final_norm");
-            return COVER_OK;
-        }
-    }
 
     // fp8 profile with more rows than the weight-streaming kernels take (config 5: M = 512 decode rows, and its prefill): the
     // projections run on the MX-scaled fp8 matrix instruction -- the input rows of every GEMM are quantised to e4m3 (per-row
@@ -536,124 +471,6 @@ int cover_decoder_forward(const cover_dec_desc* d, const cover_dec_pass* p, void
         e.a8 = q8; e.a8_scale = (const float*)q8s; e.ld_a8 = kp;
         return launch_quantize_act_fp8((const bf16_t*)src, K, rows, K, (uint8_t*)q8, kp, (float*)q8s, st);
     };
-    // weight-streaming passes (<= 64 rows), opt-in (COVER_TAIL_REDUCE=1, read per call: the tests toggle it): the split-K reductions of
-    // o_proj / down (+ residual + RMSNorm) run at the tail of the launch that wrote the slabs instead of as launches of their own
-    // (gemm_bf16.hip "Tail reduction": same code, bit-identical results; measured SLOWER than the reduction launches, so off by default)
-    unsigned* tail_sync = nullptr;
-    {
-        const char* te = getenv("COVER_TAIL_REDUCE");
-        if (rows <= 64 && te && te[0] == '1') {
-            tail_sync = (unsigned*)tsync;
-            // (a kernel, not hipMemsetAsync: as a memset node of the captured decode graph the latter gave wrong tokens on replay -- ROCm 7.2;
-            //  eager it was fine -- tests/test_fullsize_gpu.py::test_fullsize_config2_n16 under COVER_TAIL_REDUCE=1 caught it)
-            hipLaunchKernelGGL(zero_words_k, dim3(1), dim3(64), 0, st, tail_sync, 64);
-            HIPCHK(hipGetLastError(), "zero tail-reduction tickets");
-        }
-    }
-    // weight-streaming passes of <= 32 rows (candidate decode), opt-in (COVER_HEAD_REDUCE=1, read per call: the tests toggle it): HEAD reduction
-    // (kernels.h GemmDeferred, gemm_bf16.hip "Head reduction") -- the split-K reduction + residual + RMSNorm of o_proj rides in the first
-    // workgroups of the gate_up launch, that of down in the next layer's qkv launch: two launches per layer less, bit-identical results.
-    // Measured SLOWER than the reduction launches (decode pass 3.72 against 3.555 ms: the release / acquire pair and three dependent
-    // cross-XCD round trips of the hand-off cost more than the 5.5 us launch + boundary they replace), so off by default. One zeroed hand-off
-    // area per reduction, behind the ticket words of the tail reduction (which is mutually exclusive with this).
-    unsigned* head_flags = nullptr;
-    {
-        const char* he = getenv("COVER_HEAD_REDUCE");
-        if (rows <= 32 && p->n_groups == 1 && variant == 0 && tail_sync == nullptr && d->n_layers <= 32 && he && he[0] == '1') {
-            head_flags = (unsigned*)tsync + 64;
-            const int nw = 2 * d->n_layers * gemm_head_words();
-            hipLaunchKernelGGL(zero_words_k, dim3((nw + 255) / 256), dim3(256), 0, st, head_flags, nw);
-            HIPCHK(hipGetLastError(), "zero head-reduction counters");
-        }
-    }
-    GemmDeferred pend;          // the hand-off in flight: armed by o_proj / down, consumed by the very next GEMM launch
-    pend.armed = false; pend.flag = nullptr;
-    // ---- deferred RMSNorm pass (cover_dec_layer.qkv_wf / gate_up_wf; the pi0 denoise steps: 200 rows = 40 candidates x 5 suffix tokens, 18 layers,
-    //      10 Euler steps per decision). Five launches per layer instead of eight:
-    //        qkv'      x (raw rows) . Wqkv'^T, rows scaled by rsqrt(mean square) from the partial sums of squares down(l-1) left, ONE fp32 slab
-    //        attention the qkv fold + RoPE inside the launch (nothing is written to the scratch suffix cache)
-    //        o_proj    UNSPLIT on 32 x 32 tiles with a sixteen-stage ring: x += attn . Wo^T in the epilogue, partial sums of squares of the new x beside it
-    //        gate_up'  x (raw rows) . Wgu'^T, row scale, GLU
-    //        down      as o_proj; its partial sums of squares feed the next layer's qkv'
-    //      No split-K slabs, no reduction / norm launches, no RoPE launch. Layer 0 takes its input norm as a launch (its input may be fp32).
-    //      OPT-IN (COVER_DEFER_NORM=1, read per call): measured on MI355X at the pi0 expert's shapes (tools/dbg/r05/bench_expert.py, 18 layers x
-    //      200 rows, eager and as a replayed graph): 74.5 us per layer-step against 67.8 us for the eight launches -- the unsplit producers save
-    //      what their reduction launch cost (o_proj 12.8 -> 10.2-11.1 us, down 13.4 -> 13.2-13.6) and no more, the consumers pay ~1-4 us for
-    //      summing the partials behind their k-loop, and the kernel boundaries saved were nearly free (the launches of a stream overlap at
-    //      their edges: eight kernels of 69.2 us of kernel time take 67.8 us). docs/OPTIMISATION_LOG.md round 5.
-    {
-        bool dn = p->n_groups == 1 && rows > 64 && rows <= 1024 && !f8 && variant == 0 && (dim % 32) == 0 && !d->layers_host[0].qkv_b;
-        for (int l = 0; l < d->n_layers && dn; ++l) dn = d->layers_host[l].qkv_wf != nullptr && d->layers_host[l].gate_up_wf != nullptr;
-        const char* dn_env = getenv("COVER_DEFER_NORM");
-        if (dn && !(dn_env && dn_env[0] == '1')) dn = false;
-        if (dn) {
-            const cover_dec_group& G = p->groups[0];
-            dn = G.write_scratch && G.T < 16 && G.own_kv_mode == 0 && !(G.seg0_shared && G.T == 1) && G.B * G.T == rows;
-        }
-        if (dn) {
-            const cover_dec_group& G = p->groups[0];
-            const cover_kv_segment& W = G.segs[G.write_seg];
-            const int parts = dim / 32;
-            float* ssq_a = (float*)dn_ssq;                      // behind o_proj
-            float* ssq_b = ssq_a + (size_t)rows * parts;        // behind down
-            const bool f32in = p->x_f32 != nullptr;
-            HIPCHK(launch_rmsnorm(f32in ? (const void*)p->x_f32 : (const void*)x, f32in ? 1 : 0, dim, d->layers_host[0].in_norm_w, d->norm_w_offset,
-                                  d->norm_style, (bf16_t*)h, dim, rows, dim, d->norm_eps, st), "dec in_norm (layer 0)");
-            for (int l = 0; l < d->n_layers; ++l) {
-                const cover_dec_layer& L = d->layers_host[l];
-                const bool first_f32 = (l == 0 && f32in);
-                cover_gemm_epi e;
-                memset(&e, 0, sizeof e);
-                e.out_scale = 1.0f; e.out_f32 = 1;
-                if (l > 0) { e.rs_in = ssq_b; e.rs_ld = parts; e.rs_parts = parts; e.rs_n = dim; e.rs_eps = d->norm_eps; }
-                HIPCHK(launch_gemm_bf16(l == 0 ? (const bf16_t*)h : (const bf16_t*)x, dim, (const bf16_t*)(l == 0 ? L.qkv_w : L.qkv_wf), sk, nqkv, rows, nqkv, dim, &e,
-                                        nullptr, 0, 0, st), "dec qkv (deferred norm, one fp32 slab)");
-                cover_rope_args ra;
-                memset(&ra, 0, sizeof ra);
-                ra.qkv = (bf16_t*)qkv; ra.ld_qkv = nqkv; ra.B = G.B; ra.T = G.T; ra.Hq = Hq; ra.Hkv = Hkv; ra.D = D;
-                ra.positions = G.positions; ra.cos_table = d->cos_table; ra.sin_table = d->sin_table; ra.n_pos = d->n_pos; ra.rope_mode = d->rope_mode;
-                ra.k_cache = (bf16_t*)L.k_cache + G.seg_k_offset[G.write_seg];
-                ra.k_slot_stride = W.k_slot_stride; ra.k_t_stride = W.k_t_stride; ra.k_h_stride = W.k_h_stride;
-                ra.vt_cache = (bf16_t*)L.vt_cache + G.seg_vt_offset[G.write_seg];
-                ra.vt_slot_stride = W.vt_slot_stride; ra.vt_h_stride = W.vt_h_stride; ra.vt_d_stride = W.vt_d_stride;
-                ra.slot_of_batch = G.write_slot_of_batch; ra.t_offset_of_batch = G.write_t_offset_of_batch; ra.t_offset = G.write_t_offset;
-                ra.n_splits = 1; ra.partial = (const float*)sk; ra.bias = nullptr;
-                cover_attn_args aa;
-                memset(&aa, 0, sizeof aa);
-                aa.q = (bf16_t*)qkv; aa.q_b_stride = (long long)G.T * nqkv; aa.q_t_stride = nqkv; aa.q_h_stride = D;
-                aa.out = (bf16_t*)attn; aa.o_b_stride = (long long)G.T * HD; aa.o_t_stride = HD; aa.o_h_stride = D;
-                aa.B = G.B; aa.Tq = G.T; aa.Hq = Hq; aa.Hkv = Hkv; aa.D = D; aa.scale = d->attn_scale; aa.n_seg = G.n_seg;
-                for (int s2 = 0; s2 < G.n_seg; ++s2) {
-                    aa.seg[s2] = G.segs[s2];
-                    aa.seg[s2].k = (const bf16_t*)L.k_cache + G.seg_k_offset[s2];
-                    aa.seg[s2].vt = (const bf16_t*)L.vt_cache + G.seg_vt_offset[s2];
-                }
-                if (attention_rope_fusable(&aa, &ra, G.write_seg)) {
-                    HIPCHK(launch_attention_rope_fused(&aa, &ra, G.write_seg, st), "dec attention (qkv fold + RoPE inside)");
-                } else {
-                    HIPCHK(launch_rope_kv_write(&ra, st), "dec rope/kv");
-                    HIPCHK(launch_attention_bf16(&aa, st), "dec attention");
-                }
-                memset(&e, 0, sizeof e);
-                e.out_scale = 1.0f;
-                e.residual = first_f32 ? (const void*)p->x_f32 : (const void*)x; e.residual_f32 = first_f32 ? 1 : 0; e.ld_residual = dim;
-                e.ssq_out = ssq_a; e.ssq_ld = parts;
-                HIPCHK(launch_gemm_bf16((const bf16_t*)attn, HD, (const bf16_t*)L.o_w, x, dim, rows, dim, HD, &e, nullptr, 0, 0, st), "dec o_proj (unsplit, residual + sums of squares)");
-                memset(&e, 0, sizeof e);
-                e.out_scale = 1.0f; e.act = d->act; e.glu = 1;
-                e.rs_in = ssq_a; e.rs_ld = parts; e.rs_parts = parts; e.rs_n = dim; e.rs_eps = d->norm_eps;
-                HIPCHK(launch_gemm_bf16((const bf16_t*)x, dim, (const bf16_t*)L.gate_up_wf, mlp, d->mlp, rows, 2 * d->mlp, dim, &e, nullptr, 0, 0, st), "dec gate_up (deferred norm)");
-                memset(&e, 0, sizeof e);
-                e.out_scale = 1.0f;
-                e.residual = x; e.ld_residual = dim;
-                e.ssq_out = ssq_b; e.ssq_ld = parts;
-                HIPCHK(launch_gemm_bf16((const bf16_t*)mlp, d->mlp, (const bf16_t*)L.down_w, x, dim, rows, dim, d->mlp, &e, nullptr, 0, 0, st), "dec down (unsplit, residual + sums of squares)");
-            }
-            if (p->final_norm)
-                HIPCHK(launch_rmsnorm(x, 0, dim, d->final_norm_w, d->norm_w_offset, d->norm_style, (bf16_t*)x, dim, rows, dim, d->norm_eps, st), "dec final_norm");
-            return COVER_OK;
-        }
-    }
     // h = in_norm_0(x); afterwards every norm is folded into the epilogue of the GEMM that produces its input
     {
         const bool f32in = p->x_f32 != nullptr;
@@ -675,7 +492,7 @@ int cover_decoder_forward(const cover_dec_desc* d, const cover_dec_pass* p, void
         int qkv_splits = 0;
         if (rows <= 64 && p->n_groups == 1 && (variant == 0 || variant == 3) && p->groups[0].own_kv_mode == 0)
             HIPCHK(launch_gemm_skinny_partial((const bf16_t*)h, dim, (const bf16_t*)L.qkv_w, (float*)sk, skb, rows, nqkv, dim, &qkv_splits, st,
-                                              L.qkv_w8, L.qkv_s, &pend), "dec qkv (partials)");
+                                              L.qkv_w8, L.qkv_s), "dec qkv (partials)");
         else {
             // few-token groups on the LDS tiles (the pi0 action expert: 200 rows, T = 5): a split-K launch leaves its slabs for
             // rope_kv_write to fold as well (same sums, same order, same rounding as the reduction launch it replaces)
@@ -683,9 +500,8 @@ int cover_decoder_forward(const cover_dec_desc* d, const cover_dec_pass* p, void
             const bool fold = rows > 64 && p->n_groups == 1 && p->groups[0].own_kv_mode == 0 && p->groups[0].T < 16 && !f8 &&
                               !(p->groups[0].seg0_shared && p->groups[0].T == 1) && !(fold_env && fold_env[0] == '0');
             HIPCHK(launch_gemm_bf16((const bf16_t*)h, dim, (const bf16_t*)L.qkv_w, qkv, nqkv, rows, nqkv, dim, &e, (float*)sk, skb, variant, st,
-                                    fold ? &qkv_splits : nullptr, nullptr, nullptr, &pend), "dec qkv");
+                                    fold ? &qkv_splits : nullptr), "dec qkv");
         }
-        pend.armed = false;
         cover_rope_args ras[2];
         cover_attn_args aas[2];
         bool pending[2] = {false, false};
@@ -790,14 +606,6 @@ int cover_decoder_forward(const cover_dec_desc* d, const cover_dec_pass* p, void
             }
             pending[g] = true;
             if (pair_ok) continue;   // both groups: launched together below
-            {   // scratch write segment + split-K slabs: fold and rotate inside the attention launch (no RoPE launch, nothing cached)
-                const char* fz_env = getenv("COVER_ROPE_ATTN_FUSE");   // read per call: the tests toggle it
-                // opt-in (=1): measured at parity with the separate RoPE launch on the pi0 profile (29.7 vs 29.4-30.1 ms per decision)
-                if (G.write_scratch && qkv_splits > 0 && fz_env && fz_env[0] == '1' && attention_rope_fusable(&aa, &ra, G.write_seg)) {
-                    HIPCHK(launch_attention_rope_fused(&aa, &ra, G.write_seg, st), "dec attention (qkv fold + RoPE inside)");
-                    continue;
-                }
-            }
             HIPCHK(launch_rope_kv_write(&ra, st), "dec rope/kv");
             if (G.seg0_shared && G.T == 1 && G.n_seg >= 2 && G.segs[0].mask_mode == COVER_MASK_LEN) {
                 // phase A: the shared segment, candidates as the query rows of one "sequence"
@@ -836,18 +644,14 @@ int cover_decoder_forward(const cover_dec_desc* d, const cover_dec_pass* p, void
         e.w8 = L.o_w8; e.w8_scale = L.o_s;
         if (f8) HIPCHK(quant(attn, HD, e), "dec quantise (o_proj input)");
         norm_q8(e);
-        if (head_flags) pend.flag = head_flags + (size_t)(2 * l) * gemm_head_words();
-        HIPCHK(launch_gemm_bf16((const bf16_t*)attn, HD, (const bf16_t*)L.o_w, x, dim, rows, dim, HD, &e, (float*)sk, skb, variant, st, nullptr, tail_sync,
-                                head_flags ? &pend : nullptr), "dec o_proj (+post_norm)");
+        HIPCHK(launch_gemm_bf16((const bf16_t*)attn, HD, (const bf16_t*)L.o_w, x, dim, rows, dim, HD, &e, (float*)sk, skb, variant, st), "dec o_proj (+post_norm)");
         memset(&e, 0, sizeof e);
         e.out_scale = 1.0f;
         e.act = d->act; e.glu = 1;
         e.w8 = L.gate_up_w8; e.w8_scale = L.gate_up_s;
         if (f8q) use_q8(dim, e);
         else if (f8) HIPCHK(quant(h, dim, e), "dec quantise (gate_up input)");
-        HIPCHK(launch_gemm_bf16((const bf16_t*)h, dim, (const bf16_t*)L.gate_up_w, mlp, d->mlp, rows, 2 * d->mlp, dim, &e, (float*)sk, skb, variant, st, nullptr, nullptr,
-                                nullptr, &pend), "dec gate_up");
-        pend.armed = false;
+        HIPCHK(launch_gemm_bf16((const bf16_t*)h, dim, (const bf16_t*)L.gate_up_w, mlp, d->mlp, rows, 2 * d->mlp, dim, &e, (float*)sk, skb, variant, st), "dec gate_up");
         memset(&e, 0, sizeof e);
         e.out_scale = 1.0f;
         e.residual = x; e.ld_residual = dim;
@@ -858,10 +662,7 @@ int cover_decoder_forward(const cover_dec_desc* d, const cover_dec_pass* p, void
         e.w8 = L.down_w8; e.w8_scale = L.down_s;
         if (f8) HIPCHK(quant(mlp, d->mlp, e), "dec quantise (down input)");
         if (l + 1 < d->n_layers) norm_q8(e);
-        const bool hand_on = head_flags && l + 1 < d->n_layers;   // (the last layer's sums have no streaming launch behind them in this pass)
-        if (hand_on) pend.flag = head_flags + (size_t)(2 * l + 1) * gemm_head_words();
-        HIPCHK(launch_gemm_bf16((const bf16_t*)mlp, d->mlp, (const bf16_t*)L.down_w, x, dim, rows, dim, d->mlp, &e, (float*)sk, skb, variant, st, nullptr, tail_sync,
-                                hand_on ? &pend : nullptr), "dec down (+next in_norm)");
+        HIPCHK(launch_gemm_bf16((const bf16_t*)mlp, d->mlp, (const bf16_t*)L.down_w, x, dim, rows, dim, d->mlp, &e, (float*)sk, skb, variant, st), "dec down (+next in_norm)");
     }
     if (p->final_norm)
         HIPCHK(launch_rmsnorm(x, 0, dim, d->final_norm_w, d->norm_w_offset, d->norm_style, (bf16_t*)x, dim, rows, dim, d->norm_eps, st), "dec final_norm");

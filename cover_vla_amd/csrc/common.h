@@ -11,6 +11,22 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
 #define WAVE 64
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize = 160 KiB) once per (kernel, DEVICE): the attribute belongs to the device's copy of the function, so a
+// process-wide `static` result would leave the second device of a process without it. One cache object per expansion site = per kernel instantiation.
+#include <atomic>
+struct LdsAttrCache { std::atomic<unsigned> ok{0}; };   // bit d: device d has the attribute
+static inline hipError_t lds_attr_160k_cached(const void* fn, LdsAttrCache& c) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const unsigned bit = 1u << (dev & 31);
+    if (c.ok.load(std::memory_order_acquire) & bit) return hipSuccess;
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) c.ok.fetch_or(bit, std::memory_order_release);
+    return e;
+}
+#define LDS_ATTR_160K(kfn) ([&]() -> hipError_t { static LdsAttrCache c_; return lds_attr_160k_cached((const void*)(kfn), c_); }())
+
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
 
 // round-to-nearest-even, NaN kept quiet: gfx950 has the conversion in hardware (v_cvt_pk_bf16_f32), one instruction per

@@ -575,7 +575,7 @@ extern "C" int cover_rn_debug(unsigned long long* out) { return (int)hipMemcpyFr
 #else
 #define RNT(slot) do { } while (0)
 #endif
-// (one row by one 512-thread block; red = 16 floats of LDS: the standalone kernel below and the tail reduction of the weight-streaming kernels)
+// (one row by one 512-thread block; red = 16 floats of LDS)
 __device__ __forceinline__ void reduce_norm_row(const float* __restrict__ partial, int S, bf16_t* C, int ldc, int M, int N, const EpiDev& epi,
                                                 const int m, float* red) {
     RNT(0);
@@ -710,157 +710,13 @@ __global__ __launch_bounds__(512) void splitk_reduce_norm(const float* __restric
     reduce_norm_row(partial, S, C, ldc, M, N, epi, blockIdx.x, red);
 }
 
-// ---------------------------------------------------------------------------------------------------
-// Tail reduction. A split-K weight-streaming launch whose slabs end in splitk_reduce_norm (o_proj and down of a candidate-decode
-// layer: residual + RMSNorm) can fold them ITSELF: every workgroup writes its slab through to memory (agent-scope stores), drains,
-// and takes a ticket; the LAST min(M, grid) arrivals wait until the ticket count says every slab is out, then run reduce_norm_row --
-// the standalone kernel's code, one row each, bit-identical results -- and the launch ends. The reduction launch (~5 us) and its
-// kernel boundary (~1.5 us) leave the chain for ~4 us at the tail of the producer.
-//   * who waits: only workgroups that have finished their own slab, for workgroups that are running or will be dispatched
-//     without their help -- no residency assumption, no deadlock; the wait is bounded (1 s of the 100 MHz clock), a give-up sets
-//     g_tail_error (cover_gemm_tail_status) and lets the launch finish
-//   * one agent-scope acquire per reducing workgroup behind the complete count (adjacent workgroups write 64-byte halves of one
-//     128-byte slab line: a reducer whose own XCD L2 allocated that line on its partial write-through store must not rest on
-//     unspecified fill behaviour for the neighbour's half). 32 000 stress passes were clean without it on this chip
-//     (tools/dbg/tail_stress.py), the memory model still asks for it; -DCOVER_TAIL_ACQUIRE=0 builds without, for A/B runs
-//   * sync[0] = arrivals, sync[1] = reducers that have seen them all; the last of those zeroes both (the caller zeroes them once
-//     per decoder pass as well, so a give-up cannot poison later passes)
-// ---------------------------------------------------------------------------------------------------
-struct TailReduce {
-    unsigned* sync;   // nullptr: plain split-K launch (the caller folds the slabs)
-    int S;
-    bf16_t* C;
-    int ldc;
-    EpiDev epi;
-};
-__device__ unsigned g_tail_error;
-int gemm_tail_status() {
-    unsigned v = 0;
-    if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_tail_error), sizeof v) != hipSuccess) return -1;
-    return (int)v;
-}
-
-// ---------------------------------------------------------------------------------------------------
-// Head reduction (kernels.h GemmDeferred; opt-in, measured 0.17 ms per decode pass SLOWER than the launches it replaces -- see capi.hip and
-// docs/OPTIMISATION_LOG.md round 5). The mirror image of the tail reduction above: the slabs of the PREVIOUS
-// GEMM are complete when this launch starts (the kernel boundary is the synchronisation), so no ticket chain is needed -- workgroups
-// 0 .. M-1 run reduce_norm_row for one row each and arrive at the hand-off's counter (one release per workgroup); every workgroup waits for
-// the release word the last arrival writes (bounded wait: g_tail_error; one acquire per workgroup: the rows were written by workgroups on
-// other XCDs) and only then runs the streaming kernel's prologue. What it removes per hand-off: one launch of 32 workgroups and its boundary
-// (~5.5 + 1.5 us); what it adds: an L2 write-back, three dependent cross-XCD round trips (arrive -> release word -> poll) and an L2
-// invalidate in front of every workgroup's first activation load -- measured +2.5 us per hand-off net. Versions on the way there: every
-// workgroup polling the counter itself every 128 cycles (+17 us per hand-off), release / acquire fences by all eight waves of a workgroup
-// (+5 us), and the head code inside the DEFAULT kernel (its branchy prologue made the compiler's counted waits in the straight-line part
-// conservative: +1.6 us per streaming launch with the feature OFF) -- hence a template instantiation of its own.
-// ---------------------------------------------------------------------------------------------------
-struct HeadReduce {
-    unsigned* flag;   // nullptr: none
-    const float* partial;
-    int S;
-    bf16_t* C;
-    int ldc, M, N;
-    EpiDev epi;
-};
-static_assert(sizeof(HeadReduce) <= sizeof(((GemmDeferred*)nullptr)->blob), "GemmDeferred::blob too small");
-static HeadReduce no_head() {
-    HeadReduce h;
-    ::memset(&h, 0, sizeof h);
-    return h;
-}
-// One hand-off = HEAD_WORDS words: the arrival counter on its own 128-byte line, then HEAD_GROUPS release words on lines of their own. The
-// LAST producer (its fetch-add returns M - 1) writes every release word; a consumer polls the word of its group (blockIdx mod 8 -- roughly
-// its XCD) with a 512-cycle sleep. (First version: every workgroup polled the counter itself every 128 cycles -- 256 pollers on one line,
-// the producers' own slab loads queued behind them on that channel: decode pass 3.74 -> 4.99 ms.)
-constexpr int HEAD_GROUPS = 8, HEAD_LINE = 32, HEAD_WORDS = (1 + HEAD_GROUPS) * HEAD_LINE;
-int gemm_head_words() { return HEAD_WORDS; }
-__device__ __forceinline__ void head_arrive(unsigned* flag, unsigned producers) {   // one lane, after the block's release fence + barrier
-    const unsigned old = __hip_atomic_fetch_add(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (old == producers - 1) {
-#pragma unroll
-        for (int g = 0; g < HEAD_GROUPS; ++g) __hip_atomic_store(flag + (1 + g) * HEAD_LINE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-}
-__device__ __forceinline__ void head_wait(const unsigned* flag, int bid) {
-    if (threadIdx.x == 0) {
-        const unsigned* rel = flag + (1 + (bid & (HEAD_GROUPS - 1))) * HEAD_LINE;
-        const unsigned long long t0 = wall_clock64();
-        while (__hip_atomic_load(rel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
-            if (wall_clock64() - t0 > 2000000ull) {   // 20 ms
-                __hip_atomic_store(&g_tail_error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                break;
-            }
-            __builtin_amdgcn_s_sleep(8);
-        }
-    }
-    // ONE wave's acquire invalidates the XCD's L2 for everybody in the block (first version: all eight waves of all 256 workgroups issued it)
-    if (threadIdx.x < 64) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
-#ifndef COVER_TAIL_ACQUIRE
-#define COVER_TAIL_ACQUIRE 1   // one buffer_inv per reducing workgroup: what the memory model asks for (the path is opt-in and slower anyway)
-#endif
-#ifndef COVER_TAIL_RELEASE
-#define COVER_TAIL_RELEASE 0
-#endif
-// slab store of 4 consecutive columns; WT = write-through (the tail reduction reads them from other XCDs inside the same launch)
-__device__ __forceinline__ void slab_store4(float* o, const float (&v)[4], int n, int N, bool wt) {
+// slab store of 4 consecutive columns of a split-K partial
+__device__ __forceinline__ void slab_store4(float* o, const float (&v)[4], int n, int N) {
     if (n + 3 < N && ((((uintptr_t)o) & 15) == 0)) {
-        if (wt) {
-            unsigned long long* po = (unsigned long long*)o;
-            __hip_atomic_store(po, (unsigned long long)__float_as_uint(v[0]) | ((unsigned long long)__float_as_uint(v[1]) << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(po + 1, (unsigned long long)__float_as_uint(v[2]) | ((unsigned long long)__float_as_uint(v[3]) << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } else {
-            *(float4*)o = make_float4(v[0], v[1], v[2], v[3]);
-        }
+        *(float4*)o = make_float4(v[0], v[1], v[2], v[3]);
     } else {
         for (int e = 0; e < 4; ++e)
-            if (n + e < N) {
-                if (wt) __hip_atomic_store(o + e, v[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                else o[e] = v[e];
-            }
-    }
-}
-// called by every thread of the block after its slab stores have been issued; smem = the block's LDS (>= 128 B, free by now)
-__device__ __forceinline__ void tail_reduce(const TailReduce& tr, const float* __restrict__ partial, int M, int N, char* smem) {
-    unsigned* sh = (unsigned*)smem;        // [0] ticket ; floats [16..32) = reduce_norm_row's scratch
-#if COVER_TAIL_RELEASE
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // A/B build: the memory model's release (L2 write-back + wait) instead of the bare wait
-#else
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's slab stores have been acknowledged (written through)
-#endif
-    __syncthreads();                                     // ... every wave's (and the LDS k-slice buffer is dead)
-    const unsigned total = gridDim.x * gridDim.y;
-    const unsigned nred = total < (unsigned)M ? total : (unsigned)M;
-    if (threadIdx.x == 0) sh[0] = __hip_atomic_fetch_add(tr.sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
-    const unsigned ticket = sh[0];
-    if (ticket + nred < total) return;                   // not one of the last nred arrivals
-    if (threadIdx.x == 0 && ticket + 1 < total) {   // (the last arrival has just seen the full count itself)
-        const unsigned long long t0 = wall_clock64();
-        while (__hip_atomic_load(tr.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < total) {
-            if (wall_clock64() - t0 > 100000000ull) {
-                __hip_atomic_store(&g_tail_error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                break;
-            }
-            __builtin_amdgcn_s_sleep(1);
-        }
-    }
-    __syncthreads();
-#if COVER_TAIL_ACQUIRE
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-#endif
-    asm volatile("" ::: "memory");
-    // partial is laundered: it is __restrict__ in the callers, and the slabs read here were written by OTHER workgroups
-    const float* pl = partial;
-    asm volatile("" : "+s"(pl)::"memory");
-    for (unsigned m = ticket - (total - nred); m < (unsigned)M; m += nred) {
-        reduce_norm_row(pl, tr.S, tr.C, tr.ldc, M, N, tr.epi, (int)m, (float*)smem + 16);
-        __syncthreads();   // the scratch is reused by the next row of this block (only when the grid has fewer blocks than rows)
-    }
-    // every reducer has seen the full count by now: the last one to say so zeroes both words (off the critical path: after the rows)
-    if (threadIdx.x == 0 && __hip_atomic_fetch_add(tr.sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nred - 1) {
-        __hip_atomic_store(tr.sync + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(tr.sync, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (n + e < N) o[e] = v[e];
     }
 }
 
@@ -872,8 +728,7 @@ __device__ __forceinline__ void tail_reduce(const TailReduce& tr, const float* _
 // ---------------------------------------------------------------------------------------------------
 template <int MF, int KS, int NBW, bool W8 = false>
 __global__ __launch_bounds__(512) void gemm_skinny2(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ Wp,
-                                                    float* __restrict__ partial, int M, int N, int Kp, const float* __restrict__ wscale,
-                                                    TailReduce tr) {
+                                                    float* __restrict__ partial, int M, int N, int Kp, const float* __restrict__ wscale) {
     constexpr int NG = 8 / KS, KC = 256 * KS, NBPB = NG * NBW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1039,10 +894,9 @@ __global__ __launch_bounds__(512) void gemm_skinny2(const bf16_t* __restrict__ A
                 const float4 sc = *(const float4*)(wscale + (size_t)(nb < N16 ? nb : N16 - 1) * 16 + 4 * g);
                 v[0] *= sc.x; v[1] *= sc.y; v[2] *= sc.z; v[3] *= sc.w;
             }
-            if (nb < N16 && m < M && n < N) slab_store4(partial + ((size_t)s * M + m) * N + n, v, n, N, tr.sync != nullptr);
+            if (nb < N16 && m < M && n < N) slab_store4(partial + ((size_t)s * M + m) * N + n, v, n, N);
         }
     }
-    if (tr.sync != nullptr) tail_reduce(tr, partial, M, N, smem);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1064,11 +918,10 @@ extern "C" int cover_sk_debug(unsigned long long* out) {
 #else
 #define SKT(slot) do { } while (0)
 #endif
-template <int MF, int KS, int NBW, int NBUF, bool W8 = false, bool HEAD = false>
+template <int MF, int KS, int NBW, int NBUF, bool W8 = false>
 __global__ __launch_bounds__(512) void gemm_skinny3(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ Wp,
                                                     void* C, int ldc, int M, int N, int Kp, EpiDev epi,
-                                                    float* __restrict__ partial, int kper, const float* __restrict__ wscale,
-                                                    TailReduce tr, HeadReduce hd) {
+                                                    float* __restrict__ partial, int kper, const float* __restrict__ wscale) {
     SKT(0);
     constexpr int NG = 8 / KS, KC = 256 * KS, NBPB = NG * NBW;
     constexpr int XB = MF * 16 * KC * 2;          // bytes of one activation chunk (fragment-major)
@@ -1165,23 +1018,6 @@ __global__ __launch_bounds__(512) void gemm_skinny3(const bf16_t* __restrict__ A
     // prologue. The activation chunk is requested BEFORE the first NBUF weight items: loads return in order, so with the
     // weights first the chunk (and with it the first MFMA, and with that the first REFILL of a weight buffer) would wait for
     // all NBUF x 8 KiB per wave to land -- the stream would drain its whole initial window before issuing anything new.
-    // head reduction (HEAD instantiations only: the default kernel's code is untouched -- a branchy prologue made the compiler's counted waits
-    // in the straight-line part conservative and cost the plain path 6 us per layer): the first hd.M workgroups fold the previous GEMM's slabs,
-    // one row each, before anything else of theirs; everybody then meets at the hand-off's release word and starts its own prologue
-    if constexpr (HEAD) {
-        const int bid = blockIdx.y * gridDim.x + blockIdx.x;
-        if (bid < hd.M) {
-            const float* pl = hd.partial;
-            asm volatile("" : "+s"(pl)::"memory");
-            reduce_norm_row(pl, hd.S, hd.C, hd.ldc, hd.M, hd.N, hd.epi, bid, (float*)smem);
-            __syncthreads();   // every wave's row stores are in the XCD's L2 (the barrier drains vmcnt) ...
-            if (tid < 64) {    // ... ONE wave writes the L2 back (a release per wave was eight L2 sweeps per workgroup), one lane arrives
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                if (tid == 0) head_arrive(hd.flag, (unsigned)hd.M);
-            }
-        }
-        head_wait(hd.flag, bid);
-    }
     if (items >= NBUF && min(KC, ke - kb) == KC) {   // straight-line: the compiler counts the weight loads behind the chunk's
         {   // whole first chunk: no per-element conditions (rows beyond M re-read row M-1; their outputs are never stored)
 #pragma unroll
@@ -1332,7 +1168,7 @@ __global__ __launch_bounds__(512) void gemm_skinny3(const bf16_t* __restrict__ A
                 if (nb < N16 && m < M && n < N) {
                     float v[4];
                     slice_sum(gsel, ii, f, v);
-                    slab_store4(partial + ((size_t)blockIdx.y * M + m) * N + n, v, n, N, tr.sync != nullptr);
+                    slab_store4(partial + ((size_t)blockIdx.y * M + m) * N + n, v, n, N);
                 }
             }
         } else if (epi.glu) {   // n-groups 0 / 1 hold the gate / up block of one output block (NG == 2, even nb_begin)
@@ -1365,7 +1201,6 @@ __global__ __launch_bounds__(512) void gemm_skinny3(const bf16_t* __restrict__ A
         }
     }
     SKT(3);
-    if (partial != nullptr && tr.sync != nullptr) tail_reduce(tr, partial, M, N, smem);
 }
 
 // out = epi(sum_s partial[s]) ; one thread per 4 output columns
@@ -1486,10 +1321,6 @@ static EpiDev make_epi(const cover_gemm_epi* e) {
     d.nq8s = e ? e->norm_out8_scale : nullptr;
     d.ldnq8 = e ? e->ld_norm_out8 : 0;
     if (!d.nq8 || !d.nq8s || !d.norm_out || d.norm_style == 2) { d.nq8 = nullptr; d.nq8s = nullptr; }
-    d.ssq_out = e ? e->ssq_out : nullptr;
-    d.rs_in = e ? e->rs_in : nullptr;
-    d.ssq_ld = e ? e->ssq_ld : 0; d.rs_ld = e ? e->rs_ld : 0; d.rs_parts = e ? e->rs_parts : 0; d.rs_n = e ? e->rs_n : 0;
-    d.rs_eps = e ? e->rs_eps : 0.f;
     return d;
 }
 
@@ -1635,16 +1466,11 @@ void gemm_plan_counts(long long* out, int n, int reset) {
     }
 }
 
-static TailReduce no_tail() {
-    TailReduce t;
-    ::memset(&t, 0, sizeof t);
-    return t;
-}
 static void launch_skinny2(const Skinny2Plan& p, const bf16_t* A, int lda, const bf16_t* Wp, float* ws, int M, int N, int K, int Kp,
-                           const uint8_t* w8, const float* w8s, hipStream_t st, const TailReduce& tr = no_tail()) {
+                           const uint8_t* w8, const float* w8s, hipStream_t st) {
     dim3 grid(p.gx, p.S), block(512);
     plan_hit(19);
-#define SK2(MF_, KS_, NBW_, W8_) launch_streaming(sk_class(N, K), (W8_ ? 1.0 : 2.0) * (double)N * (double)K, gemm_skinny2<MF_, KS_, NBW_, W8_>, grid, block, p.lds, st, A, lda, W8_ ? (const bf16_t*)w8 : Wp, ws, M, N, Kp, w8s, tr)
+#define SK2(MF_, KS_, NBW_, W8_) launch_streaming(sk_class(N, K), (W8_ ? 1.0 : 2.0) * (double)N * (double)K, gemm_skinny2<MF_, KS_, NBW_, W8_>, grid, block, p.lds, st, A, lda, W8_ ? (const bf16_t*)w8 : Wp, ws, M, N, Kp, w8s)
     if (w8 && w8s && p.MF <= 2) {
         if (p.MF == 1) { if (p.NBW == 6) SK2(1, 4, 6, true); else if (p.NBW == 4) SK2(1, 4, 4, true); else if (p.NBW == 3) SK2(1, 4, 3, true); else SK2(1, 4, 2, true); }
         else { if (p.NBW == 6) SK2(2, 4, 6, true); else if (p.NBW == 4) SK2(2, 4, 4, true); else if (p.NBW == 3) SK2(2, 4, 3, true); else SK2(2, 4, 2, true); }
@@ -1658,22 +1484,17 @@ static void launch_skinny2(const Skinny2Plan& p, const bf16_t* A, int lda, const
 }
 
 static hipError_t launch_skinny3(const Skinny3Plan& p, const bf16_t* A, int lda, const bf16_t* Wp, void* C, int ldc, int M, int N,
-                                 int Kp, const EpiDev& epi, float* partial, hipStream_t st, const TailReduce& tr = no_tail(),
-                                 const HeadReduce& hd = no_head()) {
+                                 int Kp, const EpiDev& epi, float* partial, hipStream_t st) {
     hipError_t e = hipSuccess;
     dim3 grid(p.gx, p.S), block(512);
     plan_hit(20);
 #define SK3(MF_, NBW_, W8_)                                                                                                  \
     do {                                                                                                                    \
-        auto kfn = hd.flag ? gemm_skinny3<MF_, 4, NBW_, NBW_, W8_, true> : gemm_skinny3<MF_, 4, NBW_, NBW_, W8_, false>;  \
-        if (p.lds > 64 * 1024) {                                                                                            \
-            static hipError_t attr0 = hipFuncSetAttribute((const void*)gemm_skinny3<MF_, 4, NBW_, NBW_, W8_, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-            static hipError_t attr1 = hipFuncSetAttribute((const void*)gemm_skinny3<MF_, 4, NBW_, NBW_, W8_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-            e = attr0 != hipSuccess ? attr0 : attr1;                                                                        \
-        }                                                                                                                   \
+        auto kfn = gemm_skinny3<MF_, 4, NBW_, NBW_, W8_>;                                                                   \
+        if (p.lds > 64 * 1024) e = LDS_ATTR_160K(kfn);                                                         \
         if (e == hipSuccess)                                                                                                \
             launch_streaming(sk_class(N, Kp), (W8_ ? 1.0 : 2.0) * (double)N * (double)Kp, kfn, grid, block, p.lds, st, A, lda,  \
-                             W8_ ? (const bf16_t*)epi.w8 : Wp, C, ldc, M, N, Kp, epi, partial, p.kper, epi.w8s, tr, hd);     \
+                             W8_ ? (const bf16_t*)epi.w8 : Wp, C, ldc, M, N, Kp, epi, partial, p.kper, epi.w8s);             \
     } while (0)
     if (epi.w8) {   // e4m3 weight stream
         if (p.MF == 1) { if (p.NBW == 4) SK3(1, 4, true); else if (p.NBW == 3) SK3(1, 3, true); else SK3(1, 2, true); }
@@ -1695,44 +1516,16 @@ static hipError_t run_norm(const EpiDev& epi, void* C, int ldc, int M, int Nout,
                           epi.nq8, epi.ldnq8, epi.nq8s);
 }
 
-// the ordinary reduction launch for an armed hand-off that the next launch cannot carry
-static hipError_t launch_deferred_reduce(const GemmDeferred* d, hipStream_t st) {
-    const HeadReduce* hp = (const HeadReduce*)d->blob;
-    launch_streaming(5, 0.0, splitk_reduce_norm, dim3(hp->M), dim3(512), 0, st, hp->partial, hp->S, hp->C, hp->ldc, hp->M, hp->N, hp->epi);
-    return hipGetLastError();
-}
-
 hipError_t launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* Wp, void* C, int ldc, int M, int N, int K,
-                            const cover_gemm_epi* epi_in, float* ws, size_t ws_bytes, int variant, hipStream_t st, int* splits_out,
-                            unsigned* tail_sync, GemmDeferred* defer_out, const GemmDeferred* head_in) {
+                            const cover_gemm_epi* epi_in, float* ws, size_t ws_bytes, int variant, hipStream_t st, int* splits_out) {
     if (splits_out) *splits_out = 0;
-    if (defer_out) defer_out->armed = false;
-    if (M <= 0 || N <= 0) return head_in && head_in->armed ? launch_deferred_reduce(head_in, st) : hipSuccess;
+    if (M <= 0 || N <= 0) return hipSuccess;
     const int Kp = (K + 127) / 128 * 128;
     EpiDev epi = make_epi(epi_in);
     if (variant == 0) variant = (M <= 64 && ws != nullptr) ? 3 : 1;
-    // head reduction: an armed hand-off rides in this launch's first workgroups when this launch is the unsplit third-generation streaming
-    // kernel with at least as many workgroups as rows to fold; anything else folds the slabs with the ordinary reduction launch first
-    HeadReduce hd = no_head();
-    if (head_in && head_in->armed) {
-        const HeadReduce* hp = (const HeadReduce*)head_in->blob;
-        bool ride = false;
-        if (variant == 3 && M <= 32) {
-            static const char* g3e = getenv("COVER_SKINNY3");
-            const Skinny3Plan q3 = plan_skinny3(M, N, Kp);
-            ride = q3.ok && q3.S == 1 && !(g3e && g3e[0] == '0') && (long long)q3.gx >= hp->M && tail_sync == nullptr;
-        }
-        if (ride) hd = *hp;
-        else {
-            hipError_t e0 = launch_deferred_reduce(head_in, st);
-            if (e0 != hipSuccess) return e0;
-        }
-    }
-    // the split-K reduction + norm of a weight-streaming launch (M <= 64) can run at the tail of that launch (see "Tail reduction")
+    // the reduction launch that can carry the norm (splitk_reduce_norm)
     const bool norm_fusable = epi.norm_w != nullptr && epi.norm_out != nullptr && !epi.glu && !epi.out_f32 && (N % 8) == 0 && N <= 8192 && (ldc % 8) == 0 &&
                               (epi.ld_norm_out % 8) == 0 && (((uintptr_t)epi.norm_w) & 15) == 0;
-    TailReduce tr = no_tail();
-    if (tail_sync != nullptr && norm_fusable && M <= 64) { tr.sync = tail_sync; tr.C = (bf16_t*)C; tr.ldc = ldc; tr.epi = epi; }
     // Third generation (full-K chunk loop per block, one block per CU): used whenever its plan fills the chip -- with the
     // epilogue fused when no grid split is needed (wide outputs), else leaving S (< the second generation's) partial slabs.
     int S3 = 0;   // > 0: the third generation has left S3 slabs in ws, fall through to the shared reduction
@@ -1747,10 +1540,8 @@ hipError_t launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* Wp, void* C,
         }
         if (p3.ok && p3.S > 1 && (ws == nullptr || ws_bytes < p3.ws_bytes)) p3.ok = false;
         if (p3.ok && (variant == 6 || !(g3 && g3[0] == '0'))) {
-            tr.S = p3.S;
-            hipError_t e = launch_skinny3(p3, A, lda, Wp, C, ldc, M, N, Kp, epi, p3.S > 1 ? ws : nullptr, st, p3.S > 1 ? tr : no_tail(), hd);
+            hipError_t e = launch_skinny3(p3, A, lda, Wp, C, ldc, M, N, Kp, epi, p3.S > 1 ? ws : nullptr, st);
             if (e != hipSuccess) return e;
-            if (p3.S > 1 && tr.sync != nullptr) return hipSuccess;   // the launch folded its own slabs
             if (p3.S == 1) {
                 if (epi.norm_w != nullptr && epi.norm_out != nullptr) e = run_norm(epi, C, ldc, M, epi.glu ? N / 2 : N, st);
                 return e;
@@ -1768,21 +1559,13 @@ hipError_t launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* Wp, void* C,
             Skinny2Plan p = plan_skinny2(M, N, Kp);
             if (ws == nullptr || ws_bytes < p.ws_bytes) return hipErrorInvalidValue;
             dim3 grid(p.gx, p.S), block(512);
-            tr.S = p.S;
-            launch_skinny2(p, A, lda, Wp, ws, M, N, K, Kp, epi.w8, epi.w8s, st, tr);
+            launch_skinny2(p, A, lda, Wp, ws, M, N, K, Kp, epi.w8, epi.w8s, st);
             S = p.S;
-            if (tr.sync != nullptr) return hipGetLastError();       // the launch folded its own slabs
         }
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
         const bool want_norm = epi.norm_w != nullptr && epi.norm_out != nullptr;
         if (norm_fusable) {
-            if (defer_out && defer_out->flag && M <= 32) {   // head reduction: the NEXT streaming launch folds these slabs in its first M workgroups
-                HeadReduce* hp = (HeadReduce*)defer_out->blob;
-                hp->flag = defer_out->flag; hp->partial = ws; hp->S = S; hp->C = (bf16_t*)C; hp->ldc = ldc; hp->M = M; hp->N = N; hp->epi = epi;
-                defer_out->armed = true;
-                return hipSuccess;
-            }
             launch_streaming(5, 0.0, splitk_reduce_norm, dim3(M), dim3(512), 0, st, (const float*)ws, S, (bf16_t*)C, ldc, M, N, epi);
             return hipGetLastError();
         }
@@ -1860,8 +1643,9 @@ hipError_t launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* Wp, void* C,
         {7, 3, 2, 2, 4},   // r (27): 224x96,  4 waves of 112x48 (one per SIMD), 4 stages (160 KiB)
         {7, 2, 1, 4, 4},   // s (28): 112x128, 4 waves of 112x32 (one per SIMD), 4 stages (120 KiB): narrow outputs at M = 448 with HALF the K slices of the 224-row tile
         {7, 4, 2, 2, 3},   // t (29): 224x128, 4 waves of 112x64, 3 stages (132 KiB)
-        {2, 2, 2, 2, 3},   // u (30): 64x64, 4 waves of 32x32, 3 stages (48 KiB, three blocks per CU): few-hundred-row GEMMs with a deferred-norm row scale
-        {1, 1, 2, 2, 16},  // v (31): 32x32, 4 waves of 16x16, 16 stages (128 KiB): UNSPLIT narrow outputs on a long K (fifteen 8-KiB k-tiles in flight)
+        // k-split wave pairs (gemm_v3.hip gemm_tiled_v3k): 2 x 2 wave tiles, each owned by the two waves of a SIMD, which split every k-tile
+        {7, 3, 2, 2, 4},   // u (30): 224x96,  4 wave pairs of 112x48, 4 stages (160 KiB)
+        {7, 4, 2, 2, 3},   // v (31): 224x128, 4 wave pairs of 112x64, 3 stages (132 KiB)
     };
     // Measured on MI355X (tools/bench_kernels.py, M = 441): this single-barrier-per-k-tile structure is latency-bound per
     // block, so residency beats tile size until the tile grid oversubscribes the chip several times over, while 64x64
@@ -1883,11 +1667,10 @@ hipError_t launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* Wp, void* C,
     // cycles of MFMA against 768 cycles of LDS-DMA on the CU's address path, and none of the DMA issue sits in an MFMA wave.
     // Cold weights: M = 2624 qkv 715 -> 867 TF, gate_up 792 -> 1026 TF, down 660 -> 833 TF (M = 448 in isolation: qkv 80.5 ->
     // 75.1 us, gate_up 125.8 -> 119.1 us). Narrow outputs keep the smaller tiles (o_proj: 664 vs 701 TF at M = 2624).
-    static const char* big_env = getenv("COVER_BIG_TILES");   // experiment knob: 0 disables the 12-wave tiles
     // (at M = 448 the micro-benchmark gain does not survive inside the decision -- 41.22 vs 40.98 ms -- so: long panels only)
     // M = 512 (decode rows of BASELINE config 5: N = 512 candidates) is two 256-row tiles: qkv 75.4 -> 60.2 us, gate_up 135.9 -> 116.9,
     // down 73.1 -> 48.4 + 13.5 (four K slices + reduction); o_proj stays on the 64 x 128 tiles (29.0 vs 25.4 + 13.5).
-    if (variant != 2 && Kp >= 2048 && M >= 512 && !(big_env && big_env[0] == '0')) {
+    if (variant != 2 && Kp >= 2048 && M >= 512) {
         if (N > 4096 && nblocks(13) >= 176) pick = N >= 16384 ? 12 : 13;
         else if (N <= 4096 && Kp >= 8192 && (nblocks(12) >= 256 || (M < 1024 && ws != nullptr))) pick = 12;
     }
@@ -1916,17 +1699,18 @@ hipError_t launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* Wp, void* C,
     // per block; split-K reduction ~4 us + slab bytes at 3 TB/s). Cold weights, M = 448, kernel timestamps, before -> after:
     // qkv 81.5 -> 52 us (224x96/128), gate_up 138 -> 78.5 us (224x192, 1.03 PFLOP/s), down 72.6 + norm -> 43 + 10 us (224x128, 4 slices).
     int S_forced = 0;
-    static const char* v3_env = getenv("COVER_V3");   // 0 keeps the loader-wave kernels where the self-loading ones (gemm_v3.hip) are the default (A/B runs)
-    const bool v3_on = !(v3_env && v3_env[0] == '0') && !f8_on && variant != 2 && (size_t)M * lda * 2 + 4096 < ((size_t)1 << 31);
+    // the self-loading kernels (gemm_v3.hip) address an activation piece with a 32-bit lane offset; the bf16 loader-wave forms of these tiles
+    // (rounds 2-4) live in docs/experiments/r06_pruned_variants.patch
+    const bool v3_on = !f8_on && variant != 2 && (size_t)M * lda * 2 + 4096 < ((size_t)1 << 31);
     {
-        static const char* no224 = getenv("COVER_TILES_224");   // experiment knob: 0 disables
         const int t224 = (M + 223) / 224, waste224 = t224 * 224 - M;
-        if (variant != 2 && Kp >= 2048 && M >= 400 && waste224 * 10 <= M && !(no224 && no224[0] == '0')) {
+        if (variant != 2 && Kp >= 2048 && M >= 400 && waste224 * 10 <= M && (v3_on || f8_on)) {
             // loader-wave kernels (gemm_tiled_pc): 224x96 (6 MFMA waves) / 224x128 / 224x192; self-loading kernels (gemm_v3.hip, round 5,
             // in-kernel probe of workgroup 0 at M = 448 / 2232): 224x96 with one wave of 112x48 per SIMD 0.62 us per k-tile, 224x128
             // 0.69-0.78, 224x192 0.91-1.02; prologue + epilogue 6 / 7 / 10 us
-            const int bns[3] = {96, 128, 192}, idx_pc[3] = {17, 15, 16}, idx_v3[3] = {27, 24, 23};
-            const double kt_pc[3] = {0.67, 0.70, 1.05}, kt_v3[3] = {0.62, 0.72, 0.93}, fix_v3[3] = {6.0, 7.0, 10.0};
+            // (round 6: 224x96 on k-split wave pairs, pick 30, instead of one wave per SIMD, pick 27)
+            const int bns[3] = {96, 128, 192}, idx_pc[3] = {17, 15, 16}, idx_v3[3] = {30, 24, 23};
+            const double kt_pc[3] = {0.67, 0.70, 1.05}, kt_v3[3] = {0.50, 0.72, 0.93}, fix_v3[3] = {6.0, 7.0, 10.0};
             double best = 1e30;
             for (int c = 0; c < 3; ++c) {
                 if (epi.glu && (bns[c] % 32)) continue;
@@ -1946,44 +1730,22 @@ hipError_t launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* Wp, void* C,
     {
         static const char* force = getenv("COVER_TILE_PICK");  // experiment knob: index into cands
         if (force && force[0] >= '0' && force[0] <= '9') pick = force[0] - '0';
-        if (force && force[0] >= 'a' && force[0] <= 'h') pick = 10 + (force[0] - 'a');
+        if (force && force[0] >= 'a' && force[0] <= 'i') pick = 10 + (force[0] - 'a');   // (b .. i: fp8 operands only)
         if (force && force[0] >= 'n' && force[0] <= 'v') pick = 10 + (force[0] - 'a');
     }
-    {
-        // experiment knob: the 64 x 64 tile of ViT-sized problems on the self-loading kernel (pick 30) instead of gemm_tiled<2, 2, .., 3 stages>
-        static const char* small3 = getenv("COVER_V3_SMALL");
-        if (small3 && small3[0] == '1' && v3_on && pick == 2) pick = 30;
-    }
-    // deferred RMSNorm (cover_gemm_epi.ssq_out / rs_in): only the self-loading kernels carry it. The producer of a residual stream runs UNSPLIT on
-    // 32 x 32 tiles with a sixteen-stage ring (M = 200, N = 1024: 224 workgroups, the whole K in one block, no slabs and no reduction
-    // launch); the consumer of the raw rows runs on 64 x 64 tiles.
-    const bool dn_prod = epi.ssq_out != nullptr, dn_cons = epi.rs_in != nullptr;
-    if (dn_prod || dn_cons) {
-        if (!v3_on || M <= 64 || (dn_prod && (epi.glu || epi.out_f32 || (N % 32) != 0 || epi.ssq_ld < N / 32 || epi.norm_out)) ||
-            (dn_cons && (epi.rs_parts <= 0 || epi.rs_n <= 0 || epi.rs_ld < epi.rs_parts)))
-            return hipErrorInvalidValue;
-        pick = dn_prod ? 31 : (pick >= 23 && pick <= 29 ? pick : 30);
-        S_forced = 1;
-    }
-    // a forced self-loading pick with COVER_V3=0 (or on a problem the self-loading kernels do not take) falls back to its loader-wave twin
-    {
-        // the 256 x 128 / 128 x 256 tiles (M >= 512 with more than 10 % of 224-row padding: config 4's 704-row prefill) on the self-loading kernel
-        // as well: layer 426 -> 416 us at M = 704 (gate_up 164 -> 157). COVER_V3_BIG=0 keeps the loader-wave kernels.
-        static const char* big3 = getenv("COVER_V3_BIG");
-        if (v3_on && !(big3 && big3[0] == '0')) pick = pick == 12 ? 25 : pick == 13 ? 26 : pick;
-    }
-    if (!v3_on && pick >= 23) pick = pick == 23 ? 16 : (pick == 24 || pick == 29 || pick == 28) ? 15 : pick == 25 ? 12 : pick == 26 ? 13 : pick == 27 ? 17 : 2;
+    // the 256 x 128 / 128 x 256 tiles (M >= 512 with more than 10 % of 224-row padding: config 4's 704-row prefill) run on the self-loading kernel
+    if (v3_on) pick = pick == 12 ? 25 : pick == 13 ? 26 : pick;
+    if (!v3_on && pick >= 23) pick = f8_on ? ((pick == 24 || pick == 29 || pick == 28) ? 15 : pick == 25 ? 12 : pick == 26 ? 13 : pick == 27 ? 17 : 10) : 0;
+    // bf16 operands: of the loader-wave tiles only the 64 x 128 four-stage one (pick 10) is still a default; the others exist as fp8 kernels
+    if (!(f8_on && gemm_fp8_tiled_supported(pick)) && ((pick >= 11 && pick <= 18) || pick == 9)) pick = (variant == 2 || pick == 9) ? 1 : 0;
     if (variant == 2 && pick > 2) pick = 0;
-    if (pick == 18 && !(f8_on && gemm_fp8_tiled_supported(18))) return hipErrorInvalidValue;   // 128 x 192 exists as an fp8 kernel only
     const Cand cd = cands[pick];
     const int bm = cd.wm * cd.wgm * 16, bn = cd.wn * cd.wgn * 16;
     const int tiles_m = (M + bm - 1) / bm, tiles_n = (N + bn - 1) / bn;
     const int nk_total = Kp / BK;
     int S = 1;
     static const char* force_pick = getenv("COVER_TILE_PICK");
-    if (dn_prod || dn_cons) {
-        S = 1;                                   // (the deferred-norm epilogues exist in the unsplit form only)
-    } else if (S_forced > 0 && !force_pick) {
+    if (S_forced > 0 && !force_pick) {
         S = S_forced;
     } else if (ws != nullptr) {
         while ((long long)tiles_m * tiles_n * S < 192 && S < 8 && nk_total / (S * 2) >= 8 &&
@@ -2000,8 +1762,8 @@ hipError_t launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* Wp, void* C,
     // the load latency (~12.8 TB/s chip-wide at 2 stages => 42.7 / 64 FLOP per byte).
     const int nst = variant == 2 ? 2 : cd.nst;
     const size_t lds = (size_t)nst * (bm + bn) * BK * 2;
-    const bool pc = pick >= 9 && pick <= 18;
-    dim3 grid(tiles_m * tiles_n, S), block(pc ? 320 : 64 * cd.wgm * cd.wgn);
+    const bool pc = pick == 10;
+    dim3 grid(tiles_m * tiles_n, S), block(pc ? 64 * cd.wgm * cd.wgn + 256 : 64 * cd.wgm * cd.wgn);
     // profiling: the GEMM kernel's own start / stop stamps; class 4 = LLM-sized weight matrix (prefill), 1 = ViT-sized
     const int tcls = (double)N * (double)Kp >= 16.0e6 ? 4 : 1;
     const double twork = 2.0 * (double)M * (double)N * (double)K;
@@ -2010,18 +1772,16 @@ hipError_t launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* Wp, void* C,
     do {                                                                                                                    \
         auto kfn = gemm_tiled<WM_, WN_, G_, NST_, WGM_, WGN_>;                                                              \
         if (lds > 64 * 1024) {                                                                                              \
-            static hipError_t attr = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-            e = attr;                                                                                                       \
+            e = LDS_ATTR_160K(kfn);                                                                                                       \
         }                                                                                                                   \
         if (e == hipSuccess)                                                                                                \
             launch_streaming(tcls, twork, kfn, grid, block, lds, st, A, lda, Wp, C, ldc, M, N, Kp, epi, tiles_m, tiles_n, kt_per, partial); \
     } while (0)
-#define LAUNCH_PC(WM_, WN_, NST_, NL_, ...)                                                                                 \
+#define LAUNCH_PC(WM_, WN_, NST_, NL_)                                                                                      \
     do {                                                                                                                    \
-        auto kfn = gemm_tiled_pc<WM_, WN_, NST_, NL_, ##__VA_ARGS__>;                                                                         \
+        auto kfn = gemm_tiled_pc<WM_, WN_, NST_, NL_>;                                                                      \
         if (lds > 64 * 1024) {                                                                                              \
-            static hipError_t attr = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-            e = attr;                                                                                                       \
+            e = LDS_ATTR_160K(kfn);                                                                                                       \
         }                                                                                                                   \
         if (e == hipSuccess)                                                                                                \
             launch_streaming(tcls, twork, kfn, grid, block, lds, st, A, lda, Wp, C, ldc, M, N, Kp, epi, tiles_m, tiles_n, kt_per, partial); \
@@ -2047,20 +1807,8 @@ hipError_t launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* Wp, void* C,
         e = launch_gemm_v3(pick, A, lda, Wp, C, ldc, M, N, Kp, epi, tiles_m, tiles_n, kt_per, S, part3, tcls, twork, st);
     } else if (pc) {
         plan_hit(pick);
-        // loader waves: one wave issues an LDS-DMA piece every ~60 cycles, four keep the CU's vector memory path busy
-        // (cold weights, M = 448: o_proj 36.0 -> 32.3 us, down 84.2 -> 76.0 us)
-        static const char* nl_env = getenv("COVER_PC_LOADERS");
-        const int nl = nl_env ? atoi(nl_env) : 4;
-        block = dim3(64 * cd.wgm * cd.wgn + 64 * (pick >= 12 || nl == 4 ? 4 : nl == 2 ? 2 : 1));
-        if (pick == 9) { if (nl == 4) LAUNCH_PC(2, 4, 3, 4); else if (nl == 2) LAUNCH_PC(2, 4, 3, 2); else LAUNCH_PC(2, 4, 3, 1); }
-        else if (pick == 10) { if (nl == 4) LAUNCH_PC(2, 4, 4, 4); else if (nl == 2) LAUNCH_PC(2, 4, 4, 2); else LAUNCH_PC(2, 4, 4, 1); }
-        else if (pick == 11) { if (nl == 4) LAUNCH_PC(4, 4, 3, 4); else LAUNCH_PC(4, 4, 3, 1); }
-        else if (pick == 12) LAUNCH_PC(4, 4, 3, 4, 4, 2);
-        else if (pick == 13) LAUNCH_PC(4, 4, 3, 4, 2, 4);
-        else if (pick == 14) LAUNCH_PC(7, 3, 4, 4, 2, 2);
-        else if (pick == 15) LAUNCH_PC(7, 2, 3, 4, 2, 4);
-        else if (pick == 16) LAUNCH_PC(7, 3, 3, 4, 2, 4);
-        else LAUNCH_PC(7, 2, 4, 4, 2, 3);
+        // 64 x 128 tile, four loader waves + four MFMA waves, four stages (narrow outputs on a long K at a few hundred rows)
+        LAUNCH_PC(2, 4, 4, 4);
     } else if (variant == 2) {
         plan_hit(pick);
         if (pick == 0) LAUNCH_T(4, 4, false, 2, 2, 2);
@@ -2112,10 +1860,9 @@ hipError_t launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* Wp, void* C,
 // Weight-streaming GEMM WITHOUT its reduction: leaves fp32 partials [S][M][N] in ws for a consumer that folds them
 // (the decoder fuses the QKV reduction into rope_kv_write). Returns the number of K slices through *S_out.
 hipError_t launch_gemm_skinny_partial(const bf16_t* A, int lda, const bf16_t* Wp, float* ws, size_t ws_bytes, int M, int N,
-                                      int K, int* S_out, hipStream_t st, const void* w8, const float* w8s, const GemmDeferred* head_in) {
+                                      int K, int* S_out, hipStream_t st, const void* w8, const float* w8s) {
     if (M <= 0 || M > 64 || N <= 0) return hipErrorInvalidValue;
     const int Kp = (K + 127) / 128 * 128;
-    const bool armed = head_in && head_in->armed;
     {
         static const char* g3 = getenv("COVER_SKINNY3");
         Skinny3Plan p3 = plan_skinny3(M, N, Kp);
@@ -2123,25 +1870,10 @@ hipError_t launch_gemm_skinny_partial(const bf16_t* A, int lda, const bf16_t* Wp
         if (p3.ok && !(g3 && g3[0] == '0') && ws != nullptr && ws_bytes >= need) {
             EpiDev none = make_epi(nullptr);
             if (w8 && w8s) { none.w8 = (const uint8_t*)w8; none.w8s = w8s; }
-            HeadReduce hd = no_head();
-            if (armed) {
-                // the head rows are folded out of the SAME workspace this launch writes its own slabs to: every workgroup stores at its very end,
-                // behind the counter that says all rows have been read and folded
-                const HeadReduce* hp = (const HeadReduce*)head_in->blob;
-                if (M <= 32 && (long long)p3.gx * p3.S >= hp->M) hd = *hp;
-                else {
-                    hipError_t e0 = launch_deferred_reduce(head_in, st);
-                    if (e0 != hipSuccess) return e0;
-                }
-            }
-            hipError_t e = launch_skinny3(p3, A, lda, Wp, nullptr, 0, M, N, Kp, none, ws, st, no_tail(), hd);
+            hipError_t e = launch_skinny3(p3, A, lda, Wp, nullptr, 0, M, N, Kp, none, ws, st);
             *S_out = p3.S;
             return e;
         }
-    }
-    if (armed) {
-        hipError_t e0 = launch_deferred_reduce(head_in, st);
-        if (e0 != hipSuccess) return e0;
     }
     Skinny2Plan p = plan_skinny2(M, N, Kp);
     if (ws == nullptr || ws_bytes < p.ws_bytes) return hipErrorInvalidValue;

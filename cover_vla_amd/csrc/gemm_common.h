@@ -29,12 +29,6 @@ struct EpiDev {
     uint8_t* nq8;           // optional e4m3 twin of norm_out (+ row scales), written by the norm that writes norm_out
     float* nq8s;
     int ldnq8;
-    // deferred RMSNorm (cover_gemm_epi.ssq_out / rs_in): producer side = partial sums of squares per (row, 32-column group) of the stored bf16
-    // output; consumer side = per-row rsqrt(mean square) applied to the fp32 sums (gemm_v3.hip does both)
-    float* ssq_out;
-    const float* rs_in;
-    int ssq_ld, rs_ld, rs_parts, rs_n;
-    float rs_eps;
 };
 
 // e4m3 quantisation of 8 consecutive bf16-valued elements k..k+7 of an activation row into the MX MFMA operand order
@@ -307,7 +301,8 @@ __device__ __forceinline__ void staged_fill_row(f32x4 (&acc)[WN][WM], char* st, 
 template <int WM, int WN, int BM, int BN>
 __device__ __forceinline__ void tiled_epilogue_staged(f32x4 (&acc)[WN][WM], const EpiDev& epi, void* C, int ldc, int M, int N, int m0,
                                                       int n0, int mw, int nw, int r, int g, float* __restrict__ partial, char* st,
-                                                      int st_bytes, int t, int nthr) {
+                                                      int st_bytes, int t, int nthr, bool owner = true) {
+    // owner: this wave holds a tile's sums (false for the second wave of a k-split pair, gemm_v3.hip: it only helps with the store loop)
     const bool raw = partial != nullptr;
     const bool glu = !raw && epi.glu;
     const bool plain = !raw && !glu && epi_is_plain(epi);
@@ -329,7 +324,7 @@ __device__ __forceinline__ void tiled_epilogue_staged(f32x4 (&acc)[WN][WM], cons
     const bool ok = (size_t)rpp * pitch <= (size_t)st_bytes && cvalid > 0 && ((cvalid * esz_out) & 15) == 0 && (ld_bytes & 15) == 0 &&
                     ((((uintptr_t)base) + (size_t)oc0 * esz_out) & 15) == 0 && !((glu || plain) && epi.out_f32);
     if (!ok) {   // uniform over the block
-        tiled_epilogue<WM, WN>(acc, epi, C, ldc, M, N, mw, nw, r, g, partial);
+        if (owner) tiled_epilogue<WM, WN>(acc, epi, C, ldc, M, N, mw, nw, r, g, partial);
         return;
     }
     const int cpr = (cvalid * esz_out) >> 4;                           // 16-byte chunks per output row
@@ -340,7 +335,7 @@ __device__ __forceinline__ void tiled_epilogue_staged(f32x4 (&acc)[WN][WM], cons
     const int r0 = pass * rpp;
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");       // every wave is done reading the pipeline stages / the previous pass's tile
     PCTL(4);
-    staged_fill_row<WM, WN, 0>(acc, st, pitch, m0, n0, mw, nw, r, g, mode, r0, rpp);
+    if (owner) staged_fill_row<WM, WN, 0>(acc, st, pitch, m0, n0, mw, nw, r, g, mode, r0, rpp);
     PCTL(5);
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     PCTL(6);
@@ -357,7 +352,6 @@ __device__ __forceinline__ void tiled_epilogue_staged(f32x4 (&acc)[WN][WM], cons
             for (int c0 = t; c0 < total; c0 += NU * nthr) {
                 int rowi[NU], chi[NU], mi[NU];
                 bool ok[NU];
-                float sq[NU] = {};
                 float4 bb[NU][2] = {}, ll[NU][2] = {}, rf[NU][2] = {};
                 uint4 rb[NU] = {};
 #pragma unroll
@@ -410,21 +404,6 @@ __device__ __forceinline__ void tiled_epilogue_staged(f32x4 (&acc)[WN][WM], cons
                     }
                     char* dst = base + (size_t)mi[u] * ld_bytes + (size_t)oc0 * esz_out + chi[u] * 16;
                     *(uint4*)dst = make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
-                    if (epi.ssq_out) {
-#pragma unroll
-                        for (int i = 0; i < 8; ++i) { const float b = bfround(v[i]); sq[u] += b * b; }
-                    }
-                }
-                if (epi.ssq_out) {
-                    // the four 16-byte chunks of a 32-column group sit in four consecutive lanes (cpr % 4 == 0, chunk index = lane mod cpr):
-                    // fixed-order sum over the quad, lane 0 of the quad stores
-#pragma unroll
-                    for (int u = 0; u < NU; ++u) {
-                        float q = sq[u];
-                        q += __shfl_xor(q, 1);
-                        q += __shfl_xor(q, 2);
-                        if (ok[u] && (chi[u] & 3) == 0) epi.ssq_out[(size_t)mi[u] * epi.ssq_ld + ((n0 + chi[u] * 8) >> 5)] = q;
-                    }
                 }
             }
             continue;

@@ -566,8 +566,7 @@ hipError_t launch_gemm_fp8_tiled(int pick, const uint8_t* A8, int lda8, const fl
     do {                                                                                                                     \
         auto kfn = gemm_tiled_pc_f8<WM_, WN_, NST_, NL_, CGM_, CGN_>;                                                        \
         if (lds > 64 * 1024) {                                                                                               \
-            static hipError_t attr = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-            e = attr;                                                                                                        \
+            e = LDS_ATTR_160K(kfn);                                                                                                        \
         }                                                                                                                    \
         if (e == hipSuccess) {                                                                                               \
             dim3 block(64 * (CGM_ * CGN_ + NL_));                                                                            \
@@ -582,8 +581,7 @@ hipError_t launch_gemm_fp8_tiled(int pick, const uint8_t* A8, int lda8, const fl
     do {                                                                                                                     \
         auto kfn = gemm_tiled_v3_f8<WM_, WN_, CGM_, CGN_, NA_, NB_>;                                                         \
         const size_t lds3 = ((size_t)NA_ * CGM_ * WM_ * 16 + (size_t)NB_ * CGN_ * WN_ * 16) * 128;                           \
-        static hipError_t attr = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-        e = attr;                                                                                                            \
+        e = LDS_ATTR_160K(kfn);                                                                                                            \
         if (e == hipSuccess) {                                                                                               \
             dim3 block(64 * CGM_ * CGN_);                                                                                    \
             hipEvent_t ea, eb;                                                                                               \

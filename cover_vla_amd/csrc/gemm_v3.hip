@@ -243,31 +243,266 @@ __global__ __launch_bounds__(64 * CGM * CGN) void gemm_tiled_v3(const bf16_t* __
     if (w < NH) run(IC<0>{});
     else run(IC<1>{});
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the surplus pieces of the clamped tail must not land in the epilogue's staging area
-    if (epi.rs_in) {
-        // deferred RMSNorm: the A rows were the RAW residual stream (the norm weight sits in the packed weight): row m of the fp32 sums is
-        // multiplied by rsqrt(mean square of row m), summed in a fixed order from the producer's partial sums of squares
-#pragma unroll
-        for (int f = 0; f < WM; ++f) {
-            int m = m0 + wm * (WM * 16) + f * 16 + r;
-            m = m < M ? m : M - 1;
-            const float* sp = epi.rs_in + (size_t)m * epi.rs_ld;
-            float q = 0.f;
-            for (int p4 = 0; p4 + 4 <= epi.rs_parts; p4 += 4) {
-                const float4 v = *(const float4*)(sp + p4);
-                q += v.x; q += v.y; q += v.z; q += v.w;
-            }
-            for (int p1 = epi.rs_parts & ~3; p1 < epi.rs_parts; ++p1) q += sp[p1];
-            const float rstd = rsqrtf(q / (float)epi.rs_n + epi.rs_eps);
-#pragma unroll
-            for (int b = 0; b < WN; ++b) acc[b][f] *= rstd;
-        }
-    }
     PCTL(2);
     V3P(5, __builtin_readcyclecounter());
     V3P(2, wall_clock64());
     V3P(6, (unsigned long long)nk);
     tiled_epilogue_staged<WM, WN, BM_, BN_>(acc, epi, C, ldc, M, N, m0, n0, m0 + wm * (WM * 16), n0 + wn * (WN * 16), r, g, partial, smem,
                                             NSTA * A_BYTES + NSTB * B_BYTES, tid, 64 * NW);
+    PCTL(3);
+    V3P(3, wall_clock64());
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K-split wave pairs ("v3k", round 6). The tiles above put CGM x CGN wave tiles on the block's waves: a 224 x 96 tile (qkv at M = 448: 256 of
+// them = one per CU) has only 2 x 2 wave tiles of 112 x 48 = ONE wave per SIMD, and that wave cannot cover its own fragment reads with its own
+// MFMAs (1 199 cycles per k-tile against 672 of MFMA issue); a 224 x 128 tile on eight waves is 112 x 32 per wave = 0.64 fragment reads per
+// MFMA. Here the two waves of a SIMD (w and w + 4) own the SAME wave tile and split every 64-deep k-tile between them: wave-pair member wk
+// runs the 32-deep step wk of every tile. Two waves per SIMD whatever the tile (one's LDS wait hides under the other's MFMAs), wave tiles
+// twice as large at the same register budget per k (112 x 64: 0.39 reads per MFMA), the same LDS images, DMA roles and counted waits as above.
+// One 32-deep step per wave per k-tile makes the loop simpler than the two-step one above:
+//   body kt:  NM MFMAs on the fragments of tile kt | the NR fragment reads of tile kt + 1 behind the first of them | this wave's DMA pieces
+//             of tile kt + NST into the stage of tile kt (every wave has read tile kt before the barrier that opened this body)
+//             own pieces of tile kt + 2 landed (counted vmcnt: NST - 2 younger tiles stay in flight), fragments complete -> barrier
+// At the end the second member hands its sums to the first through the (dead) ring, which runs the epilogue's fill; all eight waves share
+// the store loop. Sums: (steps 0 of all tiles) + (steps 1 of all tiles) in fp32 -- another order than the kernels above, same rounding points.
+// ---------------------------------------------------------------------------------------------------
+template <int WM, int WN, int CGM, int CGN, int NST>
+__global__ __launch_bounds__(128 * CGM * CGN) void gemm_tiled_v3k(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ Wp, void* C, int ldc, int M, int N,
+                                                               int Kp, EpiDev epi, int tiles_m, int tiles_n, int kt_per, float* __restrict__ partial) {
+    PCTL(0);
+    V3P(0, wall_clock64());
+    constexpr int NT = CGM * CGN, NW = 2 * NT, NH = NT;                   // wave tiles; waves (pair member wk = w / NT); waves per DMA role
+    constexpr int BM_ = CGM * WM * 16, BN_ = CGN * WN * 16;
+    constexpr int A_BYTES = BM_ * BK * 2, B_BYTES = BN_ * BK * 2;
+    constexpr int AT = A_BYTES / 1024, BT = B_BYTES / 1024;
+    constexpr int PTA = AT / NH, PTB = BT / NH;
+    constexpr int NM = WM * WN, NR = WM + WN;
+    static_assert(NW == 8, "two waves per SIMD");
+    static_assert(AT % NH == 0 && BT % NH == 0, "pieces must split evenly over the waves of a role");
+    static_assert(NST >= 3, "the ring holds the tile being read, the tile landing and at least one in flight");
+    static_assert((NST - 2) * PTA <= 63 && (NST - 2) * PTB <= 63, "counted vmcnt must fit its 6-bit field");
+    static_assert(PTA <= NM && PTB <= NM, "at most one piece behind an MFMA");
+    static_assert(NST * (A_BYTES + B_BYTES) <= 160 * 1024, "LDS");
+    static_assert(NT * NM * 1024 <= NST * (A_BYTES + B_BYTES), "the pair hand-off fits the ring");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* As = smem;                   // [NST][A_BYTES]
+    char* Bs = smem + NST * A_BYTES;   // [NST][B_BYTES]
+    const int nwg = tiles_m * tiles_n;
+    int bid = blockIdx.x;
+    {   // XCD-aware bijective remap (as above)
+        const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+        const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+        bid = base + (bid >> 3);
+    }
+    const int tn = bid / tiles_m, tm = bid % tiles_m;
+    const int m0 = tm * BM_, n0 = tn * BN_;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int K32 = Kp >> 5;
+    const int N16 = (N + 15) >> 4;
+    const int nk_total = Kp / BK;
+    const int kt0 = blockIdx.y * kt_per;
+    const int nk = min(kt_per, nk_total - kt0);
+    const uint32_t as_u32 = __builtin_amdgcn_readfirstlane(lds_addr_u32(As));
+    const uint32_t bs_u32 = __builtin_amdgcn_readfirstlane(lds_addr_u32(Bs));
+    const int wk = w / NT, ww = w % NT;
+    const int wm = ww / CGN, wn = ww % CGN;
+    const int r = lane & 15, g = lane >> 4;
+    f32x4 acc[WN][WM];
+#pragma unroll
+    for (int b = 0; b < WN; ++b)
+#pragma unroll
+        for (int f = 0; f < WM; ++f) acc[b][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // fragment addresses of this wave's step (wk) in stage 0
+    const uint32_t a_addr = lds_addr_u32(As) + ((wm * (WM * 16) + r) * 8 + ((wk * 4 + g) ^ (r & 7))) * 16;
+    const uint32_t b_addr = lds_addr_u32(Bs) + (wn * WN * 2 * 64 + lane) * 16 + wk * 1024;
+    auto read_nth = [&](uint32_t aa, uint32_t ba, int j, u32x4(&xf)[WM], u32x4(&wf)[WN]) {   // first-use order: w0, x0 .. x(WM-1), w1 .. w(WN-1)
+        if (j == 0) asm volatile("ds_read_b128 %0, %1" : "=v"(wf[0]) : "v"(ba));
+        else if (j <= WM) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(xf[j - 1]) : "v"(aa), "n"((j - 1) * 2048));
+        else asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(wf[j - WM]) : "v"(ba), "n"((j - WM) * 2048));
+    };
+    auto landed = [&](u32x4(&xf)[WM], u32x4(&wf)[WN]) {
+#pragma unroll
+        for (int f = 0; f < WM; ++f) asm volatile("" : "+v"(xf[f]));
+#pragma unroll
+        for (int b = 0; b < WN; ++b) asm volatile("" : "+v"(wf[b]));
+    };
+    auto run = [&](auto ROLE) {
+        constexpr int role = decltype(ROLE)::value;
+        constexpr int PT = role ? PTB : PTA, SB = role ? B_BYTES : A_BYTES, KSH = role ? 11 : 7;
+        constexpr int RSPAN = (NM * 2) / 3 < NR ? NM : (NM * 2) / 3;      // the reads sit behind the first two thirds of the MFMAs: landed when the last one issues
+        constexpr bool XS = NM >= 28;
+        const int wl = w % NH;
+        uint32_t voff[PT];
+        const char* sbase[PT];
+        uint32_t dst0[PT];
+#pragma unroll
+        for (int i = 0; i < PT; ++i) {
+            const int j = wl + NH * i;
+            if constexpr (role == 0) {
+                const int row = j * 8 + (lane >> 3), c = lane & 7;
+                int gr = m0 + row;
+                gr = gr < M ? gr : M - 1;
+                voff[i] = (uint32_t)(((size_t)gr * lda + ((c ^ (row & 7)) << 3)) * 2);
+                sbase[i] = (const char*)(A + (size_t)kt0 * BK);
+                dst0[i] = as_u32 + j * 1024;
+            } else {
+                const int nbi = j >> 1, kbi = j & 1;
+                int nb = (n0 >> 4) + nbi;
+                nb = nb < N16 ? nb : N16 - 1;
+                voff[i] = lane * 16;
+                sbase[i] = (const char*)(Wp + ((size_t)nb * K32 + (size_t)kt0 * 2 + kbi) * 512);
+                dst0[i] = bs_u32 + j * 1024;
+            }
+        }
+        auto issue = [&](int i, int stage, int t) { glds16_s(voff[i], sbase[i] + ((size_t)(uint32_t)t << KSH), dst0[i] + stage * SB); };
+        // NM MFMAs on (xf, wf); behind them the reads of stage rs into (xn, wn_) and this wave's pieces of tile dt into stage ds.
+        // XS (large wave tiles: 112 x 64 = 112 accumulator registers): the activation fragments are SINGLE-buffered -- the MFMA order is m-fragment
+        // outer, so fragment f is dead after its WN MFMAs and the next tile's fragment f is read into the same registers right behind them (it has
+        // the rest of the body to land; the LDS round trip is far longer than the matrix pipe holds its operands); only the weight fragments
+        // keep two sets.
+        auto group = [&](u32x4(&xf)[WM], const u32x4(&wf)[WN], u32x4(&xn)[WM], u32x4(&wn_)[WN], int rs, int ds, int dt, auto RD) {
+            constexpr bool rd = decltype(RD)::value != 0;
+            const uint32_t aa = a_addr + rs * A_BYTES, ba = b_addr + rs * B_BYTES;
+            if constexpr (XS) {
+#pragma unroll
+                for (int f = 0; f < WM; ++f)
+#pragma unroll
+                    for (int b = 0; b < WN; ++b) {
+                        const int i = f * WN + b;
+                        acc[b][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[b]), __builtin_bit_cast(bf16x8, xf[f]), acc[b][f], 0, 0, 0);
+                        if (rd) {
+#pragma unroll
+                            for (int j = 0; j < WN; ++j)      // weight fragment j of the next tile: spread over the first two thirds
+                                if ((j * RSPAN) / WN == i) read_nth(aa, ba, j == 0 ? 0 : WM + j, xn, wn_);
+                            if (b == WN - 1) read_nth(aa, ba, 1 + f, xf, wn_);
+#pragma unroll
+                            for (int p = 0; p < PT; ++p)
+                                if (((2 * p + 1) * NM) / (2 * PT) == i) issue(p, ds, dt);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+            } else {
+#pragma unroll
+                for (int b = 0; b < WN; ++b)
+#pragma unroll
+                    for (int f = 0; f < WM; ++f) {
+                        const int i = b * WM + f;
+                        acc[b][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[b]), __builtin_bit_cast(bf16x8, xf[f]), acc[b][f], 0, 0, 0);
+                        if (rd) {
+#pragma unroll
+                            for (int j = 0; j < NR; ++j)
+                                if ((j * RSPAN) / NR == i) read_nth(aa, ba, j, xn, wn_);
+#pragma unroll
+                            for (int p = 0; p < PT; ++p)
+                                if (((2 * p + 1) * NM) / (2 * PT) == i) issue(p, ds, dt);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+            }
+        };
+        // ---- prologue: every stage of the ring is requested; tiles 0 and 1 have landed before anybody reads ----
+#pragma unroll
+        for (int s = 0; s < NST; ++s)
+#pragma unroll
+            for (int p = 0; p < PT; ++p) issue(p, s, min(s, nk - 1));
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * PT) : "memory");
+        __builtin_amdgcn_s_barrier();
+        PCTL(1);
+        V3P(1, wall_clock64());
+        V3P(4, __builtin_readcyclecounter());
+        u32x4 xa[WM], wa[WN], xb[XS ? 1 : WM], wb[WN];
+#pragma unroll
+        for (int j = 0; j < NR; ++j) read_nth(a_addr, b_addr, j, xa, wa);
+        asm volatile("s_waitcnt lgkmcnt(0)");
+        __builtin_amdgcn_s_barrier();          // every wave has read tile 0: body 0 may refill its stage
+        landed(xa, wa);
+        int rs = 1, ds = 0;                    // stage of tile kt + 1 (read) / of tile kt (refilled with tile kt + NST)
+        auto finish = [&](int) {
+            asm volatile("s_waitcnt lgkmcnt(0)");
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * PT) : "memory");
+            __builtin_amdgcn_s_barrier();
+            ds = rs;
+            rs = rs == NST - 1 ? 0 : rs + 1;
+        };
+        int kt = 0;
+        if constexpr (XS) {
+            for (; kt + 2 <= nk - 1; kt += 2) {
+                group(xa, wa, xa, wb, rs, ds, min(kt + NST, nk - 1), IC<1>{});
+                finish(0);
+#pragma unroll
+                for (int f = 0; f < WM; ++f) asm volatile("" : "+v"(xa[f]));
+#pragma unroll
+                for (int b = 0; b < WN; ++b) asm volatile("" : "+v"(wb[b]));
+                group(xa, wb, xa, wa, rs, ds, min(kt + 1 + NST, nk - 1), IC<1>{});
+                finish(0);
+                landed(xa, wa);
+            }
+            if (kt < nk - 1) {
+                group(xa, wa, xa, wb, rs, ds, min(kt + NST, nk - 1), IC<1>{});
+                finish(0);
+#pragma unroll
+                for (int f = 0; f < WM; ++f) asm volatile("" : "+v"(xa[f]));
+#pragma unroll
+                for (int b = 0; b < WN; ++b) asm volatile("" : "+v"(wb[b]));
+                group(xa, wb, xa, wa, 0, 0, 0, IC<0>{});
+            } else {
+                group(xa, wa, xa, wb, 0, 0, 0, IC<0>{});
+            }
+        } else {
+            auto& xbb = reinterpret_cast<u32x4(&)[WM]>(xb);
+            for (; kt + 2 <= nk - 1; kt += 2) {
+                group(xa, wa, xbb, wb, rs, ds, min(kt + NST, nk - 1), IC<1>{});
+                finish(0);
+                landed(xbb, wb);
+                group(xbb, wb, xa, wa, rs, ds, min(kt + 1 + NST, nk - 1), IC<1>{});
+                finish(0);
+                landed(xa, wa);
+            }
+            if (kt < nk - 1) {
+                group(xa, wa, xbb, wb, rs, ds, min(kt + NST, nk - 1), IC<1>{});
+                finish(0);
+                landed(xbb, wb);
+                group(xbb, wb, xa, wa, 0, 0, 0, IC<0>{});
+            } else {
+                group(xa, wa, xbb, wb, 0, 0, 0, IC<0>{});
+            }
+        }
+    };
+    if (w < NH) run(IC<0>{});
+    else run(IC<1>{});
+    PCTL(2);
+    V3P(5, __builtin_readcyclecounter());
+    V3P(2, wall_clock64());
+    V3P(6, (unsigned long long)nk);
+    // ---- the pair's sums: member 1 -> ring -> member 0 ----
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // the surplus pieces of the clamped tail have landed; nobody reads the ring any more ...
+    __builtin_amdgcn_s_barrier();                                   // ... in any wave
+    {
+        const uint32_t red = lds_addr_u32(smem) + (uint32_t)((ww * NM) * 64 + lane) * 16;
+        if (wk == 1) {
+#pragma unroll
+            for (int b = 0; b < WN; ++b)
+#pragma unroll
+                for (int f = 0; f < WM; ++f)
+                    asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(red), "v"(acc[b][f]), "n"((b * WM + f) * 1024) : "memory");
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (wk == 0) {
+#pragma unroll
+            for (int b = 0; b < WN; ++b)
+#pragma unroll
+                for (int f = 0; f < WM; ++f) {
+                    f32x4 o;
+                    asm volatile("ds_read_b128 %0, %1 offset:%2\n\ts_waitcnt lgkmcnt(0)" : "=v"(o) : "v"(red), "n"((b * WM + f) * 1024) : "memory");
+                    acc[b][f] += o;
+                }
+        }
+    }
+    tiled_epilogue_staged<WM, WN, BM_, BN_>(acc, epi, C, ldc, M, N, m0, n0, m0 + wm * (WM * 16), n0 + wn * (WN * 16), r, g, partial, smem,
+                                            NST * (A_BYTES + B_BYTES), tid, 64 * NW, wk == 0);
     PCTL(3);
     V3P(3, wall_clock64());
 }
@@ -286,8 +521,21 @@ hipError_t launch_gemm_v3(int pick, const bf16_t* A, int lda, const bf16_t* Wp, 
         auto kfn = gemm_tiled_v3<WM_, WN_, CGM_, CGN_, NA_, NB_>;                                                            \
         const size_t lds = ((size_t)NA_ * CGM_ * WM_ * 16 + (size_t)NB_ * CGN_ * WN_ * 16) * BK * 2;                         \
         dim3 block(64 * CGM_ * CGN_);                                                                                        \
-        static hipError_t attr = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-        e = attr;                                                                                                            \
+        e = LDS_ATTR_160K(kfn);                                                                                                            \
+        if (e == hipSuccess) {                                                                                               \
+            hipEvent_t ea, eb;                                                                                               \
+            if (prof_enabled() && prof_reserve(prof_cls, prof_work, &ea, &eb) >= 0)                                          \
+                hipExtLaunchKernelGGL(kfn, grid, block, (uint32_t)lds, st, ea, eb, 0, A, lda, Wp, C, ldc, M, N, Kp, epi, tiles_m, tiles_n, kt_per, partial); \
+            else                                                                                                             \
+                hipLaunchKernelGGL(kfn, grid, block, lds, st, A, lda, Wp, C, ldc, M, N, Kp, epi, tiles_m, tiles_n, kt_per, partial); \
+        }                                                                                                                    \
+    } while (0)
+#define LAUNCH_V3K(WM_, WN_, CGM_, CGN_, NST_)                                                                               \
+    do {                                                                                                                     \
+        auto kfn = gemm_tiled_v3k<WM_, WN_, CGM_, CGN_, NST_>;                                                               \
+        const size_t lds = ((size_t)NST_ * (CGM_ * WM_ * 16 + CGN_ * WN_ * 16)) * BK * 2;                                   \
+        dim3 block(128 * CGM_ * CGN_);                                                                                       \
+        e = LDS_ATTR_160K(kfn);                                                                                              \
         if (e == hipSuccess) {                                                                                               \
             hipEvent_t ea, eb;                                                                                               \
             if (prof_enabled() && prof_reserve(prof_cls, prof_work, &ea, &eb) >= 0)                                          \
@@ -304,11 +552,12 @@ hipError_t launch_gemm_v3(int pick, const bf16_t* A, int lda, const bf16_t* Wp, 
         case 27: if (ring == 34) LAUNCH_V3(7, 3, 2, 2, 3, 4); else LAUNCH_V3(7, 3, 2, 2, 4, 4); break;          // 224x96,  4 waves of 112x48 (one per SIMD)
         case 28: LAUNCH_V3(7, 2, 1, 4, 4, 4); break;                                                            // 112x128, 4 waves of 112x32 (one per SIMD), 4 stages
         case 29: if (ring == 34) LAUNCH_V3(7, 4, 2, 2, 3, 4); else LAUNCH_V3(7, 4, 2, 2, 3, 3); break;          // 224x128, 4 waves of 112x64
-        case 30: LAUNCH_V3(2, 2, 2, 2, 3, 3); break;                                                            // 64x64,   4 waves of 32x32 (three blocks per CU)
-        case 31: if (ring == 8) LAUNCH_V3(1, 1, 2, 2, 8, 8); else LAUNCH_V3(1, 1, 2, 2, 16, 16); break;         // 32x32,   4 waves of 16x16, 16-stage ring
+        case 30: LAUNCH_V3K(7, 3, 2, 2, 4); break;                                                              // 224x96,  4 wave PAIRS of 112x48 splitting k (two waves per SIMD)
+        case 31: LAUNCH_V3K(7, 4, 2, 2, 3); break;                                                              // 224x128, 4 wave pairs of 112x64
         default: return hipErrorInvalidValue;
     }
 #undef LAUNCH_V3
+#undef LAUNCH_V3K
     if (e == hipSuccess) e = hipGetLastError();
     return e;
 }

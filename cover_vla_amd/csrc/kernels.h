@@ -9,33 +9,13 @@ typedef uint16_t bf16_t;
 
 // ---- gemm_bf16.hip -------------------------------------------------------------------------------
 // C[M,N] = epi(A[M,K] x W[N,K]^T); W pre-packed by cover_pack_weight_bf16 (fragment-major).
-// Head reduction (decode passes, M <= 32; gemm_bf16.hip "Head reduction"): the split-K reduction (+ residual + RMSNorm) that completes a
-// weight-streaming GEMM is a 32-workgroup launch of ~5.5 us between two kernels that want the whole chip. Instead of launching it, the GEMM
-// hands it on (`defer_out`: armed = the slabs are in the workspace and NOTHING has folded them yet) and the NEXT weight-streaming launch runs
-// it in its first M workgroups while all the others already have their first weights in flight (`head_in`); everybody meets at a counter
-// (`flag`: one zeroed word per hand-off, owned by the caller's stream) before the first activation row is read. A launch that cannot carry the
-// head (anything but the third-generation streaming kernel) folds the slabs with the ordinary reduction launch first: an armed hand-off is
-// always consumed by the launch it is given to. Same code (reduce_norm_row), same results bit for bit. Opt-in (capi.hip COVER_HEAD_REDUCE=1):
-// measured slower than the reduction launches, like the tail reduction.
-int gemm_head_words();   // words of one hand-off's `flag` area (arrival counter + release words on lines of their own), all zero before the producer runs
-struct GemmDeferred {
-    bool armed;
-    unsigned* flag;
-    alignas(16) unsigned char blob[448];   // gemm_bf16.hip's HeadReduce (device struct)
-};
 hipError_t launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* Wp, void* C, int ldc, int M, int N, int K,
                             const cover_gemm_epi* epi, float* splitk_ws, size_t splitk_ws_bytes, int variant,
-                            hipStream_t st, int* splits_out = nullptr, unsigned* tail_sync = nullptr, GemmDeferred* defer_out = nullptr,
-                            const GemmDeferred* head_in = nullptr);
-// tail_sync (optional, two zeroed words of device memory owned by the caller's stream): a weight-streaming launch (M <= 64) whose split-K
-// slabs would be folded by splitk_reduce_norm folds them at its own tail instead (gemm_bf16.hip "Tail reduction": same code, same results,
-// one launch less). gemm_tail_status(): 0, or 1 once a bounded wait of that protocol gave up (synchronous read of a device word).
-int gemm_tail_status();
+                            hipStream_t st, int* splits_out = nullptr);
 // splits_out (optional): a split-K launch of the LDS-tiled kernels with a bias-only epilogue leaves its S raw fp32 slabs [S][M][N] in ws
 // and returns S here instead of folding them (the decoder folds them in rope_kv_write: one launch less per layer); 0 = C is written.
 hipError_t launch_gemm_skinny_partial(const bf16_t* A, int lda, const bf16_t* Wp, float* ws, size_t ws_bytes, int M, int N,
-                                      int K, int* S_out, hipStream_t st, const void* w8 = nullptr, const float* w8s = nullptr,
-                                      const GemmDeferred* head_in = nullptr);
+                                      int K, int* S_out, hipStream_t st, const void* w8 = nullptr, const float* w8s = nullptr);
 #define COVER_GEMM_PLANS 32
 void gemm_plan_counts(long long* out, int n, int reset);   // per-plan launch counters (tests): see gemm_bf16.hip
 int gemm_v3_probe(unsigned long long* out);                  // 16 words: in-kernel probe of the last gemm_v3.hip launch (g_v3_probe)
@@ -49,10 +29,6 @@ hipError_t launch_pack_weight_bf16(const bf16_t* W, int ldw, int N, int K, bf16_
 // ---- attention.hip -------------------------------------------------------------------------------
 hipError_t launch_attention_bf16(const cover_attn_args* a, hipStream_t st);
 hipError_t launch_attention_bf16_pair(const cover_attn_args* a0, const cover_attn_args* a1, hipStream_t st);
-// RoPE + split-K fold of the qkv projection inside the attention launch (attention.hip "FuseDev"): r describes the slabs / tables exactly as
-// launch_rope_kv_write would get them; wseg = the segment of a whose keys / values are this pass's own rows. Nothing is written to the caches.
-bool attention_rope_fusable(const cover_attn_args* a, const cover_rope_args* r, int wseg);
-hipError_t launch_attention_rope_fused(const cover_attn_args* a, const cover_rope_args* r, int wseg, hipStream_t st);
 hipError_t launch_decode_attention_fused(const cover_decode_attn_args* a, hipStream_t st);
 hipError_t launch_decode_own_attention(const cover_own_attn_args* a, hipStream_t st);   // decode_own.hip
 

@@ -205,13 +205,10 @@ class Decoder:
 
     def __init__(self, sd, *, dim, layers, Hq, Hkv, D, mlp, act, norm, eps, rope, n_pos=1024, device="cuda:0",
                  cache: Optional[KvGeometry] = None, share_cache_with: Optional["Decoder"] = None, final_norm_bf16=True,
-                 fp8_weights=False, fold_norm=False):
+                 fp8_weights=False):
         """final_norm_bf16: the stack's final norm weight is a bf16 parameter in the reference (PaliGemma's language model, HF
         bf16 Llama) -- False for the pi0 action expert, whose final norm is outside the name filter of
-        to_bfloat16_like_physical_intelligence (paligemma_with_expert.py:219-227) and stays fp32. Layer norms are bf16 in all.
-        fold_norm: also pack qkv / gate_up with the layer's input / post-attention RMSNorm weight folded in along k (W * (offset + w)[None, :],
-        one more bf16 rounding of the weight, none of the normalised activations): few-token passes of 65 .. 1024 rows whose write segment
-        is scratch (the pi0 denoise steps) then run five launches per layer instead of eight (cover_dec_layer.qkv_wf, capi.hip)."""
+        to_bfloat16_like_physical_intelligence (paligemma_with_expert.py:219-227) and stays fp32. Layer norms are bf16 in all."""
         dev = torch.device(device)
         self.dev, self.dim, self.n_layers, self.Hq, self.Hkv, self.D, self.mlp = dev, dim, layers, Hq, Hkv, D, mlp
         self.act, self.norm, self.eps = act, norm, eps
@@ -236,20 +233,11 @@ class Decoder:
             n1 = _bf_f32(sd[p + "input_layernorm.weight"], dev)
             n2 = _bf_f32(sd[p + "post_attention_layernorm.weight"], dev)
             self._keep += [qkv, o, gu, down, n1, n2]
-            qkv_f = gu_f = None
-            if fold_norm and not fp8_weights:
-                off = 0.0 if norm == "llama" else 1.0
-                # (the reference holds these weights in bf16: the fold starts from the bf16 values)
-                qkv_f = ops.pack_linear(wqkv.to(dev).to(BF).float() * (off + n1)[None, :])
-                gu_f = ops.pack_linear(torch.cat([sd[p + "mlp.gate_proj.weight"], sd[p + "mlp.up_proj.weight"]], 0).to(dev).to(BF).float() * (off + n2)[None, :], glu=True)
-                self._keep += [qkv_f, gu_f]
             a = arr[i]
             a.in_norm_w, a.post_norm_w = n1.data_ptr(), n2.data_ptr()
             a.qkv_w, a.qkv_b = qkv.wp.data_ptr(), None
             a.o_w, a.gate_up_w, a.down_w = o.wp.data_ptr(), gu.wp.data_ptr(), down.wp.data_ptr()
             a.k_cache, a.vt_cache = self.k_cache[i].data_ptr(), self.vt_cache[i].data_ptr()
-            a.qkv_wf = qkv_f.wp.data_ptr() if qkv_f is not None else None
-            a.gate_up_wf = gu_f.wp.data_ptr() if gu_f is not None else None
             if fp8_weights:
                 a.qkv_w8, a.qkv_s, a.o_w8, a.o_s = qkv.w8.data_ptr(), qkv.w8s.data_ptr(), o.w8.data_ptr(), o.w8s.data_ptr()
                 a.gate_up_w8, a.gate_up_s = gu.w8.data_ptr(), gu.w8s.data_ptr()
@@ -322,8 +310,13 @@ class Decoder:
         g._keep = keep
         return g
 
-    def forward(self, x: torch.Tensor, groups, final_norm=False, x_f32: Optional[torch.Tensor] = None, gemm_variant=0):
-        """x bf16 [rows, dim] (overwritten with the output hidden states)."""
+    def workspace(self, rows: int) -> torch.Tensor:
+        """A pass workspace of its own for up to `rows` rows: independent passes of one decoder that run CONCURRENTLY on different streams
+        (row-group chains of the pi0 denoise loop) must not share the decoder's."""
+        return torch.empty(L.lib().cover_decoder_workspace_bytes(C.byref(self.desc), rows), dtype=torch.uint8, device=self.dev)
+
+    def forward(self, x: torch.Tensor, groups, final_norm=False, x_f32: Optional[torch.Tensor] = None, gemm_variant=0, ws: Optional[torch.Tensor] = None):
+        """x bf16 [rows, dim] (overwritten with the output hidden states). ws: a workspace from workspace() instead of the decoder's own."""
         p = L.DecPass()
         p.n_groups, p.final_norm = len(groups), 1 if final_norm else 0
         p.x_f32 = x_f32.data_ptr() if x_f32 is not None else None
@@ -332,10 +325,15 @@ class Decoder:
         rows = x.shape[0]
         h = L.lib()
         need = h.cover_decoder_workspace_bytes(C.byref(self.desc), rows)
-        if self._ws is None or self._ws.numel() < need:
-            self._ws = torch.empty(need, dtype=torch.uint8, device=self.dev)
-            self.ws_gen += 1
-        ws = L.Workspace(self._ws.data_ptr(), self._ws.numel())
+        if ws is not None:
+            if ws.numel() < need:
+                raise ValueError("Decoder.forward: the caller's workspace is too small for this pass")
+            ws = L.Workspace(ws.data_ptr(), ws.numel())
+        else:
+            if self._ws is None or self._ws.numel() < need:
+                self._ws = torch.empty(need, dtype=torch.uint8, device=self.dev)
+                self.ws_gen += 1
+            ws = L.Workspace(self._ws.data_ptr(), self._ws.numel())
         L.check(h.cover_decoder_forward(C.byref(self.desc), C.byref(p), x.data_ptr(), ws, gemm_variant,
                                         torch.cuda.current_stream().cuda_stream), "decoder_forward")
         return x

@@ -275,25 +275,14 @@ class OpenVLA:
                 cur.wait_stream(self._cap)
             else:
                 st["graph"].launch()
-            self._check_opt_in_protocols()
-            return st["tokens"].t().contiguous(), st["sel"].t().contiguous()
+                return st["tokens"].t().contiguous(), st["sel"].t().contiguous()
         # step-major buffers: row i of each is contiguous, so the kernels of step i read / write them in place (no per-step slice copies)
         tokens = torch.empty(self.n_gen, N, dtype=torch.int64, device=dev)
         sel = torch.empty(self.n_gen, N, dtype=torch.float32, device=dev)
         fed = tokens if force_tokens is None else force_tokens.t().contiguous()
         self._decode_body(x, N, n_samples, Lt, prompt_of_cand, cand_len, last_row, pos_all, u_t, temperature, tokens, sel, fed, trace,
                           torch.arange(P, dtype=torch.int32, device=dev), prompt_lens.to(torch.int32).contiguous(), mark)
-        self._check_opt_in_protocols()
         return tokens.t().contiguous(), sel.t().contiguous()
-
-    def _check_opt_in_protocols(self):
-        """The opt-in in-kernel synchronisation protocols (COVER_DECODE_CHAIN, COVER_TAIL_REDUCE, COVER_HEAD_REDUCE) end a bounded wait that
-        times out with a status word instead of a hang; their results are then garbage. When one is switched on, every decision checks the
-        words before its tokens are handed back (this synchronises the device: the opt-in paths are measurement paths)."""
-        if os.environ.get("COVER_DECODE_CHAIN", "0") in ("1", "2"):
-            ops.decode_chain_status()
-        if os.environ.get("COVER_TAIL_REDUCE", "0") == "1" or os.environ.get("COVER_HEAD_REDUCE", "0") == "1":
-            ops.gemm_tail_status()
 
     def _decode_body(self, x, N, n_samples, Lt, prompt_of_cand, cand_len, last_row, pos_all, uniforms, temperature, tokens, sel, fed, trace,
                      prompt_slots, prompt_lens_i32, mark=lambda name: None):

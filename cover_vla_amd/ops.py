@@ -103,13 +103,8 @@ def gemm(a: torch.Tensor, lin: PackedLinear, *, act: str = "none", residual: Opt
          layer_scale: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, out_f32: bool = False,
          out_scale: float = 1.0, variant: int = 0, ws: Optional[torch.Tensor] = None, norm_w: Optional[torch.Tensor] = None,
          norm_out: Optional[torch.Tensor] = None, norm_style: int = 0, norm_w_offset: float = 0.0, norm_eps: float = 1e-6,
-         norm_b: Optional[torch.Tensor] = None, a8: Optional[tuple] = None, ssq_out: Optional[torch.Tensor] = None,
-         rs_in: Optional[torch.Tensor] = None, rs_n: int = 0, rs_eps: float = 1e-6
-         ) -> torch.Tensor:
+         norm_b: Optional[torch.Tensor] = None, a8: Optional[tuple] = None) -> torch.Tensor:
     """out[M, n_out] = epi(a[M, K] @ W^T). `a` is bf16 with row stride >= padded K (zero padded).
-    Deferred RMSNorm (cover_gemm_epi.ssq_out / rs_in, M > 64): ssq_out fp32 [M, N / 32] receives the partial sums of squares of the stored bf16
-    output rows (producer of a residual stream: unsplit, bf16 output); rs_in fp32 [M, parts] are such partials of the INPUT rows: row m of the
-    fp32 sums is multiplied by rsqrt(sum(rs_in[m]) / rs_n + rs_eps) before the epilogue (the norm weight folded into `lin` by the caller).
     a8 = (q uint8 [M, >= padded K], scales fp32 [M]) from quantize_act_fp8: with an fp8 weight twin and M > 64 the GEMM runs on the
     MX-scaled fp8 matrix instruction (config 5) on those operands."""
     _chk_dev(a, residual, out)
@@ -139,30 +134,12 @@ def gemm(a: torch.Tensor, lin: PackedLinear, *, act: str = "none", residual: Opt
         e.norm_w, e.norm_out, e.ld_norm_out = norm_w.data_ptr(), norm_out.data_ptr(), norm_out.stride(0)
         e.norm_style, e.norm_w_offset, e.norm_eps = norm_style, norm_w_offset, norm_eps
         e.norm_b = _ptr(norm_b)
-    if ssq_out is not None:
-        _chk_dev(ssq_out)
-        assert ssq_out.dtype == torch.float32 and ssq_out.shape[0] == M and ssq_out.stride(1) == 1
-        e.ssq_out, e.ssq_ld = ssq_out.data_ptr(), ssq_out.stride(0)
-    if rs_in is not None:
-        _chk_dev(rs_in)
-        assert rs_in.dtype == torch.float32 and rs_in.shape[0] == M and rs_in.stride(1) == 1 and rs_n > 0
-        e.rs_in, e.rs_ld, e.rs_parts, e.rs_n, e.rs_eps = rs_in.data_ptr(), rs_in.stride(0), rs_in.shape[1], rs_n, rs_eps
     if ws is None:
         ws = gemm_workspace(M, lin.N, lin.K, a.device)   # None when this shape needs no split-K scratch
     L.check(h.cover_gemm_bf16(a.data_ptr(), a.stride(0), lin.wp.data_ptr(), out.data_ptr(), out.stride(0), M, lin.N,
                               lin.K, C.byref(e), _ptr(ws), ws.numel() * 4 if ws is not None else 0, variant,
                               _stream()), "gemm_bf16")
     return out
-
-
-def gemm_tail_status() -> None:
-    """Raises if a bounded wait of the weight-streaming kernels' tail reduction gave up (reads a device word: synchronise first)."""
-    L.check(L.lib().cover_gemm_tail_status(), "gemm_tail_status")
-
-
-def decode_chain_status() -> None:
-    """Raises if a grid barrier of the persistent decode chain gave up since the last call (synchronises the device)."""
-    L.check(L.lib().cover_decode_chain_status(), "decode_chain_status")
 
 
 def gemm_probe() -> dict:
@@ -624,6 +601,45 @@ class Graph:
 
     def launch(self):
         L.check(L.lib().cover_graph_launch(self.handle, _stream()), "graph_launch")
+
+
+class PooledGraph:
+    """A launch sequence that ALLOCATES its intermediates (ordinary op wrappers) as one replayable hipGraph.
+
+    call 1 runs `fn()` eagerly inside a private torch memory pool (this sizes every intermediate and leaves their blocks in the pool),
+    call 2 captures it inside the same pool (every allocation is served from the pool's cache: no hipMalloc under capture), later calls
+    replay. The pool belongs to this object alone, so the blocks the captured kernels write to are never handed to anybody else between
+    replays. `fn` takes no arguments: it reads static input tensors the caller refreshes before every call, and returns tensors that stay
+    valid (static) from the capture on. Streams that `fn` forks to and joins from become parallel branches of the graph."""
+
+    def __init__(self, fn, device):
+        self.fn, self.dev = fn, device
+        self.pool = torch.cuda.MemPool()
+        self.graph, self.out, self.calls = None, None, 0
+        self._cap = None
+
+    def __call__(self):
+        self.calls += 1
+        if self.graph is not None:
+            self.graph.launch()
+            return self.out
+        if self.calls == 1:
+            with torch.cuda.use_mem_pool(self.pool, device=self.dev):
+                out = self.fn()
+            # (this call's outputs live in the pool until the caller drops them; the capture below then allocates its own)
+            return out
+        cur = torch.cuda.current_stream()
+        if self._cap is None:
+            self._cap = torch.cuda.Stream(device=self.dev)
+        self._cap.wait_stream(cur)
+        with torch.cuda.use_mem_pool(self.pool, device=self.dev):
+            with torch.cuda.stream(self._cap):
+                with Graph() as g:
+                    self.out = self.fn()
+        cur.wait_stream(self._cap)
+        self.graph = g
+        self.graph.launch()          # the capture itself executed nothing
+        return self.out
 
 
 class Timer:

@@ -51,13 +51,16 @@ class PI0FlowMatching:
                           act="gelu_tanh", norm="gemma", eps=1e-6, rope="pi0", n_pos=n_pos, device=device, cache=geom)
         self.expert = Decoder(sub("expert."), dim=c["ex_dim"], layers=c["layers"], Hq=c["Hq"], Hkv=c["Hkv"], D=c["D"],
                               mlp=c["ex_mlp"], act="gelu_tanh", norm="gemma", eps=1e-6, rope="pi0", n_pos=n_pos, device=device,
-                              share_cache_with=self.lm, final_norm_bf16=False, fold_norm=os.environ.get("COVER_DEFER_NORM", "0") == "1")   # (the folded weight copies are only packed when the opt-in path is on)
+                              share_cache_with=self.lm, final_norm_bf16=False)
         # pi0's own projections stay fp32 (modeling_pi0.py:488-494)
         self.p = {n: (_f32(sd[n + ".weight"], dev), _f32(sd[n + ".bias"], dev))
                   for n in ("state_proj", "action_in_proj", "action_out_proj", "action_time_mlp_in", "action_time_mlp_out")}
         self.vis_len = torch.tensor([1] + [S] * self.chunk, dtype=torch.int32, device=dev)
         self.max_batch, self.max_prompts, self.max_lang = max_batch, max_prompts, max_lang
-        self._den = {}     # static buffers (+ hipGraph) of the denoise loop per batch size
+        self._den = {}     # static buffers (+ hipGraph) of the denoise loop per (batch size, chains)
+        # denoise loop: independent row-group chains on streams of their own, replayed as one hipGraph (see sample_actions)
+        self.n_chains = int(os.environ.get("COVER_PI0_CHAINS", "2"))
+        self.denoise_graph = os.environ.get("COVER_PI0_GRAPH", "1") != "0"
         self._fold = {}    # folded suffix-embedding constants per step size (_suffix_fold)
         self._cap = None   # capture stream
 
@@ -226,16 +229,24 @@ class PI0FlowMatching:
         if on_prefix_enqueued is not None:
             on_prefix_enqueued()
 
-        # ---- suffix constants: persistent buffers per batch size. With COVER_PI0_GRAPH=1 the ten Euler steps (~190 launches
-        # each) are replayed as ONE hipGraph from the third call on (call 1 runs eagerly and sizes every workspace, call 2
-        # captures): bit-identical, but measured no faster at B = 40 (37.0 vs 36.7 ms per decision -- the loop is bound by
-        # the GPU's ~1 us per kernel boundary, not by the host), so it stays off by default.
+        # ---- denoise loop (modeling_pi0.py:697-752). The rows of the batch never interact inside it (every row attends its own prompt's prefix
+        # and its own suffix), and at B = 40 a layer-step is eight dependent launches of <= 224 workgroups that last 5-15 us each: the chip is
+        # mostly fill and drain. The batch is therefore cut into `n_chains` contiguous row groups, each an independent chain of launches on a
+        # stream of its own (own buffers = row slices of the batch's, own decoder workspace, own suffix-KV slots), forked from and joined to the
+        # caller's stream, and the whole fork / loop / join is replayed as ONE hipGraph with n_chains parallel branches from the third call
+        # on (call 1 runs eagerly and sizes everything, call 2 captures). Row results do not depend on the cut (tests: chains 1 vs 2 vs 4).
+        # self.n_chains (COVER_PI0_CHAINS, default 2); self.denoise_graph = False (COVER_PI0_GRAPH=0) keeps the eager loop (host-bound with
+        # more than one chain).
         S, W, A = 1 + self.chunk, self.W, self.max_action_dim
-        st = self._den.get(B)
+        n_ch = max(1, min(self.n_chains, B))
+        if trace is not None:
+            n_ch = 1
+        st = self._den.get((B, n_ch))
         if st is None:
-            st = dict(calls=0, graph=None,
+            st = dict(calls=0, graph=None, ws_gen=-1,
                       row_prompt=torch.empty(B, dtype=torch.int32, device=dev), row_plen=torch.empty(B, dtype=torch.int32, device=dev),
                       spos=torch.empty(B, S, dtype=torch.int32, device=dev),
+                      slots=torch.arange(B, dtype=torch.int32, device=dev),
                       suffix=torch.empty(B, S, W, dtype=torch.float32, device=dev),
                       x_t=torch.empty(B, self.chunk, A, dtype=torch.float32, device=dev),
                       cat=torch.empty(B * self.chunk, 2 * W, dtype=torch.float32, device=dev),
@@ -243,18 +254,27 @@ class PI0FlowMatching:
                       xb=torch.empty(B * S, W, dtype=BF, device=dev), out32=torch.empty(B, S, W, dtype=torch.float32, device=dev),
                       tvec=torch.empty(B * self.chunk, dtype=torch.float32, device=dev),
                       temb=torch.empty(B * self.chunk, W, dtype=BF, device=dev))
-            st["g1"] = self.expert.group(B, S, st["spos"].view(-1),
-                                         [dict(region=0, length=Tp, len_of_batch=st["row_plen"], slot_of_batch=st["row_prompt"]),
-                                          dict(region=1, length=S, mask=ops.MASK_VISLEN, vis_len=self.vis_len)], 1, write_scratch=True)   # suffix K/V: per-step temporaries
-            self._den[B] = st
+            cuts = [(B * i) // n_ch for i in range(n_ch + 1)]
+            st["chains"] = []
+            for ci in range(n_ch):
+                b0, b1 = cuts[ci], cuts[ci + 1]
+                sl = st["slots"][b0:b1]
+                g = self.expert.group(b1 - b0, S, st["spos"][b0:b1].view(-1),
+                                      [dict(region=0, length=Tp, len_of_batch=st["row_plen"][b0:b1], slot_of_batch=st["row_prompt"][b0:b1]),
+                                       dict(region=1, length=S, mask=ops.MASK_VISLEN, vis_len=self.vis_len, slot_of_batch=sl)], 1,
+                                      write_slot=sl, write_scratch=True)   # suffix K/V: per-step temporaries in the rows' own slots
+                st["chains"].append(dict(b0=b0, b1=b1, g=g, ws=self.expert.workspace((b1 - b0) * S),
+                                         stream=torch.cuda.Stream(device=dev) if ci > 0 else None))
+            self._den[(B, n_ch)] = st
         st["calls"] += 1
-        if st.get("Tp") != Tp:                      # the prefix width is baked into the group (and into a captured graph)
-            st["g1"].segs[0].len = Tp
+        if st.get("Tp") != Tp:                      # the prefix width is baked into the groups (and into a captured graph)
+            for ch in st["chains"]:
+                ch["g"].segs[0].len = Tp
             st["Tp"], st["graph"] = Tp, None
         st["row_prompt"].copy_(prompt_of_row)
         st["row_plen"].copy_(plen[prompt_of_row])
         st["spos"].copy_(st["row_plen"][:, None] + torch.arange(S, device=dev, dtype=torch.int32)[None])
-        suffix, x_t, cat, hid, xb, out32, tvec, temb, g1 = (st[k] for k in ("suffix", "x_t", "cat", "hid", "xb", "out32", "tvec", "temb", "g1"))
+        suffix, x_t, cat, hid, xb, out32, tvec, temb = (st[k] for k in ("suffix", "x_t", "cat", "hid", "xb", "out32", "tvec", "temb"))
         stp = ops.gemm_f32(state.float().contiguous(), self.p["state_proj"][0], bias=self.p["state_proj"][1])
         ops.cast_bf16_to_f32(ops.cast_f32_to_bf16(stp), out=suffix.view(B, S * W)[:, :W])  # bf16-rounded state token
         x_t.copy_(noise.to(torch.float32))
@@ -262,8 +282,14 @@ class PI0FlowMatching:
         vs = []
 
         fold = self._suffix_fold(dt) if os.environ.get("COVER_PI0_SUFFIX_FOLD", "1") != "0" else None
+        ch_rows = self.chunk
 
-        def euler_loop():
+        def euler_chain(ch):
+            """The whole Euler loop for the rows [b0, b1) of the batch, queued on the current stream."""
+            b0, b1 = ch["b0"], ch["b1"]
+            n = b1 - b0
+            x_c, hid_c, suf_c = x_t[b0:b1], hid[b0 * ch_rows:b1 * ch_rows], suffix[b0:b1]
+            xb_c, out_c = xb[b0 * S:b1 * S], out32[b0:b1]
             # the reference loops `while time >= -dt/2` on an fp32 tensor: exactly num_steps iterations (modeling_pi0.py:697-715)
             time = torch.tensor(1.0, dtype=torch.float32)
             dt32 = torch.tensor(dt, dtype=torch.float32)
@@ -272,31 +298,42 @@ class PI0FlowMatching:
                 if fold is not None:
                     # embed_suffix (modeling_pi0.py:569-629) with its two linear maps in front of the SiLU folded (see _suffix_fold):
                     # hid = silu(x_t Wc^T + c_step): two launches per step instead of six
-                    ops.gemm_f32(x_t.view(B * self.chunk, A), fold["Wc"], bias=fold["ctab"][step], act="silu", out=hid)
+                    ops.gemm_f32(x_c.view(n * ch_rows, A), fold["Wc"], bias=fold["ctab"][step], act="silu", out=hid_c)
                 else:
-                    tvec.fill_(float(time))
-                    ops.sincos_time_embed(tvec, W, 4e-3, 4.0, out=temb)
-                    ops.cast_bf16_to_f32(temb, out=cat[:, W:])
-                    ops.gemm_f32(x_t.view(B * self.chunk, A), self.p["action_in_proj"][0], bias=self.p["action_in_proj"][1], out=cat[:, :W])
-                    ops.gemm_f32(cat, self.p["action_time_mlp_in"][0], bias=self.p["action_time_mlp_in"][1], act="silu", out=hid)
+                    tv_c, te_c, cat_c = tvec[b0 * ch_rows:b1 * ch_rows], temb[b0 * ch_rows:b1 * ch_rows], cat[b0 * ch_rows:b1 * ch_rows]
+                    tv_c.fill_(float(time))
+                    ops.sincos_time_embed(tv_c, W, 4e-3, 4.0, out=te_c)
+                    ops.cast_bf16_to_f32(te_c, out=cat_c[:, W:])
+                    ops.gemm_f32(x_c.view(n * ch_rows, A), self.p["action_in_proj"][0], bias=self.p["action_in_proj"][1], out=cat_c[:, :W])
+                    ops.gemm_f32(cat_c, self.p["action_time_mlp_in"][0], bias=self.p["action_time_mlp_in"][1], act="silu", out=hid_c)
                 step += 1
                 wo, bo = self.p["action_time_mlp_out"]
-                ops.gemm_f32_raw(hid.data_ptr(), W, 1, wo.data_ptr(), W, 1, suffix.data_ptr() + 4 * W, W, self.chunk, W, W,
-                                 bias=bo, batch=B, a_bs=self.chunk * W, c_bs=S * W)  # rows 1..chunk of every suffix
+                ops.gemm_f32_raw(hid_c.data_ptr(), W, 1, wo.data_ptr(), W, 1, suf_c.data_ptr() + 4 * W, W, ch_rows, W, W,
+                                 bias=bo, batch=n, a_bs=ch_rows * W, c_bs=S * W)  # rows 1..chunk of every suffix
                 if trace is not None and not vs:
                     trace["suffix_embs_t1"] = suffix.clone()
-                self.expert.forward(xb, [g1], final_norm=True, x_f32=suffix.view(B * S, W))
-                ops.cast_bf16_to_f32(xb, out=out32.view(B * S, W))
+                self.expert.forward(xb_c, [ch["g"]], final_norm=True, x_f32=suf_c.view(n * S, W), ws=ch["ws"])
+                ops.cast_bf16_to_f32(xb_c, out=out_c.view(n * S, W))
                 # v_t = action_out_proj(suffix_out[:, -chunk:]) ; x_t += dt * v_t   (modeling_pi0.py:748-751, 713)
                 wp, bp = self.p["action_out_proj"]
-                ops.gemm_f32_raw(out32.data_ptr() + 4 * W, W, 1, wp.data_ptr(), W, 1, x_t.data_ptr(), A, self.chunk, A, W,
-                                 bias=bp, residual_ptr=x_t.data_ptr(), ld_res=A, alpha=float(dt32), batch=B, a_bs=S * W,
-                                 c_bs=self.chunk * A)
+                ops.gemm_f32_raw(out_c.data_ptr() + 4 * W, W, 1, wp.data_ptr(), W, 1, x_c.data_ptr(), A, ch_rows, A, W,
+                                 bias=bp, residual_ptr=x_c.data_ptr(), ld_res=A, alpha=float(dt32), batch=n, a_bs=S * W,
+                                 c_bs=ch_rows * A)
                 if trace is not None:
                     vs.append(x_t.clone())
                 time = time + dt32
 
-        use_graph = trace is None and os.environ.get("COVER_PI0_GRAPH", "0") == "1" and st["calls"] >= 2
+        def euler_loop():
+            cur = torch.cuda.current_stream()
+            for ch in st["chains"][1:]:
+                ch["stream"].wait_stream(cur)
+                with torch.cuda.stream(ch["stream"]):
+                    euler_chain(ch)
+            euler_chain(st["chains"][0])
+            for ch in st["chains"][1:]:
+                cur.wait_stream(ch["stream"])
+
+        use_graph = trace is None and self.denoise_graph and st["calls"] >= 2
         if not use_graph:
             euler_loop()
         else:

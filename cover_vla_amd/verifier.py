@@ -340,19 +340,28 @@ class SigLIP2Encoder:
         self.text_pos = sd["text.pos"].to(BF).contiguous().to(dev)
         self.text_proj = ops.pack_linear(sd["text.proj.weight"].to(dev), sd["text.proj.bias"])
 
-    def extract_features(self, images: torch.Tensor, text: torch.Tensor):
-        """images fp32 [B,3,384,384] (open_clip-preprocessed), text int64 [B,64] -> (pf fp32 [B,P,D], tf fp32 [B,64,D])."""
+    def extract_features(self, images: torch.Tensor, text: torch.Tensor, text_stream: Optional[torch.cuda.Stream] = None):
+        """images fp32 [B,3,384,384] (open_clip-preprocessed), text int64 [B,64] -> (pf fp32 [B,P,D], tf fp32 [B,64,D]).
+        text_stream: run the text tower there, beside the image tower on the current stream (the two towers are independent chains of
+        launches that each fill a fraction of the chip); joined before returning."""
         B = images.shape[0]
+        cur = torch.cuda.current_stream()
+        ts = text_stream if text_stream is not None else cur
+        if ts is not cur:
+            ts.wait_stream(cur)
+        with torch.cuda.stream(ts):
+            T = text.shape[1]
+            t = ops.embed_gather(self.tok_emb, text.reshape(-1).contiguous())
+            ops.add_rows(t, self.text_pos[:T])
+            t = self.text.forward(t.view(B, T, self.dim), post_ln=True)      # transformer -> ln_final
+            tp = ops.gemm(t.view(B * T, self.dim), self.text_proj)           # text_projection (Linear)
+            tf = ops.l2norm_rows_f32(ops.cast_bf16_to_f32(tp)).view(B, T, self.dim)
         x = self.image.embed(images.float().contiguous())
         a = self.image.forward(x, n_layers=self.layers, last_attn_only=True)
         pf = ops.cast_bf16_to_f32(a.view(B * self.num_patches, self.dim))
         pf = ops.l2norm_rows_f32(pf).view(B, self.num_patches, self.dim)
-        T = text.shape[1]
-        t = ops.embed_gather(self.tok_emb, text.reshape(-1).contiguous())
-        ops.add_rows(t, self.text_pos[:T])
-        t = self.text.forward(t.view(B, T, self.dim), post_ln=True)      # transformer -> ln_final
-        tp = ops.gemm(t.view(B * T, self.dim), self.text_proj)           # text_projection (Linear)
-        tf = ops.l2norm_rows_f32(ops.cast_bf16_to_f32(tp)).view(B, T, self.dim)
+        if ts is not cur:
+            cur.wait_stream(ts)
         return pf, tf
 
 
@@ -410,6 +419,30 @@ class EfficientEnsembleMerged:
         it = m.image_text(patch_features[0].contiguous(), text_features[0].contiguous())
         act = m.trajectory(hb, pad)
         return it.expand(hb.shape[0], -1), act
+
+    def shared_embeddings_graph(self, img_tensor: torch.Tensor, text_tokens: torch.Tensor) -> torch.Tensor:
+        """image_text_embeddings(*extract_shared_features(img, text)) for ONE (image, instruction) pair, replayed as one hipGraph from the
+        third call on, with the SigLIP2 image tower and text tower as parallel branches (ops.PooledGraph): ~600 launches become one host
+        call, and the two towers -- 576 and 64 rows, a fraction of the chip each -- overlap. Same kernels, same results as the eager pair of
+        calls. Returns the per-member embeddings [M, 512] (a static tensor, overwritten by the next call)."""
+        key = (tuple(img_tensor.shape), tuple(text_tokens.shape))
+        st = self._shared_graphs.get(key) if hasattr(self, "_shared_graphs") else None
+        if st is None:
+            if not hasattr(self, "_shared_graphs"):
+                self._shared_graphs = {}
+            img = torch.empty_like(img_tensor, device=self._dev)
+            txt = torch.empty_like(text_tokens, device=self._dev)
+            side = torch.cuda.Stream(device=self._dev)
+
+            def fn():
+                pf, tf = self.encoder.extract_features(img, txt, text_stream=side)
+                return self.image_text_embeddings(pf, tf)
+
+            st = dict(img=img, txt=txt, g=ops.PooledGraph(fn, self._dev))
+            self._shared_graphs[key] = st
+        st["img"].copy_(img_tensor)
+        st["txt"].copy_(text_tokens)
+        return st["g"]()
 
     def image_text_embeddings(self, patch_features, text_features) -> torch.Tensor:
         """Per-member image-text embeddings [M, 512] of ONE (image, text) pair. Independent of the candidates, so a caller

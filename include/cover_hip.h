@@ -87,19 +87,6 @@ typedef struct cover_gemm_epi {
      * would make of the stored bf16 norm_out rows -- the next GEMM's fp8 operand without another launch. */
     void* norm_out8;
     float* norm_out8_scale;
-    /* Deferred RMSNorm (round 5; LDS-tiled launches with more than 64 rows only). A PRODUCER GEMM that writes a residual stream x
-     * leaves, beside it, the rows' partial sums of squares: ssq_out[m * ssq_ld + n / 32] = sum over the 32-column group of the stored
-     * bf16 values squared (what a norm kernel reading x back would sum; unsplit launch, bf16 output, N % 32 == 0, ssq_ld >= N / 32).
-     * The CONSUMER GEMM takes x itself as its A operand, with the norm weight folded into its packed weight along k at load time
-     * (W'[n, k] = W[n, k] * (norm_w_offset + norm_w[k])), and multiplies row m of its fp32 sums by
-     * rsqrt(sum_{p < rs_parts} rs_in[m * rs_ld + p] / rs_n + rs_eps) before its own epilogue: norm(x) W^T without the norm launch and
-     * without the reduction launch the norm used to ride on. One rounding point moves: norm(x) is no longer rounded to bf16 before
-     * the product (the weight product W' is). NULL = off. */
-    float* ssq_out;
-    const float* rs_in;
-    int ssq_ld, rs_ld, rs_parts, rs_n;
-    float rs_eps;
-    int _pad_epi;
 } cover_gemm_epi;
 
 /* bytes needed for the packed form of an [N, K] weight (K padded to a multiple of 128, N to 16) */
@@ -451,12 +438,6 @@ typedef struct cover_dec_layer {
     /* optional e4m3 twins (cover_pack_weight_fp8) + packed-order scales of the four projections; NULL = bf16 only */
     const void* qkv_w8; const float* qkv_s; const void* o_w8; const float* o_s;
     const void* gate_up_w8; const float* gate_up_s; const void* down_w8; const float* down_s;
-    /* optional (deferred RMSNorm, cover_gemm_epi.rs_in): the qkv / gate_up weights with this layer's input / post-attention norm weight
-     * folded in along k (W * (norm_w_offset + norm_w)[None, :], packed like qkv_w / gate_up_w). When every layer carries both, passes of
-     * 65 .. 1024 rows over ONE few-token group whose write segment is scratch (the pi0 denoise steps) run five launches per layer --
-     * qkv', attention with the qkv fold + RoPE inside, o_proj (unsplit, residual + partial sums of squares), gate_up', down (the
-     * same) -- instead of eight. NULL = the norms stay where they are. */
-    const void* qkv_wf; const void* gate_up_wf;
 } cover_dec_layer;
 typedef struct cover_dec_desc {
     int dim, Hq, Hkv, D, mlp, n_layers, act;  /* act: COVER_ACT_GELU_TANH (Gemma) / COVER_ACT_SILU (Llama) */
@@ -509,21 +490,6 @@ size_t cover_decoder_workspace_bytes(const cover_dec_desc* d, int rows);
 /* x: bf16 [rows, dim] input embeddings, overwritten with the output hidden states */
 int cover_decoder_forward(const cover_dec_desc* d, const cover_dec_pass* p, void* x, cover_workspace ws,
                           int gemm_variant, void* stream);
-
-/* Persistent decode chain (opt-in, COVER_DECODE_CHAIN=1: cover_decoder_forward then takes it for single-token candidate passes of <= 32
- * rows at the 7B decoder shapes; measured at parity with the separate launches, which are the default): its grid barriers spin with a
- * bound and record a code instead of hanging.
- * Synchronises the device and returns COVER_OK when every barrier since the last call completed, COVER_EHIP (+ cover_last_error)
- * otherwise -- the outputs of that pass are then invalid; the barrier state is reset. */
-int cover_decode_chain_status(void);
-
-/* Tail reduction of the weight-streaming decoder passes (<= 64 rows; opt-in, COVER_TAIL_REDUCE=1 -- measured slower than the reduction
- * launches it replaces): the split-K slabs of o_proj / down are folded (+ residual + RMSNorm) by the last workgroups of the launch that
- * wrote them instead of by a reduction launch. The wait of those
- * workgroups for the other slabs is bounded. Synchronises nothing by itself (reads one device word: call it after a stream / device
- * synchronise); COVER_OK, or COVER_EHIP (+ cover_last_error) once a wait has given up -- the outputs of that pass are then invalid (the
- * word is sticky: it stays set for the rest of the process). */
-int cover_gemm_tail_status(void);
 
 /* hipGraph capture helpers: everything launched on `stream` between begin/end becomes one replayable graph */
 int cover_graph_begin(void* stream);

@@ -216,21 +216,26 @@ def test_pi0_sampler_matches_reference_golden(dev, name):
     # compare_with_jax.py's atol 3e-2 is stated on a trained checkpoint's normalised actions (|a| <= 1); the seeded weights here (std 0.1, ten
     # Euler steps) give chunks of magnitude up to `amax`, so the element-wise bar scales with it: two bf16 evaluations, 3 % of the range
     assert mx < 3e-2 * max(1.0, amax), (mx, amax)
-    # the denoise loop as a replayed hipGraph (call 2 captures, call 3 replays) == the eager loop, bit for bit; and a
-    # different noise / prompt assignment flows through the same graph
+    # the denoise loop as independent row-group chains on streams of their own, replayed as ONE hipGraph (call 2 captures, call 3 replays):
+    # for every chain count the replayed graph == the eager loop of the same cut, bit for bit, also with another noise assignment flowing
+    # through the same graph; across chain counts the rows agree to the order of the fp32 sums (the GEMMs see other row counts)
     args = ([im.to(dev) for im in images], [m.to(dev) for m in img_masks], toks.to(dev), masks.to(dev), state.to(dev))
     noise2 = torch.flip(noise, dims=[0]).contiguous()
-    x3e = model.sample_actions(*args, noise=noise2.to(dev))
-    os.environ["COVER_PI0_GRAPH"] = "1"
-    try:
+    for n_ch in (1, 2, 4):
+        model.n_chains, model.denoise_graph = n_ch, False
+        xe = model.sample_actions(*args, noise=noise.to(dev))
+        x3e = model.sample_actions(*args, noise=noise2.to(dev))
+        model.denoise_graph = True
         x1 = model.sample_actions(*args, noise=noise.to(dev))
         x2 = model.sample_actions(*args, noise=noise.to(dev))
-        assert model._den[B]["graph"] is not None
+        key = (B, min(n_ch, B))
+        assert model._den[key]["graph"] is not None and len(model._den[key]["chains"]) == min(n_ch, B)
         x3 = model.sample_actions(*args, noise=noise2.to(dev))
-    finally:
-        os.environ.pop("COVER_PI0_GRAPH", None)
-    assert np.array_equal(x1.cpu().numpy(), x) and np.array_equal(x2.cpu().numpy(), x)
-    assert torch.equal(x3, x3e)
+        assert torch.equal(x1, xe) and torch.equal(x2, xe) and torch.equal(x3, x3e), n_ch
+        d = np.linalg.norm(xe.cpu().numpy() - x) / np.linalg.norm(upd)
+        assert d < 1e-2, (n_ch, d)
+        if n_ch == 1:
+            assert np.array_equal(xe.cpu().numpy(), x)
 
 
 def test_pi0_prefix_without_trailing_pad_columns_equals_full_width(dev):
@@ -545,44 +550,6 @@ def test_expert_layer_200_rows_qkv_slabs_folded_by_rope_equals_reduction_launch(
     assert torch.isfinite(outs[0][0].float()).all() and outs[0][0].float().abs().max() > 0
     for a, b in zip(outs[0], outs[1]):
         assert torch.equal(a, b)
-    # the same pass with the write segment declared scratch (what pi0.py's denoise steps do): the slabs are folded and rotated INSIDE the
-    # attention launch (attention.hip FuseDev), no RoPE launch, nothing written to the suffix caches -- bit-identical layer output, and the
-    # suffix regions keep what the previous pass left there; opt-in (COVER_ROPE_ATTN_FUSE=1), the RoPE launch is the default
-    g1s = ex.group(B, S, spos.view(-1), [dict(region=0, length=T, len_of_batch=row_plen, slot_of_batch=row_prompt),
-                                          dict(region=1, length=S, mask=ops.MASK_VISLEN, vis_len=vis_len)], 1, write_scratch=True)
-    o1 = geom.k_off[1]
-    for fz in ("1", "0"):
-        os.environ["COVER_ROPE_ATTN_FUSE"] = fz
-        try:
-            ex.k_cache[0][o1:].fill_(7.0)
-            xb = torch.empty(B * S, W, dtype=BF, device=dev)
-            ex.forward(xb, [g1s], final_norm=True, x_f32=suf.view(B * S, W).contiguous())
-            torch.cuda.synchronize()
-            assert torch.equal(xb, outs[1][0]), fz
-            untouched = bool((ex.k_cache[0][o1:].float() == 7.0).all())
-            assert untouched == (fz == "1"), (fz, untouched)      # "1": fused (cache not written); "0": the RoPE launch wrote the suffix keys
-        finally:
-            os.environ.pop("COVER_ROPE_ATTN_FUSE", None)
-    # the same pass on the deferred-RMSNorm path (COVER_DEFER_NORM=1 + a decoder packed with fold_norm=True): qkv (layer 0: unfolded, behind the
-    # input-norm launch) as ONE fp32 slab folded inside the attention launch, o_proj / down UNSPLIT on the 32 x 32 sixteen-stage tiles with the
-    # residual and the partial sums of squares in the epilogue, gate_up on the norm-folded weight with the row scale. Two bf16 rounding points
-    # move (the normalised rows are not rounded, the folded weight is): one layer's output within 6e-3 of the eight-launch path.
-    exf = Decoder(sub("expert."), dim=g2["ex_dim"], layers=1, Hq=g2["Hq"], Hkv=g2["Hkv"], D=g2["D"], mlp=g2["ex_mlp"], act="gelu_tanh",
-                  norm="gemma", eps=1e-6, rope="pi0", n_pos=n_pos, device="cuda:0", share_cache_with=lm, final_norm_bf16=False, fold_norm=True)
-    g1f = exf.group(B, S, spos.view(-1), [dict(region=0, length=T, len_of_batch=row_plen, slot_of_batch=row_prompt),
-                                           dict(region=1, length=S, mask=ops.MASK_VISLEN, vis_len=vis_len)], 1, write_scratch=True)
-    os.environ["COVER_DEFER_NORM"] = "1"
-    try:
-        ops.gemm_plan_counts(reset=True)
-        xb = torch.empty(B * S, W, dtype=BF, device=dev)
-        exf.forward(xb, [g1f], final_norm=True, x_f32=suf.view(B * S, W).contiguous())
-        torch.cuda.synchronize()
-        counts = ops.gemm_plan_counts()
-    finally:
-        os.environ.pop("COVER_DEFER_NORM", None)
-    assert counts[31] == 2 and counts[30] == 1 and sum(counts) == 4, counts         # o_proj + down | gate_up | + layer 0's qkv on its usual tile
-    ref = outs[1][0].float()
-    assert ((xb.float() - ref).norm() / ref.norm()).item() < 6e-3
 
 
 # ------------------------------------------------------------------------------------------------ serving boundary on the device

@@ -8,7 +8,7 @@ cd "$(dirname "$0")/../cover_vla_amd/csrc"
 mkdir -p ../../tools/ab /tmp/ab_$name
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-unused-variable "$@" -c $src -o /tmp/ab_$name/${src%.hip}.o
 objs=""
-for o in gemm_bf16 gemm_v3 gemm_fp8 attention decode_attn decode_own decode_chain rowops f32ops select image prof capi; do
+for o in gemm_bf16 gemm_v3 gemm_fp8 attention decode_attn decode_own rowops f32ops select image prof capi; do
   if [ "$o.hip" = "$src" ]; then objs="$objs /tmp/ab_$name/$o.o"; else objs="$objs $o.o"; fi
 done
 hipcc --offload-arch=gfx950 -shared -fPIC $objs -o ../../tools/ab/libcover_hip_$name.so

@@ -3,7 +3,7 @@
 # leg, the P1 line with its own kernel table, and the secondary configurations. Everything lands in gpurun_out/ (merged back); copy what is
 # to be judged into profiles/.
 set -x
-TAG=${1:-r05}
+TAG=${1:-r06}
 SHA=$(sha256sum cover_vla_amd/libcover_hip.so | cut -c1-16)
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
@@ -28,8 +28,8 @@ python tools/rocpd_stats.py gpurun_out/${TAG}_pi0/pi0_results.db patchify_k > gp
 python bench.py --config 3 --gpus 1 --steps 10 --warmup 2 --no-cpu-baseline > gpurun_out/${TAG}_config3_w1_line.json 2>/dev/null
 python bench.py --dtype fp8 --no-cpu-baseline > gpurun_out/${TAG}_fp8_n32_bench_line.json 2>/dev/null
 python bench.py --dtype fp8 --samples 64 --horizon 8 --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/${TAG}_config5_fp8_n512_h8_bench_line.json 2>/dev/null
-python bench.py --samples 2 --steps 10 --warmup 2 --no-cpu-baseline --no-profile > gpurun_out/${TAG}_config2_n16_bench_line.json 2>/dev/null
-python bench.py --samples 8 --cams 2 --members 2 --steps 10 --warmup 2 --no-cpu-baseline --no-profile > gpurun_out/${TAG}_config4_2cam_n64_bench_line.json 2>/dev/null
+python bench.py --samples 2 --steps 10 --warmup 2 --no-cpu-baseline > gpurun_out/${TAG}_config2_n16_bench_line.json 2>/dev/null
+python bench.py --samples 8 --cams 2 --members 2 --steps 10 --warmup 2 --no-cpu-baseline > gpurun_out/${TAG}_config4_2cam_n64_bench_line.json 2>/dev/null
 python tools/bench_pi0fast.py 2>/dev/null | tail -1 > gpurun_out/${TAG}_pi0fast_line.json
 for f in config3_w1_line fp8_n32_bench_line config5_fp8_n512_h8_bench_line config2_n16_bench_line config4_2cam_n64_bench_line pi0_bench_line; do python -c "import json,sys; d=json.load(open('gpurun_out/${TAG}_'+sys.argv[1]+'.json')); print(sys.argv[1], d['ms_per_step'], d['value'])" $f; done
 cat gpurun_out/${TAG}_pi0fast_line.json

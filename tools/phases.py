@@ -26,7 +26,8 @@ for _ in range(R):
     # Diagnostics: 0 = side work queued from the sampler's after-prefill hook (it then runs UNDER decode passes 1-2 and slows them:
     # the "decode1 / decode2 excess" of profiles/r03_phases.txt was this mode, not a property of the bench's schedule),
     # 1 = no side work (stale embeddings), 2 = towers on the side stream, heads in the tail, 3 = side work queued before the policy
-    MODE = int(os.environ.get("SIDE_MODE", "4"))
+    # 5 (default since round 6) = the verifier's towers + heads as ONE replayed hipGraph on the side stream, launched by this thread before the policy
+    MODE = int(os.environ.get("SIDE_MODE", "5"))
 
     def side_work():
         if MODE == 1 and "its" in globals().get("_cache", {}):
@@ -43,6 +44,11 @@ for _ in range(R):
                 _cache["its"] = out["its"]
 
     fut = None
+    if MODE == 5:
+        ev5 = torch.cuda.Event(); ev5.record(main)
+        pipe.side.wait_event(ev5)
+        with torch.cuda.stream(pipe.side):
+            out["its"] = pipe.ver.shared_embeddings_graph(i["img384"], i["text"])
     if MODE == 3:   # diagnostic: side work queued BEFORE the policy (overlaps the vision phase and the start of the prefill)
         side_work()
     if MODE == 4:   # side work queued by a second host thread while this one queues the policy
@@ -60,7 +66,7 @@ for _ in range(R):
 
         fut = _cache["pool"].submit(threaded)
     tokens, _ = pipe.policy.sample(i["frame"], i["toks"], i["lens"], bench.N_SAMPLES, i["u"], 1.0, trace=tr,
-                                   on_prefill_enqueued=None if MODE in (3, 4) else side_work)
+                                   on_prefill_enqueued=None if MODE in (3, 4, 5) else side_work)
     if fut is not None:
         out["its"] = fut.result()
     if "its" not in out:
