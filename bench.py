@@ -50,6 +50,7 @@ N_PROMPTS, N_SAMPLES, LT = 8, 4, 24
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_PEAK_TF = 2500.0      # bf16 dense
 FP8_PEAK_TF = 5000.0       # MX-scaled fp8 dense (MI355X_MICROARCH.md chip table; measured 4.65 PF)
+SIDE_GRAPH_DEFAULT = "2"   # verifier towers: "0" eager launches from a second host thread, "1" one hipGraph launched by the main thread, "2" by the second thread
 N_PROF = 10                # include/cover_hip.h COVER_PROF_CLASSES: 6 / 8 / 9 = the split-K reductions behind the ViT-sized / LLM-sized / fp8 tiled GEMMs
 BASE_METRIC = "candidate actions scored/sec (whole node), OpenVLA-7B N=32, 224^2 RGB"
 
@@ -153,9 +154,11 @@ class Pipeline:
                 tokens, _ = self.policy.sample(i["frame"], i["toks"], i["lens"], S, i["u"], 1.0)
             finally:
                 self.policy.vision_graph, self.policy.vision_overlap, self.policy.decode_graph = keep
-        elif os.environ.get("COVER_SIDE_GRAPH", "1") != "0":
-            # round 6: the verifier's two towers + image-text heads as ONE replayed hipGraph (image tower and text tower as parallel branches),
-            # launched on the side stream by THIS thread before the policy: one host call instead of ~600 from a second thread
+        elif os.environ.get("COVER_SIDE_GRAPH", SIDE_GRAPH_DEFAULT) == "1":
+            # round 6 experiment: the verifier's two towers + image-text heads as ONE replayed hipGraph (image tower and text tower as parallel
+            # branches) launched on the side stream by THIS thread before the policy. Measured SLOWER (35.1-35.3 vs 34.45 ms): launching a
+            # ~600-node graph costs this thread 1.6 ms before the policy's first launch (profiles/r06_side_graph_ab.txt). "2" = the same graph
+            # launched by the second host thread (below).
             ev = torch.cuda.Event()
             ev.record(main)
             self.side.wait_event(ev)
@@ -178,6 +181,8 @@ class Pipeline:
                     gate.wait()
                 self.side.wait_event(ev)
                 with torch.cuda.stream(self.side):
+                    if os.environ.get("COVER_SIDE_GRAPH", SIDE_GRAPH_DEFAULT) == "2":
+                        return self.ver.shared_embeddings_graph(i["img384"], i["text"])
                     return side_work()
 
             def vision_hook():
@@ -298,9 +303,11 @@ class Pi0Pipeline:
                 torch.cuda.set_device(self.dev)
                 self.side.wait_event(ev)
                 with torch.cuda.stream(self.side):
+                    if os.environ.get("COVER_SIDE_GRAPH", SIDE_GRAPH_DEFAULT) == "2":
+                        return self.ver.shared_embeddings_graph(i["img384"], i["text"])
                     return self._side_work()
 
-            if os.environ.get("COVER_SIDE_GRAPH", "1") != "0":   # the verifier's towers as one replayed graph on the side stream (see Pipeline.decision)
+            if os.environ.get("COVER_SIDE_GRAPH", SIDE_GRAPH_DEFAULT) == "1":   # (see Pipeline.decision)
                 self.side.wait_event(ev)
                 with torch.cuda.stream(self.side):
                     its = self.ver.shared_embeddings_graph(i["img384"], i["text"])

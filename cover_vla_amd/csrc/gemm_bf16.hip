@@ -1645,7 +1645,7 @@ hipError_t launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* Wp, void* C,
         {7, 4, 2, 2, 3},   // t (29): 224x128, 4 waves of 112x64, 3 stages (132 KiB)
         // k-split wave pairs (gemm_v3.hip gemm_tiled_v3k): 2 x 2 wave tiles, each owned by the two waves of a SIMD, which split every k-tile
         {7, 3, 2, 2, 4},   // u (30): 224x96,  4 wave pairs of 112x48, 4 stages (160 KiB)
-        {7, 4, 2, 2, 3},   // v (31): 224x128, 4 wave pairs of 112x64, 3 stages (132 KiB)
+        {0, 0, 0, 0, 0},   // (31: 224x128 on 4 wave pairs of 112x64 was built and not kept -- registers; gemm_v3.hip)
     };
     // Measured on MI355X (tools/bench_kernels.py, M = 441): this single-barrier-per-k-tile structure is latency-bound per
     // block, so residency beats tile size until the tile grid oversubscribes the chip several times over, while 64x64
@@ -1710,7 +1710,7 @@ hipError_t launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* Wp, void* C,
             // 0.69-0.78, 224x192 0.91-1.02; prologue + epilogue 6 / 7 / 10 us
             // (round 6: 224x96 on k-split wave pairs, pick 30, instead of one wave per SIMD, pick 27)
             const int bns[3] = {96, 128, 192}, idx_pc[3] = {17, 15, 16}, idx_v3[3] = {30, 24, 23};
-            const double kt_pc[3] = {0.67, 0.70, 1.05}, kt_v3[3] = {0.50, 0.72, 0.93}, fix_v3[3] = {6.0, 7.0, 10.0};
+            const double kt_pc[3] = {0.67, 0.70, 1.05}, kt_v3[3] = {0.60, 0.72, 0.93}, fix_v3[3] = {6.0, 7.0, 10.0};
             double best = 1e30;
             for (int c = 0; c < 3; ++c) {
                 if (epi.glu && (bns[c] % 32)) continue;
@@ -1731,7 +1731,7 @@ hipError_t launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* Wp, void* C,
         static const char* force = getenv("COVER_TILE_PICK");  // experiment knob: index into cands
         if (force && force[0] >= '0' && force[0] <= '9') pick = force[0] - '0';
         if (force && force[0] >= 'a' && force[0] <= 'i') pick = 10 + (force[0] - 'a');   // (b .. i: fp8 operands only)
-        if (force && force[0] >= 'n' && force[0] <= 'v') pick = 10 + (force[0] - 'a');
+        if (force && force[0] >= 'n' && force[0] <= 'u') pick = 10 + (force[0] - 'a');
     }
     // the 256 x 128 / 128 x 256 tiles (M >= 512 with more than 10 % of 224-row padding: config 4's 704-row prefill) run on the self-loading kernel
     if (v3_on) pick = pick == 12 ? 25 : pick == 13 ? 26 : pick;

@@ -346,6 +346,40 @@ __device__ __forceinline__ void tiled_epilogue_staged(f32x4 (&acc)[WN][WM], cons
         // the staged sums are read and the SAME arithmetic (epi_value4's rounding points) runs on registers.
         const bool al = (!epi.bias || (((uintptr_t)epi.bias) & 15) == 0) && (!epi.lscale || (((uintptr_t)epi.lscale) & 15) == 0) && (n0 & 7) == 0 &&
                         (!epi.residual || ((((uintptr_t)epi.residual) & 15) == 0 && ((epi.ldr * (epi.res_f32 ? 4 : 2)) & 15) == 0));
+        if (al && epi.residual && !epi.res_f32 && !epi.bias && !epi.lscale && epi.act == ACT_NONE && epi.out_scale == 1.0f) {
+            // Residual-only epilogue (decoder o_proj / down without a split: x += A W^T in place), EIGHT chunks per thread in flight. The general
+            // loop below keeps two: with the output aliasing the residual every iteration's loads wait behind the previous iteration's stores
+            // (one vmcnt), so a 224-row tile was 5-10 dependent memory round trips -- 13.3 us of store loop in the pi0 prefix o_proj at
+            // M = 2 232 on 256 threads, 7.3 us on 512 (profiles/r06_v3_schedule_ab.txt). Same arithmetic: bf16(sum) + residual, rounded once more.
+            constexpr int NV = 8;
+            for (int c0 = t; c0 < total; c0 += NV * nthr) {
+                uint4 rb[NV];
+                int rowi[NV], chi[NV], mi[NV];
+                bool okv[NV];
+#pragma unroll
+                for (int u = 0; u < NV; ++u) {
+                    const int c = c0 + u * nthr;
+                    rowi[u] = div_cpr(c < total ? c : 0); chi[u] = (c < total ? c : 0) - rowi[u] * cpr; mi[u] = m0 + r0 + rowi[u];
+                    okv[u] = c < total && mi[u] < M;
+                    const int mm = okv[u] ? mi[u] : (M - 1);
+                    rb[u] = *(const uint4*)((const bf16_t*)epi.residual + (size_t)mm * epi.ldr + n0 + chi[u] * 8);
+                }
+#pragma unroll
+                for (int u = 0; u < NV; ++u) {
+                    if (!okv[u]) continue;
+                    const char* lrow = st + (size_t)rowi[u] * pitch;
+                    const float4 a4 = *(const float4*)(lrow + chi[u] * 32), b4 = *(const float4*)(lrow + chi[u] * 32 + 16);
+                    const float v[8] = {a4.x, a4.y, a4.z, a4.w, b4.x, b4.y, b4.z, b4.w};
+                    const uint32_t rw[4] = {rb[u].x, rb[u].y, rb[u].z, rb[u].w};
+                    uint32_t ow[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        ow[i] = pack_bf2(bfround(v[2 * i]) + bf2f((bf16_t)(rw[i] & 0xffffu)), bfround(v[2 * i + 1]) + bf2f((bf16_t)(rw[i] >> 16)));
+                    *(uint4*)(base + (size_t)mi[u] * ld_bytes + (size_t)oc0 * esz_out + chi[u] * 16) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+                }
+            }
+            continue;
+        }
         if (al) {
             constexpr int NU = 2;   // chunks per thread in flight (four were measured on the one-wave-per-SIMD kernels: the 13 us store loop of the pi0 prefix
             // o_proj -- 224 x 96 tiles with an in-place residual at M = 2 232 -- did not move, so it is not this loop's round trips; four spill the 224 x 192 tile)

@@ -332,7 +332,6 @@ __global__ __launch_bounds__(128 * CGM * CGN) void gemm_tiled_v3k(const bf16_t* 
         constexpr int role = decltype(ROLE)::value;
         constexpr int PT = role ? PTB : PTA, SB = role ? B_BYTES : A_BYTES, KSH = role ? 11 : 7;
         constexpr int RSPAN = (NM * 2) / 3 < NR ? NM : (NM * 2) / 3;      // the reads sit behind the first two thirds of the MFMAs: landed when the last one issues
-        constexpr bool XS = NM >= 28;
         const int wl = w % NH;
         uint32_t voff[PT];
         const char* sbase[PT];
@@ -358,49 +357,28 @@ __global__ __launch_bounds__(128 * CGM * CGN) void gemm_tiled_v3k(const bf16_t* 
         }
         auto issue = [&](int i, int stage, int t) { glds16_s(voff[i], sbase[i] + ((size_t)(uint32_t)t << KSH), dst0[i] + stage * SB); };
         // NM MFMAs on (xf, wf); behind them the reads of stage rs into (xn, wn_) and this wave's pieces of tile dt into stage ds.
-        // XS (large wave tiles: 112 x 64 = 112 accumulator registers): the activation fragments are SINGLE-buffered -- the MFMA order is m-fragment
-        // outer, so fragment f is dead after its WN MFMAs and the next tile's fragment f is read into the same registers right behind them (it has
-        // the rest of the body to land; the LDS round trip is far longer than the matrix pipe holds its operands); only the weight fragments
-        // keep two sets.
-        auto group = [&](u32x4(&xf)[WM], const u32x4(&wf)[WN], u32x4(&xn)[WM], u32x4(&wn_)[WN], int rs, int ds, int dt, auto RD) {
+        // (A 112 x 64 wave tile -- 224 x 128 on four pairs, with the activation fragments single-buffered -- was built too: 112 accumulator
+        // registers leave the loop 14 spills per k-tile and the epilogue 600; measured 47.7 / 76.4 us against 34.2 / 56.7 for o_proj / down at
+        // M = 448 on the eight-wave 224 x 128 kernel. Not kept: profiles/r06_v3_schedule_ab.txt.)
+        auto group = [&](const u32x4(&xf)[WM], const u32x4(&wf)[WN], u32x4(&xn)[WM], u32x4(&wn_)[WN], int rs, int ds, int dt, auto RD) {
             constexpr bool rd = decltype(RD)::value != 0;
             const uint32_t aa = a_addr + rs * A_BYTES, ba = b_addr + rs * B_BYTES;
-            if constexpr (XS) {
 #pragma unroll
-                for (int f = 0; f < WM; ++f)
+            for (int b = 0; b < WN; ++b)
 #pragma unroll
-                    for (int b = 0; b < WN; ++b) {
-                        const int i = f * WN + b;
-                        acc[b][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[b]), __builtin_bit_cast(bf16x8, xf[f]), acc[b][f], 0, 0, 0);
-                        if (rd) {
+                for (int f = 0; f < WM; ++f) {
+                    const int i = b * WM + f;
+                    acc[b][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[b]), __builtin_bit_cast(bf16x8, xf[f]), acc[b][f], 0, 0, 0);
+                    if (rd) {
 #pragma unroll
-                            for (int j = 0; j < WN; ++j)      // weight fragment j of the next tile: spread over the first two thirds
-                                if ((j * RSPAN) / WN == i) read_nth(aa, ba, j == 0 ? 0 : WM + j, xn, wn_);
-                            if (b == WN - 1) read_nth(aa, ba, 1 + f, xf, wn_);
+                        for (int j = 0; j < NR; ++j)
+                            if ((j * RSPAN) / NR == i) read_nth(aa, ba, j, xn, wn_);
 #pragma unroll
-                            for (int p = 0; p < PT; ++p)
-                                if (((2 * p + 1) * NM) / (2 * PT) == i) issue(p, ds, dt);
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
+                        for (int p = 0; p < PT; ++p)
+                            if (((2 * p + 1) * NM) / (2 * PT) == i) issue(p, ds, dt);
                     }
-            } else {
-#pragma unroll
-                for (int b = 0; b < WN; ++b)
-#pragma unroll
-                    for (int f = 0; f < WM; ++f) {
-                        const int i = b * WM + f;
-                        acc[b][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[b]), __builtin_bit_cast(bf16x8, xf[f]), acc[b][f], 0, 0, 0);
-                        if (rd) {
-#pragma unroll
-                            for (int j = 0; j < NR; ++j)
-                                if ((j * RSPAN) / NR == i) read_nth(aa, ba, j, xn, wn_);
-#pragma unroll
-                            for (int p = 0; p < PT; ++p)
-                                if (((2 * p + 1) * NM) / (2 * PT) == i) issue(p, ds, dt);
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-            }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
         };
         // ---- prologue: every stage of the ring is requested; tiles 0 and 1 have landed before anybody reads ----
 #pragma unroll
@@ -412,62 +390,32 @@ __global__ __launch_bounds__(128 * CGM * CGN) void gemm_tiled_v3k(const bf16_t* 
         PCTL(1);
         V3P(1, wall_clock64());
         V3P(4, __builtin_readcyclecounter());
-        u32x4 xa[WM], wa[WN], xb[XS ? 1 : WM], wb[WN];
+        u32x4 xa[WM], wa[WN], xb[WM], wb[WN];
 #pragma unroll
         for (int j = 0; j < NR; ++j) read_nth(a_addr, b_addr, j, xa, wa);
         asm volatile("s_waitcnt lgkmcnt(0)");
         __builtin_amdgcn_s_barrier();          // every wave has read tile 0: body 0 may refill its stage
         landed(xa, wa);
         int rs = 1, ds = 0;                    // stage of tile kt + 1 (read) / of tile kt (refilled with tile kt + NST)
-        auto finish = [&](int) {
+        auto body = [&](const u32x4(&xf)[WM], const u32x4(&wf)[WN], u32x4(&xn)[WM], u32x4(&wn_)[WN], int kt) {
+            group(xf, wf, xn, wn_, rs, ds, min(kt + NST, nk - 1), IC<1>{});
             asm volatile("s_waitcnt lgkmcnt(0)");
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * PT) : "memory");
             __builtin_amdgcn_s_barrier();
+            landed(xn, wn_);
             ds = rs;
             rs = rs == NST - 1 ? 0 : rs + 1;
         };
         int kt = 0;
-        if constexpr (XS) {
-            for (; kt + 2 <= nk - 1; kt += 2) {
-                group(xa, wa, xa, wb, rs, ds, min(kt + NST, nk - 1), IC<1>{});
-                finish(0);
-#pragma unroll
-                for (int f = 0; f < WM; ++f) asm volatile("" : "+v"(xa[f]));
-#pragma unroll
-                for (int b = 0; b < WN; ++b) asm volatile("" : "+v"(wb[b]));
-                group(xa, wb, xa, wa, rs, ds, min(kt + 1 + NST, nk - 1), IC<1>{});
-                finish(0);
-                landed(xa, wa);
-            }
-            if (kt < nk - 1) {
-                group(xa, wa, xa, wb, rs, ds, min(kt + NST, nk - 1), IC<1>{});
-                finish(0);
-#pragma unroll
-                for (int f = 0; f < WM; ++f) asm volatile("" : "+v"(xa[f]));
-#pragma unroll
-                for (int b = 0; b < WN; ++b) asm volatile("" : "+v"(wb[b]));
-                group(xa, wb, xa, wa, 0, 0, 0, IC<0>{});
-            } else {
-                group(xa, wa, xa, wb, 0, 0, 0, IC<0>{});
-            }
+        for (; kt + 2 <= nk - 1; kt += 2) {
+            body(xa, wa, xb, wb, kt);
+            body(xb, wb, xa, wa, kt + 1);
+        }
+        if (kt < nk - 1) {
+            body(xa, wa, xb, wb, kt);
+            group(xb, wb, xa, wa, 0, 0, 0, IC<0>{});
         } else {
-            auto& xbb = reinterpret_cast<u32x4(&)[WM]>(xb);
-            for (; kt + 2 <= nk - 1; kt += 2) {
-                group(xa, wa, xbb, wb, rs, ds, min(kt + NST, nk - 1), IC<1>{});
-                finish(0);
-                landed(xbb, wb);
-                group(xbb, wb, xa, wa, rs, ds, min(kt + 1 + NST, nk - 1), IC<1>{});
-                finish(0);
-                landed(xa, wa);
-            }
-            if (kt < nk - 1) {
-                group(xa, wa, xbb, wb, rs, ds, min(kt + NST, nk - 1), IC<1>{});
-                finish(0);
-                landed(xbb, wb);
-                group(xbb, wb, xa, wa, 0, 0, 0, IC<0>{});
-            } else {
-                group(xa, wa, xbb, wb, 0, 0, 0, IC<0>{});
-            }
+            group(xa, wa, xb, wb, 0, 0, 0, IC<0>{});
         }
     };
     if (w < NH) run(IC<0>{});
@@ -490,15 +438,19 @@ __global__ __launch_bounds__(128 * CGM * CGN) void gemm_tiled_v3k(const bf16_t* 
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        if (wk == 0) {
+        if (wk == 0) {   // one n-block (WM reads in flight) per round trip
 #pragma unroll
-            for (int b = 0; b < WN; ++b)
+            for (int b = 0; b < WN; ++b) {
+                f32x4 o[WM];
+#pragma unroll
+                for (int f = 0; f < WM; ++f) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(o[f]) : "v"(red), "n"((b * WM + f) * 1024) : "memory");
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
                 for (int f = 0; f < WM; ++f) {
-                    f32x4 o;
-                    asm volatile("ds_read_b128 %0, %1 offset:%2\n\ts_waitcnt lgkmcnt(0)" : "=v"(o) : "v"(red), "n"((b * WM + f) * 1024) : "memory");
-                    acc[b][f] += o;
+                    asm volatile("" : "+v"(o[f]));
+                    acc[b][f] += o[f];
                 }
+            }
         }
     }
     tiled_epilogue_staged<WM, WN, BM_, BN_>(acc, epi, C, ldc, M, N, m0, n0, m0 + wm * (WM * 16), n0 + wn * (WN * 16), r, g, partial, smem,
@@ -553,7 +505,6 @@ hipError_t launch_gemm_v3(int pick, const bf16_t* A, int lda, const bf16_t* Wp, 
         case 28: LAUNCH_V3(7, 2, 1, 4, 4, 4); break;                                                            // 112x128, 4 waves of 112x32 (one per SIMD), 4 stages
         case 29: if (ring == 34) LAUNCH_V3(7, 4, 2, 2, 3, 4); else LAUNCH_V3(7, 4, 2, 2, 3, 3); break;          // 224x128, 4 waves of 112x64
         case 30: LAUNCH_V3K(7, 3, 2, 2, 4); break;                                                              // 224x96,  4 wave PAIRS of 112x48 splitting k (two waves per SIMD)
-        case 31: LAUNCH_V3K(7, 4, 2, 2, 3); break;                                                              // 224x128, 4 wave pairs of 112x64
         default: return hipErrorInvalidValue;
     }
 #undef LAUNCH_V3

@@ -158,9 +158,10 @@ def gemm_probe() -> dict:
 
 
 def gemm_plan_counts(reset: bool = False) -> list:
-    """Launch counters per GEMM kernel plan since the last reset (cover_gemm_plan_counts): [0..18] tiled picks (14..17 = 224-row
-    tiles), [19] / [20] / [22] weight-streaming generations 2 / 3 / 1, [21] fp8 MFMA tiles, [23..29] self-loading tiles
-    (gemm_v3.hip: 8 waves 224x192, 224x128, 256x128, 128x256; 4 waves 224x96, 224x192, 224x128, 64x64, 32x32 with a 16-stage ring)."""
+    """Launch counters per GEMM kernel plan since the last reset (cover_gemm_plan_counts; the map is in include/cover_hip.h): [0..8] gemm_tiled
+    picks, [10] the 64x128 loader-wave tile, [19] / [20] / [22] weight-streaming generations 2 / 3 / 1, [21] fp8 MFMA tiles, self-loading tiles
+    (gemm_v3.hip) 8 waves [23] 224x192, [24] 224x128, [25] 256x128, [26] 128x256, 4 waves [27] 224x96, [28] 112x128, [29] 224x128, k-split
+    wave pairs [30] 224x96."""
     n = 32
     buf = (C.c_longlong * n)()
     L.lib().cover_gemm_plan_counts(buf, n, 1 if reset else 0)

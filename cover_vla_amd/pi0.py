@@ -59,7 +59,7 @@ class PI0FlowMatching:
         self.max_batch, self.max_prompts, self.max_lang = max_batch, max_prompts, max_lang
         self._den = {}     # static buffers (+ hipGraph) of the denoise loop per (batch size, chains)
         # denoise loop: independent row-group chains on streams of their own, replayed as one hipGraph (see sample_actions)
-        self.n_chains = int(os.environ.get("COVER_PI0_CHAINS", "2"))
+        self.n_chains = int(os.environ.get("COVER_PI0_CHAINS", "1"))
         self.denoise_graph = os.environ.get("COVER_PI0_GRAPH", "1") != "0"
         self._fold = {}    # folded suffix-embedding constants per step size (_suffix_fold)
         self._cap = None   # capture stream
@@ -235,13 +235,18 @@ class PI0FlowMatching:
         # stream of its own (own buffers = row slices of the batch's, own decoder workspace, own suffix-KV slots), forked from and joined to the
         # caller's stream, and the whole fork / loop / join is replayed as ONE hipGraph with n_chains parallel branches from the third call
         # on (call 1 runs eagerly and sizes everything, call 2 captures). Row results do not depend on the cut (tests: chains 1 vs 2 vs 4).
-        # self.n_chains (COVER_PI0_CHAINS, default 2); self.denoise_graph = False (COVER_PI0_GRAPH=0) keeps the eager loop (host-bound with
-        # more than one chain).
+        # self.n_chains (COVER_PI0_CHAINS); self.denoise_graph = False (COVER_PI0_GRAPH=0) keeps the eager loop (host-bound with more than one
+        # chain). MEASURED (MI355X, B = 40, profiles/r06_pi0_chains_ab.txt): 1 chain eager 29.2 ms per decision, 1 chain replayed 29.0,
+        # 2 chains 29.7-30.3, 4 chains 40.4-41.5, 8 chains 54.6-55.1 -- the branches of the graph do not overlap: a launch at 100 rows lasts
+        # nearly as long as one at 200 (it is fill / drain and a dependent round trip either way) and the branches overlap little, so the
+        # decision grows with the number of launches. The default is therefore ONE chain, replayed.
         S, W, A = 1 + self.chunk, self.W, self.max_action_dim
         n_ch = max(1, min(self.n_chains, B))
         if trace is not None:
             n_ch = 1
-        st = self._den.get((B, n_ch))
+        # (the A/B knobs that are read per call are part of the key: a captured graph has their value baked in)
+        knobs = (os.environ.get("COVER_PI0_SUFFIX_FOLD", "1"), os.environ.get("COVER_QKV_FOLD", "1"))
+        st = self._den.get((B, n_ch, knobs))
         if st is None:
             st = dict(calls=0, graph=None, ws_gen=-1,
                       row_prompt=torch.empty(B, dtype=torch.int32, device=dev), row_plen=torch.empty(B, dtype=torch.int32, device=dev),
@@ -265,7 +270,7 @@ class PI0FlowMatching:
                                       write_slot=sl, write_scratch=True)   # suffix K/V: per-step temporaries in the rows' own slots
                 st["chains"].append(dict(b0=b0, b1=b1, g=g, ws=self.expert.workspace((b1 - b0) * S),
                                          stream=torch.cuda.Stream(device=dev) if ci > 0 else None))
-            self._den[(B, n_ch)] = st
+            self._den[(B, n_ch, knobs)] = st
         st["calls"] += 1
         if st.get("Tp") != Tp:                      # the prefix width is baked into the groups (and into a captured graph)
             for ch in st["chains"]:

@@ -124,13 +124,15 @@ size_t cover_gemm_workspace_bytes(int M, int N, int K);
 int cover_gemm_bf16(const void* A, int lda, const void* Wp, void* C, int ldc, int M, int N, int K,
                     const cover_gemm_epi* epi, void* splitk_ws, size_t splitk_ws_bytes, int variant, void* stream);
 /* Which kernel plan every GEMM launch of this process took since the last reset (test / audit hook: a parity test can assert
- * that a shape really ran on the tile it means to cover). counts[0..18] = LDS-tiled configurations (14..17 = the 224-row
- * loader-wave tiles of the M = 448 prefill pass, 12/13 = 256x128 / 128x256), [19] = second-generation weight streaming,
- * [20] = third generation, [21] = fp8 MFMA tiles, [22] = first generation, [23..29] = the self-loading tiles of gemm_v3.hip
- * (8 waves: 224x192, 224x128, 256x128, 128x256; 4 waves: 224x96, 224x192, 224x128, 64x64, 32x32 / 16 stages). Copies min(n, 32) counters,
- * returns 32. */
+ * that a shape really ran on the tile it means to cover). counts[i], i = index into the tile table of launch_gemm_bf16 (gemm_bf16.hip):
+ *   [0..8]  gemm_tiled: 0 128x128, 1 64x128, 2 64x64 (3 stages), 3 128x128 (4 stages), 4 256x128, 5 128x256, 6 128x128 (8 waves), 7 64x128 (3 stages),
+ *           8 128x128 (3 stages)        [10] gemm_tiled_pc 64x128, four loader waves, 4 stages (bf16; 9, 11..18 exist as fp8 kernels only and count in [21])
+ *   [19] second-generation weight streaming (gemm_skinny2)   [20] third generation (gemm_skinny3)   [21] fp8 MFMA tiles (any)   [22] first generation
+ *   self-loading tiles (gemm_v3.hip), 8 waves: [23] 224x192, [24] 224x128, [25] 256x128, [26] 128x256; 4 waves (one per SIMD): [27] 224x96,
+ *   [28] 112x128, [29] 224x128; k-split wave pairs (gemm_tiled_v3k): [30] 224x96, [31] 224x128 (not instantiated: registers).
+ * Copies min(n, 32) counters, returns 32. */
 int cover_gemm_plan_counts(long long* counts, int n, int reset);
-/* In-kernel probe of the most recent launch of the self-loading tiled GEMM (gemm_v3.hip; plan counters 23..31), written by one thread of
+/* In-kernel probe of the most recent launch of the self-loading tiled GEMM (gemm_v3.hip; plan counters 23..30), written by one thread of
  * its first workgroup: out[0..3] = 100 MHz wall-clock stamps at kernel start / k-loop start / k-loop end / kernel end, out[4..5] = shader
  * cycle counter at k-loop start / end, out[6] = k-tiles of the loop. (out[5] - out[4]) / (out[2] - out[1]) / 10 ns = the clock the loop ran
  * at; out[12..14] = stamps inside the LDS-staged epilogue (pipeline stages released / LDS tile filled / tile published, the store loop runs

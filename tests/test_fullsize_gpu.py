@@ -182,16 +182,17 @@ def test_fullsize_pi0_profile_b40(dev):
     assert idx1 == idx2 and torch.equal(x1, x2) and 0 <= idx1 < B
     assert x1.shape == (B, 4, 32) and torch.isfinite(x1).all() and torch.isfinite(pp.last_scores).all()
     rel = lambda a, b: ((a - b).norm() / (b - i["noise"]).norm()).item()          # relative to the size of the update, as the golden tests
-    # the serialised (profiled) decision runs the denoise loop as ONE eager chain; the default is row-group chains replayed as a hipGraph:
-    # same rows up to the order of the fp32 sums (the GEMMs see 100 instead of 200 rows), and bit-identical for equal chain counts
+    # the serialised (profiled) decision runs the denoise loop eagerly, the default replays it as a hipGraph: bit-identical. Cut into
+    # independent row-group chains (parallel branches of the graph; measured slower, so not the default) the rows agree up to the order
+    # of the fp32 sums (the GEMMs see 100 / 50 instead of 200 rows)
     _, xs = pp.decision(serial=True)
-    assert rel(xs, x1) < 5e-3, rel(xs, x1)
+    assert torch.equal(xs, x1)
     keep_ch = pp.model.n_chains
-    for n_ch in (1, 4):
+    for n_ch in (2, 4):
         pp.model.n_chains = n_ch
         for _ in range(3):
             _, xc = pp.decision()
-        assert rel(xc, x1) < 5e-3 and (n_ch != 1 or torch.equal(xc, xs)), (n_ch, rel(xc, x1))
+        assert rel(xc, x1) < 5e-3, (n_ch, rel(xc, x1))
     pp.model.n_chains = keep_ch
     # rows of one prompt with identical noise are identical; different noise gives different rows
     nz = i["noise"].view(P, S, 4, 32)[:, :1].expand(P, S, 4, 32).reshape(B, 4, 32).contiguous()

@@ -27,7 +27,8 @@ for _ in range(R):
     # the "decode1 / decode2 excess" of profiles/r03_phases.txt was this mode, not a property of the bench's schedule),
     # 1 = no side work (stale embeddings), 2 = towers on the side stream, heads in the tail, 3 = side work queued before the policy
     # 5 (default since round 6) = the verifier's towers + heads as ONE replayed hipGraph on the side stream, launched by this thread before the policy
-    MODE = int(os.environ.get("SIDE_MODE", "5"))
+    # 6 = the same graph launched by the second host thread (bench.py's default)
+    MODE = int(os.environ.get("SIDE_MODE", "6"))
 
     def side_work():
         if MODE == 1 and "its" in globals().get("_cache", {}):
@@ -51,7 +52,7 @@ for _ in range(R):
             out["its"] = pipe.ver.shared_embeddings_graph(i["img384"], i["text"])
     if MODE == 3:   # diagnostic: side work queued BEFORE the policy (overlaps the vision phase and the start of the prefill)
         side_work()
-    if MODE == 4:   # side work queued by a second host thread while this one queues the policy
+    if MODE in (4, 6):   # side work queued by a second host thread while this one queues the policy
         import concurrent.futures
         if "pool" not in _cache:
             _cache["pool"] = concurrent.futures.ThreadPoolExecutor(max_workers=1)
@@ -61,12 +62,14 @@ for _ in range(R):
             torch.cuda.set_device(dev)
             pipe.side.wait_event(ev0)
             with torch.cuda.stream(pipe.side):
+                if MODE == 6:
+                    return pipe.ver.shared_embeddings_graph(i["img384"], i["text"])
                 pf, tf = pipe.ver.extract_shared_features(i["img384"], i["text"])
                 return pipe.ver.image_text_embeddings(pf, tf)
 
         fut = _cache["pool"].submit(threaded)
     tokens, _ = pipe.policy.sample(i["frame"], i["toks"], i["lens"], bench.N_SAMPLES, i["u"], 1.0, trace=tr,
-                                   on_prefill_enqueued=None if MODE in (3, 4, 5) else side_work)
+                                   on_prefill_enqueued=None if MODE in (3, 4, 5, 6) else side_work)
     if fut is not None:
         out["its"] = fut.result()
     if "its" not in out:
