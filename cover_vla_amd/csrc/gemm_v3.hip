@@ -35,13 +35,14 @@ int gemm_v3_probe(unsigned long long* out) { return hipMemcpyFromSymbol(out, HIP
 
 template <int V> using IC = std::integral_constant<int, V>;
 // Experiment knobs (compile time; tools/ab_build.sh builds the variants):
-//   COVER_V3_RDSPAN_NUM / _DEN  the NR fragment reads of the next step sit behind the first NM * NUM / DEN MFMAs of a step (1 / 1 = spread over all of them)
+//   COVER_V3_RDSPAN_NUM / _DEN  the NR fragment reads of the next step sit behind the first NM * NUM / DEN MFMAs of a step (1 / 1 = spread over all of them:
+//                               the round-5 schedule, where the last read went out behind MFMA 18 of 21 and the step's lgkmcnt(0) waited for it)
 //   COVER_V3_PRIO               1: the weight-role waves (second half) run at s_setprio 1 inside the loop, 2: the activation-role waves
 //   COVER_V3_DEPHASE_NUM / _DEN the weight-role waves pass the mid-tile barrier NM * NUM / DEN MFMAs into the tile's second step, so that the two waves of a
 //                               SIMD do not reach their `s_waitcnt lgkmcnt(0)` at the same moment
-#ifndef COVER_V3_RDSPAN_NUM
-#define COVER_V3_RDSPAN_NUM 1
-#define COVER_V3_RDSPAN_DEN 1
+#ifndef COVER_V3_RDSPAN_NUM   // default 4 / 7 (12 of 21 MFMAs): pi0 prefix layer 552 -> 542 us over three same-box repetitions, M = 448 flat (profiles/r06_v3_schedule_ab.txt)
+#define COVER_V3_RDSPAN_NUM 4
+#define COVER_V3_RDSPAN_DEN 7
 #endif
 #ifndef COVER_V3_PRIO
 #define COVER_V3_PRIO 0
