@@ -493,6 +493,25 @@ def _cpu_info():
     return model, {"amx_bf16": "amx_bf16" in flags, "avx512_bf16": "avx512_bf16" in flags, "avx512f": "avx512f" in flags}
 
 
+def sampled_pick_decided(logits, t, u, err, temperature=1.0, eps=1e-4):
+    """Is the inverse-CDF pick of bin t on uniform u DATA-DECIDED against logit perturbations of magnitude <= err? logits [..., bins] (float64),
+    t [...] int64 (the picked bin: first j with cumsum_j > u * total), u, err [...]. Exact worst case: with p_j = exp(l_j / T) and c = the
+    normalised mass up to an edge, the perturbation that moves the edge furthest up multiplies every p_j below it by e^(err/T) and every p_j
+    above it by e^(-err/T): c -> c e^a / (c e^a + (1 - c) e^-a), a = err / T (and down with the signs swapped). The pick survives every
+    perturbation iff the lower edge of bin t cannot reach u and the upper edge cannot fall to u (eps = 1e-4 of the total mass: the sequential fp32
+    cumsum of 256 terms in both selectors is good to ~2e-5 relative)."""
+    l = logits.double()
+    p = torch.exp((l - l.amax(dim=-1, keepdim=True)) / temperature)
+    cs = torch.cumsum(p, -1) / p.sum(-1, keepdim=True)
+    nb = l.shape[-1]
+    hi_edge = torch.gather(cs, -1, t[..., None])[..., 0]
+    lo_edge = torch.where(t > 0, torch.gather(cs, -1, (t - 1).clamp(min=0)[..., None])[..., 0], torch.zeros_like(hi_edge))
+    ea = torch.exp(err.double() / temperature)
+    up = lambda c: (c * ea) / (c * ea + (1 - c) / ea)
+    down = lambda c: (c / ea) / (c / ea + (1 - c) * ea)
+    return (up(lo_edge) < u - eps) & ((down(hi_edge) > u + eps) | (t == nb - 1))
+
+
 def oracle_agreement(pipe, tok_o, logits_o, sel_o, n_prompts, free=None):
     """Full-size agreement of the HIP path with the CPU oracle on the SAME decision (checkpoint, frame, prompts, uniforms): what
     run_simpler_eval_with_openpi.py:305-326 (one batched policy call) and :346-365 (verifier scores -> grouped arg-max) produce.
@@ -520,15 +539,8 @@ def oracle_agreement(pipe, tok_o, logits_o, sel_o, n_prompts, free=None):
     lo_ = logits_o[:, :n_gen, lo:hi].double()
     u = i["u"][:N_, :n_gen].cpu().double()
     err = (lg - lo_).abs().amax(dim=2)                                                                # [N, n_gen]
-    p = torch.exp(lo_ - lo_.amax(dim=2, keepdim=True))
-    cs = torch.cumsum(p, 2) / p.sum(2, keepdim=True)
     t = (tok_o[:, :n_gen] - lo).clamp(0, hi - lo - 1)
-    hi_edge = torch.gather(cs, 2, t[..., None])[..., 0]
-    lo_edge = torch.where(t > 0, torch.gather(cs, 2, (t - 1).clamp(min=0)[..., None])[..., 0], torch.zeros_like(hi_edge))
-    ea = torch.exp(err)
-    moved = lambda cc, up: (cc * (ea if up else 1 / ea)) / (cc * (ea if up else 1 / ea) + (1 - cc) * ((1 / ea) if up else ea))
-    eps = 1e-5                                                                                        # the fp32 cumsum of both selectors
-    decided = (moved(lo_edge, True) < u - eps) & ((moved(hi_edge, False) > u + eps) | (t == hi - lo - 1))
+    decided = sampled_pick_decided(lo_, t, u, err)
     same = tok_g[:, :n_gen] == tok_o[:, :n_gen]
     n_dec = int(decided.sum())
     rel = ((lg - lo_).flatten(1).norm(dim=1) / lo_.flatten(1).norm(dim=1))

@@ -460,15 +460,12 @@ __global__ __launch_bounds__(128 * CGM * CGN) void gemm_tiled_v3k(const bf16_t* 
     V3P(3, wall_clock64());
 }
 
-// pick -> instantiation (the tile table of launch_gemm_bf16 continues with these indices). COVER_V3_RING=<a><b> (two digits) selects another
-// instantiated ring-depth pair for A/B runs.
+// pick -> instantiation (the tile table of launch_gemm_bf16 continues with these indices)
 hipError_t launch_gemm_v3(int pick, const bf16_t* A, int lda, const bf16_t* Wp, void* C, int ldc, int M, int N, int Kp, const EpiDev& epi, int tiles_m,
                           int tiles_n, int kt_per, int S, float* partial, int prof_cls, double prof_work, hipStream_t st) {
     hipError_t e = hipSuccess;
     if ((size_t)M * lda * 2 + 4096 >= ((size_t)1 << 31)) return hipErrorInvalidValue;   // 32-bit lane offsets of the activation pieces
     dim3 grid(tiles_m * tiles_n, S);
-    static const char* ring_env = getenv("COVER_V3_RING");
-    const int ring = ring_env ? atoi(ring_env) : 0;
 #define LAUNCH_V3(WM_, WN_, CGM_, CGN_, NA_, NB_)                                                                            \
     do {                                                                                                                     \
         auto kfn = gemm_tiled_v3<WM_, WN_, CGM_, CGN_, NA_, NB_>;                                                            \
@@ -498,14 +495,14 @@ hipError_t launch_gemm_v3(int pick, const bf16_t* A, int lda, const bf16_t* Wp, 
         }                                                                                                                    \
     } while (0)
     switch (pick) {
-        case 23: if (ring == 23) LAUNCH_V3(7, 3, 2, 4, 2, 3); else LAUNCH_V3(7, 3, 2, 4, 3, 3); break;          // 224x192, 8 waves of 112x48
-        case 24: if (ring == 34) LAUNCH_V3(7, 2, 2, 4, 3, 4); else LAUNCH_V3(7, 2, 2, 4, 3, 3); break;          // 224x128, 8 waves of 112x32
-        case 25: LAUNCH_V3(8, 2, 2, 4, 3, 3); break;                                                            // 256x128, 8 waves of 128x32
-        case 26: LAUNCH_V3(4, 4, 2, 4, 3, 3); break;                                                            // 128x256, 8 waves of 64x64
-        case 27: if (ring == 34) LAUNCH_V3(7, 3, 2, 2, 3, 4); else LAUNCH_V3(7, 3, 2, 2, 4, 4); break;          // 224x96,  4 waves of 112x48 (one per SIMD)
-        case 28: LAUNCH_V3(7, 2, 1, 4, 4, 4); break;                                                            // 112x128, 4 waves of 112x32 (one per SIMD), 4 stages
-        case 29: if (ring == 34) LAUNCH_V3(7, 4, 2, 2, 3, 4); else LAUNCH_V3(7, 4, 2, 2, 3, 3); break;          // 224x128, 4 waves of 112x64
+        case 23: LAUNCH_V3(7, 3, 2, 4, 3, 3); break;          // 224x192, 8 waves of 112x48
+        case 24: LAUNCH_V3(7, 2, 2, 4, 3, 3); break;          // 224x128, 8 waves of 112x32
+        case 25: LAUNCH_V3(8, 2, 2, 4, 3, 3); break;          // 256x128, 8 waves of 128x32
+        case 26: LAUNCH_V3(4, 4, 2, 4, 3, 3); break;          // 128x256, 8 waves of 64x64
+        case 27: LAUNCH_V3(7, 3, 2, 2, 4, 4); break;          // 224x96,  4 waves of 112x48 (one per SIMD): the A/B partner of pick 30
+        // (round 5 also instantiated other ring depths -- (2,3), (3,4) -- and 4-wave 112x128 / 224x128 tiles: measured flat / slower, removed in round 6)
         case 30: LAUNCH_V3K(7, 3, 2, 2, 4); break;                                                              // 224x96,  4 wave PAIRS of 112x48 splitting k (two waves per SIMD)
+        case 31: LAUNCH_V3K(7, 2, 2, 2, 4); break;                                                              // 224x64,  4 wave pairs of 112x32: narrow outputs (o_proj / down at M = 448) with TWO K slices instead of four
         default: return hipErrorInvalidValue;
     }
 #undef LAUNCH_V3

@@ -160,7 +160,7 @@ def gemm_probe() -> dict:
 def gemm_plan_counts(reset: bool = False) -> list:
     """Launch counters per GEMM kernel plan since the last reset (cover_gemm_plan_counts; the map is in include/cover_hip.h): [0..8] gemm_tiled
     picks, [10] the 64x128 loader-wave tile, [19] / [20] / [22] weight-streaming generations 2 / 3 / 1, [21] fp8 MFMA tiles, self-loading tiles
-    (gemm_v3.hip) 8 waves [23] 224x192, [24] 224x128, [25] 256x128, [26] 128x256, 4 waves [27] 224x96, [28] 112x128, [29] 224x128, k-split
+    (gemm_v3.hip) 8 waves [23] 224x192, [24] 224x128, [25] 256x128, [26] 128x256, 4 waves [27] 224x96, k-split
     wave pairs [30] 224x96."""
     n = 32
     buf = (C.c_longlong * n)()

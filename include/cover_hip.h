@@ -129,7 +129,8 @@ int cover_gemm_bf16(const void* A, int lda, const void* Wp, void* C, int ldc, in
  *           8 128x128 (3 stages)        [10] gemm_tiled_pc 64x128, four loader waves, 4 stages (bf16; 9, 11..18 exist as fp8 kernels only and count in [21])
  *   [19] second-generation weight streaming (gemm_skinny2)   [20] third generation (gemm_skinny3)   [21] fp8 MFMA tiles (any)   [22] first generation
  *   self-loading tiles (gemm_v3.hip), 8 waves: [23] 224x192, [24] 224x128, [25] 256x128, [26] 128x256; 4 waves (one per SIMD): [27] 224x96,
- *   [28] 112x128, [29] 224x128; k-split wave pairs (gemm_tiled_v3k): [30] 224x96, [31] 224x128 (not instantiated: registers).
+ *   k-split wave pairs (gemm_tiled_v3k): [30] 224x96 ([28], [29], [31]: 112x128 / 224x128 on four waves and 224x128 on wave pairs -- built, measured
+ *   slower, not instantiated).
  * Copies min(n, 32) counters, returns 32. */
 int cover_gemm_plan_counts(long long* counts, int n, int reset);
 /* In-kernel probe of the most recent launch of the self-loading tiled GEMM (gemm_v3.hip; plan counters 23..30), written by one thread of

@@ -464,3 +464,40 @@ def test_pi0fast_policy_host_glue_matches_reference_golden():
     with pytest.raises(ValueError):
         pol.reset()
         pol.select_action({"observation.state": state, "task": ["x"] * 4})
+
+
+def test_sampled_pick_decided_is_the_exact_worst_case():
+    """bench.sampled_pick_decided (the criterion of cpu_baseline.agreement): a pick it calls decided survives every logit perturbation within
+    +-err (random ones AND the two extremal ones that push the bin's edges furthest), and a pick it calls undecided is flipped by one of the
+    two extremal perturbations -- i.e. the bound is tight, not merely sufficient."""
+    import torch
+    import bench
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    from cover_ref import openvla as OR
+    g = torch.Generator().manual_seed(5)
+    n_dec = n_und = 0
+    for case in range(400):
+        nb = 32
+        l = (torch.randn(nb, generator=g) * (0.5 + 3.0 * torch.rand(1, generator=g))).double()
+        u = float(torch.rand(1, generator=g))
+        err = float(10 ** (-3 + 2.5 * torch.rand(1, generator=g)))
+        t = OR.select_token(l.float(), 0, nb, u, 1.0)
+        dec = bool(bench.sampled_pick_decided(l[None], torch.tensor([t]), torch.tensor([u]).double(), torch.tensor([err]).double())[0])
+        idx = torch.arange(nb)
+        extremal = [torch.where(idx < t, err, -err), torch.where(idx <= t, -err, err)]     # lower edge up / upper edge down
+        picks = [OR.select_token((l + d).float(), 0, nb, u, 1.0) for d in extremal]
+        if dec:
+            n_dec += 1
+            assert all(p == t for p in picks), (case, t, picks, u, err)
+            for _ in range(20):
+                d = (torch.rand(nb, generator=g).double() * 2 - 1) * err
+                assert OR.select_token((l + d).float(), 0, nb, u, 1.0) == t
+        else:
+            # the margin the criterion leaves to fp32 rounding (eps) is the only room for an undecided pick that no extremal perturbation flips
+            lo_edge = float(torch.softmax(l, 0)[:t].sum())
+            hi_edge = float(torch.softmax(l, 0)[: t + 1].sum())
+            near = min(abs(u - lo_edge), abs(hi_edge - u))
+            flipped = any(p != t for p in picks)
+            n_und += int(flipped)
+            assert flipped or near < 0.05 + 2.5 * err, (case, t, picks, u, err, near)
+    assert n_dec > 50 and n_und > 50, (n_dec, n_und)
