@@ -1644,7 +1644,7 @@ hipError_t launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* Wp, void* C,
         {0, 0, 0, 0, 0}, {0, 0, 0, 0, 0},   // (28, 29: 112x128 and 224x128 on four waves -- measured slower in round 5, removed in round 6)
         // k-split wave pairs (gemm_v3.hip gemm_tiled_v3k): 2 x 2 wave tiles, each owned by the two waves of a SIMD, which split every k-tile
         {7, 3, 2, 2, 4},   // u (30): 224x96,  4 wave pairs of 112x48, 4 stages (160 KiB)
-        {7, 2, 2, 2, 4},   // v (31): 224x64,  4 wave pairs of 112x32, 4 stages (144 KiB): narrow outputs at M = 448 with HALF the K slices (and slab bytes) of 224x128
+        {0, 0, 0, 0, 0},   // (31: 224x128 on wave pairs of 112x64 and 224x64 on pairs of 112x32 were built and not kept; gemm_v3.hip)
     };
     // Measured on MI355X (tools/bench_kernels.py, M = 441): this single-barrier-per-k-tile structure is latency-bound per
     // block, so residency beats tile size until the tile grid oversubscribes the chip several times over, while 64x64
@@ -1730,7 +1730,7 @@ hipError_t launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* Wp, void* C,
         static const char* force = getenv("COVER_TILE_PICK");  // experiment knob: index into cands
         if (force && force[0] >= '0' && force[0] <= '9') pick = force[0] - '0';
         if (force && force[0] >= 'a' && force[0] <= 'i') pick = 10 + (force[0] - 'a');   // (b .. i: fp8 operands only)
-        if (force && force[0] >= 'n' && force[0] <= 'v' && force[0] != 's' && force[0] != 't') pick = 10 + (force[0] - 'a');
+        if (force && force[0] >= 'n' && force[0] <= 'u' && force[0] != 's' && force[0] != 't') pick = 10 + (force[0] - 'a');
     }
     // the 256 x 128 / 128 x 256 tiles (M >= 512 with more than 10 % of 224-row padding: config 4's 704-row prefill) run on the self-loading kernel
     if (v3_on) pick = pick == 12 ? 25 : pick == 13 ? 26 : pick;

@@ -502,7 +502,8 @@ hipError_t launch_gemm_v3(int pick, const bf16_t* A, int lda, const bf16_t* Wp, 
         case 27: LAUNCH_V3(7, 3, 2, 2, 4, 4); break;          // 224x96,  4 waves of 112x48 (one per SIMD): the A/B partner of pick 30
         // (round 5 also instantiated other ring depths -- (2,3), (3,4) -- and 4-wave 112x128 / 224x128 tiles: measured flat / slower, removed in round 6)
         case 30: LAUNCH_V3K(7, 3, 2, 2, 4); break;                                                              // 224x96,  4 wave PAIRS of 112x48 splitting k (two waves per SIMD)
-        case 31: LAUNCH_V3K(7, 2, 2, 2, 4); break;                                                              // 224x64,  4 wave pairs of 112x32: narrow outputs (o_proj / down at M = 448) with TWO K slices instead of four
+        // (224x64 on 4 wave pairs of 112x32 with TWO K slices for o_proj / down at M = 448: 34.4 / 67.3 us against 33.0 / 55.4 on 224x128 x 4 slices --
+        //  905-1 107 cycles per k-tile for half the FLOPs of a 1 155-1 400-cycle tile; not kept: profiles/r06_v3_schedule_ab.txt)
         default: return hipErrorInvalidValue;
     }
 #undef LAUNCH_V3
