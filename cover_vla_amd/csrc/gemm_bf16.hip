@@ -575,6 +575,9 @@ extern "C" int cover_rn_debug(unsigned long long* out) { return (int)hipMemcpyFr
 #else
 #define RNT(slot) do { } while (0)
 #endif
+#ifndef COVER_RN_RES_EARLY
+#define COVER_RN_RES_EARLY 1   // 0 = the operand loads BEHIND the slab sums (rounds 1-5), for A/B builds
+#endif
 // (one row by one 512-thread block; red = 16 floats of LDS)
 __device__ __forceinline__ void reduce_norm_row(const float* __restrict__ partial, int S, bf16_t* C, int ldc, int M, int N, const EpiDev& epi,
                                                 const int m, float* red) {
@@ -592,6 +595,22 @@ __device__ __forceinline__ void reduce_norm_row(const float* __restrict__ partia
             nw[c][1] = *(const float4*)(epi.norm_w + n0 + 4);
         }
     }
+    // Round 6: with a residual-only epilogue (decoder o_proj / down: x += slab sums, bf16 residual -- two of these launches per layer-step of
+    // every decode pass) the residual chunk is requested in the SAME batch as the first slab loads instead of by epi_value4 behind the slab
+    // sums: the kernel was two dependent memory round trips (slabs 1.1 us, residual 1.1 us of 3.6 us in the per-block timeline,
+    // tools/dbg/rn_timeline.py), now one: 3.6 -> 2.6 us in-kernel, headline 34.31 -> 33.49 ms over three same-box alternations
+    // (profiles/r06_reduce_residual_early_ab.txt). Same arithmetic and rounding points as epi_value4. A general form (bias / layer scale / fp32
+    // residual requested early through uniform branches) measured NO gain on the same decision: the branches cost what the round trip saves.
+    // (A round-2 note here said a 16-byte residual load AHEAD of the slabs had measured slower; behind the first slab batch it does not.)
+    const bool res_only = COVER_RN_RES_EARLY != 0 && epi.residual && !epi.res_f32 && !epi.bias && !epi.lscale && epi.act == ACT_NONE && epi.out_scale == 1.0f &&
+                          (N & 7) == 0 && (((uintptr_t)epi.residual) & 15) == 0 && ((epi.ldr * 2) & 15) == 0;
+#ifndef COVER_RN_BIAS_EARLY
+#define COVER_RN_BIAS_EARLY 1
+#endif
+    // the same for the ViT towers' proj / fc2 reductions (SigLIP, SigLIP2: bias + bf16 residual, no layer scale)
+    const bool res_bias = COVER_RN_BIAS_EARLY != 0 && !res_only && epi.residual && !epi.res_f32 && epi.bias && !epi.lscale && epi.act == ACT_NONE &&
+                          epi.out_scale == 1.0f && (N & 7) == 0 && (((uintptr_t)epi.residual) & 15) == 0 && ((epi.ldr * 2) & 15) == 0 &&
+                          (((uintptr_t)epi.bias) & 15) == 0;
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
         const int n0 = (threadIdx.x + c * 512) * 8;
@@ -599,6 +618,9 @@ __device__ __forceinline__ void reduce_norm_row(const float* __restrict__ partia
             float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
             const float* p0 = partial + (size_t)m * N + n0;
             const size_t sstride = (size_t)M * N;
+            uint4 rr = make_uint4(0, 0, 0, 0);
+            float4 bq0 = make_float4(0.f, 0.f, 0.f, 0.f), bq1 = bq0;
+            const bf16_t* rsrc = (const bf16_t*)epi.residual + (size_t)m * epi.ldr + n0;
             int s = 0;
             for (; s + 4 <= S; s += 4) {  // four slices in flight
                 float4 a[4], b[4];
@@ -607,6 +629,8 @@ __device__ __forceinline__ void reduce_norm_row(const float* __restrict__ partia
                     a[j] = *(const float4*)(p0 + (s + j) * sstride);
                     b[j] = *(const float4*)(p0 + (s + j) * sstride + 4);
                 }
+                if (res_only && s == 0) rr = *(const uint4*)rsrc;
+                if (res_bias && s == 0) { rr = *(const uint4*)rsrc; bq0 = *(const float4*)(epi.bias + n0); bq1 = *(const float4*)(epi.bias + n0 + 4); }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     v[0] += a[j].x; v[1] += a[j].y; v[2] += a[j].z; v[3] += a[j].w;
@@ -615,14 +639,30 @@ __device__ __forceinline__ void reduce_norm_row(const float* __restrict__ partia
             }
             for (; s < S; ++s) {
                 const float4 a = *(const float4*)(p0 + s * sstride), b = *(const float4*)(p0 + s * sstride + 4);
+                if (res_only && s == 0) rr = *(const uint4*)rsrc;      // (fewer than four slabs)
+                if (res_bias && s == 0) { rr = *(const uint4*)rsrc; bq0 = *(const float4*)(epi.bias + n0); bq1 = *(const float4*)(epi.bias + n0 + 4); }
                 v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w; v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
             }
             if (c == 0) RNT(1);
-            // (the bf16 residual row is read in here, eight 2-byte loads BEHIND the slabs: 1.2 of the kernel's 3.5 us by the
-            // timeline -- yet requesting it as one 16-byte load ahead of the slabs made the decision 0.4 ms slower in a same-box
-            // A/B (35.0 vs 35.4 ms), so it stays)
-            epi_value4(epi, m, n0, N, v);
-            epi_value4(epi, m, n0 + 4, N, v + 4);
+            if (res_only) {   // epi_value4's arithmetic for a residual-only epilogue: bf16(sum) + residual
+                const uint32_t rw[4] = {rr.x, rr.y, rr.z, rr.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    v[2 * i] = bfround(v[2 * i]) + bf2f((bf16_t)(rw[i] & 0xffffu));
+                    v[2 * i + 1] = bfround(v[2 * i + 1]) + bf2f((bf16_t)(rw[i] >> 16));
+                }
+            } else if (res_bias) {   // bf16(sum + bias) + residual
+                const uint32_t rw[4] = {rr.x, rr.y, rr.z, rr.w};
+                const float bv[8] = {bq0.x, bq0.y, bq0.z, bq0.w, bq1.x, bq1.y, bq1.z, bq1.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    v[2 * i] = bfround(v[2 * i] + bv[2 * i]) + bf2f((bf16_t)(rw[i] & 0xffffu));
+                    v[2 * i + 1] = bfround(v[2 * i + 1] + bv[2 * i + 1]) + bf2f((bf16_t)(rw[i] >> 16));
+                }
+            } else {
+                epi_value4(epi, m, n0, N, v);
+                epi_value4(epi, m, n0 + 4, N, v + 4);
+            }
             if (c == 0) RNT(2);
             uint4 u;
             u.x = pack_bf2(v[0], v[1]); u.y = pack_bf2(v[2], v[3]); u.z = pack_bf2(v[4], v[5]); u.w = pack_bf2(v[6], v[7]);

@@ -1,0 +1,16 @@
+# round 6, GPU call 10: the reduction's epilogue operands requested with the first slab batch (default now) vs behind the slab sums (-DCOVER_RN_RES_EARLY=0 = rounds 1-5)
+cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+O=gpurun_out/r06; mkdir -p $O
+timeout 1200 python -m pytest tests/test_kernels_gpu.py tests/test_models_gpu.py -q 2>&1 | tail -3 | tee $O/c10_tests.txt
+for rep in 1 2 3; do for v in rn0 new; do
+  lib=$PWD/tools/ab/libcover_hip_$v.so; [ $v = new ] && lib=$PWD/cover_vla_amd/libcover_hip.so
+  echo "== $v headline (rep $rep)"; COVER_LIB_PATH=$lib timeout 600 python bench.py --no-cpu-baseline --no-profile --steps 20 --warmup 4 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.readline()); print(d['ms_per_step'])"
+done; done | tee $O/c10_rn_early_ab.txt
+for rep in 1 2; do for v in rn0 new; do
+  lib=$PWD/tools/ab/libcover_hip_$v.so; [ $v = new ] && lib=$PWD/cover_vla_amd/libcover_hip.so
+  echo "== $v P1 (rep $rep)"; COVER_LIB_PATH=$lib timeout 600 python bench.py --profile pi0 --no-cpu-baseline --no-profile --steps 20 --warmup 4 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.readline()); print(d['ms_per_step'])"
+done; done | tee -a $O/c10_rn_early_ab.txt
+for v in rn0 new; do
+  lib=$PWD/tools/ab/libcover_hip_$v.so; [ $v = new ] && lib=$PWD/cover_vla_amd/libcover_hip.so
+  echo "== $v config 5"; COVER_LIB_PATH=$lib timeout 900 python bench.py --dtype fp8 --samples 64 --horizon 8 --steps 3 --warmup 1 --no-cpu-baseline --no-profile --no-agreement 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.readline()); print(d['ms_per_step'])"
+done | tee -a $O/c10_rn_early_ab.txt

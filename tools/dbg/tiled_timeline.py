@@ -7,17 +7,28 @@ from cover_vla_amd import ops, _lib as L
 dev = torch.device("cuda:0")
 fn = L.lib().cover_pc_timeline
 fn.argtypes = [C.c_void_p]
-for M, N, K in [(261, 3072, 1024), (261, 4096, 1024), (256, 4608, 1152), (261, 1024, 1024), (576, 4096, 1024)]:
+# EXPERT=1: the pi0 action expert's four projections at M = 200 (qkv with an fp32 slab output as the decoder requests it, o_proj / down with the
+# residual + RMSNorm epilogue through split-K, gate_up with GLU): what the 8 launches per layer-step of the denoise loop look like from inside
+expert = os.environ.get("EXPERT") == "1"
+cases = ([(200, 2560, 1024, "f32"), (200, 1024, 2048, "norm"), (200, 8192, 1024, "glu"), (200, 1024, 4096, "norm")] if expert else
+         [(261, 3072, 1024, "bias"), (261, 4096, 1024, "bias"), (256, 4608, 1152, "bias"), (261, 1024, 1024, "bias"), (576, 4096, 1024, "bias")])
+for M, N, K, kind in cases:
     g = torch.Generator(device=dev).manual_seed(N)
-    bias = torch.randn(N, device=dev, generator=g)
-    lins = [ops.pack_linear((torch.randn(N, K, device=dev, generator=g) * 0.02).bfloat16(), bias) for _ in range(8)]
+    bias = torch.randn(N, device=dev, generator=g) if kind == "bias" else None
+    lins = [ops.pack_linear((torch.randn(N, K, device=dev, generator=g) * 0.02).bfloat16(), bias, glu=kind == "glu") for _ in range(8)]
     a = torch.randn(M, K, device=dev, generator=g).bfloat16()
-    o = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
-    for i in range(8): ops.gemm(a, lins[i], out=o, act="gelu_tanh")
+    o = torch.empty(M, lins[0].n_out, dtype=torch.float32 if kind == "f32" else torch.bfloat16, device=dev)
+    ws = ops.gemm_workspace(M, N, K, dev)
+    kw = dict(act="gelu_tanh") if kind in ("bias", "glu") else {}
+    if kind == "norm":
+        kw = dict(residual=o, norm_w=torch.ones(N, device=dev), norm_out=torch.empty(M, N, dtype=torch.bfloat16, device=dev), norm_style=0, norm_w_offset=1.0, norm_eps=1e-6)
+    for i in range(8): ops.gemm(a, lins[i], out=o, ws=ws, **kw)
     torch.cuda.synchronize()
     buf = np.zeros(8192, dtype=np.uint64)
-    ops.gemm(a, lins[0], out=o, act="gelu_tanh")
+    ops.gemm_plan_counts(reset=True)
+    ops.gemm(a, lins[0], out=o, ws=ws, **kw)
     torch.cuda.synchronize()
+    print(kind, "plans", [i for i, v in enumerate(ops.gemm_plan_counts()) if v], end="  ")
     fn(buf.ctypes.data)
     t = buf.reshape(1024, 8).astype(np.float64)
     t = t[t[:, 0] > 0]
