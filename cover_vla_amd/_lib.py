@@ -32,7 +32,8 @@ class GemmEpi(C.Structure):
                 ("act", c_i), ("glu", c_i), ("out_f32", c_i), ("out_scale", c_f),
                 ("norm_w", c_p), ("norm_out", c_p), ("ld_norm_out", c_i), ("norm_style", c_i), ("norm_w_offset", c_f),
                 ("norm_eps", c_f), ("norm_b", c_p), ("w8", c_p), ("w8_scale", c_p), ("a8", c_p), ("a8_scale", c_p), ("ld_a8", c_i), ("ld_norm_out8", c_i),
-                ("norm_out8", c_p), ("norm_out8_scale", c_p)]
+                ("norm_out8", c_p), ("norm_out8_scale", c_p),
+                ("a8_mx", c_p), ("out8", c_p), ("out8_mx", c_p), ("ld_out8", c_i), ("w8_klinear", c_i)]
 
 
 class KvSegment(C.Structure):
@@ -132,7 +133,7 @@ class DecLayer(C.Structure):
     _fields_ = [("in_norm_w", c_p), ("post_norm_w", c_p), ("qkv_w", c_p), ("qkv_b", c_p), ("o_w", c_p),
                 ("gate_up_w", c_p), ("down_w", c_p), ("k_cache", c_p), ("vt_cache", c_p),
                 ("qkv_w8", c_p), ("qkv_s", c_p), ("o_w8", c_p), ("o_s", c_p), ("gate_up_w8", c_p), ("gate_up_s", c_p),
-                ("down_w8", c_p), ("down_s", c_p)]
+                ("down_w8", c_p), ("down_s", c_p), ("down_klinear", c_i), ("_pad_dl", c_i)]
 
 
 class DecDesc(C.Structure):
@@ -178,6 +179,8 @@ SYMBOLS = {
     "cover_quantize_rows_fp8": (c_i, [c_p, c_i, c_i, c_i, c_p, c_p, c_p]),
     "cover_pack_weight_fp8": (c_i, [c_p, c_i, c_p, c_i, c_i, c_p, c_p, c_i, c_p]),
     "cover_quantize_act_fp8": (c_i, [c_p, c_i, c_i, c_i, c_p, c_i, c_p, c_p]),
+    "cover_quantize_act_fp8_mx": (c_i, [c_p, c_i, c_i, c_i, c_p, c_i, c_p, c_p]),
+    "cover_pack_weight_fp8_klinear": (c_i, [c_p, c_i, c_p, c_i, c_i, c_p, c_p, c_p]),
     "cover_gemm_workspace_bytes": (C.c_size_t, [c_i, c_i, c_i]),
     "cover_gemm_bf16": (c_i, [c_p, c_i, c_p, c_p, c_i, c_i, c_i, c_i, _P(GemmEpi), c_p, C.c_size_t, c_i, c_p]),
     "cover_gemm_plan_counts": (c_i, [C.POINTER(C.c_longlong), c_i, c_i]),

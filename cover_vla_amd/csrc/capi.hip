@@ -64,6 +64,18 @@ int cover_pack_weight_fp8(const void* Wdq, int ldw, const float* scales, int N, 
            "pack_weight_fp8");
     return COVER_OK;
 }
+int cover_pack_weight_fp8_klinear(const void* Wdq, int ldw, const float* scales, int N, int K, void* Wq, float* scales_packed, void* stream) {
+    if (!Wdq || !scales || !Wq || !scales_packed || N <= 0 || K <= 0) return fail(COVER_EINVAL, "cover_pack_weight_fp8_klinear: bad arguments");
+    HIPCHK(launch_pack_weight_fp8((const bf16_t*)Wdq, ldw, scales, N, K, (uint8_t*)Wq, scales_packed, cover_packed_k(K), 0, ST(stream), 1),
+           "pack_weight_fp8 (k-linear)");
+    return COVER_OK;
+}
+int cover_quantize_act_fp8_mx(const void* X, int ldx, int M, int K, void* out8, int ld8, void* mx, void* stream) {
+    if (!X || !out8 || !mx || M < 0 || K <= 0) return fail(COVER_EINVAL, "cover_quantize_act_fp8_mx: bad arguments");
+    HIPCHK(launch_quantize_act_fp8_mx((const bf16_t*)X, ldx, M, K, (uint8_t*)out8, ld8, (uint8_t*)mx, ST(stream)),
+           "quantize_act_fp8_mx (ld8 >= padded K, ld8 % 16 == 0, ldx % 8 == 0)");
+    return COVER_OK;
+}
 int cover_quantize_act_fp8(const void* X, int ldx, int M, int K, void* out8, int ld8, float* scales, void* stream) {
     if (!X || !out8 || !scales || M < 0 || K <= 0) return fail(COVER_EINVAL, "cover_quantize_act_fp8: bad arguments");
     HIPCHK(launch_quantize_act_fp8((const bf16_t*)X, ldx, M, K, (uint8_t*)out8, ld8, scales, ST(stream)),
@@ -402,7 +414,7 @@ int cover_vit_forward(const cover_vit_desc* d, void* x, int n_seq, int T, void* 
 }
 
 static size_t dec_ws(const cover_dec_desc* d, int rows, Carver* c, void** h, void** qkv, void** attn, void** mlp, void** sk,
-                     size_t* sk_bytes, void** st_o = nullptr, void** st_ml = nullptr, void** q8 = nullptr, void** q8s = nullptr) {
+                     size_t* sk_bytes, void** st_o = nullptr, void** st_ml = nullptr, void** q8 = nullptr, void** q8s = nullptr, void** q8mx = nullptr) {
     Carver tmp{nullptr, 0, 0};
     Carver& cc = c ? *c : tmp;
     const int nqkv = (d->Hq + 2 * d->Hkv) * d->D;
@@ -418,6 +430,7 @@ static size_t dec_ws(const cover_dec_desc* d, int rows, Carver* c, void** h, voi
         kmax = kmax > d->Hq * d->D ? kmax : d->Hq * d->D;
         p = cc.take((size_t)rows * ((kmax + 127) / 128 * 128)); if (q8) *q8 = p;
         p = cc.take((size_t)rows * 4); if (q8s) *q8s = p;
+        p = cc.take((size_t)rows * ((kmax + 127) / 128 * 4)); if (q8mx) *q8mx = p;   // MX block scales of the down_proj input ([k-tile][row][4])
     }
     size_t skb = 0;
     {
@@ -450,9 +463,9 @@ int cover_decoder_forward(const cover_dec_desc* d, const cover_dec_pass* p, void
         rows += G.B * G.T;
     }
     Carver c{(char*)ws.ptr, ws.bytes, 0};
-    void *h, *qkv, *attn, *mlp, *sk, *st_o, *st_ml, *q8, *q8s;
+    void *h, *qkv, *attn, *mlp, *sk, *st_o, *st_ml, *q8, *q8s, *q8mx;
     size_t skb;
-    const size_t need = dec_ws(d, rows, &c, &h, &qkv, &attn, &mlp, &sk, &skb, &st_o, &st_ml, &q8, &q8s);
+    const size_t need = dec_ws(d, rows, &c, &h, &qkv, &attn, &mlp, &sk, &skb, &st_o, &st_ml, &q8, &q8s, &q8mx);
     if (!ws.ptr || ws.bytes < need) return fail(COVER_EWORKSPACE, "cover_decoder_forward: workspace too small");
     const int dim = d->dim, Hq = d->Hq, Hkv = d->Hkv, D = d->D, nqkv = (Hq + 2 * Hkv) * D, HD = Hq * D;
 
@@ -471,6 +484,15 @@ int cover_decoder_forward(const cover_dec_desc* d, const cover_dec_pass* p, void
         e.a8 = q8; e.a8_scale = (const float*)q8s; e.ld_a8 = kp;
         return launch_quantize_act_fp8((const bf16_t*)src, K, rows, K, (uint8_t*)q8, kp, (float*)q8s, st);
     };
+    // MX block scales for the down_proj input (its weight twin is the k-linear image): the GLU epilogue of gate_up writes e4m3 rows + one E8M0 scale per 32
+    // columns INTO THE mlp BUFFER (no bf16 GLU output, no quantiser launch); COVER_FP8_MX_FUSE=0 keeps the bf16 output and runs cover_quantize_act_fp8_mx
+    // on it (same bytes, one launch more: the A/B of the fusion). Sizes below the fp8 tiles' (tests on small geometries) stay on the bf16 kernels.
+    const int mlp_p = (d->mlp + 127) / 128 * 128;
+    const bool down_kl = d->layers_host[0].down_klinear != 0;
+    const bool mx = f8 && down_kl && rows >= 400 && dim >= 2048 && d->mlp >= 2048 && (d->mlp % 32) == 0 &&
+                    (d->act == COVER_ACT_SILU || d->act == COVER_ACT_GELU_TANH);
+    const char* mxf_env = getenv("COVER_FP8_MX_FUSE");
+    const bool mx_fused = mx && !(mxf_env && mxf_env[0] == '0');
     // h = in_norm_0(x); afterwards every norm is folded into the epilogue of the GEMM that produces its input
     {
         const bool f32in = p->x_f32 != nullptr;
@@ -651,6 +673,7 @@ int cover_decoder_forward(const cover_dec_desc* d, const cover_dec_pass* p, void
         e.w8 = L.gate_up_w8; e.w8_scale = L.gate_up_s;
         if (f8q) use_q8(dim, e);
         else if (f8) HIPCHK(quant(h, dim, e), "dec quantise (gate_up input)");
+        if (mx_fused) { e.out8 = mlp; e.out8_mx = q8mx; e.ld_out8 = mlp_p; }
         HIPCHK(launch_gemm_bf16((const bf16_t*)h, dim, (const bf16_t*)L.gate_up_w, mlp, d->mlp, rows, 2 * d->mlp, dim, &e, (float*)sk, skb, variant, st), "dec gate_up");
         memset(&e, 0, sizeof e);
         e.out_scale = 1.0f;
@@ -659,8 +682,13 @@ int cover_decoder_forward(const cover_dec_desc* d, const cover_dec_pass* p, void
             e.norm_w = d->layers_host[l + 1].in_norm_w; e.norm_out = h; e.ld_norm_out = dim; e.norm_style = d->norm_style;
             e.norm_w_offset = d->norm_w_offset; e.norm_eps = d->norm_eps;
         }
-        e.w8 = L.down_w8; e.w8_scale = L.down_s;
-        if (f8) HIPCHK(quant(mlp, d->mlp, e), "dec quantise (down input)");
+        e.w8 = L.down_w8; e.w8_scale = L.down_s; e.w8_klinear = L.down_klinear;
+        if (mx) {
+            if (!mx_fused) HIPCHK(launch_quantize_act_fp8_mx((const bf16_t*)mlp, d->mlp, rows, d->mlp, (uint8_t*)q8, mlp_p, (uint8_t*)q8mx, st), "dec quantise (down input, MX)");
+            e.a8 = mx_fused ? mlp : q8; e.ld_a8 = mlp_p; e.a8_mx = q8mx;
+        } else if (f8 && !L.down_klinear) {
+            HIPCHK(quant(mlp, d->mlp, e), "dec quantise (down input)");
+        }   // (a k-linear twin below the MX sizes: bf16 operands on the bf16 image)
         if (l + 1 < d->n_layers) norm_q8(e);
         HIPCHK(launch_gemm_bf16((const bf16_t*)mlp, d->mlp, (const bf16_t*)L.down_w, x, dim, rows, dim, d->mlp, &e, (float*)sk, skb, variant, st), "dec down (+next in_norm)");
     }

@@ -432,6 +432,15 @@ __global__ __launch_bounds__(64 * (CGM * CGN + NL)) void gemm_tiled_pc(const bf1
     PCTL(3);
 }
 
+// k offset (inside a 64-aligned chunk) of the 8-wide run that lane group gg multiplies in 32-deep step kst. The bf16 image and the default e4m3
+// image hold k = 32 kst + 8 gg there; the k-linear e4m3 image (cover_pack_weight_fp8_klinear: the 16 bytes of a lane in a 64-deep block are 16
+// CONSECUTIVE k -- the matrix instruction's own k order, in which an MX block scale covers 32 neighbouring columns) holds k = 64 (kst / 2) + 16 gg + 8 (kst % 2).
+template <bool W8>
+__device__ __forceinline__ int x_run_k(int kst, int gg, int kl) {
+    if constexpr (W8) return kl ? ((kst >> 1) << 6) + gg * 16 + (kst & 1) * 8 : kst * 32 + gg * 8;
+    else return kst * 32 + gg * 8;
+}
+
 // MFMA weight fragment of 32-deep step u of a 256-deep item: bf16 items hold it as loaded; e4m3 items (16 bytes per lane = the
 // 8-wide k runs of steps 2j and 2j + 1) are converted with v_cvt_scalef32_pk_bf16_fp8 (scale 1: exact, every e4m3 value is a
 // bf16 value)
@@ -768,7 +777,7 @@ __device__ __forceinline__ void slab_store4(float* o, const float (&v)[4], int n
 // ---------------------------------------------------------------------------------------------------
 template <int MF, int KS, int NBW, bool W8 = false>
 __global__ __launch_bounds__(512) void gemm_skinny2(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ Wp,
-                                                    float* __restrict__ partial, int M, int N, int Kp, const float* __restrict__ wscale) {
+                                                    float* __restrict__ partial, int M, int N, int Kp, const float* __restrict__ wscale, int kl) {
     constexpr int NG = 8 / KS, KC = 256 * KS, NBPB = NG * NBW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -820,7 +829,7 @@ __global__ __launch_bounds__(512) void gemm_skinny2(const bf16_t* __restrict__ A
             const int fi = j * 8 + w, kst = fi / MF, f = fi - kst * MF;
             int row = f * 16 + rr;
             row = row < M ? row : M - 1;
-            xr[j] = *(const uint4*)(A + (size_t)row * lda + k0 + kst * 32 + gg * 8);
+            xr[j] = *(const uint4*)(A + (size_t)row * lda + k0 + x_run_k<W8>(kst, gg, kl));
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -867,7 +876,7 @@ __global__ __launch_bounds__(512) void gemm_skinny2(const bf16_t* __restrict__ A
 #pragma unroll 4
             for (int fi = w; fi < NFR; fi += 8) {
                 const int kst = fi / MF, f = fi - kst * MF;
-                const int row = f * 16 + rr, kk = kst * 32 + gg * 8;
+                const int row = f * 16 + rr, kk = x_run_k<W8>(kst, gg, kl);
                 uint4 v = make_uint4(0, 0, 0, 0);
                 if (row < M && kk < kc) v = *(const uint4*)(A + (size_t)row * lda + k0 + kk);
                 *(uint4*)(smem + fi * 1024 + lane * 16) = v;
@@ -961,7 +970,7 @@ extern "C" int cover_sk_debug(unsigned long long* out) {
 template <int MF, int KS, int NBW, int NBUF, bool W8 = false>
 __global__ __launch_bounds__(512) void gemm_skinny3(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ Wp,
                                                     void* C, int ldc, int M, int N, int Kp, EpiDev epi,
-                                                    float* __restrict__ partial, int kper, const float* __restrict__ wscale) {
+                                                    float* __restrict__ partial, int kper, const float* __restrict__ wscale, int kl) {
     SKT(0);
     constexpr int NG = 8 / KS, KC = 256 * KS, NBPB = NG * NBW;
     constexpr int XB = MF * 16 * KC * 2;          // bytes of one activation chunk (fragment-major)
@@ -1024,7 +1033,7 @@ __global__ __launch_bounds__(512) void gemm_skinny3(const bf16_t* __restrict__ A
 #pragma unroll
         for (int j = 0; j < XL; ++j) {
             const int fi = j * 8 + w, kst = fi / MF, f = fi - kst * MF;
-            const int row = f * 16 + srr, kk = kst * 32 + sgg * 8;
+            const int row = f * 16 + srr, kk = x_run_k<W8>(kst, sgg, kl);
             xr[j] = make_uint4(0, 0, 0, 0);
             if (row < M && kk < kc) xr[j] = *(const uint4*)(A + (size_t)row * lda + k0 + kk);
         }
@@ -1065,7 +1074,7 @@ __global__ __launch_bounds__(512) void gemm_skinny3(const bf16_t* __restrict__ A
                 const int fi = j * 8 + w, kst = fi / MF, f = fi - kst * MF;
                 int row = f * 16 + srr;
                 row = row < M ? row : M - 1;
-                xr[j] = *(const uint4*)(A + (size_t)row * lda + kb + kst * 32 + sgg * 8);
+                xr[j] = *(const uint4*)(A + (size_t)row * lda + kb + x_run_k<W8>(kst, sgg, kl));
             }
         }
 #pragma unroll
@@ -1102,7 +1111,7 @@ __global__ __launch_bounds__(512) void gemm_skinny3(const bf16_t* __restrict__ A
                 const int fi = j * 8 + w, kst = fi / MF, f = fi - kst * MF;
                 int row = f * 16 + srr;
                 row = row < M ? row : M - 1;
-                xr[j] = *(const uint4*)(A + (size_t)row * lda + k1 + kst * 32 + sgg * 8);
+                xr[j] = *(const uint4*)(A + (size_t)row * lda + k1 + x_run_k<W8>(kst, sgg, kl));
             }
             __builtin_amdgcn_sched_barrier(0);   // (the scheduler otherwise hoists the first MFMAs of all items and sinks the refills)
             const char* xb = smem + (c0 & 1) * XB;
@@ -1361,6 +1370,13 @@ static EpiDev make_epi(const cover_gemm_epi* e) {
     d.nq8s = e ? e->norm_out8_scale : nullptr;
     d.ldnq8 = e ? e->ld_norm_out8 : 0;
     if (!d.nq8 || !d.nq8s || !d.norm_out || d.norm_style == 2) { d.nq8 = nullptr; d.nq8s = nullptr; }
+    d.w8_kl = (e && d.w8) ? e->w8_klinear : 0;
+    d.a8mx = (e && d.w8 && e->a8) ? (const uint8_t*)e->a8_mx : nullptr;
+    if (d.a8mx) { d.a8 = (const uint8_t*)e->a8; d.a8s = nullptr; }   // (a8_scale is not needed with block scales)
+    d.o8 = e ? (uint8_t*)e->out8 : nullptr;
+    d.o8mx = e ? (uint8_t*)e->out8_mx : nullptr;
+    d.ldo8 = e ? e->ld_out8 : 0;
+    if (!d.o8 || !d.o8mx) { d.o8 = nullptr; d.o8mx = nullptr; }
     return d;
 }
 
@@ -1507,10 +1523,10 @@ void gemm_plan_counts(long long* out, int n, int reset) {
 }
 
 static void launch_skinny2(const Skinny2Plan& p, const bf16_t* A, int lda, const bf16_t* Wp, float* ws, int M, int N, int K, int Kp,
-                           const uint8_t* w8, const float* w8s, hipStream_t st) {
+                           const uint8_t* w8, const float* w8s, int kl, hipStream_t st) {
     dim3 grid(p.gx, p.S), block(512);
     plan_hit(19);
-#define SK2(MF_, KS_, NBW_, W8_) launch_streaming(sk_class(N, K), (W8_ ? 1.0 : 2.0) * (double)N * (double)K, gemm_skinny2<MF_, KS_, NBW_, W8_>, grid, block, p.lds, st, A, lda, W8_ ? (const bf16_t*)w8 : Wp, ws, M, N, Kp, w8s)
+#define SK2(MF_, KS_, NBW_, W8_) launch_streaming(sk_class(N, K), (W8_ ? 1.0 : 2.0) * (double)N * (double)K, gemm_skinny2<MF_, KS_, NBW_, W8_>, grid, block, p.lds, st, A, lda, W8_ ? (const bf16_t*)w8 : Wp, ws, M, N, Kp, w8s, kl)
     if (w8 && w8s && p.MF <= 2) {
         if (p.MF == 1) { if (p.NBW == 6) SK2(1, 4, 6, true); else if (p.NBW == 4) SK2(1, 4, 4, true); else if (p.NBW == 3) SK2(1, 4, 3, true); else SK2(1, 4, 2, true); }
         else { if (p.NBW == 6) SK2(2, 4, 6, true); else if (p.NBW == 4) SK2(2, 4, 4, true); else if (p.NBW == 3) SK2(2, 4, 3, true); else SK2(2, 4, 2, true); }
@@ -1534,7 +1550,7 @@ static hipError_t launch_skinny3(const Skinny3Plan& p, const bf16_t* A, int lda,
         if (p.lds > 64 * 1024) e = LDS_ATTR_160K(kfn);                                                         \
         if (e == hipSuccess)                                                                                                \
             launch_streaming(sk_class(N, Kp), (W8_ ? 1.0 : 2.0) * (double)N * (double)Kp, kfn, grid, block, p.lds, st, A, lda,  \
-                             W8_ ? (const bf16_t*)epi.w8 : Wp, C, ldc, M, N, Kp, epi, partial, p.kper, epi.w8s);             \
+                             W8_ ? (const bf16_t*)epi.w8 : Wp, C, ldc, M, N, Kp, epi, partial, p.kper, epi.w8s, epi.w8_kl);             \
     } while (0)
     if (epi.w8) {   // e4m3 weight stream
         if (p.MF == 1) { if (p.NBW == 4) SK3(1, 4, true); else if (p.NBW == 3) SK3(1, 3, true); else SK3(1, 2, true); }
@@ -1563,6 +1579,14 @@ hipError_t launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* Wp, void* C,
     const int Kp = (K + 127) / 128 * 128;
     EpiDev epi = make_epi(epi_in);
     if (variant == 0) variant = (M <= 64 && ws != nullptr) ? 3 : 1;
+    // MX block scales (cover_gemm_epi.a8_mx / out8): the self-loading fp8 tiles only
+    const bool mx_any = epi.a8mx != nullptr || epi.o8 != nullptr;
+    if (mx_any) {
+        if (variant != 1 || !epi.a8 || !epi.w8 || M <= 64 || (size_t)M * epi.lda8 + 4096 >= ((size_t)1 << 31)) return hipErrorInvalidValue;
+        if (epi.a8mx && (!epi.w8_kl || epi.glu)) return hipErrorInvalidValue;
+        if (epi.o8 && (!epi.glu || (epi.act != ACT_SILU && epi.act != ACT_GELU_TANH) || ((N / 2) % 32) != 0 || epi.ldo8 < N / 2 || (epi.ldo8 & 15) || epi.out_f32))
+            return hipErrorInvalidValue;
+    }
     // the reduction launch that can carry the norm (splitk_reduce_norm)
     const bool norm_fusable = epi.norm_w != nullptr && epi.norm_out != nullptr && !epi.glu && !epi.out_f32 && (N % 8) == 0 && N <= 8192 && (ldc % 8) == 0 &&
                               (epi.ld_norm_out % 8) == 0 && (((uintptr_t)epi.norm_w) & 15) == 0;
@@ -1599,7 +1623,7 @@ hipError_t launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* Wp, void* C,
             Skinny2Plan p = plan_skinny2(M, N, Kp);
             if (ws == nullptr || ws_bytes < p.ws_bytes) return hipErrorInvalidValue;
             dim3 grid(p.gx, p.S), block(512);
-            launch_skinny2(p, A, lda, Wp, ws, M, N, K, Kp, epi.w8, epi.w8s, st);
+            launch_skinny2(p, A, lda, Wp, ws, M, N, K, Kp, epi.w8, epi.w8s, epi.w8_kl, st);
             S = p.S;
         }
         hipError_t e = hipGetLastError();
@@ -1754,6 +1778,7 @@ hipError_t launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* Wp, void* C,
             for (int c = 0; c < 3; ++c) {
                 if (epi.glu && (bns[c] % 32)) continue;
                 if (f8_on && bns[c] == 192) continue;   // no fp8 instantiation of the 224 x 192 tile (registers)
+                if (mx_any && bns[c] == 96) continue;   // (the fp8 224 x 96 tile is a loader-wave kernel: no block scales)
                 for (int S = 1; S <= 8; S *= 2) {
                     if (S > 1 && (ws == nullptr || (size_t)S * M * N * sizeof(float) > ws_bytes || epi.glu || (Kp / BK) / S < 8)) break;
                     const long long blocks = (long long)t224 * ((N + bns[c] - 1) / bns[c]) * S;
@@ -1775,6 +1800,10 @@ hipError_t launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* Wp, void* C,
     // the 256 x 128 / 128 x 256 tiles (M >= 512 with more than 10 % of 224-row padding: config 4's 704-row prefill) run on the self-loading kernel
     if (v3_on) pick = pick == 12 ? 25 : pick == 13 ? 26 : pick;
     if (!v3_on && pick >= 23) pick = f8_on ? (pick == 24 ? 15 : pick == 25 ? 12 : pick == 26 ? 13 : pick == 27 ? 17 : 10) : 0;
+    if (mx_any) {
+        if (!f8_on) return hipErrorInvalidValue;                                   // (COVER_FP8_MFMA=0 with block-scaled operands)
+        if (pick != 12 && pick != 13 && pick != 15 && pick != 18) pick = 13;      // any M on the 128 x 256 self-loading tile
+    }
     // bf16 operands: of the loader-wave tiles only the 64 x 128 four-stage one (pick 10) is still a default; the others exist as fp8 kernels
     if (!(f8_on && gemm_fp8_tiled_supported(pick)) && ((pick >= 11 && pick <= 18) || pick == 9)) pick = (variant == 2 || pick == 9) ? 1 : 0;
     if (variant == 2 && pick > 2) pick = 0;
@@ -1793,6 +1822,7 @@ hipError_t launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* Wp, void* C,
         static const char* split_env = getenv("COVER_TILE_SPLIT");   // experiment knob: force the number of K slices
         if (split_env && atoi(split_env) >= 1 && (size_t)atoi(split_env) * M * N * sizeof(float) <= ws_bytes) S = atoi(split_env);
     }
+    if (epi.o8) S = 1;   // (the block-scaled GLU output is written by the GEMM's own epilogue, not by a split-K reduction)
     const int kt_per = (nk_total + S - 1) / S;
     S = (nk_total + kt_per - 1) / kt_per;
     float* partial = S > 1 ? ws : nullptr;
@@ -1917,7 +1947,7 @@ hipError_t launch_gemm_skinny_partial(const bf16_t* A, int lda, const bf16_t* Wp
     Skinny2Plan p = plan_skinny2(M, N, Kp);
     if (ws == nullptr || ws_bytes < p.ws_bytes) return hipErrorInvalidValue;
     dim3 grid(p.gx, p.S), block(512);
-    launch_skinny2(p, A, lda, Wp, ws, M, N, K, Kp, (const uint8_t*)w8, w8s, st);
+    launch_skinny2(p, A, lda, Wp, ws, M, N, K, Kp, (const uint8_t*)w8, w8s, 0, st);
     *S_out = p.S;
     return hipGetLastError();
 }
@@ -1958,7 +1988,7 @@ __global__ __launch_bounds__(256) void quantize_rows_fp8_k(const bf16_t* __restr
 }
 
 __global__ void pack_weight_fp8_k(const bf16_t* __restrict__ Wdq, int ldw, const float* __restrict__ scales, int N, int K,
-                                  uint8_t* __restrict__ Wq, float* __restrict__ scales_packed, int Kp, int glu) {
+                                  uint8_t* __restrict__ Wq, float* __restrict__ scales_packed, int Kp, int glu, int kl) {
     const int K64 = Kp >> 6;
     const int N16 = (N + 15) >> 4;
     const long long total = (long long)N16 * K64 * 64;
@@ -1978,7 +2008,8 @@ __global__ void pack_weight_fp8_k(const bf16_t* __restrict__ Wdq, int ldw, const
         uint32_t o[4];
 #pragma unroll
         for (int half_ = 0; half_ < 2; ++half_) {      // k32 step 0 / 1 of the 64-block
-            const int k = kb * 64 + half_ * 32 + (lane >> 4) * 8;
+            // default image: the lane's 8-wide runs of the two 32-deep steps of the 64-block; k-linear image: the lane's 16 consecutive k of the block
+            const int k = kl ? kb * 64 + (lane >> 4) * 16 + half_ * 8 : kb * 64 + half_ * 32 + (lane >> 4) * 8;
             float v[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = (n < N && k + e < K) ? bf2f(Wdq[(size_t)n * ldw + k + e]) * inv : 0.f;
@@ -1999,11 +2030,11 @@ hipError_t launch_quantize_rows_fp8(const bf16_t* W, int ldw, int N, int K, floa
     return hipGetLastError();
 }
 hipError_t launch_pack_weight_fp8(const bf16_t* Wdq, int ldw, const float* scales, int N, int K, uint8_t* Wq, float* scales_packed,
-                                  int Kpad, int glu, hipStream_t st) {
+                                  int Kpad, int glu, hipStream_t st, int kl) {
     const long long total = (long long)((N + 15) / 16) * (Kpad / 64) * 64;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 65535) blocks = 65535;
-    hipLaunchKernelGGL(pack_weight_fp8_k, dim3(blocks), dim3(256), 0, st, Wdq, ldw, scales, N, K, Wq, scales_packed, Kpad, glu);
+    hipLaunchKernelGGL(pack_weight_fp8_k, dim3(blocks), dim3(256), 0, st, Wdq, ldw, scales, N, K, Wq, scales_packed, Kpad, glu, kl);
     return hipGetLastError();
 }
 

@@ -29,6 +29,14 @@ struct EpiDev {
     uint8_t* nq8;           // optional e4m3 twin of norm_out (+ row scales), written by the norm that writes norm_out
     float* nq8s;
     int ldnq8;
+    // MX block scales (config 5, down_proj): w8_kl = 1: w8 is the k-linear e4m3 image (cover_pack_weight_fp8_klinear); a8mx: e8m0 block scales of a8
+    // ([Kp / 128][M][4] bytes, one per 32 consecutive k; a8 is then PLAIN row-major e4m3 and a8s is not read); o8 / o8mx: a GLU GEMM writes its output
+    // rows in that form (pitch ldo8 bytes) INSTEAD of bf16 C -- the next GEMM's operand without a quantiser launch
+    int w8_kl;
+    const uint8_t* a8mx;
+    uint8_t* o8;
+    uint8_t* o8mx;
+    int ldo8;
 };
 
 // e4m3 quantisation of 8 consecutive bf16-valued elements k..k+7 of an activation row into the MX MFMA operand order
@@ -49,6 +57,24 @@ __device__ __forceinline__ float e4m3_pow2_scale(float mx) {
         s = ldexpf(1.0f, f == 0.5f ? e - 1 : e);
     }
     return s;
+}
+// MX block quantisation (cover_quantize_act_fp8_mx's arithmetic) of 8 consecutive bf16-valued elements held by this thread; the four lanes 4q .. 4q + 3
+// of the wave hold the four chunks of ONE 32-wide block and must all be active. s = smallest power of two >= 2^-126 with amax_block / s <= 448
+// (2^0 for an all-zero block); returns its e8m0 byte (127 + log2 s) and the 8 e4m3 bytes RNE(v / s).
+__device__ __forceinline__ uint32_t mx_quant_chunk(const float (&v)[8], uint2& q) {
+    float mx = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) mx = fmaxf(mx, fabsf(v[e]));
+    mx = fmaxf(mx, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, mx), 0xB1, 0xf, 0xf, true)));   // quad_perm [1,0,3,2]
+    mx = fmaxf(mx, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, mx), 0x4E, 0xf, 0xf, true)));   // quad_perm [2,3,0,1]
+    const float s = fmaxf(e4m3_pow2_scale(mx), 1.1754943508222875e-38f);
+    const float inv = 1.0f / s;   // exact
+    int lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[0] * inv, v[1] * inv, 0, false);
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[2] * inv, v[3] * inv, lo, true);
+    int hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[4] * inv, v[5] * inv, 0, false);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[6] * inv, v[7] * inv, hi, true);
+    q = make_uint2((uint32_t)lo, (uint32_t)hi);
+    return (__builtin_bit_cast(uint32_t, s) >> 23) & 0xffu;
 }
 
 // val[4] are 4 consecutive columns n0..n0+3 of row m: bias / activation / layer-scale / residual / scale, in place.
@@ -298,7 +324,7 @@ __device__ __forceinline__ void staged_fill_row(f32x4 (&acc)[WN][WM], char* st, 
 
 // BM x BN tile of the block at (m0, n0); the calling threads are `nthr` consecutive threads with index `t` (every one of them
 // owns accumulators). `st` = the block's dynamic LDS (at least st_bytes large), free to overwrite.
-template <int WM, int WN, int BM, int BN>
+template <int WM, int WN, int BM, int BN, bool MXO = false>   // MXO: the kernel can write the block-scaled e4m3 GLU output (epi.o8; gemm_fp8.hip)
 __device__ __forceinline__ void tiled_epilogue_staged(f32x4 (&acc)[WN][WM], const EpiDev& epi, void* C, int ldc, int M, int N, int m0,
                                                       int n0, int mw, int nw, int r, int g, float* __restrict__ partial, char* st,
                                                       int st_bytes, int t, int nthr, bool owner = true) {
@@ -324,6 +350,7 @@ __device__ __forceinline__ void tiled_epilogue_staged(f32x4 (&acc)[WN][WM], cons
     const bool ok = (size_t)rpp * pitch <= (size_t)st_bytes && cvalid > 0 && ((cvalid * esz_out) & 15) == 0 && (ld_bytes & 15) == 0 &&
                     ((((uintptr_t)base) + (size_t)oc0 * esz_out) & 15) == 0 && !((glu || plain) && epi.out_f32);
     if (!ok) {   // uniform over the block
+        if (epi.o8 && !raw) __builtin_trap();   // the block-scaled output exists in the staged GLU store loop only (the launcher checks its conditions)
         if (owner) tiled_epilogue<WM, WN>(acc, epi, C, ldc, M, N, mw, nw, r, g, partial);
         return;
     }
@@ -447,8 +474,9 @@ __device__ __forceinline__ void tiled_epilogue_staged(f32x4 (&acc)[WN][WM], cons
         // GLU store loop with the activation selected ONCE (the per-element switch of act_apply inside an 8-wide body was a scalar branch per
         // element): output columns 8 ch .. 8 ch + 7 = pair ch / 2, half ch % 2: gate at tile column 32 (ch / 2) + 8 (ch % 2), up 16 further.
         // epi_store4_glu's arithmetic on the already bf16-rounded gate / up values.
-        auto body = [&](auto ACT) {
+        auto body = [&](auto ACT, auto MXO_) {
             constexpr int act = decltype(ACT)::value;
+            constexpr bool mxo = decltype(MXO_)::value;   // e4m3 + MX block scales instead of bf16 (epi.o8): see cover_gemm_epi.out8
             for (int c = t; c < total; c += nthr) {
                 const int row = div_cpr(c), ch = c - row * cpr;
                 const int m = m0 + r0 + row;
@@ -462,11 +490,33 @@ __device__ __forceinline__ void tiled_epilogue_staged(f32x4 (&acc)[WN][WM], cons
                     const float g0 = bfround(act_apply_bf16(bf2f((bf16_t)(gw[i] & 0xffffu)), act)), g1 = bfround(act_apply_bf16(bf2f((bf16_t)(gw[i] >> 16)), act));
                     ow[i] = pack_bf2(g0 * bf2f((bf16_t)(uw[i] & 0xffffu)), g1 * bf2f((bf16_t)(uw[i] >> 16)));
                 }
-                *(uint4*)(base + (size_t)m * ld_bytes + (size_t)oc0 * esz_out + ch * 16) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+                if constexpr (!mxo) {
+                    *(uint4*)(base + (size_t)m * ld_bytes + (size_t)oc0 * esz_out + ch * 16) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+                } else {
+                    // the bf16 values that would have been stored, block-quantised: chunk ch of the row sits in lane % 4 == ch % 4 (cpr % 4 == 0, nthr % 4 == 0),
+                    // so a quad holds one 32-wide block; rows and the loop bound are uniform over a quad
+                    float v[8];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { v[2 * i] = bf2f((bf16_t)(ow[i] & 0xffffu)); v[2 * i + 1] = bf2f((bf16_t)(ow[i] >> 16)); }
+                    uint2 q;
+                    const uint32_t sb = mx_quant_chunk(v, q);
+                    const int col = oc0 + ch * 8;
+                    *(uint2*)(epi.o8 + (size_t)m * epi.ldo8 + col) = q;
+                    if ((ch & 3) == 0) epi.o8mx[((size_t)(col >> 7) * M + m) * 4 + ((col >> 5) & 3)] = (uint8_t)sb;
+                }
             }
         };
-        if (epi.act == ACT_SILU) body(std::integral_constant<int, ACT_SILU>{});
-        else body(std::integral_constant<int, ACT_GELU_TANH>{});
+        if (epi.o8) {
+            if constexpr (MXO) {
+                if (epi.act == ACT_SILU) body(std::integral_constant<int, ACT_SILU>{}, std::true_type{});
+                else body(std::integral_constant<int, ACT_GELU_TANH>{}, std::true_type{});
+            } else {
+                __builtin_trap();   // (the launcher sends such a GEMM to a kernel instantiated with MXO)
+            }
+        } else {
+            if (epi.act == ACT_SILU) body(std::integral_constant<int, ACT_SILU>{}, std::false_type{});
+            else body(std::integral_constant<int, ACT_GELU_TANH>{}, std::false_type{});
+        }
         continue;
     }
     for (int c = t; c < total; c += nthr) {
@@ -516,6 +566,20 @@ __device__ __forceinline__ void glds16_s(uint32_t voff, const void* sbase, uint3
         "s_mov_b32 m0, %3\n\t"
         "s_nop 0\n\t"
         "global_load_lds_dwordx4 %1, %2\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voff), "s"(sbase), "s"(lds_wave_base_u32)
+        : "memory");
+}
+
+// the 4-byte form: LDS destination = M0 + lane * 4
+__device__ __forceinline__ void glds4_s(uint32_t voff, const void* sbase, uint32_t lds_wave_base_u32) {
+    uint32_t keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %3\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dword %1, %2\n\t"
         "s_mov_b32 m0, %0"
         : "=&s"(keep)
         : "v"(voff), "s"(sbase), "s"(lds_wave_base_u32)

@@ -64,29 +64,40 @@ __device__ __forceinline__ void read_w_frags_range(u32x4 (&wlo)[WN], u32x4 (&whi
         read_w_frags_range<B + 1, BEND, WN>(wlo, whi, ba);
     }
 }
-__device__ __forceinline__ f32x4 mfma_f8(const u32x4& wl, const u32x4& wh, const u32x4& xl, const u32x4& xh, f32x4 c) {
+// sx: the E8M0 block scale of the activation operand in byte 0 (every lane: the scale of ITS 32 operand bytes); 2^0 without MX block scales
+__device__ __forceinline__ f32x4 mfma_f8(const u32x4& wl, const u32x4& wh, const u32x4& xl, const u32x4& xh, f32x4 c, int sx = 0x7f7f7f7f) {
     const i32x8 wa = {(int)wl[0], (int)wl[1], (int)wl[2], (int)wl[3], (int)wh[0], (int)wh[1], (int)wh[2], (int)wh[3]};
     const i32x8 xa = {(int)xl[0], (int)xl[1], (int)xl[2], (int)xl[3], (int)xh[0], (int)xh[1], (int)xh[2], (int)xh[3]};
-    return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wa, xa, c, 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);   // every E8M0 block scale = 2^0
+    return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wa, xa, c, 0, 0, 0, 0x7f7f7f7f, 0, sx);   // weight block scales 2^0 (per-channel scales in the epilogue)
 }
-// MFMAs of one k-tile, b outer / f inner, behind counted waits. Read issue order: w[0], x[0..WM), w[1..WN) (two reads each).
-template <int B, int F, int WM, int WN>
-__device__ __forceinline__ void mfma_tile(f32x4 (&acc)[WN][WM], u32x4 (&xlo)[WM], u32x4 (&xhi)[WM], u32x4 (&wlo)[WN], u32x4 (&whi)[WN]) {
-    if constexpr (B < WN) {
-        constexpr int TOTAL = 2 * (WM + WN);
-        // reads that must have landed: b == 0: w[0] + x[0..f] = 2 + 2 (f + 1); b >= 1: everything up to w[b] = 2 + 2 WM + 2 b
-        constexpr int need = (B == 0) ? 2 + 2 * (F + 1) : 2 + 2 * WM + 2 * B;
-        if constexpr (B == 0 || F == 0) {
-            wait_lgkm<TOTAL - need>();
-            asm volatile("" : "+v"(wlo[B]), "+v"(whi[B]), "+v"(xlo[F]), "+v"(xhi[F]));   // ties the fragments to the wait
-            __builtin_amdgcn_sched_barrier(0);
+// activation block scales of the current k-tile, per m-fragment: none (per-row scales, applied in the epilogue) ...
+struct NoScale {
+    __device__ __forceinline__ void prepare() const {}
+    __device__ __forceinline__ int operator()(int) const { return 0x7f7f7f7f; }
+};
+// ... or MX: raw[f] = the dword [k-tile][row] of four E8M0 bytes (k-blocks g = 0..3 of the tile) that this lane's ds_read_b32 of fragment f fetched for the
+// NEXT tile; prepare() -- called behind a wait that covers those reads -- moves the lane's own byte (g = lane / 16) down for the MFMAs of that tile
+template <int WM>
+struct MxScale {
+    uint32_t raw[WM];
+    int s[WM];
+    int sh;
+    __device__ __forceinline__ void prepare() {
+#pragma unroll
+        for (int f = 0; f < WM; ++f) {
+            asm volatile("" : "+v"(raw[f]));
+            s[f] = (int)((raw[f] >> sh) & 0xffu);
         }
-        acc[B][F] = mfma_f8(wlo[B], whi[B], xlo[F], xhi[F], acc[B][F]);
-        if constexpr (F + 1 < WM) mfma_tile<B, F + 1, WM, WN>(acc, xlo, xhi, wlo, whi);
-        else mfma_tile<B + 1, 0, WM, WN>(acc, xlo, xhi, wlo, whi);
+    }
+    __device__ __forceinline__ int operator()(int f) const { return s[f]; }
+};
+template <int F, int WM>
+__device__ __forceinline__ void read_mx_scales(MxScale<WM>& sc, uint32_t addr) {
+    if constexpr (F < WM) {
+        asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(sc.raw[F]) : "v"(addr), "n"(F * 64));
+        read_mx_scales<F + 1, WM>(sc, addr);
     }
 }
-
 
 // ---- software-pipelined consumer: fragments are refilled IN PLACE, as soon as their last MFMA of the tile has issued -------------
 // Steady state of tile kt (registers hold every fragment of tile kt; the reads of x[0..WM) and w[WN-1] are the youngest in flight):
@@ -98,42 +109,43 @@ __device__ __forceinline__ void mfma_tile(f32x4 (&acc)[WN][WM], u32x4 (&xlo)[WM]
 // so the LDS latency of tile kt+1's fragments hides behind tile kt's MFMAs and no second fragment set is needed (a full second
 // set does not fit the 168 registers of a 12-wave block). Issue order of the next tile's reads: w'[0..WN-2], x'[0..WM), w'[WN-1]
 // (two reads each: the k-halves c = 0, 1), which is what the waits of the next phase 0 count.
-template <int F, int WM, int WN>
-__device__ __forceinline__ void phase0(f32x4 (&acc)[WN][WM], u32x4 (&xlo)[WM], u32x4 (&xhi)[WM], u32x4 (&wlo)[WN], u32x4 (&whi)[WN]) {
+template <int F, int WM, int WN, typename SC>
+__device__ __forceinline__ void phase0(f32x4 (&acc)[WN][WM], u32x4 (&xlo)[WM], u32x4 (&xhi)[WM], u32x4 (&wlo)[WN], u32x4 (&whi)[WN], SC& sc) {
     if constexpr (F < WM) {
         wait_lgkm<2 * (WM - 1 - F) + 2>();                       // younger reads allowed in flight: x[F+1..WM) and w[WN-1]
         asm volatile("" : "+v"(wlo[0]), "+v"(whi[0]), "+v"(xlo[F]), "+v"(xhi[F]));
+        if constexpr (F == 0) sc.prepare();                      // (the tile's block-scale reads are older than every fragment read)
         __builtin_amdgcn_sched_barrier(0);
-        acc[0][F] = mfma_f8(wlo[0], whi[0], xlo[F], xhi[F], acc[0][F]);
-        phase0<F + 1, WM, WN>(acc, xlo, xhi, wlo, whi);
+        acc[0][F] = mfma_f8(wlo[0], whi[0], xlo[F], xhi[F], acc[0][F], sc(F));
+        phase0<F + 1, WM, WN>(acc, xlo, xhi, wlo, whi, sc);
     }
 }
-template <int B, int WM, int WN, bool REFILL>
-__device__ __forceinline__ void mid_phases(f32x4 (&acc)[WN][WM], u32x4 (&xlo)[WM], u32x4 (&xhi)[WM], u32x4 (&wlo)[WN], u32x4 (&whi)[WN], uint32_t ba) {
+template <int B, int WM, int WN, bool REFILL, typename SC>
+__device__ __forceinline__ void mid_phases(f32x4 (&acc)[WN][WM], u32x4 (&xlo)[WM], u32x4 (&xhi)[WM], u32x4 (&wlo)[WN], u32x4 (&whi)[WN], uint32_t ba, SC& sc) {
     if constexpr (B < WN - 1) {
 #pragma unroll
-        for (int f = 0; f < WM; ++f) acc[B][f] = mfma_f8(wlo[B], whi[B], xlo[f], xhi[f], acc[B][f]);
+        for (int f = 0; f < WM; ++f) acc[B][f] = mfma_f8(wlo[B], whi[B], xlo[f], xhi[f], acc[B][f], sc(f));
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (REFILL) {
             ds_read128<B * 2048>(wlo[B], ba);
             ds_read128<B * 2048 + 1024>(whi[B], ba);
             __builtin_amdgcn_sched_barrier(0);
         }
-        mid_phases<B + 1, WM, WN, REFILL>(acc, xlo, xhi, wlo, whi, ba);
+        mid_phases<B + 1, WM, WN, REFILL>(acc, xlo, xhi, wlo, whi, ba, sc);
     }
 }
-template <int F, int WM, int WN, bool REFILL>
+template <int F, int WM, int WN, bool REFILL, typename SC>
 __device__ __forceinline__ void last_phase(f32x4 (&acc)[WN][WM], u32x4 (&xlo)[WM], u32x4 (&xhi)[WM], u32x4 (&wlo)[WN], u32x4 (&whi)[WN], uint32_t a0, uint32_t a1,
-                                           uint32_t ba) {
+                                           uint32_t ba, SC& sc) {
     if constexpr (F < WM) {
-        acc[WN - 1][F] = mfma_f8(wlo[WN - 1], whi[WN - 1], xlo[F], xhi[F], acc[WN - 1][F]);
+        acc[WN - 1][F] = mfma_f8(wlo[WN - 1], whi[WN - 1], xlo[F], xhi[F], acc[WN - 1][F], sc(F));
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (REFILL) {
             ds_read128<F * 2048>(xlo[F], a0);
             ds_read128<F * 2048>(xhi[F], a1);
             __builtin_amdgcn_sched_barrier(0);
         }
-        last_phase<F + 1, WM, WN, REFILL>(acc, xlo, xhi, wlo, whi, a0, a1, ba);
+        last_phase<F + 1, WM, WN, REFILL>(acc, xlo, xhi, wlo, whi, a0, a1, ba, sc);
     } else if constexpr (REFILL) {
         ds_read128<(WN - 1) * 2048>(wlo[WN - 1], ba);
         ds_read128<(WN - 1) * 2048 + 1024>(whi[WN - 1], ba);
@@ -233,6 +245,7 @@ __global__ __launch_bounds__(64 * (CGM * CGN + NL)) void gemm_tiled_pc_f8(const 
     const uint32_t b_addr = lds_addr_u32(Bs) + (wn * WN * 2 * 64 + lane) * 16;
     static_assert(WN >= 2, "the pipelined consumer refills w[0] while w[WN-1] is still needed");
     u32x4 xlo[WM], xhi[WM], wlo[WN], whi[WN];
+    NoScale sc;   // per-row activation scales: applied to the sums below
     // prologue: tile 0 published; all of its fragments requested in the steady-state order w[0..WN-2], x[0..WM), w[WN-1]
     asm volatile("s_barrier" ::: "memory");
     {
@@ -244,7 +257,7 @@ __global__ __launch_bounds__(64 * (CGM * CGN + NL)) void gemm_tiled_pc_f8(const 
     }
     int nxt = NST > 1 ? 1 : 0;                                    // stage of tile kt + 1
     for (int kt = 0; kt + 1 < nk; ++kt) {
-        phase0<0, WM, WN>(acc, xlo, xhi, wlo, whi);
+        phase0<0, WM, WN>(acc, xlo, xhi, wlo, whi, sc);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // w[WN-1] landed too: stage kt is free; tile kt+1 is published
         asm volatile("" : "+v"(wlo[WN - 1]), "+v"(whi[WN - 1]));
         __builtin_amdgcn_sched_barrier(0);
@@ -252,17 +265,17 @@ __global__ __launch_bounds__(64 * (CGM * CGN + NL)) void gemm_tiled_pc_f8(const 
         ds_read128<0>(wlo[0], ba);
         ds_read128<1024>(whi[0], ba);
         __builtin_amdgcn_sched_barrier(0);
-        mid_phases<1, WM, WN, true>(acc, xlo, xhi, wlo, whi, ba);
-        last_phase<0, WM, WN, true>(acc, xlo, xhi, wlo, whi, a0, a1, ba);
+        mid_phases<1, WM, WN, true>(acc, xlo, xhi, wlo, whi, ba, sc);
+        last_phase<0, WM, WN, true>(acc, xlo, xhi, wlo, whi, a0, a1, ba, sc);
         nxt = nxt == NST - 1 ? 0 : nxt + 1;
     }
     {   // last tile: no refills
-        phase0<0, WM, WN>(acc, xlo, xhi, wlo, whi);
+        phase0<0, WM, WN>(acc, xlo, xhi, wlo, whi, sc);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         asm volatile("" : "+v"(wlo[WN - 1]), "+v"(whi[WN - 1]));
         __builtin_amdgcn_sched_barrier(0);
-        mid_phases<1, WM, WN, false>(acc, xlo, xhi, wlo, whi, 0u);
-        last_phase<0, WM, WN, false>(acc, xlo, xhi, wlo, whi, 0u, 0u, 0u);
+        mid_phases<1, WM, WN, false>(acc, xlo, xhi, wlo, whi, 0u, sc);
+        last_phase<0, WM, WN, false>(acc, xlo, xhi, wlo, whi, 0u, 0u, 0u, sc);
     }
     // quantisation scales (constant along k): row scale of A x channel scale of W, on the fp32 sums
     {
@@ -300,11 +313,12 @@ __global__ __launch_bounds__(64 * (CGM * CGN + NL)) void gemm_tiled_pc_f8(const 
 // ---------------------------------------------------------------------------------------------------
 template <int V> using IC8 = std::integral_constant<int, V>;
 // DMA slot s of a tile = behind the MFMAs of middle phase s + 1 (s < WN - 2), then behind MFMA s - (WN - 2) of the last phase
-template <int B, int WM, int WN, bool REFILL, typename DMA>
-__device__ __forceinline__ void mid_phases_dma(f32x4 (&acc)[WN][WM], u32x4 (&xlo)[WM], u32x4 (&xhi)[WM], u32x4 (&wlo)[WN], u32x4 (&whi)[WN], uint32_t ba, DMA& dma) {
+template <int B, int WM, int WN, bool REFILL, typename DMA, typename SC>
+__device__ __forceinline__ void mid_phases_dma(f32x4 (&acc)[WN][WM], u32x4 (&xlo)[WM], u32x4 (&xhi)[WM], u32x4 (&wlo)[WN], u32x4 (&whi)[WN], uint32_t ba, DMA& dma,
+                                               SC& sc) {
     if constexpr (B < WN - 1) {
 #pragma unroll
-        for (int f = 0; f < WM; ++f) acc[B][f] = mfma_f8(wlo[B], whi[B], xlo[f], xhi[f], acc[B][f]);
+        for (int f = 0; f < WM; ++f) acc[B][f] = mfma_f8(wlo[B], whi[B], xlo[f], xhi[f], acc[B][f], sc(f));
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (REFILL) {
             ds_read128<B * 2048>(wlo[B], ba);
@@ -312,14 +326,14 @@ __device__ __forceinline__ void mid_phases_dma(f32x4 (&acc)[WN][WM], u32x4 (&xlo
             dma(IC8<B - 1>{});
             __builtin_amdgcn_sched_barrier(0);
         }
-        mid_phases_dma<B + 1, WM, WN, REFILL>(acc, xlo, xhi, wlo, whi, ba, dma);
+        mid_phases_dma<B + 1, WM, WN, REFILL>(acc, xlo, xhi, wlo, whi, ba, dma, sc);
     }
 }
-template <int F, int WM, int WN, bool REFILL, typename DMA>
+template <int F, int WM, int WN, bool REFILL, typename DMA, typename SC>
 __device__ __forceinline__ void last_phase_dma(f32x4 (&acc)[WN][WM], u32x4 (&xlo)[WM], u32x4 (&xhi)[WM], u32x4 (&wlo)[WN], u32x4 (&whi)[WN], uint32_t a0, uint32_t a1,
-                                               uint32_t ba, DMA& dma) {
+                                               uint32_t ba, DMA& dma, SC& sc) {
     if constexpr (F < WM) {
-        acc[WN - 1][F] = mfma_f8(wlo[WN - 1], whi[WN - 1], xlo[F], xhi[F], acc[WN - 1][F]);
+        acc[WN - 1][F] = mfma_f8(wlo[WN - 1], whi[WN - 1], xlo[F], xhi[F], acc[WN - 1][F], sc(F));
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (REFILL) {
             ds_read128<F * 2048>(xlo[F], a0);
@@ -327,7 +341,7 @@ __device__ __forceinline__ void last_phase_dma(f32x4 (&acc)[WN][WM], u32x4 (&xlo
             dma(IC8<WN - 2 + F>{});
             __builtin_amdgcn_sched_barrier(0);
         }
-        last_phase_dma<F + 1, WM, WN, REFILL>(acc, xlo, xhi, wlo, whi, a0, a1, ba, dma);
+        last_phase_dma<F + 1, WM, WN, REFILL>(acc, xlo, xhi, wlo, whi, a0, a1, ba, dma, sc);
     } else if constexpr (REFILL) {
         ds_read128<(WN - 1) * 2048>(wlo[WN - 1], ba);
         ds_read128<(WN - 1) * 2048 + 1024>(whi[WN - 1], ba);
@@ -335,10 +349,18 @@ __device__ __forceinline__ void last_phase_dma(f32x4 (&acc)[WN][WM], u32x4 (&xlo
     }
 }
 
-template <int WM, int WN, int CGM, int CGN, int NSTA, int NSTB>
+// MX = 1: MX block-scaled activations (cover_gemm_epi.a8_mx): A8 rows are plain row-major e4m3, W8 is the k-linear image. The matrix instruction's own k
+// order (probed: tools/dbg/mx_probe2.py, profiles/r06_mx_block_scales.txt) is: operand bytes 0..15 of lane (row, g) = k 16 g .. 16 g + 15 of the 128-deep
+// step, bytes 16..31 = k 64 + 16 g ..; block b = k 32 b .. 32 b + 31 takes its E8M0 scale from lane group b. So the LDS read pattern is the one of the
+// per-row-scale kernel (chunks g and 4 + g of the row's 128 B) and lane (row, g) hands over byte g of the dword a8mx[k-tile][row]. Every activation-role wave moves one more piece per tile: 64 of the tile's (up to 256) dwords, global_load_lds_dword, into a ring of
+// NSTA x 1 KiB behind the weight ring; every wave reads its WM dwords of tile kt + 1 right behind the barrier that publishes it (older than every
+// fragment read of that tile, so the counted lgkmcnt waits of the phases cover them) and shifts its own byte down in phase 0 of that tile.
+// MX = 2: the kernel can WRITE that form from a GLU epilogue (cover_gemm_epi.out8); its own operands carry per-row scales as with MX = 0.
+template <int WM, int WN, int CGM, int CGN, int NSTA, int NSTB, int MX = 0>
 __global__ __launch_bounds__(64 * CGM * CGN) void gemm_tiled_v3_f8(const uint8_t* __restrict__ A8, int lda8, const uint8_t* __restrict__ W8, void* C, int ldc, int M,
                                                                    int N, int Kp, EpiDev epi, int tiles_m, int tiles_n, int kt_per, float* __restrict__ partial,
                                                                    const float* __restrict__ a_scale, const float* __restrict__ w_scale) {
+    constexpr bool MXA = MX == 1;
     constexpr int NW = CGM * CGN, NH = NW / 2;
     constexpr int BM_ = CGM * WM * 16, BN_ = CGN * WN * 16;
     constexpr int A_BYTES = BM_ * 128, B_BYTES = BN_ * 128;   // one 128-deep k-tile: 128 B per row
@@ -349,10 +371,13 @@ __global__ __launch_bounds__(64 * CGM * CGN) void gemm_tiled_v3_f8(const uint8_t
     static_assert(AT % NH == 0 && BT % NH == 0, "pieces must split evenly over the waves of a role");
     static_assert(WN >= 2, "the pipelined consumer refills w[0] while w[WN-1] is still needed");
     static_assert(NSTA >= 2 && NSTB >= 2 && (NSTA - 1) * PTA <= 63 && (NSTB - 1) * PTB <= 63, "ring depths / counted vmcnt field");
-    static_assert(NSTA * A_BYTES + NSTB * B_BYTES <= 160 * 1024, "LDS");
+    static_assert(NSTA * A_BYTES + NSTB * B_BYTES + (MXA ? NSTA * 1024 : 0) <= 160 * 1024, "LDS");
+    static_assert(!MXA || BM_ <= 64 * NH, "one block-scale dword per row, 64 rows per activation-role wave");
+    static_assert(!MXA || (NSTA - 1) * (PTA + 1) <= 63, "counted vmcnt field (with the block-scale piece)");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* As = smem;                    // [NSTA][A_BYTES]
     char* Bs = smem + NSTA * A_BYTES;   // [NSTB][B_BYTES]
+    char* Ss = smem + NSTA * A_BYTES + NSTB * B_BYTES;   // MX: [NSTA][256 rows x 4 B]
     const int nwg = tiles_m * tiles_n;
     int bid = blockIdx.x;
     {
@@ -381,16 +406,29 @@ __global__ __launch_bounds__(64 * CGM * CGN) void gemm_tiled_v3_f8(const uint8_t
     const uint32_t a_addr0 = lds_addr_u32(As) + ((wm * (WM * 16) + r) * 8 + ((0 * 4 + g) ^ (r & 7))) * 16;
     const uint32_t a_addr1 = lds_addr_u32(As) + ((wm * (WM * 16) + r) * 8 + ((1 * 4 + g) ^ (r & 7))) * 16;
     const uint32_t b_addr = lds_addr_u32(Bs) + (wn * WN * 2 * 64 + lane) * 16;
+    const uint32_t s_addr = lds_addr_u32(Ss) + (wm * (WM * 16) + r) * 4;
+    const uint32_t ss_u32 = __builtin_amdgcn_readfirstlane(lds_addr_u32(Ss));
+    using Scale = std::conditional_t<MXA, MxScale<WM>, NoScale>;
 
     auto run = [&](auto ROLE) {
         constexpr int role = decltype(ROLE)::value;
-        constexpr int PT = role ? PTB : PTA, NST = role ? NSTB : NSTA, SB = role ? B_BYTES : A_BYTES, KSH = role ? 11 : 7;
+        constexpr int PTD = role ? PTB : PTA;                       // 16-byte DMA pieces per tile
+        constexpr int PT = PTD + ((MXA && role == 0) ? 1 : 0);      // ... + the block-scale piece (piece PTD)
+        constexpr int NST = role ? NSTB : NSTA, SB = role ? B_BYTES : A_BYTES, KSH = role ? 11 : 7;
         const int wl = w % NH;
         uint32_t voff[PT];
         const char* sbase[PT];
         uint32_t dst0[PT];
+        if constexpr (MXA && role == 0) {   // rows 64 wl .. 64 wl + 63 of the tile (clamped: rows beyond the tile / beyond M are never read back)
+            int gr = m0 + wl * 64 + lane;
+            gr = gr < M ? gr : M - 1;
+            voff[PTD] = (uint32_t)gr * 4u;
+            sbase[PTD] = (const char*)epi.a8mx + (size_t)kt0 * M * 4;
+            dst0[PTD] = ss_u32 + wl * 256;
+        }
+        const size_t mx_step = (size_t)M * 4;   // bytes from one k-tile's block scales to the next
 #pragma unroll
-        for (int i = 0; i < PT; ++i) {
+        for (int i = 0; i < PTD; ++i) {
             const int j = wl + NH * i;
             if constexpr (role == 0) {   // A: LDS chunk position p = j*64 + lane: row = p>>3, c = p&7 holds global chunk c ^ (row&7)
                 const int row = j * 8 + (lane >> 3), c = lane & 7;
@@ -408,7 +446,10 @@ __global__ __launch_bounds__(64 * CGM * CGN) void gemm_tiled_v3_f8(const uint8_t
                 dst0[i] = bs_u32 + j * 1024;
             }
         }
-        auto issue = [&](int i, int stage, int t) { glds16_s(voff[i], sbase[i] + ((size_t)(uint32_t)t << KSH), dst0[i] + stage * SB); };
+        auto issue = [&](int i, int stage, int t) {
+            if (MXA && role == 0 && i == PTD) glds4_s(voff[i], sbase[i] + (size_t)(uint32_t)t * mx_step, dst0[i] + stage * 1024);
+            else glds16_s(voff[i], sbase[i] + ((size_t)(uint32_t)t << KSH), dst0[i] + stage * SB);
+        };
         // ---- prologue: this wave's pieces of tiles 0 .. NST-1 (every stage), then tile 0 landed -> barrier -> all of its fragments requested
 #pragma unroll
         for (int s2 = 0; s2 < NST; ++s2)
@@ -417,6 +458,8 @@ __global__ __launch_bounds__(64 * CGM * CGN) void gemm_tiled_v3_f8(const uint8_t
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 1) * PT) : "memory");
         asm volatile("s_barrier" ::: "memory");
         u32x4 xlo[WM], xhi[WM], wlo[WN], whi[WN];
+        Scale sc;
+        if constexpr (MXA) { sc.sh = 8 * g; read_mx_scales<0, WM>(sc, s_addr); }
         {
             const uint32_t ba = b_addr;
             read_w_frags_range<0, WN - 1, WN>(wlo, whi, ba);
@@ -427,12 +470,13 @@ __global__ __launch_bounds__(64 * CGM * CGN) void gemm_tiled_v3_f8(const uint8_t
         int na = NSTA > 1 ? 1 : 0, nb_ = NSTB > 1 ? 1 : 0;    // read stages of tile kt + 1 in the activation / weight ring
         int cr = 0;                                           // this role's ring: stage of tile kt (released by the barrier behind phase 0)
         for (int kt = 0; kt + 1 < nk; ++kt) {
-            phase0<0, WM, WN>(acc, xlo, xhi, wlo, whi);
+            phase0<0, WM, WN>(acc, xlo, xhi, wlo, whi, sc);
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * PT) : "memory");   // own pieces of tile kt + 1 landed; NST - 2 younger tiles in flight
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");          // w[WN-1] landed too: stage kt is free; tile kt+1 is published
             asm volatile("" : "+v"(wlo[WN - 1]), "+v"(whi[WN - 1]));
             __builtin_amdgcn_sched_barrier(0);
             const uint32_t a0 = a_addr0 + na * A_BYTES, a1 = a_addr1 + na * A_BYTES, ba = b_addr + nb_ * B_BYTES;
+            if constexpr (MXA) read_mx_scales<0, WM>(sc, s_addr + na * 1024);   // tile kt + 1's block scales (this tile's were shifted down in phase 0)
             ds_read128<0>(wlo[0], ba);
             ds_read128<1024>(whi[0], ba);
             __builtin_amdgcn_sched_barrier(0);
@@ -443,19 +487,19 @@ __global__ __launch_bounds__(64 * CGM * CGN) void gemm_tiled_v3_f8(const uint8_t
                 for (int p = 0; p < PT; ++p)
                     if ((p * NSLOT) / PT == slot) issue(p, ds, dt);
             };
-            mid_phases_dma<1, WM, WN, true>(acc, xlo, xhi, wlo, whi, ba, dma);
-            last_phase_dma<0, WM, WN, true>(acc, xlo, xhi, wlo, whi, a0, a1, ba, dma);
+            mid_phases_dma<1, WM, WN, true>(acc, xlo, xhi, wlo, whi, ba, dma, sc);
+            last_phase_dma<0, WM, WN, true>(acc, xlo, xhi, wlo, whi, a0, a1, ba, dma, sc);
             na = na == NSTA - 1 ? 0 : na + 1;
             nb_ = nb_ == NSTB - 1 ? 0 : nb_ + 1;
             cr = cr == NST - 1 ? 0 : cr + 1;
         }
         {   // last tile: no refills, no DMA
-            phase0<0, WM, WN>(acc, xlo, xhi, wlo, whi);
+            phase0<0, WM, WN>(acc, xlo, xhi, wlo, whi, sc);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             asm volatile("" : "+v"(wlo[WN - 1]), "+v"(whi[WN - 1]));
             __builtin_amdgcn_sched_barrier(0);
-            mid_phases<1, WM, WN, false>(acc, xlo, xhi, wlo, whi, 0u);
-            last_phase<0, WM, WN, false>(acc, xlo, xhi, wlo, whi, 0u, 0u, 0u);
+            mid_phases<1, WM, WN, false>(acc, xlo, xhi, wlo, whi, 0u, sc);
+            last_phase<0, WM, WN, false>(acc, xlo, xhi, wlo, whi, 0u, 0u, 0u, sc);
         }
     };
     if (w < NH) run(IC8<0>{});
@@ -469,7 +513,7 @@ __global__ __launch_bounds__(64 * CGM * CGN) void gemm_tiled_v3_f8(const uint8_t
         for (int f = 0; f < WM; ++f) {
             int m = mw + f * 16 + r;
             m = m < M ? m : M - 1;
-            as[f] = a_scale[m];
+            as[f] = MXA ? 1.0f : a_scale[m];   // (block scales went into the matrix instruction)
         }
 #pragma unroll
         for (int b = 0; b < WN; ++b) {
@@ -482,8 +526,8 @@ __global__ __launch_bounds__(64 * CGM * CGN) void gemm_tiled_v3_f8(const uint8_t
             }
         }
     }
-    tiled_epilogue_staged<WM, WN, BM_, BN_>(acc, epi, C, ldc, M, N, m0, n0, m0 + wm * (WM * 16), n0 + wn * (WN * 16), r, g, partial, smem,
-                                            NSTA * A_BYTES + NSTB * B_BYTES, tid, 64 * NW);
+    tiled_epilogue_staged<WM, WN, BM_, BN_, MX == 2>(acc, epi, C, ldc, M, N, m0, n0, m0 + wm * (WM * 16), n0 + wn * (WN * 16), r, g, partial, smem,
+                                                     NSTA * A_BYTES + NSTB * B_BYTES, tid, 64 * NW);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -546,6 +590,43 @@ __global__ __launch_bounds__(256) void quantize_act_fp8_k(const bf16_t* __restri
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// The MX form (cover_quantize_act_fp8_mx): plain row-major e4m3, one power-of-two scale per 32 consecutive k of a row, E8M0 bytes in
+// mx[k / 128][m][(k / 32) % 4]. One 256-thread block per row, 8 elements per thread per step; the four lanes of a quad hold one block.
+// (The GLU epilogue of gemm_tiled_v3_f8<.., MX = 2> writes the same bytes without this launch: tiled_epilogue_staged / mx_quant_chunk.)
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void quantize_act_fp8_mx_k(const bf16_t* __restrict__ X, int ldx, int M, int K, int Kp, uint8_t* __restrict__ out, int ld8,
+                                                             uint8_t* __restrict__ mx) {
+    const int m = blockIdx.x;
+    const bf16_t* x = X + (size_t)m * ldx;
+    uint8_t* o = out + (size_t)m * ld8;
+    const int nch = Kp >> 3;   // a multiple of 16: whole quads
+    for (int c = threadIdx.x; c < nch; c += 256) {
+        const int k = c * 8;
+        float v[8];
+        if (k + 8 <= K) {
+            const uint4 q = *(const uint4*)(x + k);
+            const uint32_t wv[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { v[2 * i] = bf2f((bf16_t)(wv[i] & 0xffffu)); v[2 * i + 1] = bf2f((bf16_t)(wv[i] >> 16)); }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (k + e < K) ? bf2f(x[k + e]) : 0.f;
+        }
+        uint2 q8;
+        const uint32_t sb = mx_quant_chunk(v, q8);
+        *(uint2*)(o + k) = q8;
+        if ((c & 3) == 0) mx[((size_t)(k >> 7) * M + m) * 4 + ((k >> 5) & 3)] = (uint8_t)sb;
+    }
+}
+hipError_t launch_quantize_act_fp8_mx(const bf16_t* X, int ldx, int M, int K, uint8_t* out, int ld8, uint8_t* mx, hipStream_t st) {
+    if (M <= 0) return hipSuccess;
+    const int Kp = (K + 127) / 128 * 128;
+    if (ld8 < Kp || (ld8 & 15) || (ldx & 7)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(quantize_act_fp8_mx_k, dim3(M), dim3(256), 0, st, X, ldx, M, K, Kp, out, ld8, mx);
+    return hipGetLastError();
+}
+
 hipError_t launch_quantize_act_fp8(const bf16_t* X, int ldx, int M, int K, uint8_t* out, int ld8, float* scales, hipStream_t st) {
     if (M <= 0) return hipSuccess;
     const int Kp = (K + 127) / 128 * 128;
@@ -577,10 +658,12 @@ hipError_t launch_gemm_fp8_tiled(int pick, const uint8_t* A8, int lda8, const fl
                 hipLaunchKernelGGL(kfn, grid, block, lds, st, A8, lda8, W8, C, ldc, M, N, Kp, epi, tiles_m, tiles_n, kt_per, partial, a_scale, w_scale); \
         }                                                                                                                    \
     } while (0)
-#define LAUNCH_F8V3(WM_, WN_, CGM_, CGN_, NA_, NB_)                                                                          \
+#define LAUNCH_F8V3(WM_, WN_, CGM_, CGN_, NA_, NB_) \
+    do { if (epi.a8mx) LAUNCH_F8V3X(WM_, WN_, CGM_, CGN_, NA_, NB_, 1); else if (epi.o8) LAUNCH_F8V3X(WM_, WN_, CGM_, CGN_, NA_, NB_, 2); else LAUNCH_F8V3X(WM_, WN_, CGM_, CGN_, NA_, NB_, 0); } while (0)
+#define LAUNCH_F8V3X(WM_, WN_, CGM_, CGN_, NA_, NB_, MX_)                                                                    \
     do {                                                                                                                     \
-        auto kfn = gemm_tiled_v3_f8<WM_, WN_, CGM_, CGN_, NA_, NB_>;                                                         \
-        const size_t lds3 = ((size_t)NA_ * CGM_ * WM_ * 16 + (size_t)NB_ * CGN_ * WN_ * 16) * 128;                           \
+        auto kfn = gemm_tiled_v3_f8<WM_, WN_, CGM_, CGN_, NA_, NB_, MX_>;                                                    \
+        const size_t lds3 = ((size_t)NA_ * CGM_ * WM_ * 16 + (size_t)NB_ * CGN_ * WN_ * 16) * 128 + (MX_ == 1 ? (size_t)NA_ * 1024 : 0); \
         e = LDS_ATTR_160K(kfn);                                                                                                            \
         if (e == hipSuccess) {                                                                                               \
             dim3 block(64 * CGM_ * CGN_);                                                                                    \
@@ -594,6 +677,9 @@ hipError_t launch_gemm_fp8_tiled(int pick, const uint8_t* A8, int lda8, const fl
     // the self-loading form (gemm_tiled_v3_f8) for the tiles whose eight MFMA waves split into two DMA roles; COVER_V3_F8=0 keeps the loader-wave form
     static const char* v3f8_env = getenv("COVER_V3_F8");
     const bool v3f8 = !(v3f8_env && v3f8_env[0] == '0') && (size_t)M * lda8 + 4096 < ((size_t)1 << 31);
+    // MX block scales (operand or output) exist on the self-loading kernels only: launch_gemm_bf16 keeps such a GEMM on their tiles
+    if ((epi.a8mx || epi.o8) && !(v3f8 && (pick == 12 || pick == 13 || pick == 15 || pick == 18))) return hipErrorInvalidValue;
+    if (epi.a8mx && !epi.w8_kl) return hipErrorInvalidValue;
     if (v3f8 && (pick == 12 || pick == 13 || pick == 15 || pick == 18)) {
         switch (pick) {
             case 12: LAUNCH_F8V3(4, 4, 4, 2, 3, 3); break;

@@ -21,8 +21,9 @@ void gemm_plan_counts(long long* out, int n, int reset);   // per-plan launch co
 int gemm_v3_probe(unsigned long long* out);                  // 16 words: in-kernel probe of the last gemm_v3.hip launch (g_v3_probe)
 hipError_t launch_quantize_rows_fp8(const bf16_t* W, int ldw, int N, int K, float* scales, bf16_t* Wdq, hipStream_t st);
 hipError_t launch_pack_weight_fp8(const bf16_t* Wdq, int ldw, const float* scales, int N, int K, uint8_t* Wq, float* scales_packed,
-                                  int Kpad, int glu, hipStream_t st);
+                                  int Kpad, int glu, hipStream_t st, int kl = 0);
 hipError_t launch_quantize_act_fp8(const bf16_t* X, int ldx, int M, int K, uint8_t* out, int ld8, float* scales, hipStream_t st);
+hipError_t launch_quantize_act_fp8_mx(const bf16_t* X, int ldx, int M, int K, uint8_t* out, int ld8, uint8_t* mx, hipStream_t st);
 hipError_t launch_pack_weight_bf16(const bf16_t* W, int ldw, int N, int K, bf16_t* Wp, int Kpad, int glu_interleave,
                                    hipStream_t st);
 

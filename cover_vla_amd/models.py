@@ -7,6 +7,7 @@ SigLIP-So400m head_dim 72 -> 96 and MLP 4304 -> 4352, patch K 588 -> 640 (zero w
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Dict, List, Optional
 
 import torch
@@ -222,6 +223,9 @@ class Decoder:
             # zero-initialised: V^T rows beyond a segment's length are read under a zero probability and must be finite
             self.k_cache = [torch.zeros(cache.elems, dtype=BF, device=dev) for _ in range(layers)]
             self.vt_cache = [torch.zeros(cache.elems, dtype=BF, device=dev) for _ in range(layers)]
+        # fp8 profile: down_proj's e4m3 twin in the k-linear operand order, so that its input can carry MX block scales written by the GLU epilogue
+        # of gate_up (cover_decoder_forward; COVER_FP8_MX=0 at load keeps the per-row-scale path with its quantiser launch)
+        mx_down = bool(fp8_weights) and os.environ.get("COVER_FP8_MX", "1") != "0" and mlp % 32 == 0
         for i in range(layers):
             p = f"layers.{i}."
             wqkv = torch.cat([sd[p + f"self_attn.{n}_proj.weight"] for n in ("q", "k", "v")], 0)
@@ -229,7 +233,7 @@ class Decoder:
             o = ops.pack_linear(sd[p + "self_attn.o_proj.weight"].to(dev), fp8=fp8_weights)
             gu = ops.pack_linear(torch.cat([sd[p + "mlp.gate_proj.weight"], sd[p + "mlp.up_proj.weight"]], 0).to(dev), glu=True,
                                  fp8=fp8_weights)
-            down = ops.pack_linear(sd[p + "mlp.down_proj.weight"].to(dev), fp8=fp8_weights)
+            down = ops.pack_linear(sd[p + "mlp.down_proj.weight"].to(dev), fp8=fp8_weights, klinear=mx_down)
             n1 = _bf_f32(sd[p + "input_layernorm.weight"], dev)
             n2 = _bf_f32(sd[p + "post_attention_layernorm.weight"], dev)
             self._keep += [qkv, o, gu, down, n1, n2]
@@ -242,6 +246,7 @@ class Decoder:
                 a.qkv_w8, a.qkv_s, a.o_w8, a.o_s = qkv.w8.data_ptr(), qkv.w8s.data_ptr(), o.w8.data_ptr(), o.w8s.data_ptr()
                 a.gate_up_w8, a.gate_up_s = gu.w8.data_ptr(), gu.w8s.data_ptr()
                 a.down_w8, a.down_s = down.w8.data_ptr(), down.w8s.data_ptr()
+                a.down_klinear = 1 if mx_down else 0
         self._arr = arr
         self.fp8_weights = fp8_weights
         self.final_norm = (_bf_f32 if final_norm_bf16 else _f32)(sd["norm.weight"], dev)

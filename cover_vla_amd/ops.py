@@ -43,6 +43,7 @@ class PackedLinear:
     w8: Optional[torch.Tensor] = None     # e4m3 twin of the same quantised weight (uint8 storage), cover_pack_weight_fp8
     w8s: Optional[torch.Tensor] = None    # fp32 per-channel power-of-two scales in packed channel order
     use_w8: bool = True                   # tests: False reads the bf16 image in the weight-streaming kernels too
+    klinear: bool = False                 # w8 is the k-linear image (cover_pack_weight_fp8_klinear): the operand order of MX block-scaled activations
 
     @property
     def n_out(self) -> int:
@@ -53,11 +54,14 @@ class PackedLinear:
         return (self.K + 127) // 128 * 128
 
 
-def pack_linear(weight: torch.Tensor, bias: Optional[torch.Tensor] = None, glu: bool = False, fp8: bool = False) -> PackedLinear:
+def pack_linear(weight: torch.Tensor, bias: Optional[torch.Tensor] = None, glu: bool = False, fp8: bool = False,
+                klinear: bool = False) -> PackedLinear:
     """weight: [N, K] (nn.Linear layout) on the device; for glu=True weight = cat([gate, up], 0).
     fp8=True: the weight is QUANTISED to e4m3 with per-output-channel power-of-two scales (cover_quantize_rows_fp8) and kept
     twice -- as the e4m3 image the HBM-bound weight-streaming kernels read (half the bytes) and as the bf16 image of the same
-    de-quantised values for the MFMA-bound tiled kernels; both give bit-identical results."""
+    de-quantised values for the MFMA-bound tiled kernels; both give bit-identical results. klinear=True (fp8, not glu): the e4m3 image in
+    the k-linear operand order, which the MX block-scaled activations of quantize_act_fp8_mx / a GLU GEMM's out8 pair with (config 5's down_proj)."""
+    assert not (klinear and (glu or not fp8))
     _chk_dev(weight)
     w = weight.to(torch.bfloat16).contiguous()
     N, K = w.shape
@@ -69,8 +73,12 @@ def pack_linear(weight: torch.Tensor, bias: Optional[torch.Tensor] = None, glu: 
         L.check(h.cover_quantize_rows_fp8(w.data_ptr(), K, N, K, scales.data_ptr(), wdq.data_ptr(), _stream()), "quantize_rows_fp8")
         w8 = torch.empty(h.cover_packed_weight_fp8_bytes(N, K), dtype=torch.uint8, device=w.device)
         w8s = torch.empty((N + 15) // 16 * 16, dtype=torch.float32, device=w.device)
-        L.check(h.cover_pack_weight_fp8(wdq.data_ptr(), K, scales.data_ptr(), N, K, w8.data_ptr(), w8s.data_ptr(), 1 if glu else 0,
-                                        _stream()), "pack_weight_fp8")
+        if klinear:
+            L.check(h.cover_pack_weight_fp8_klinear(wdq.data_ptr(), K, scales.data_ptr(), N, K, w8.data_ptr(), w8s.data_ptr(), _stream()),
+                    "pack_weight_fp8_klinear")
+        else:
+            L.check(h.cover_pack_weight_fp8(wdq.data_ptr(), K, scales.data_ptr(), N, K, w8.data_ptr(), w8s.data_ptr(), 1 if glu else 0,
+                                            _stream()), "pack_weight_fp8")
         w = wdq
     nbytes = h.cover_packed_weight_bytes(N, K)
     wp = torch.empty(nbytes // 2, dtype=torch.bfloat16, device=w.device)
@@ -78,7 +86,7 @@ def pack_linear(weight: torch.Tensor, bias: Optional[torch.Tensor] = None, glu: 
     # the bias of a bf16 nn.Linear is a bf16 parameter in the reference (paligemma.to(bf16), HF bf16 checkpoints): round it
     # ONCE at load; the epilogue then adds exactly that value in fp32
     b = None if bias is None else bias.detach().to(torch.bfloat16).to(torch.float32).contiguous().to(w.device)
-    return PackedLinear(wp, N, K, b, glu, w8, w8s)
+    return PackedLinear(wp, N, K, b, glu, w8, w8s, klinear=klinear)
 
 
 def quantize_act_fp8(x: torch.Tensor, K: Optional[int] = None):
@@ -94,6 +102,20 @@ def quantize_act_fp8(x: torch.Tensor, K: Optional[int] = None):
     return q, sc
 
 
+def quantize_act_fp8_mx(x: torch.Tensor, K: Optional[int] = None):
+    """bf16 [M, >= K] rows -> (e4m3 rows uint8 [M, padded K], PLAIN row-major; E8M0 block scales uint8 [padded K / 128, M, 4]: one power-of-two
+    scale per 32 consecutive k of a row) -- cover_quantize_act_fp8_mx, the operand form of a k-linear fp8 weight."""
+    _chk_dev(x)
+    assert x.dtype == torch.bfloat16 and x.dim() == 2 and x.stride(1) == 1
+    M = x.shape[0]
+    K = x.shape[1] if K is None else K
+    kp = (K + 127) // 128 * 128
+    q = torch.empty(M, kp, dtype=torch.uint8, device=x.device)
+    mx = torch.empty(kp // 128, M, 4, dtype=torch.uint8, device=x.device)
+    L.check(L.lib().cover_quantize_act_fp8_mx(x.data_ptr(), x.stride(0), M, K, q.data_ptr(), kp, mx.data_ptr(), _stream()), "quantize_act_fp8_mx")
+    return q, mx
+
+
 def gemm_workspace(M: int, N: int, K: int, device) -> Optional[torch.Tensor]:
     n = L.lib().cover_gemm_workspace_bytes(M, N, K)
     return torch.empty(max(n, 4) // 4, dtype=torch.float32, device=device) if n else None
@@ -103,10 +125,12 @@ def gemm(a: torch.Tensor, lin: PackedLinear, *, act: str = "none", residual: Opt
          layer_scale: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, out_f32: bool = False,
          out_scale: float = 1.0, variant: int = 0, ws: Optional[torch.Tensor] = None, norm_w: Optional[torch.Tensor] = None,
          norm_out: Optional[torch.Tensor] = None, norm_style: int = 0, norm_w_offset: float = 0.0, norm_eps: float = 1e-6,
-         norm_b: Optional[torch.Tensor] = None, a8: Optional[tuple] = None) -> torch.Tensor:
+         norm_b: Optional[torch.Tensor] = None, a8: Optional[tuple] = None, out8: Optional[tuple] = None) -> torch.Tensor:
     """out[M, n_out] = epi(a[M, K] @ W^T). `a` is bf16 with row stride >= padded K (zero padded).
     a8 = (q uint8 [M, >= padded K], scales fp32 [M]) from quantize_act_fp8: with an fp8 weight twin and M > 64 the GEMM runs on the
-    MX-scaled fp8 matrix instruction (config 5) on those operands."""
+    MX-scaled fp8 matrix instruction (config 5) on those operands. With a k-linear weight twin a8 = (q, mx uint8 [kp / 128, M, 4]) from
+    quantize_act_fp8_mx (or another GEMM's out8). out8 = (q uint8 [M, >= n_out], mx uint8 [ceil(n_out / 128), M, 4]): a GLU GEMM on the fp8
+    tiles writes its output rows block-quantised into them INSTEAD of `out` (which is returned untouched)."""
     _chk_dev(a, residual, out)
     assert a.dtype == torch.bfloat16 and a.dim() == 2 and a.stride(1) == 1
     M = a.shape[0]
@@ -125,11 +149,23 @@ def gemm(a: torch.Tensor, lin: PackedLinear, *, act: str = "none", residual: Opt
     e.out_scale = out_scale
     if lin.w8 is not None and lin.use_w8:
         e.w8, e.w8_scale = lin.w8.data_ptr(), lin.w8s.data_ptr()
+        e.w8_klinear = 1 if lin.klinear else 0
         if a8 is not None:
             q, qs = a8
             _chk_dev(q, qs)
-            assert q.dtype == torch.uint8 and q.shape[0] == M and q.stride(1) == 1 and qs.dtype == torch.float32
-            e.a8, e.a8_scale, e.ld_a8 = q.data_ptr(), qs.data_ptr(), q.stride(0)
+            assert q.dtype == torch.uint8 and q.shape[0] == M and q.stride(1) == 1
+            if lin.klinear:
+                assert qs.dtype == torch.uint8 and qs.is_contiguous() and tuple(qs.shape) == (lin.kp // 128, M, 4)
+                e.a8, e.a8_mx, e.ld_a8 = q.data_ptr(), qs.data_ptr(), q.stride(0)
+            else:
+                assert qs.dtype == torch.float32
+                e.a8, e.a8_scale, e.ld_a8 = q.data_ptr(), qs.data_ptr(), q.stride(0)
+    if out8 is not None:
+        q, qs = out8
+        _chk_dev(q, qs)
+        assert q.dtype == torch.uint8 and q.shape[0] == M and q.stride(1) == 1 and qs.dtype == torch.uint8 and qs.is_contiguous()
+        assert tuple(qs.shape) == ((lin.n_out + 127) // 128, M, 4)
+        e.out8, e.out8_mx, e.ld_out8 = q.data_ptr(), qs.data_ptr(), q.stride(0)
     if norm_w is not None:
         e.norm_w, e.norm_out, e.ld_norm_out = norm_w.data_ptr(), norm_out.data_ptr(), norm_out.stride(0)
         e.norm_style, e.norm_w_offset, e.norm_eps = norm_style, norm_w_offset, norm_eps

@@ -87,6 +87,18 @@ typedef struct cover_gemm_epi {
      * would make of the stored bf16 norm_out rows -- the next GEMM's fp8 operand without another launch. */
     void* norm_out8;
     float* norm_out8_scale;
+    /* MX block-scaled activations (config 5, the GLU output that feeds down_proj; no reference arithmetic -- SURVEY.md 7 step 9).
+     * w8_klinear = 1: w8 is the k-linear image of cover_pack_weight_fp8_klinear, read by every kernel that takes w8.
+     * a8_mx: e8m0 block scales of a8 as cover_quantize_act_fp8_mx lays them out ([cover_packed_k(K) / 128][M][4] bytes, byte = 127 + log2 of the
+     *   power-of-two scale of 32 consecutive k of a row); a8 is then plain row-major e4m3 (pitch ld_a8), a8_scale is not read, and w8 must be the
+     *   k-linear image. C = epi(w8_scale[n] * sum_blocks 2^(mx - 127) * sum_k a8 * w8) on v_mfma_scale_f32_16x16x128_f8f6f4's own block scales.
+     * out8 / out8_mx / ld_out8 (glu = 1, act SiLU / tanh-GELU, N / 2 a multiple of 32, M > 64 on the fp8 tiles): the GEMM writes its output rows
+     *   in exactly that form -- what cover_quantize_act_fp8_mx makes of the bf16 rows it would have stored -- INSTEAD of C. */
+    const void* a8_mx;
+    void* out8;
+    void* out8_mx;
+    int ld_out8;
+    int w8_klinear;
 } cover_gemm_epi;
 
 /* bytes needed for the packed form of an [N, K] weight (K padded to a multiple of 128, N to 16) */
@@ -112,6 +124,15 @@ int cover_pack_weight_fp8(const void* Wdq, int ldw, const float* scales, int N, 
  * MX MFMA operand (inside every 64-wide block, byte 16 g + 8 h + e holds k = 32 h + 8 g + e), zero padded to cover_packed_k(K).
  * ld8 in BYTES. */
 int cover_quantize_act_fp8(const void* X, int ldx, int M, int K, void* out8, int ld8, float* scales, void* stream);
+/* The MX form of the same (config 5's down_proj input): out8[m] = RNE_e4m3(X[m] / s) in PLAIN row-major order (zero padded to cover_packed_k(K),
+ * ld8 in BYTES), one power-of-two scale per 32 consecutive k of a row -- s = smallest 2^e (e >= -126) with amax_block / 2^e <= 448, 2^0 for an
+ * all-zero block -- stored as e8m0 bytes (127 + e) in mx[cover_packed_k(K) / 128][M][4] (k-tile major: what one workgroup of the consuming GEMM
+ * reads per 128-deep k-tile is one contiguous run of dwords). The weight of the consuming GEMM must be packed with cover_pack_weight_fp8_klinear. */
+int cover_quantize_act_fp8_mx(const void* X, int ldx, int M, int K, void* out8, int ld8, void* mx, void* stream);
+/* cover_pack_weight_fp8 with the k-linear operand order: block [n/16][k/64] of the image holds, for lane (n % 16, g), the 16 CONSECUTIVE bytes
+ * k = 64 (k/64) + 16 g + 0..15 (the default image: two 8-wide runs 32 apart) -- the k order of v_mfma_scale_f32_16x16x128_f8f6f4 itself, in which one
+ * MX block scale covers 32 neighbouring k. No glu interleave (down / o projections). */
+int cover_pack_weight_fp8_klinear(const void* Wdq, int ldw, const float* scales, int N, int K, void* Wq, float* scales_packed, void* stream);
 
 /* variant: 0 = auto, 1 = LDS-tiled with async global->LDS (global_load_lds), 2 = LDS-tiled register-staged,
  *          3 = weight-streaming (requires M <= 64; the library picks the second-generation split-K kernel or, for
@@ -441,6 +462,8 @@ typedef struct cover_dec_layer {
     /* optional e4m3 twins (cover_pack_weight_fp8) + packed-order scales of the four projections; NULL = bf16 only */
     const void* qkv_w8; const float* qkv_s; const void* o_w8; const float* o_s;
     const void* gate_up_w8; const float* gate_up_s; const void* down_w8; const float* down_s;
+    int down_klinear;                         /* 1: down_w8 is the k-linear image (cover_pack_weight_fp8_klinear): MX block-scaled down_proj input */
+    int _pad_dl;
 } cover_dec_layer;
 typedef struct cover_dec_desc {
     int dim, Hq, Hkv, D, mlp, n_layers, act;  /* act: COVER_ACT_GELU_TANH (Gemma) / COVER_ACT_SILU (Llama) */

@@ -135,14 +135,27 @@ def fake_quant_rows_e4m3(x):
     return ((xf / s).to(torch.float8_e4m3fn).float() * s).to(x.dtype)
 
 
+def fake_quant_blocks_e4m3(x):
+    """What cover_quantize_act_fp8_mx (or the GLU epilogue that writes the same bytes) + the block-scaled fp8 MFMA see of a bf16 activation tensor
+    [..., K], K a multiple of 32: one power-of-two scale per 32 consecutive elements (smallest 2^e, e >= -126, with amax_block / 2^e <= 448), RNE to OCP
+    e4m3, de-quantised. Config 5's down_proj input (no reference arithmetic: SURVEY.md 7 step 9)."""
+    xf = x.float()
+    blk = xf.reshape(*xf.shape[:-1], xf.shape[-1] // 32, 32)
+    amax = blk.abs().amax(dim=-1, keepdim=True)
+    e = torch.where(amax > 0, torch.ceil(torch.log2(amax.double() / 448.0)), torch.zeros_like(amax, dtype=torch.float64)).clamp(min=-126)
+    s = torch.pow(2.0, e).float()
+    return ((blk / s).to(torch.float8_e4m3fn).float() * s).reshape(xf.shape).to(x.dtype)
+
+
 def decoder_forward(cfg: DecoderCfg, sd, x, positions, mask, past=None, keep_kv=True, final_norm=True, n_pos=4096, act_fp8=False,
-                    kv_fp8=False):
+                    kv_fp8=False, act_mx_down=False):
     """x [B,T,dim] (bf16, or fp32 for the pi0 suffix at layer 0). past: list of (K,V) [B,Tp,Hkv,D] per layer (post-RoPE) or
     None. mask bool [B,T,Tp+T]. Returns (hidden [B,T,dim], new list of (K,V) including this pass's tokens if keep_kv).
     act_fp8: the input rows of the four projections are e4m3-quantised per row (the fp8 MFMA profile, config 5).
     kv_fp8: this pass's K (after RoPE) and V rows are e4m3-quantised per (token, head) row before they enter the cache (the fp8
-    own-token KV cache of config 5)."""
+    own-token KV cache of config 5). act_mx_down (with act_fp8): the down_proj input carries MX block scales instead of one scale per row."""
     fq = fake_quant_rows_e4m3 if act_fp8 else (lambda t: t)
+    fq_down = fake_quant_blocks_e4m3 if (act_fp8 and act_mx_down) else fq
     tabs = cfg.tables(n_pos)
     B, T, _ = x.shape
     new_kv = []
@@ -169,7 +182,7 @@ def decoder_forward(cfg: DecoderCfg, sd, x, positions, mask, past=None, keep_kv=
         o += x  # in-place add into the bf16 o_proj output (paligemma_with_expert.py:332): fp32 x is rounded here
         res = o.clone()
         h = fq(cfg.rms(o, sd[p + "post_attention_layernorm.weight"]))
-        h = lin(fq(act(lin(h, sd[p + "mlp.gate_proj.weight"])) * lin(h, sd[p + "mlp.up_proj.weight"])), sd[p + "mlp.down_proj.weight"])
+        h = lin(fq_down(act(lin(h, sd[p + "mlp.gate_proj.weight"])) * lin(h, sd[p + "mlp.up_proj.weight"])), sd[p + "mlp.down_proj.weight"])
         h += res
         x = h
     if final_norm:

@@ -202,6 +202,206 @@ def test_fp8_activation_error_bound_with_outliers(dev, M, N, K):
     assert rel < 4e-2, rel
 
 
+# ---------------------------------------------------------------------------------------------- MX block scales (config 5's down_proj input)
+def mx_quant_reference(x: torch.Tensor, K: int):
+    """CPU restatement of cover_quantize_act_fp8_mx (and of the GLU epilogue that writes the same bytes): one power-of-two scale per 32 consecutive
+    k of a row -- the smallest 2^e (e >= -126) with amax_block / 2^e <= 448, 2^0 for an all-zero block -- RNE e4m3 of x / s in plain row-major order,
+    zero padding to a multiple of 128; E8M0 bytes 127 + e laid out [k / 128][m][(k / 32) % 4]."""
+    M = x.shape[0]
+    kp = (K + 127) // 128 * 128
+    xp = torch.zeros(M, kp, dtype=torch.float32)
+    xp[:, :K] = x[:, :K].float()
+    blk = xp.view(M, kp // 32, 32)
+    amax = blk.abs().amax(-1)
+    e = torch.where(amax > 0, torch.ceil(torch.log2(amax.double() / 448.0)), torch.zeros_like(amax, dtype=torch.float64)).clamp(min=-126)
+    s = torch.pow(2.0, e).float()
+    q = (blk / s[..., None]).to(torch.float8_e4m3fn)
+    mx = (e + 127).to(torch.uint8).view(M, kp // 128, 4).permute(1, 0, 2).contiguous()
+    return q.view(M, kp), mx, (q.float() * s[..., None]).view(M, kp)
+
+
+@pytest.mark.parametrize("M,K", [(5, 4096), (70, 11008), (17, 200), (3, 128)])
+def test_mx_activation_quantiser_matches_restatement(dev, M, K):
+    g = torch.Generator().manual_seed(K + M + 7)
+    x = (torch.randn(M, K, generator=g) * torch.logspace(-2, 1, M)[:, None]).bfloat16()
+    x[:, 32:64] *= 50.0                                    # a block far from its neighbours' range
+    if M > 2:
+        x[1] = 0                                           # all-zero blocks: scale 2^0
+        x[2, 0] = 448.0 * 2 ** -3                          # a block amax exactly on a power-of-two boundary
+        x[2, 1:32] = x[2, 1:32].clamp(-40, 40)
+    q, mx = ops.quantize_act_fp8_mx(x.to(dev))
+    q_ref, mx_ref, _ = mx_quant_reference(x, K)
+    assert q.shape == q_ref.shape and mx.shape == mx_ref.shape
+    assert torch.equal(mx.cpu(), mx_ref)
+    assert torch.equal(q.cpu().view(torch.float8_e4m3fn).float(), q_ref.float())   # (+0 / -0 of exact zeros compare equal as values)
+
+
+@pytest.mark.parametrize("M,N,K,norm", [(512, 4096, 11008, True), (448, 4096, 11008, True), (200, 4096, 4096, False), (530, 1040, 2304, False),
+                                        (1024, 8192, 2304, False)])
+def test_fp8_mx_tiled_gemm_matches_fp32_on_quantised_operands(dev, M, N, K, norm):
+    """Block-scaled activations x k-linear e4m3 weights on v_mfma_scale_f32_16x16x128_f8f6f4's OWN block scales (gemm_tiled_v3_f8<.., MX = 1>: split-K
+    plans, the 256 x 128 / 224 x 128 / 128 x 256 tiles, ragged rows and columns) vs an fp64 matmul of the SAME de-quantised operands: rel-L2 <= 3e-3 --
+    and tighter than the per-row-scale path on activations whose blocks differ in range (that is what the block scales are for)."""
+    g = torch.Generator(device=dev).manual_seed(M + N + K)
+    w = torch.randn(N, K, device=dev, generator=g) * 0.02
+    w[: N // 4] *= 6.0
+    bias = torch.randn(N, device=dev, generator=g) * 0.1
+    lin = ops.pack_linear(w, bias, fp8=True, klinear=True)
+    lin0 = ops.pack_linear(w, bias, fp8=True)
+    a = torch.zeros(M, lin.kp, dtype=torch.bfloat16, device=dev)
+    a[:, :K] = (torch.randn(M, K, device=dev, generator=g) * torch.logspace(-1, 1, M, device=dev)[:, None]).bfloat16()
+    a[:, 64:96] *= 40.0                                    # one block of every row with its own range
+    q, mx = ops.quantize_act_fp8_mx(a, K)
+    res = torch.randn(M, N, device=dev, generator=g).bfloat16() if norm else None
+    kw = {}
+    if norm:
+        nw = (torch.rand(N, device=dev, generator=g) + 0.5).float()
+        kw = dict(norm_w=nw, norm_out=torch.empty(M, N, dtype=torch.bfloat16, device=dev), norm_style=1, norm_eps=1e-5)
+    ops.gemm_plan_counts(reset=True)
+    y8 = ops.gemm(a, lin, residual=res, a8=(q, mx), **kw)
+    assert ops.gemm_plan_counts()[21] == 1, "the fp8 tiles were not taken"
+    n8 = kw["norm_out"].clone() if norm else None
+    _, _, adq = mx_quant_reference(a.cpu(), K)
+    wdq, _ = dequant_reference(w.cpu())
+    ref = (adq[:, :K].double() @ wdq.double().T + bias.cpu().bfloat16().double()).float().bfloat16().float()
+    if res is not None:
+        ref = ref + res.float().cpu()
+    rel = ((y8.float().cpu() - ref).norm() / ref.norm()).item()
+    assert rel < 3e-3, rel
+    # the un-quantised product, for the size of the quantisation error itself: block scales vs one scale per row
+    exact = (a[:, :K].double().cpu() @ wdq.double().T + bias.cpu().bfloat16().double()).float()
+    if res is not None:
+        exact = exact + res.float().cpu()
+    q0, s0 = ops.quantize_act_fp8(a, K)
+    ops.gemm_plan_counts(reset=True)
+    y0 = ops.gemm(a, lin0, residual=res, a8=(q0, s0), **({**kw, "norm_out": torch.empty_like(kw["norm_out"])} if norm else {}))
+    row_on_fp8 = ops.gemm_plan_counts()[21] == 1             # (shapes outside the planner's fp8 range run the row-scale twin on the bf16 kernels)
+    e_mx = ((y8.float().cpu() - exact).norm() / exact.norm()).item()
+    e_row = ((y0.float().cpu() - exact).norm() / exact.norm()).item()
+    print(f"M={M} N={N} K={K}: MX GEMM vs fp64-on-quantised rel-L2 {rel:.2e}; quantisation error vs bf16 activations: block scales {e_mx:.3e}, "
+          f"row scales {e_row:.3e}{'' if row_on_fp8 else ' (bf16 kernel)'}")
+    # e4m3 is a floating-point format: its relative step does not depend on the scale, so on activations whose blocks differ by a factor of 40 the block
+    # scales buy NO accuracy over one scale per row (what they buy is a quantiser that needs only the producer's own tile) ...
+    assert e_mx <= 1.02 * e_row or not row_on_fp8
+    if row_on_fp8:   # ... until a row's range exceeds e4m3's: a block 3e4 x the rest pushes the rest of the row below the row scale's subnormals
+        a2 = a.clone()
+        a2[:, 64:96] *= 750.0
+        q2, mx2 = ops.quantize_act_fp8_mx(a2, K)
+        q3, s3 = ops.quantize_act_fp8(a2, K)
+        wd = wdq.double()[:, 96:K]                                   # the part of the product the hot block does not dominate
+        ex2 = a2[:, 96:K].double().cpu() @ wd.T
+        _, _, adq2 = mx_quant_reference(a2.cpu(), K)
+        e2_mx = ((adq2[:, 96:K].double() @ wd.T - ex2).norm() / ex2.norm()).item()
+        adq3 = _dequant_act(q3.cpu(), s3.cpu(), K)
+        e2_row = ((adq3[:, 96:K].double() @ wd.T - ex2).norm() / ex2.norm()).item()
+        print(f"   with one block 3e4 x the rest: the rest of the product, block scales {e2_mx:.3e}, row scales {e2_row:.3e}")
+        assert e2_mx < 0.5 * e2_row
+    if norm:
+        yo = y8.float().cpu()
+        want = (nw.cpu() * (yo * torch.rsqrt(yo.pow(2).mean(-1, keepdim=True) + 1e-5)).bfloat16().float())
+        assert ((n8.float().cpu() - want).norm() / want.norm()).item() < 4e-3
+
+
+@pytest.mark.parametrize("M,N,K,act", [(512, 22016, 4096, "silu"), (448, 22016, 4096, "silu"), (300, 2 * 2080, 2304, "gelu_tanh")])
+def test_glu_gemm_writes_the_mx_form_of_its_bf16_output(dev, M, N, K, act):
+    """out8 of a GLU GEMM on the fp8 tiles = cover_quantize_act_fp8_mx of the bf16 rows the same GEMM stores without it: e4m3 bytes and E8M0 scales
+    bit for bit (ragged last column tile, 128 x 192 / 224 x 128 / 128 x 256 tiles)."""
+    g = torch.Generator(device=dev).manual_seed(M + N + K + 3)
+    w = torch.randn(N, K, device=dev, generator=g) * 0.02
+    lin = ops.pack_linear(w, None, glu=True, fp8=True)
+    a = torch.zeros(M, lin.kp, dtype=torch.bfloat16, device=dev)
+    a[:, :K] = (torch.randn(M, K, device=dev, generator=g) * torch.logspace(-1, 1, M, device=dev)[:, None]).bfloat16()
+    q, sc = ops.quantize_act_fp8(a, K)
+    ops.gemm_plan_counts(reset=True)
+    y = ops.gemm(a, lin, act=act, a8=(q, sc))
+    same_kernel = ops.gemm_plan_counts()[21] == 1            # (out8 keeps ANY shape on the fp8 tiles; without it the planner sends small ones to the bf16 kernels)
+    n_out = N // 2
+    kp_o = (n_out + 127) // 128 * 128
+    o8 = torch.zeros(M, kp_o, dtype=torch.uint8, device=dev)
+    omx = torch.full((kp_o // 128, M, 4), 127, dtype=torch.uint8, device=dev)
+    ops.gemm(a, lin, act=act, a8=(q, sc), out8=(o8, omx))
+    yp = torch.zeros(M, kp_o, dtype=torch.bfloat16, device=dev)
+    yp[:, :n_out] = y
+    q_ref, mx_ref = ops.quantize_act_fp8_mx(yp, n_out)
+    nb = n_out // 32                                            # whole blocks the GEMM owns (n_out % 32 == 0 is required)
+    if not same_kernel:   # bf16-activation reference: the bytes differ by the activation quantisation; the de-quantised rows must agree to e4m3 precision
+        e = omx.permute(1, 0, 2).reshape(M, -1)[:, :nb].float().cpu() - 127.0
+        deq = (o8[:, :n_out].cpu().view(torch.float8_e4m3fn).float().view(M, nb, 32) * torch.pow(2.0, e)[..., None]).view(M, n_out)
+        rel = ((deq - y.float().cpu()).norm() / y.float().cpu().norm()).item()
+        assert rel < 6e-2, rel
+        de = (e - (mx_ref.permute(1, 0, 2).reshape(M, -1)[:, :nb].float().cpu() - 127.0)).abs().max().item()
+        assert de <= 1.0, de
+        return
+    assert torch.equal(omx.permute(1, 0, 2).reshape(M, -1)[:, :nb].cpu(), mx_ref.permute(1, 0, 2).reshape(M, -1)[:, :nb].cpu())
+    assert torch.equal(o8[:, :n_out].cpu().view(torch.float8_e4m3fn).float(), q_ref[:, :n_out].cpu().view(torch.float8_e4m3fn).float())
+    # and the restatement agrees with both
+    q_cpu, mx_cpu, _ = mx_quant_reference(y.cpu(), n_out)
+    assert torch.equal(mx_ref.cpu(), mx_cpu) and torch.equal(q_ref.cpu().view(torch.float8_e4m3fn).float(), q_cpu.float())
+
+
+@pytest.mark.parametrize("M,N,K", [(32, 4096, 11008), (32, 4096, 4096), (7, 4096, 11008), (16, 1024, 2304), (20, 8192, 6272)])
+def test_klinear_weight_stream_equals_the_bf16_stream(dev, M, N, K):
+    """The weight-streaming kernels on the k-linear e4m3 image (second and third generation, split and unsplit plans, ragged K): the lanes multiply
+    other k than with the default image, the SET of products per output is the same -- identical to the bf16 stream of the same quantised weights up
+    to the summation order (rel-L2 <= 2e-3 against each other and <= 6e-3 against fp32)."""
+    g = torch.Generator(device=dev).manual_seed(N + K + M + 11)
+    w = torch.randn(N, K, device=dev, generator=g) * 0.02
+    w[: N // 3] *= 8.0
+    bias = torch.randn(N, device=dev, generator=g) * 0.1
+    lin = ops.pack_linear(w, bias, fp8=True, klinear=True)
+    a = torch.zeros(M, lin.kp, dtype=torch.bfloat16, device=dev)
+    a[:, :K] = torch.randn(M, K, device=dev, generator=g).bfloat16()
+    y8 = ops.gemm(a, lin, variant=3)
+    lin.use_w8 = False
+    y16 = ops.gemm(a, lin, variant=3)
+    assert ((y8.float() - y16.float()).norm() / y16.float().norm()).item() < 2e-3
+    wdq, _ = dequant_reference(w.cpu())
+    ref = a[:, :K].float().cpu() @ wdq.float().T + bias.cpu().to(torch.bfloat16).float()
+    assert ((y8.float().cpu() - ref).norm() / ref.norm()).item() < 6e-3
+
+
+def test_decoder_mx_down_input_fused_equals_unfused_and_matches_oracle(dev):
+    """cover_decoder_forward with the MX block-scaled down_proj input (two Llama-style layers at 2048 wide, MLP 4096, one causal pass of 448 rows -- the
+    smallest geometry that takes the fp8 tiles): (1) the GLU epilogue of gate_up writes the SAME operand bytes as the standalone quantiser launch it
+    replaces (COVER_FP8_MX_FUSE=0) -- hidden rows bit-identical; (2) against the oracle on the de-quantised weights with the same quantisers at the
+    projections' inputs (per row, and per 32-block at down_proj) the device path deviates from the bf16-activation oracle no more than the oracle's own
+    fake-quantised evaluation does (the statistical bar of tests/fp8_mfma_model_case.py); (3) plan counters: every projection ran on the fp8 tiles."""
+    from cover_ref import blocks as Bk
+    from cover_vla_amd.models import Decoder, KvGeometry
+    dim, Hq, D, mlp, T, layers = 2048, 16, 128, 4096, 448, 2
+    g = synth._G(21, True)
+    sd = synth.decoder_state(g, dim=dim, layers=layers, Hq=Hq, Hkv=Hq, D=D, mlp=mlp, rms_base=1.0)
+    x0 = (torch.randn(T, dim, generator=torch.Generator().manual_seed(3)) * 0.5).bfloat16()
+    pos = torch.arange(T, dtype=torch.int32, device=dev)
+    outs = {}
+    for fuse in ("1", "0"):
+        os.environ["COVER_FP8_MX_FUSE"] = fuse
+        try:
+            llm = Decoder(sd, dim=dim, layers=layers, Hq=Hq, Hkv=Hq, D=D, mlp=mlp, act="silu", norm="llama", eps=1e-5, rope="hf", n_pos=T + 8,
+                          device="cuda:0", cache=KvGeometry(Hq, D, [1], [T]), fp8_weights=True)
+            assert llm._arr[0].down_klinear == 1
+            x = x0.clone().to(dev)
+            ops.gemm_plan_counts(reset=True)
+            llm.forward(x, [llm.group(1, T, pos, [dict(region=0, length=T, mask=ops.MASK_CAUSAL)], 0)], final_norm=True)
+            counts = ops.gemm_plan_counts()
+            assert counts[21] == 4 * layers and sum(counts) == 4 * layers, counts
+            outs[fuse] = x.cpu()
+        finally:
+            os.environ.pop("COVER_FP8_MX_FUSE", None)
+    assert torch.equal(outs["1"].view(torch.int16), outs["0"].view(torch.int16))
+    cfg = Bk.DecoderCfg(dim, layers, Hq, Hq, D, mlp, "silu", "llama", 1e-5, "hf")
+    osd = Bk.to_bf16({k: (dequant_reference(v)[0].float() if k.endswith("_proj.weight") else v) for k, v in sd.items()})
+    mask = torch.tril(torch.ones(T, T, dtype=torch.bool))[None]
+    with torch.no_grad():
+        ref = Bk.decoder_forward(cfg, osd, x0[None].clone(), pos.cpu()[None].long(), mask, n_pos=T + 8)[0][0].float()
+        rq = Bk.decoder_forward(cfg, osd, x0[None].clone(), pos.cpu()[None].long(), mask, n_pos=T + 8, act_fp8=True, act_mx_down=True)[0][0].float()
+    rel = lambda a, b: ((a - b).norm() / b.norm()).item()
+    e_h, e_q, e_hq = rel(outs["1"].float(), ref), rel(rq, ref), rel(outs["1"].float(), rq)
+    print(f"MX down input, 2 layers x 448 rows: device vs bf16-activation oracle {e_h:.4f}, fake-quant oracle vs the same {e_q:.4f}, device vs fake-quant oracle {e_hq:.4f}")
+    assert e_q > 0.005 and e_h > 0.005
+    assert e_h <= 1.25 * e_q + 0.005 and e_hq <= 1.6 * e_q, (e_h, e_q, e_hq)
+
+
 def _dequant_sd(sd):
     out = dict(sd)
     for k, v in sd.items():
@@ -259,7 +459,7 @@ def test_openvla_fp8_mfma_decode_rows_match_oracle(dev):
     """Model-level run of the fp8 MFMA path (more than 64 decode rows on e4m3 weights) in a child process with the tile knob that
     gives the small config an fp8-capable tile; see tests/fp8_mfma_model_case.py."""
     import subprocess
-    env = dict(os.environ, COVER_TILE_PICK="a")
+    env = dict(os.environ, COVER_TILE_PICK="a", COVER_FP8_MX="0")   # (per-row activation scales on every projection: what the oracle's act_fp8 flags restate)
     p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fp8_mfma_model_case.py")], env=env, capture_output=True, text=True, timeout=900)
     print(p.stdout[-1500:])
     assert p.returncode == 0 and "FP8_MFMA_MODEL_OK" in p.stdout, (p.stdout[-2000:], p.stderr[-3000:])
