@@ -50,7 +50,8 @@ class AttnArgs(C.Structure):
                 ("o_b_stride", c_ll), ("o_t_stride", c_ll), ("o_h_stride", c_ll),
                 ("B", c_i), ("Tq", c_i), ("Hq", c_i), ("Hkv", c_i), ("D", c_i), ("scale", c_f),
                 ("n_seg", c_i), ("_pad", c_i), ("seg", KvSegment * 3),
-                ("state_in_o", c_p), ("state_in_ml", c_p), ("state_out_o", c_p), ("state_out_ml", c_p)]
+                ("state_in_o", c_p), ("state_in_ml", c_p), ("state_out_o", c_p), ("state_out_ml", c_p),
+                ("out8", c_p), ("out8_mx", c_p), ("out8_rows", c_i), ("_pad2", c_i)]
 
 
 class DecodeAttnArgs(C.Structure):
@@ -133,7 +134,7 @@ class DecLayer(C.Structure):
     _fields_ = [("in_norm_w", c_p), ("post_norm_w", c_p), ("qkv_w", c_p), ("qkv_b", c_p), ("o_w", c_p),
                 ("gate_up_w", c_p), ("down_w", c_p), ("k_cache", c_p), ("vt_cache", c_p),
                 ("qkv_w8", c_p), ("qkv_s", c_p), ("o_w8", c_p), ("o_s", c_p), ("gate_up_w8", c_p), ("gate_up_s", c_p),
-                ("down_w8", c_p), ("down_s", c_p), ("down_klinear", c_i), ("_pad_dl", c_i)]
+                ("down_w8", c_p), ("down_s", c_p), ("down_klinear", c_i), ("o_klinear", c_i)]
 
 
 class DecDesc(C.Structure):

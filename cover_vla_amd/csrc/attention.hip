@@ -41,6 +41,7 @@ struct AttnDev {
     SegDev seg[3];
     const float* si_o; const float* si_ml;
     float* so_o; float* so_ml;
+    uint8_t* o8; uint8_t* o8mx; int o8_rows;   // MX block-scaled e4m3 output INSTEAD of `out` (cover_attn_args.out8): same strides, in bytes
 };
 
 #ifdef COVER_AT_DEBUG
@@ -51,11 +52,14 @@ extern "C" int cover_at_debug(unsigned long long* out) { return (int)hipMemcpyFr
 #define ATT(slot) do { } while (0)
 #endif
 // NWS: waves per block in key-split mode (4 or 8), a compile-time constant there so that the merge below is straight-line code
-template <int D, bool KSPLIT, int NWS = 4>
+// MXO: the output rows are written as e4m3 with one E8M0 scale per 32 columns (cover_quantize_act_fp8_mx's arithmetic on the bf16 values that would have
+// been stored): key-split mode with two ADJACENT d blocks per wave (DB == 2 NWS), so that a wave holds whole 32-column blocks after the merge
+template <int D, bool KSPLIT, int NWS = 4, bool MXO = false>
 __device__ __forceinline__ void attn_body(const AttnDev& a, int bx, int kvh, int b) {
     ATT(0);
     constexpr int KS = D / 32;  // k-steps of QK^T
     constexpr int DB = D / 16;  // 16-row d blocks of O^T
+    static_assert(!MXO || (KSPLIT && DB == 2 * NWS), "block-scaled output: two adjacent d blocks per wave");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -235,7 +239,7 @@ __device__ __forceinline__ void attn_body(const AttnDev& a, int bx, int kvh, int
         }
 #pragma unroll
         for (int dbi = 0; dbi < (DB + NWS - 1) / NWS; ++dbi) {
-            const int db = w + dbi * NWS;
+            const int db = MXO ? 2 * w + dbi : w + dbi * NWS;
             if (db < DB) {
                 float x[NWS][4];
 #pragma unroll
@@ -247,14 +251,14 @@ __device__ __forceinline__ void attn_body(const AttnDev& a, int bx, int kvh, int
                     float acc = 0.f;
 #pragma unroll
                     for (int i = 0; i < NWS; ++i) acc += x[i][e] * f[i];
-                    oacc[dbi][e] = acc;              // this wave's dbi-th block (db = w + dbi * NWS) now lives in slot dbi
+                    oacc[dbi][e] = acc;              // this wave's dbi-th block (db = w + dbi * NWS; MXO: 2 w + dbi) now lives in slot dbi
                 }
             }
         }
         l_run = lt;
         m_run = mx;
-        db_first = w;
-        db_step = NWS;
+        db_first = MXO ? 2 * w : w;
+        db_step = MXO ? 1 : NWS;
     }
     ATT(4);
 
@@ -273,6 +277,39 @@ __device__ __forceinline__ void attn_body(const AttnDev& a, int bx, int kvh, int
         }
         return;
     }
+    if constexpr (MXO) {
+        // slots 0, 1 = d blocks 2w, 2w + 1 = columns 32 w .. 32 w + 31 of head h: lane (r, g) holds 2 x 4 of the block's values of query row r, the other 24
+        // sit in the lanes r + 16 g'. (MHA only: a query row is a token.)
+        float v[8];
+        float mx = 0.f;
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[k * 4 + e] = bf2f(f2bf(oacc[k][e] * inv));
+                mx = fmaxf(mx, fabsf(v[k * 4 + e]));
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        float sc = 1.0f;
+        if (mx > 0.f) {   // smallest power of two >= 2^-126 with mx / sc <= 448 (e4m3_pow2_scale of gemm_common.h)
+            int ex;
+            const float fr = frexpf(mx / 448.0f, &ex);
+            sc = ldexpf(1.0f, fr == 0.5f ? ex - 1 : ex);
+        }
+        sc = fmaxf(sc, 1.1754943508222875e-38f);
+        const float is = 1.0f / sc;
+        const long long ro = (long long)b * a.o_b + (long long)t * a.o_t;
+        const int col = h * (int)a.o_h + 32 * w;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            int pk = __builtin_amdgcn_cvt_pk_fp8_f32(v[k * 4] * is, v[k * 4 + 1] * is, 0, false);
+            pk = __builtin_amdgcn_cvt_pk_fp8_f32(v[k * 4 + 2] * is, v[k * 4 + 3] * is, pk, true);
+            *(uint32_t*)(a.o8 + ro + col + k * 16 + 4 * g) = (uint32_t)pk;
+        }
+        if (g == 0) a.o8mx[((size_t)(col >> 7) * a.o8_rows + (size_t)(ro / a.o_t)) * 4 + ((col >> 5) & 3)] = (uint8_t)((__builtin_bit_cast(uint32_t, sc) >> 23) & 0xffu);
+        return;
+    }
     bf16_t* op = a.out + (long long)b * a.o_b + (long long)t * a.o_t + (long long)h * a.o_h + 4 * g;
 #pragma unroll
     for (int k = 0; k < DB; ++k) {
@@ -287,9 +324,9 @@ __device__ __forceinline__ void attn_body(const AttnDev& a, int bx, int kvh, int
     ATT(5);
 }
 
-template <int D, bool KSPLIT, int NWS = 4>
+template <int D, bool KSPLIT, int NWS = 4, bool MXO = false>
 __global__ __launch_bounds__((KSPLIT && D > 128) ? 64 * NWS : 512) void attn_kernel(AttnDev a) {
-    attn_body<D, KSPLIT, NWS>(a, blockIdx.x, blockIdx.y, blockIdx.z);
+    attn_body<D, KSPLIT, NWS, MXO>(a, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 // Two independent attention problems (the two row groups of a prefill pass: shared-prefix rows and the prompts' text rows)
 // in ONE launch: both are far too small to fill the chip, so back to back they cost two latency floors. Key-split mode
@@ -326,6 +363,15 @@ static hipError_t launch_d(const AttnDev& a, hipStream_t st) {
     // tiles over ~280 keys) is a chain of ~10 dependent key tiles per wave: split the keys over the block's waves there too
     // (config 5: 24.7 -> see profiles/ us per layer)
     if (a.si_o != nullptr && !e_max && D <= 128) ks_max = 4095;
+    if (a.o8) {   // block-scaled output: the key-split kernel with four waves at D = 128 only (attention_mx_ok below says when)
+        if constexpr (D == 128) {
+            if (qtiles > ks_max) return hipErrorInvalidValue;
+            const size_t lds = (size_t)(4 * (D / 16) * 4 * 64 + 2 * 4 * 16) * sizeof(float);
+            hipLaunchKernelGGL((attn_kernel<D, true, 4, true>), dim3(tiles, a.Hkv, a.B), dim3(256), lds, st, a);
+            return hipGetLastError();
+        }
+        return hipErrorInvalidValue;
+    }
     if (qtiles <= ks_max) {
         // too few query tiles to fill the chip (single-token decode, ViT-sized sequences): split the key tiles over the
         // 4 (or, when even 4 waves per tile leave most CUs idle and D allows the LDS merge buffer, 8) waves of a block
@@ -345,6 +391,17 @@ static hipError_t launch_d(const AttnDev& a, hipStream_t st) {
     return hipGetLastError();
 }
 
+// Can this problem write its output block-scaled (cover_attn_args.out8)? MHA at D = 128 (a head = four 32-column blocks = one 128-deep k-tile of the consuming
+// GEMM), whole rows of Hq * D bytes, final output (no state_out), and few enough query tiles for the key-split kernel (as launch_d decides).
+bool attention_mx_ok(const cover_attn_args* x) {
+    if (x->D != 128 || x->Hq != x->Hkv || x->state_out_o != nullptr || x->B <= 0 || x->Tq <= 0) return false;
+    if (x->o_h_stride != 128 || x->o_t_stride != (long long)x->Hq * 128 || (x->o_b_stride % x->o_t_stride) != 0) return false;
+    static const char* e_max = getenv("COVER_ATTN_KSPLIT_MAX");
+    const long long ks_max = (x->state_in_o != nullptr && !e_max) ? 4095 : (e_max ? atoll(e_max) : 1023);
+    const long long qtiles = (long long)((x->Tq + 15) / 16) * x->Hkv * x->B;
+    return qtiles <= ks_max;
+}
+
 static hipError_t build_attn_dev(const cover_attn_args* x, AttnDev& a) {
     if (x->n_seg < 1 || x->n_seg > 3 || x->Hq % x->Hkv != 0) return hipErrorInvalidValue;
     a.q = (const bf16_t*)x->q;
@@ -358,6 +415,9 @@ static hipError_t build_attn_dev(const cover_attn_args* x, AttnDev& a) {
     a.n_seg = x->n_seg;
     a.si_o = x->state_in_o; a.si_ml = x->state_in_ml; a.so_o = x->state_out_o; a.so_ml = x->state_out_ml;
     if ((a.si_o == nullptr) != (a.si_ml == nullptr) || (a.so_o == nullptr) != (a.so_ml == nullptr)) return hipErrorInvalidValue;
+    a.o8 = (uint8_t*)x->out8; a.o8mx = (uint8_t*)x->out8_mx; a.o8_rows = x->out8_rows;
+    if (!a.o8 || !a.o8mx) { a.o8 = nullptr; a.o8mx = nullptr; }
+    if (a.o8 && !attention_mx_ok(x)) return hipErrorInvalidValue;
     for (int i = 0; i < x->n_seg; ++i) {
         const cover_kv_segment& s = x->seg[i];
         SegDev& d = a.seg[i];

@@ -493,6 +493,11 @@ int cover_decoder_forward(const cover_dec_desc* d, const cover_dec_pass* p, void
                     (d->act == COVER_ACT_SILU || d->act == COVER_ACT_GELU_TANH);
     const char* mxf_env = getenv("COVER_FP8_MX_FUSE");
     const bool mx_fused = mx && !(mxf_env && mxf_env[0] == '0');
+    // the same for the o_proj input: the attention kernel of the large-N decode pass writes the block-scaled rows INTO THE attn BUFFER (a head = one
+    // 128-deep k-tile of o_proj); every other pass (prefill: two groups) keeps the bf16 rows and quantises them with one launch
+    const bool o_kl = d->layers_host[0].o_klinear != 0;
+    const bool mxo = f8 && o_kl && rows >= 400 && dim >= 2048 && D == 128 && Hq == Hkv;
+    bool mxo_fused = false;   // set per layer by the attention launch below
     // h = in_norm_0(x); afterwards every norm is folded into the epilogue of the GEMM that produces its input
     {
         const bool f32in = p->x_f32 != nullptr;
@@ -502,6 +507,7 @@ int cover_decoder_forward(const cover_dec_desc* d, const cover_dec_pass* p, void
     }
     for (int l = 0; l < d->n_layers; ++l) {
         const cover_dec_layer& L = d->layers_host[l];
+        mxo_fused = false;
         const bool first_f32 = (l == 0 && p->x_f32 != nullptr);
         cover_gemm_epi e;
         memset(&e, 0, sizeof e);
@@ -575,6 +581,11 @@ int cover_decoder_forward(const cover_dec_desc* d, const cover_dec_pass* p, void
                 }
                 sa.seg[1].slot_of_batch = G.seg1_slot_of_group; sa.seg[1].len_of_batch = G.seg1_len_of_group;
                 sa.state_in_o = oa.state_o; sa.state_in_ml = oa.state_ml;
+                if (mxo && p->n_groups == 1 && !(mxf_env && mxf_env[0] == '0')) {
+                    sa.out8 = attn; sa.out8_mx = q8mx; sa.out8_rows = rows;
+                    if (attention_mx_ok(&sa)) mxo_fused = true;
+                    else { sa.out8 = nullptr; sa.out8_mx = nullptr; }
+                }
                 HIPCHK(launch_attention_bf16(&sa, st), "dec attention (shared prefix + prompt text, resumed from the own-token state)");
                 continue;
             }
@@ -663,8 +674,13 @@ int cover_decoder_forward(const cover_dec_desc* d, const cover_dec_pass* p, void
         e.residual = first_f32 ? (const void*)p->x_f32 : (const void*)x; e.residual_f32 = first_f32 ? 1 : 0; e.ld_residual = dim;
         e.norm_w = L.post_norm_w; e.norm_out = h; e.ld_norm_out = dim; e.norm_style = d->norm_style;
         e.norm_w_offset = d->norm_w_offset; e.norm_eps = d->norm_eps;
-        e.w8 = L.o_w8; e.w8_scale = L.o_s;
-        if (f8) HIPCHK(quant(attn, HD, e), "dec quantise (o_proj input)");
+        e.w8 = L.o_w8; e.w8_scale = L.o_s; e.w8_klinear = L.o_klinear;
+        if (mxo) {
+            if (!mxo_fused) HIPCHK(launch_quantize_act_fp8_mx((const bf16_t*)attn, HD, rows, HD, (uint8_t*)q8, HD, (uint8_t*)q8mx, st), "dec quantise (o_proj input, MX)");
+            e.a8 = mxo_fused ? attn : q8; e.ld_a8 = HD; e.a8_mx = q8mx;
+        } else if (f8 && !L.o_klinear) {
+            HIPCHK(quant(attn, HD, e), "dec quantise (o_proj input)");
+        }   // (a k-linear twin below the MX sizes: bf16 operands on the bf16 image)
         norm_q8(e);
         HIPCHK(launch_gemm_bf16((const bf16_t*)attn, HD, (const bf16_t*)L.o_w, x, dim, rows, dim, HD, &e, (float*)sk, skb, variant, st), "dec o_proj (+post_norm)");
         memset(&e, 0, sizeof e);

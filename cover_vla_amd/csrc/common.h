@@ -133,6 +133,19 @@ __device__ __forceinline__ void glds16_asm(const void* gsrc, uint32_t lds_wave_b
         : "v"(gsrc), "s"(lds_wave_base_u32)
         : "memory");
 }
+// the 4-byte form: LDS destination = M0 + lane * 4
+__device__ __forceinline__ void glds4_asm(const void* gsrc, uint32_t lds_wave_base_u32) {
+    uint32_t keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dword %1, off\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(gsrc), "s"(lds_wave_base_u32)
+        : "memory");
+}
 __device__ __forceinline__ uint32_t lds_addr_u32(const void* p) {
     return (uint32_t)(uintptr_t)((const __attribute__((address_space(3))) char*)p);
 }

@@ -1802,7 +1802,7 @@ hipError_t launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* Wp, void* C,
     if (!v3_on && pick >= 23) pick = f8_on ? (pick == 24 ? 15 : pick == 25 ? 12 : pick == 26 ? 13 : pick == 27 ? 17 : 10) : 0;
     if (mx_any) {
         if (!f8_on) return hipErrorInvalidValue;                                   // (COVER_FP8_MFMA=0 with block-scaled operands)
-        if (pick != 12 && pick != 13 && pick != 15 && pick != 18) pick = 13;      // any M on the 128 x 256 self-loading tile
+        if (pick != 12 && pick != 13 && pick != 15 && pick != 18 && !(pick == 10 && epi.a8mx && !epi.o8)) pick = 13;   // any M on the 128 x 256 self-loading tile (the 64 x 128 loader-wave tile reads block scales too)
     }
     // bf16 operands: of the loader-wave tiles only the 64 x 128 four-stage one (pick 10) is still a default; the others exist as fp8 kernels
     if (!(f8_on && gemm_fp8_tiled_supported(pick)) && ((pick >= 11 && pick <= 18) || pick == 9)) pick = (variant == 2 || pick == 9) ? 1 : 0;

@@ -153,7 +153,9 @@ __device__ __forceinline__ void last_phase(f32x4 (&acc)[WN][WM], u32x4 (&xlo)[WM
     }
 }
 
-template <int WM, int WN, int NST, int NL, int CGM, int CGN>
+// MXA: MX block-scaled activations (cover_gemm_epi.a8_mx; see gemm_tiled_v3_f8 below for the operand order): tiles of at most 64 rows, the tile's 64 scale
+// dwords of a k-tile are one more piece of EVERY loader wave (the same 256 bytes to the same place: every wave's counted vmcnt stays uniform)
+template <int WM, int WN, int NST, int NL, int CGM, int CGN, bool MXA = false>
 __global__ __launch_bounds__(64 * (CGM * CGN + NL)) void gemm_tiled_pc_f8(const uint8_t* __restrict__ A8, int lda8, const uint8_t* __restrict__ W8,
                                                                           void* C, int ldc, int M, int N, int Kp, EpiDev epi, int tiles_m, int tiles_n,
                                                                           int kt_per, float* __restrict__ partial, const float* __restrict__ a_scale,
@@ -165,6 +167,8 @@ __global__ __launch_bounds__(64 * (CGM * CGN + NL)) void gemm_tiled_pc_f8(const 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* As = smem;                   // [NST][A_BYTES]
     char* Bs = smem + NST * A_BYTES;   // [NST][B_BYTES]
+    char* Ss = smem + NST * (A_BYTES + B_BYTES);   // MXA: [NST][64 rows x 4 B]
+    static_assert(!MXA || BM_ <= 64, "one block-scale dword per row, one piece per tile");
     const int nwg = tiles_m * tiles_n;
     int bid = blockIdx.x;
     {   // XCD-aware bijective remap: the row tiles that share a weight tile run on one XCD (one L2)
@@ -184,8 +188,9 @@ __global__ __launch_bounds__(64 * (CGM * CGN + NL)) void gemm_tiled_pc_f8(const 
 
     if (w >= NCW) {   // ---------------- loader waves ----------------
         constexpr int PT = (AT + BT) / NL;
+        constexpr int PTX = PT + (MXA ? 1 : 0);   // pieces a wave issues per tile (with the block-scale piece)
         static_assert((AT + BT) % NL == 0 && AT % NL == 0, "pieces must split evenly over the loader waves");
-        static_assert((NST - 2) * PT <= 63, "counted vmcnt must fit its 6-bit field");
+        static_assert((NST - 2) * PTX <= 63, "counted vmcnt must fit its 6-bit field");
         const int l = w - NCW;
         const uint8_t* src[PT];
         uint32_t dst[PT];
@@ -212,10 +217,18 @@ __global__ __launch_bounds__(64 * (CGM * CGN + NL)) void gemm_tiled_pc_f8(const 
                 step[i] = 2048;
             }
         }
+        const uint8_t* ssrc = nullptr;
+        const uint32_t ss_u32 = __builtin_amdgcn_readfirstlane(lds_addr_u32(Ss));
+        if constexpr (MXA) {
+            int gr = m0 + lane;
+            gr = gr < M ? gr : M - 1;
+            ssrc = epi.a8mx + ((size_t)kt0 * M + gr) * 4;
+        }
         auto issue = [&](int buf, int kt) {
 #pragma unroll
             for (int i = 0; i < PT; ++i)
                 glds16_asm(src[i] + kt * step[i], dst[i] + buf * ((l + i * NL) < AT ? A_BYTES : B_BYTES));
+            if constexpr (MXA) glds4_asm(ssrc + (size_t)kt * M * 4, ss_u32 + buf * 256);
         };
 #pragma unroll
         for (int s = 0; s < NST - 1; ++s)
@@ -223,8 +236,8 @@ __global__ __launch_bounds__(64 * (CGM * CGN + NL)) void gemm_tiled_pc_f8(const 
         int cur = 0;
         for (int kt = 0; kt < nk; ++kt) {
             const int younger = min(nk - 1 - kt, NST - 2);   // tiles issued after kt that may stay in flight
-            if (NST >= 4 && younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PT) : "memory");
-            else if (younger >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PT) : "memory");
+            if (NST >= 4 && younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PTX) : "memory");
+            else if (younger >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PTX) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             if (kt + NST - 1 < nk) issue(cur == 0 ? NST - 1 : cur - 1, kt + NST - 1);   // stage (kt-1) % NST: every consumer is past tile kt-1
@@ -245,9 +258,11 @@ __global__ __launch_bounds__(64 * (CGM * CGN + NL)) void gemm_tiled_pc_f8(const 
     const uint32_t b_addr = lds_addr_u32(Bs) + (wn * WN * 2 * 64 + lane) * 16;
     static_assert(WN >= 2, "the pipelined consumer refills w[0] while w[WN-1] is still needed");
     u32x4 xlo[WM], xhi[WM], wlo[WN], whi[WN];
-    NoScale sc;   // per-row activation scales: applied to the sums below
+    std::conditional_t<MXA, MxScale<WM>, NoScale> sc;   // NoScale: per-row activation scales, applied to the sums below
+    const uint32_t s_addr = lds_addr_u32(Ss) + (wm * (WM * 16) + r) * 4;
     // prologue: tile 0 published; all of its fragments requested in the steady-state order w[0..WN-2], x[0..WM), w[WN-1]
     asm volatile("s_barrier" ::: "memory");
+    if constexpr (MXA) { sc.sh = 8 * g; read_mx_scales<0, WM>(sc, s_addr); }
     {
         const uint32_t ba = b_addr;
         read_w_frags_range<0, WN - 1, WN>(wlo, whi, ba);
@@ -262,6 +277,7 @@ __global__ __launch_bounds__(64 * (CGM * CGN + NL)) void gemm_tiled_pc_f8(const 
         asm volatile("" : "+v"(wlo[WN - 1]), "+v"(whi[WN - 1]));
         __builtin_amdgcn_sched_barrier(0);
         const uint32_t a0 = a_addr0 + nxt * A_BYTES, a1 = a_addr1 + nxt * A_BYTES, ba = b_addr + nxt * B_BYTES;
+        if constexpr (MXA) read_mx_scales<0, WM>(sc, s_addr + nxt * 256);   // tile kt + 1's block scales (this tile's were shifted down in phase 0)
         ds_read128<0>(wlo[0], ba);
         ds_read128<1024>(whi[0], ba);
         __builtin_amdgcn_sched_barrier(0);
@@ -285,7 +301,7 @@ __global__ __launch_bounds__(64 * (CGM * CGN + NL)) void gemm_tiled_pc_f8(const 
         for (int f = 0; f < WM; ++f) {
             int m = mw + f * 16 + r;
             m = m < M ? m : M - 1;
-            as[f] = a_scale[m];
+            as[f] = MXA ? 1.0f : a_scale[m];
         }
 #pragma unroll
         for (int b = 0; b < WN; ++b) {
@@ -643,9 +659,10 @@ hipError_t launch_gemm_fp8_tiled(int pick, const uint8_t* A8, int lda8, const fl
                                  int prof_cls, double prof_work, hipStream_t st) {
     hipError_t e = hipSuccess;
     dim3 grid(tiles_m * tiles_n, S);
-#define LAUNCH_F8(WM_, WN_, NST_, NL_, CGM_, CGN_)                                                                           \
+#define LAUNCH_F8(WM_, WN_, NST_, NL_, CGM_, CGN_) LAUNCH_F8X(WM_, WN_, NST_, NL_, CGM_, CGN_, false, lds)
+#define LAUNCH_F8X(WM_, WN_, NST_, NL_, CGM_, CGN_, MX_, lds)                                                                \
     do {                                                                                                                     \
-        auto kfn = gemm_tiled_pc_f8<WM_, WN_, NST_, NL_, CGM_, CGN_>;                                                        \
+        auto kfn = gemm_tiled_pc_f8<WM_, WN_, NST_, NL_, CGM_, CGN_, MX_>;                                                   \
         if (lds > 64 * 1024) {                                                                                               \
             e = LDS_ATTR_160K(kfn);                                                                                                        \
         }                                                                                                                    \
@@ -678,7 +695,7 @@ hipError_t launch_gemm_fp8_tiled(int pick, const uint8_t* A8, int lda8, const fl
     static const char* v3f8_env = getenv("COVER_V3_F8");
     const bool v3f8 = !(v3f8_env && v3f8_env[0] == '0') && (size_t)M * lda8 + 4096 < ((size_t)1 << 31);
     // MX block scales (operand or output) exist on the self-loading kernels only: launch_gemm_bf16 keeps such a GEMM on their tiles
-    if ((epi.a8mx || epi.o8) && !(v3f8 && (pick == 12 || pick == 13 || pick == 15 || pick == 18))) return hipErrorInvalidValue;
+    if ((epi.a8mx || epi.o8) && !(v3f8 && (pick == 12 || pick == 13 || pick == 15 || pick == 18)) && !(pick == 10 && epi.a8mx && !epi.o8)) return hipErrorInvalidValue;
     if (epi.a8mx && !epi.w8_kl) return hipErrorInvalidValue;
     if (v3f8 && (pick == 12 || pick == 13 || pick == 15 || pick == 18)) {
         switch (pick) {
@@ -691,7 +708,10 @@ hipError_t launch_gemm_fp8_tiled(int pick, const uint8_t* A8, int lda8, const fl
         return e;
     }
     switch (pick) {
-        case 10: LAUNCH_F8(2, 4, 4, 4, 2, 2); break;
+        case 10:
+            if (epi.a8mx) { const size_t ldsx = lds + 4 * 256; LAUNCH_F8X(2, 4, 4, 4, 2, 2, true, ldsx); }   // (+ the block-scale ring)
+            else LAUNCH_F8(2, 4, 4, 4, 2, 2);
+            break;
         case 12: LAUNCH_F8(4, 4, 3, 4, 4, 2); break;
         case 13: LAUNCH_F8(4, 4, 3, 4, 2, 4); break;
         case 15: LAUNCH_F8(7, 2, 3, 4, 2, 4); break;
@@ -700,6 +720,7 @@ hipError_t launch_gemm_fp8_tiled(int pick, const uint8_t* A8, int lda8, const fl
         default: return hipErrorInvalidValue;
     }
 #undef LAUNCH_F8
+#undef LAUNCH_F8X
     if (e == hipSuccess) e = hipGetLastError();
     return e;
 }

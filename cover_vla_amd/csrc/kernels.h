@@ -29,6 +29,7 @@ hipError_t launch_pack_weight_bf16(const bf16_t* W, int ldw, int N, int K, bf16_
 
 // ---- attention.hip -------------------------------------------------------------------------------
 hipError_t launch_attention_bf16(const cover_attn_args* a, hipStream_t st);
+bool attention_mx_ok(const cover_attn_args* x);   // can this problem write cover_attn_args.out8?
 hipError_t launch_attention_bf16_pair(const cover_attn_args* a0, const cover_attn_args* a1, hipStream_t st);
 hipError_t launch_decode_attention_fused(const cover_decode_attn_args* a, hipStream_t st);
 hipError_t launch_decode_own_attention(const cover_own_attn_args* a, hipStream_t st);   // decode_own.hip

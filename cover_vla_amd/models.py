@@ -226,11 +226,12 @@ class Decoder:
         # fp8 profile: down_proj's e4m3 twin in the k-linear operand order, so that its input can carry MX block scales written by the GLU epilogue
         # of gate_up (cover_decoder_forward; COVER_FP8_MX=0 at load keeps the per-row-scale path with its quantiser launch)
         mx_down = bool(fp8_weights) and os.environ.get("COVER_FP8_MX", "1") != "0" and mlp % 32 == 0
+        mx_o = bool(fp8_weights) and os.environ.get("COVER_FP8_MX", "1") not in ("0", "down") and D == 128 and Hq == Hkv   # (the attention output likewise)
         for i in range(layers):
             p = f"layers.{i}."
             wqkv = torch.cat([sd[p + f"self_attn.{n}_proj.weight"] for n in ("q", "k", "v")], 0)
             qkv = ops.pack_linear(wqkv.to(dev), fp8=fp8_weights)
-            o = ops.pack_linear(sd[p + "self_attn.o_proj.weight"].to(dev), fp8=fp8_weights)
+            o = ops.pack_linear(sd[p + "self_attn.o_proj.weight"].to(dev), fp8=fp8_weights, klinear=mx_o)
             gu = ops.pack_linear(torch.cat([sd[p + "mlp.gate_proj.weight"], sd[p + "mlp.up_proj.weight"]], 0).to(dev), glu=True,
                                  fp8=fp8_weights)
             down = ops.pack_linear(sd[p + "mlp.down_proj.weight"].to(dev), fp8=fp8_weights, klinear=mx_down)
@@ -247,6 +248,7 @@ class Decoder:
                 a.gate_up_w8, a.gate_up_s = gu.w8.data_ptr(), gu.w8s.data_ptr()
                 a.down_w8, a.down_s = down.w8.data_ptr(), down.w8s.data_ptr()
                 a.down_klinear = 1 if mx_down else 0
+                a.o_klinear = 1 if mx_o else 0
         self._arr = arr
         self.fp8_weights = fp8_weights
         self.final_norm = (_bf_f32 if final_norm_bf16 else _f32)(sd["norm.weight"], dev)

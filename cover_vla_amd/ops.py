@@ -235,11 +235,17 @@ def fill_segment(s: L.KvSegment, seg: Segment) -> None:
 
 
 def attention(q: torch.Tensor, q_strides: Sequence[int], out: Optional[torch.Tensor], o_strides: Sequence[int], B: int, Tq: int,
-              Hq: int, Hkv: int, D: int, scale: float, segments: Sequence[Segment], state_in=None, state_out=None):
-    """state_in / state_out: optional (o fp32 [B,Tq,Hq,D], ml fp32 [B,Tq,Hq,2]) pairs chaining calls over KV segments."""
+              Hq: int, Hkv: int, D: int, scale: float, segments: Sequence[Segment], state_in=None, state_out=None, out8=None):
+    """state_in / state_out: optional (o fp32 [B,Tq,Hq,D], ml fp32 [B,Tq,Hq,2]) pairs chaining calls over KV segments.
+    out8 = (q uint8 [rows, Hq * D], mx uint8 [Hq * D / 128, rows, 4]): the output rows block-quantised (quantize_act_fp8_mx's form) INSTEAD of `out`
+    (MHA, D = 128, few query tiles: cover_attn_args.out8)."""
     _chk_dev(q, out)
     a = L.AttnArgs()
     a.q, a.out = q.data_ptr(), _ptr(out)
+    if out8 is not None:
+        _chk_dev(out8[0], out8[1])
+        assert out8[0].dtype == torch.uint8 and out8[1].dtype == torch.uint8 and out8[1].is_contiguous() and out8[0].is_contiguous()
+        a.out8, a.out8_mx, a.out8_rows = out8[0].data_ptr(), out8[1].data_ptr(), out8[0].shape[0]
     if state_in is not None:
         a.state_in_o, a.state_in_ml = state_in[0].data_ptr(), state_in[1].data_ptr()
     if state_out is not None:

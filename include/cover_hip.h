@@ -203,6 +203,12 @@ typedef struct cover_attn_args {
      * candidates instead of once per candidate. */
     const float* state_in_o; const float* state_in_ml;
     float* state_out_o; float* state_out_ml;
+    /* Optional MX block-scaled output INSTEAD of `out` (config 5: the o_proj operand without a quantiser launch; no reference arithmetic):
+     * out8 = e4m3 rows addressed with the o_*_stride values in BYTES, out8_mx = E8M0 scales [Hq * D / 128][out8_rows][4] as cover_quantize_act_fp8_mx
+     * lays them out (row = byte offset of (b, t) / o_t_stride), exactly what that function makes of the bf16 rows `out` would have received.
+     * MHA, D = 128, o_h_stride = 128, o_t_stride = Hq * 128, no state_out, at most 1023 query tiles (4095 with state_in): otherwise COVER_EINVAL. */
+    void* out8; void* out8_mx;
+    int out8_rows; int _pad2;
 } cover_attn_args;
 int cover_attention_bf16(const cover_attn_args* args, void* stream);
 
@@ -463,7 +469,7 @@ typedef struct cover_dec_layer {
     const void* qkv_w8; const float* qkv_s; const void* o_w8; const float* o_s;
     const void* gate_up_w8; const float* gate_up_s; const void* down_w8; const float* down_s;
     int down_klinear;                         /* 1: down_w8 is the k-linear image (cover_pack_weight_fp8_klinear): MX block-scaled down_proj input */
-    int _pad_dl;
+    int o_klinear;                            /* the same for o_w8: MX block-scaled attention output */
 } cover_dec_layer;
 typedef struct cover_dec_desc {
     int dim, Hq, Hkv, D, mlp, n_layers, act;  /* act: COVER_ACT_GELU_TANH (Gemma) / COVER_ACT_SILU (Llama) */

@@ -148,14 +148,15 @@ def fake_quant_blocks_e4m3(x):
 
 
 def decoder_forward(cfg: DecoderCfg, sd, x, positions, mask, past=None, keep_kv=True, final_norm=True, n_pos=4096, act_fp8=False,
-                    kv_fp8=False, act_mx_down=False):
+                    kv_fp8=False, act_mx_down=False, act_mx_o=False):
     """x [B,T,dim] (bf16, or fp32 for the pi0 suffix at layer 0). past: list of (K,V) [B,Tp,Hkv,D] per layer (post-RoPE) or
     None. mask bool [B,T,Tp+T]. Returns (hidden [B,T,dim], new list of (K,V) including this pass's tokens if keep_kv).
     act_fp8: the input rows of the four projections are e4m3-quantised per row (the fp8 MFMA profile, config 5).
     kv_fp8: this pass's K (after RoPE) and V rows are e4m3-quantised per (token, head) row before they enter the cache (the fp8
-    own-token KV cache of config 5). act_mx_down (with act_fp8): the down_proj input carries MX block scales instead of one scale per row."""
+    own-token KV cache of config 5). act_mx_down / act_mx_o (with act_fp8): the down_proj / o_proj input carries MX block scales instead of one scale per row."""
     fq = fake_quant_rows_e4m3 if act_fp8 else (lambda t: t)
     fq_down = fake_quant_blocks_e4m3 if (act_fp8 and act_mx_down) else fq
+    fq_o = fake_quant_blocks_e4m3 if (act_fp8 and act_mx_o) else fq
     tabs = cfg.tables(n_pos)
     B, T, _ = x.shape
     new_kv = []
@@ -177,7 +178,7 @@ def decoder_forward(cfg: DecoderCfg, sd, x, positions, mask, past=None, keep_kv=
             kk, vv = k, v
         if keep_kv:
             new_kv.append((kk, vv))
-        a = fq(eager_attention(q, kk, vv, mask, cfg.D ** -0.5, scores_bf16=cfg.scores_bf16).to(BF))
+        a = fq_o(eager_attention(q, kk, vv, mask, cfg.D ** -0.5, scores_bf16=cfg.scores_bf16).to(BF))
         o = lin(a, sd[p + "self_attn.o_proj.weight"])
         o += x  # in-place add into the bf16 o_proj output (paligemma_with_expert.py:332): fp32 x is rounded here
         res = o.clone()

@@ -360,11 +360,44 @@ def test_klinear_weight_stream_equals_the_bf16_stream(dev, M, N, K):
     assert ((y8.float().cpu() - ref).norm() / ref.norm()).item() < 6e-3
 
 
+@pytest.mark.parametrize("B,Tq,Tk,chained", [(4, 64, 300, False), (8, 64, 281, True), (3, 50, 77, False)])
+def test_attention_writes_the_mx_form_of_its_bf16_output(dev, B, Tq, Tk, chained):
+    """cover_attn_args.out8: the key-split attention kernel at D = 128 (32 heads: a head = one 128-deep k-tile of o_proj) writes e4m3 rows + E8M0 block scales
+    that are bit for bit cover_quantize_act_fp8_mx of the bf16 rows the same call stores without it -- also resumed from a state (the config-5 decode pass:
+    8 prompts x 64 samples = 1 024 query tiles) and with ragged query tiles / per-batch key lengths."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_kernels_gpu import bf, make_cache
+    H, D = 32, 128
+    g = torch.Generator().manual_seed(B + Tq + Tk)
+    q = bf(torch.randn(B, Tq, H, D, generator=g))
+    k = bf(torch.randn(B, Tk, H, D, generator=g))
+    v = bf(torch.randn(B, Tk, H, D, generator=g) * torch.logspace(-1, 1, H)[None, None, :, None])
+    lens = torch.tensor([max(1, Tk - 7 * i) for i in range(B)], dtype=torch.int32)
+    kc, vt, ks, vs = make_cache(k, v, dev)
+    seg = ops.Segment(kc, vt, ks, vs, length=Tk, len_of_batch=lens.to(dev))
+    rows = B * Tq
+    st = (Tq * H * D, H * D, D)
+    state = None
+    if chained:
+        state = ((torch.randn(B, Tq, H, D, generator=g) * 0.3).to(dev), torch.stack([torch.randn(B, Tq, H, generator=g), torch.rand(B, Tq, H, generator=g) + 0.5], -1).to(dev))
+    out = torch.empty(rows, H * D, dtype=torch.bfloat16, device=dev)
+    ops.attention(q.to(dev), st, out, st, B, Tq, H, H, D, D ** -0.5, [seg], state_in=state)
+    o8 = torch.zeros(rows, H * D, dtype=torch.uint8, device=dev)
+    omx = torch.zeros(H * D // 128, rows, 4, dtype=torch.uint8, device=dev)
+    ops.attention(q.to(dev), st, None, st, B, Tq, H, H, D, D ** -0.5, [seg], state_in=state, out8=(o8, omx))
+    q_ref, mx_ref = ops.quantize_act_fp8_mx(out)
+    assert torch.equal(omx.cpu(), mx_ref.cpu())
+    assert torch.equal(o8.cpu().view(torch.float8_e4m3fn).float(), q_ref.cpu().view(torch.float8_e4m3fn).float())
+    # a problem the key-split kernel does not take is refused, not silently written as bf16
+    with pytest.raises(RuntimeError):
+        ops.attention(q.to(dev), st, None, st, B, Tq, H, 8, D, D ** -0.5, [seg], out8=(o8, omx))           # GQA
+
+
 def test_decoder_mx_down_input_fused_equals_unfused_and_matches_oracle(dev):
-    """cover_decoder_forward with the MX block-scaled down_proj input (two Llama-style layers at 2048 wide, MLP 4096, one causal pass of 448 rows -- the
+    """cover_decoder_forward with the MX block-scaled down_proj and o_proj inputs (two Llama-style layers at 2048 wide, MLP 4096, one causal pass of 448 rows -- the
     smallest geometry that takes the fp8 tiles): (1) the GLU epilogue of gate_up writes the SAME operand bytes as the standalone quantiser launch it
     replaces (COVER_FP8_MX_FUSE=0) -- hidden rows bit-identical; (2) against the oracle on the de-quantised weights with the same quantisers at the
-    projections' inputs (per row, and per 32-block at down_proj) the device path deviates from the bf16-activation oracle no more than the oracle's own
+    projections' inputs (per row at qkv / gate_up, per 32-block at o_proj / down_proj) the device path deviates from the bf16-activation oracle no more than the oracle's own
     fake-quantised evaluation does (the statistical bar of tests/fp8_mfma_model_case.py); (3) plan counters: every projection ran on the fp8 tiles."""
     from cover_ref import blocks as Bk
     from cover_vla_amd.models import Decoder, KvGeometry
@@ -394,7 +427,7 @@ def test_decoder_mx_down_input_fused_equals_unfused_and_matches_oracle(dev):
     mask = torch.tril(torch.ones(T, T, dtype=torch.bool))[None]
     with torch.no_grad():
         ref = Bk.decoder_forward(cfg, osd, x0[None].clone(), pos.cpu()[None].long(), mask, n_pos=T + 8)[0][0].float()
-        rq = Bk.decoder_forward(cfg, osd, x0[None].clone(), pos.cpu()[None].long(), mask, n_pos=T + 8, act_fp8=True, act_mx_down=True)[0][0].float()
+        rq = Bk.decoder_forward(cfg, osd, x0[None].clone(), pos.cpu()[None].long(), mask, n_pos=T + 8, act_fp8=True, act_mx_down=True, act_mx_o=True)[0][0].float()
     rel = lambda a, b: ((a - b).norm() / b.norm()).item()
     e_h, e_q, e_hq = rel(outs["1"].float(), ref), rel(rq, ref), rel(outs["1"].float(), rq)
     print(f"MX down input, 2 layers x 448 rows: device vs bf16-activation oracle {e_h:.4f}, fake-quant oracle vs the same {e_q:.4f}, device vs fake-quant oracle {e_hq:.4f}")

@@ -1,6 +1,8 @@
 """Full-size (BASELINE.json shapes) checks on the GPU through size-independent properties: the CPU oracle cannot run a
 7B-parameter decision in seconds, so at OpenVLA-7B N=32 the HIP path is checked for determinism, row independence,
 permutation equivariance, agreement between the two independent GEMM kernels, and softmax normalisation."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -299,6 +301,20 @@ def test_fullsize_config5_fp8_n512_horizon8(pipe, dev):
     perm = torch.tensor([3, 0, 7, 1, 6, 2, 5, 4], device=dev)
     tokp, _ = p5.policy.sample(i["frame"], i["toks"][perm], i["lens"][perm], S, u.view(P, S, G)[perm].reshape(P * S, G).contiguous(), 1.0)
     assert torch.equal(tokp.view(P, S, G), tv[perm])
+    # MX block scales (down_proj input written by gate_up's GLU epilogue, o_proj input written by the attention kernel): the fused producers write the
+    # bytes of the quantiser launches they replace -- the same decision, token for token and score for score, with the launches back in
+    llm = p5.policy.llm
+    assert llm._arr[0].down_klinear == 1 and llm._arr[0].o_klinear == 1
+    s1 = p5.last_scores.clone()
+    os.environ["COVER_FP8_MX_FUSE"] = "0"
+    keep_graph = p5.policy.decode_graph
+    p5.policy.decode_graph = False                           # (the knob is read per call: a replayed graph would still hold the fused launches)
+    try:
+        idx3, tok3, _ = p5.decision()
+    finally:
+        os.environ.pop("COVER_FP8_MX_FUSE", None)
+        p5.policy.decode_graph = keep_graph
+    assert idx3 == idx1 and torch.equal(tok3, tok1) and torch.equal(p5.last_scores, s1)
     del p5
     torch.cuda.empty_cache()
 
