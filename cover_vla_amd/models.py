@@ -225,7 +225,8 @@ class Decoder:
             self.vt_cache = [torch.zeros(cache.elems, dtype=BF, device=dev) for _ in range(layers)]
         # fp8 profile: down_proj's e4m3 twin in the k-linear operand order, so that its input can carry MX block scales written by the GLU epilogue
         # of gate_up (cover_decoder_forward; COVER_FP8_MX=0 at load keeps the per-row-scale path with its quantiser launch)
-        mx_down = bool(fp8_weights) and os.environ.get("COVER_FP8_MX", "1") != "0" and mlp % 32 == 0
+        # (mlp a multiple of 128: the GLU epilogue writes whole 32-column blocks of the REAL columns only, a padded last k-tile would be read unwritten)
+        mx_down = bool(fp8_weights) and os.environ.get("COVER_FP8_MX", "1") != "0" and mlp % 128 == 0
         mx_o = bool(fp8_weights) and os.environ.get("COVER_FP8_MX", "1") not in ("0", "down") and D == 128 and Hq == Hkv   # (the attention output likewise)
         for i in range(layers):
             p = f"layers.{i}."

@@ -93,7 +93,9 @@ typedef struct cover_gemm_epi {
      *   power-of-two scale of 32 consecutive k of a row); a8 is then plain row-major e4m3 (pitch ld_a8), a8_scale is not read, and w8 must be the
      *   k-linear image. C = epi(w8_scale[n] * sum_blocks 2^(mx - 127) * sum_k a8 * w8) on v_mfma_scale_f32_16x16x128_f8f6f4's own block scales.
      * out8 / out8_mx / ld_out8 (glu = 1, act SiLU / tanh-GELU, N / 2 a multiple of 32, M > 64 on the fp8 tiles): the GEMM writes its output rows
-     *   in exactly that form -- what cover_quantize_act_fp8_mx makes of the bf16 rows it would have stored -- INSTEAD of C. */
+     *   in exactly that form -- what cover_quantize_act_fp8_mx makes of the bf16 rows it would have stored -- INSTEAD of C. Only the N / 2 real
+     *   columns and their scale bytes are written: when N / 2 is not a multiple of 128, zero the pad columns of out8 and set the pad scale bytes to 127
+     *   once (the consuming GEMM reads whole 128-deep k-tiles; an E8M0 byte 255 is a NaN). */
     const void* a8_mx;
     void* out8;
     void* out8_mx;
