@@ -42,6 +42,7 @@ struct AttnDev {
     const float* si_o; const float* si_ml;
     float* so_o; float* so_ml;
     uint8_t* o8; uint8_t* o8mx; int o8_rows;   // MX block-scaled e4m3 output INSTEAD of `out` (cover_attn_args.out8): same strides, in bytes
+    bool shared;                               // host side: launch the workgroup-shared-keys form (attn_shared_k)
 };
 
 #ifdef COVER_AT_DEBUG
@@ -324,6 +325,260 @@ __device__ __forceinline__ void attn_body(const AttnDev& a, int bx, int kvh, int
     ATT(5);
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Many query rows over SHARED keys (round 6; the attention pass of the large-N candidate decode: 64 samples of a prompt attend the same
+// [shared prefix | prompt text] keys). attn_body gives every 16-row query tile its own wave(s) and every wave its own copy of the K / V^T
+// fragments from global memory: at 8 prompts x 64 samples x 32 heads that is 1 024 workgroups pulling 144 KB each through the L2 -- 147 MB per
+// launch for 4.6 MB of distinct keys; the per-block timeline (tools/dbg/at_timeline.py, SHAPE=c5) shows 6 us between a block's Q and its first K tile
+// and 23 us per launch. Here a workgroup = (64 query rows, head, batch entry): four waves with one 16-row tile each, the K / V^T tile of 32 keys staged
+// ONCE per workgroup in LDS (LDS-DMA ring of four stages, three tiles ahead, one barrier per tile; swizzled rows: conflict-free 16-byte reads)
+// -- a quarter of the L2 traffic, one workgroup per (prompt, head) = one round of 256 on the chip. Per lane the arithmetic is attn_body's, in the same
+// order (non-key-split mode): the results are bit-identical to attn_kernel<128, false>. MHA, D = 128, length masks only. Config 5 on one box, alternating
+// (profiles/r06_attn_shared_keys.txt): 411.5 -> 403.2 / 405.3 ms per decision (1 792 launches, ~4 us each); what is left of a launch is one wave per SIMD
+// walking ten dependent tiles (LDS reads -> MFMA -> two cross-row reductions -> exp2 -> MFMA) with nobody to overlap.
+// ---------------------------------------------------------------------------------------------------
+template <bool MXO>
+__global__ __launch_bounds__(256) void attn_shared_k(AttnDev a) {
+    constexpr int D = 128, KS = D / 32, DB = D / 16;
+    constexpr int KT_BYTES = 32 * 256, VT_BYTES = D * 64, ST_BYTES = KT_BYTES + VT_BYTES, NST = 4, DIST = 3;
+    __shared__ __attribute__((aligned(16))) char smem[NST * ST_BYTES];   // 64 KiB
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 15, g = lane >> 4;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int t = blockIdx.x * 64 + w * 16 + r;
+    const bool q_ok = t < a.Tq;
+    const int tc = q_ok ? t : a.Tq - 1;
+
+    bf16x8 qf[KS];
+    float m_run = -INFINITY, l_run = 0.f;
+    f32x4 oacc[DB];
+    const long long srow = ((long long)b * a.Tq + tc) * a.Hq + h;
+    // segment table (workgroup-uniform; scalars and compare-selects: a run-time index into an array would put it in scratch)
+    int len0 = 0, len1 = 0, len2 = 0;
+    const bf16_t *kp0 = nullptr, *kp1 = nullptr, *kp2 = nullptr, *vp0 = nullptr, *vp1 = nullptr, *vp2 = nullptr;
+    long long kt0 = 0, kt1 = 0, kt2 = 0, vd0 = 0, vd1 = 0, vd2 = 0;
+#define COVER_SEG_SETUP(I, LEN, KP, VP, KT, VD)                                          \
+    if (I < a.n_seg) {                                                                   \
+        const int slot_ = a.seg[I].slot_of_batch ? a.seg[I].slot_of_batch[b] : b;        \
+        LEN = a.seg[I].len_of_batch ? a.seg[I].len_of_batch[b] : a.seg[I].len;           \
+        KP = a.seg[I].k + (long long)slot_ * a.seg[I].k_slot + (long long)h * a.seg[I].k_h;    \
+        VP = a.seg[I].vt + (long long)slot_ * a.seg[I].vt_slot + (long long)h * a.seg[I].vt_h; \
+        KT = a.seg[I].k_t;                                                               \
+        VD = a.seg[I].vt_d;                                                              \
+    }
+    COVER_SEG_SETUP(0, len0, kp0, vp0, kt0, vd0)
+    COVER_SEG_SETUP(1, len1, kp1, vp1, kt1, vd1)
+    COVER_SEG_SETUP(2, len2, kp2, vp2, kt2, vd2)
+#undef COVER_SEG_SETUP
+    // The K / V^T tiles travel by LDS-DMA (global_load_lds_dwordx4: no staging registers, no LDS write instructions) into a ring of NST stages, DIST tiles
+    // ahead of the arithmetic: a tile is 0.5 us of MFMA + softmax against ~2 us of load latency, so one tile of look-ahead leaves the chain of ~10 tiles
+    // latency-bound (first version, register-staged double buffer: 30.9 us launch to launch against 34.5 of the per-tile kernel, decisions -1.7 ms; this
+    // one 29.9 against 35.0, decisions -7.3 ms). The DMA writes a wave's
+    // 64 x 16 bytes linearly, so the swizzles are applied on the GLOBAL side: LDS position (key row k, pos) holds the row's chunk pos ^ swz(k), position
+    // (d row, pos) of the V^T tile holds chunk pos ^ ((d >> 2) & 3) -- conflict-free 16-byte reads at a 256-byte / 64-byte row pitch. Every thread issues
+    // exactly four pieces per tile (past the end: the last tile again), so one counted vmcnt per tile is exact.
+    const uint32_t lds_u32 = __builtin_amdgcn_readfirstlane(lds_addr_u32(smem));
+    auto issue = [&](const bf16_t* kp, const bf16_t* vp, long long kt, long long vd, int len, int t0, int stage) __attribute__((always_inline)) {
+        const uint32_t base = lds_u32 + stage * ST_BYTES;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int k = 8 * w + 4 * j + (lane >> 4);
+            const int c = (lane & 15) ^ ((k & 3) | ((k >> 3) << 2));
+            int key = t0 + k;
+            key = key < len ? key : len - 1;
+            glds16_asm(kp + (long long)key * kt + c * 8, base + (8 * w + 4 * j) * 256);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int d = (2 * w + j) * 16 + (lane >> 2);
+            const int c = (lane & 3) ^ ((d >> 2) & 3);
+            glds16_asm(vp + (long long)d * vd + t0 + c * 8, base + KT_BYTES + (2 * w + j) * 1024);
+        }
+    };
+    // issue cursor: the tile the next DMA batch fetches (workgroup-uniform; explicit per-segment code, see above)
+    int iseg = len0 > 0 ? 0 : (len1 > 0 ? 1 : (len2 > 0 ? 2 : 3)), it0 = 0;
+    const bf16_t *ikp = kp0, *ivp = vp0;
+    long long ikt = kt0, ivd = vd0;
+    int ilen = len0;
+    if (iseg == 1) { ikp = kp1; ivp = vp1; ikt = kt1; ivd = vd1; ilen = len1; }
+    if (iseg == 2) { ikp = kp2; ivp = vp2; ikt = kt2; ivd = vd2; ilen = len2; }
+    int istage = 0;
+    auto issue_next = [&]() __attribute__((always_inline)) {
+        issue(ikp, ivp, ikt, ivd, ilen, it0, istage);   // (past the last tile the cursor stays on it: a harmless re-load into a stage nobody reads any more)
+        istage = istage == NST - 1 ? 0 : istage + 1;
+        if (iseg < 3 && it0 + 32 < ilen) {
+            it0 += 32;
+        } else if (iseg == 0 && len1 > 0) {
+            iseg = 1; it0 = 0; ikp = kp1; ivp = vp1; ikt = kt1; ivd = vd1; ilen = len1;
+        } else if (iseg <= 1 && len2 > 0) {
+            iseg = 2; it0 = 0; ikp = kp2; ivp = vp2; ikt = kt2; ivd = vd2; ilen = len2;
+        } else {
+            iseg = 3;   // done: keep fetching the last tile
+        }
+    };
+    int cstage = 0;
+    auto tile = [&](int vis, int t0) __attribute__((always_inline)) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (DIST - 1)) : "memory");   // this thread's pieces of the tile have landed ...
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");          // ... everybody's have, and everybody is done with the previous tile's stage
+        issue_next();                                                           // tile + DIST, into the stage of tile - 1
+        const char* ks_ = smem + cstage * ST_BYTES;
+        const char* vs_ = ks_ + KT_BYTES;
+        const int k0 = 8 * (r >> 2) + (r & 3), k1 = k0 + 4;
+        f32x4 s0 = (f32x4){0.f, 0.f, 0.f, 0.f}, s1 = s0;
+#pragma unroll
+        for (int ksi = 0; ksi < KS; ++ksi) {
+            const int pos = ((ksi * 4 + g) ^ r) << 4;   // swz(k0) = swz(k1) = r
+            const uint4 kr0 = *(const uint4*)(ks_ + k0 * 256 + pos);
+            const uint4 kr1 = *(const uint4*)(ks_ + k1 * 256 + pos);
+            s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(kr0), qf[ksi], s0, 0, 0, 0);
+            s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(kr1), qf[ksi], s1, 0, 0, 0);
+        }
+        float sc[8];
+        float tmax = -INFINITY;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float v = (e < 4 ? s0[e] : s1[e - 4]) * a.scale_log2e;
+            const int key = t0 + 8 * g + e;
+            sc[e] = (key < vis) ? v : -INFINITY;
+            tmax = fmaxf(tmax, sc[e]);
+        }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 16));
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+        const float m_new = fmaxf(m_run, tmax);
+        float alpha = 1.f, psum = 0.f;
+        float p[8];
+        if (m_new == -INFINITY) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) p[e] = 0.f;
+        } else {
+            alpha = exp2f(m_run - m_new);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                p[e] = exp2f(sc[e] - m_new);
+                psum += p[e];
+            }
+        }
+        psum += __shfl_xor(psum, 16);
+        psum += __shfl_xor(psum, 32);
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+        uint4 pp;
+        pp.x = pack_bf2(p[0], p[1]);
+        pp.y = pack_bf2(p[2], p[3]);
+        pp.z = pack_bf2(p[4], p[5]);
+        pp.w = pack_bf2(p[6], p[7]);
+        const bf16x8 pf = as_bf16x8(pp);
+#pragma unroll
+        for (int db = 0; db < DB; ++db) {
+            const bf16x8 vf = as_bf16x8(*(const uint4*)(vs_ + (db * 16 + r) * 64 + ((g ^ (r >> 2)) << 4)));
+            f32x4 o = oacc[db];
+            o[0] *= alpha; o[1] *= alpha; o[2] *= alpha; o[3] *= alpha;
+            oacc[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, o, 0, 0, 0);
+        }
+        cstage = cstage == NST - 1 ? 0 : cstage + 1;
+    };
+    if (iseg < 3) {
+#pragma unroll
+        for (int i = 0; i < DIST; ++i) issue_next();   // tiles 0 .. DIST - 1
+    }
+    // Q fragments and the resumed state AFTER the first DMA batch: the compiler's wait for them then covers pieces that are needed at the first tile anyway
+    {
+        const bf16_t* qp = a.q + (long long)b * a.q_b + (long long)tc * a.q_t + (long long)h * a.q_h + g * 8;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) qf[ks] = as_bf16x8(*(const uint4*)(qp + ks * 32));
+    }
+#pragma unroll
+    for (int db = 0; db < DB; ++db) oacc[db] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (a.si_o && q_ok) {   // resume from a previous call's state
+        m_run = a.si_ml[srow * 2];
+        l_run = a.si_ml[srow * 2 + 1];
+        const float* so = a.si_o + srow * D + 4 * g;
+#pragma unroll
+        for (int db = 0; db < DB; ++db) {
+            const float4 v = *(const float4*)(so + db * 16);
+            oacc[db] = (f32x4){v.x * l_run, v.y * l_run, v.z * l_run, v.w * l_run};
+        }
+    }
+    // every ordinary load is CONSUMED here, once: the compiler's wait-count pass does not see the DMA pieces and would otherwise re-wait for "its four
+    // youngest loads" (the Q fragments) with vmcnt(0) inside every tile -- draining the ring
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(qf[ks]));
+#pragma unroll
+    for (int db = 0; db < DB; ++db) asm volatile("" : "+v"(oacc[db]));
+    asm volatile("" : "+v"(m_run), "+v"(l_run));
+    if (iseg < 3) {
+        for (int t0 = 0; t0 < len0; t0 += 32) tile(len0, t0);
+        for (int t0 = 0; t0 < len1; t0 += 32) tile(len1, t0);
+        for (int t0 = 0; t0 < len2; t0 += 32) tile(len2, t0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the surplus re-loads of the tail)
+    }
+    if (!q_ok) return;
+    const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
+    if constexpr (MXO) {
+        const long long ro = (long long)b * a.o_b + (long long)t * a.o_t;
+#pragma unroll
+        for (int j = 0; j < DB / 2; ++j) {   // d blocks 2j, 2j + 1 = columns 32 j .. 32 j + 31 of head h
+            float v[8];
+            float mx = 0.f;
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[k * 4 + e] = bf2f(f2bf(oacc[2 * j + k][e] * inv));
+                    mx = fmaxf(mx, fabsf(v[k * 4 + e]));
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 16));
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            float scl = 1.0f;
+            if (mx > 0.f) {
+                int ex;
+                const float fr = frexpf(mx / 448.0f, &ex);
+                scl = ldexpf(1.0f, fr == 0.5f ? ex - 1 : ex);
+            }
+            scl = fmaxf(scl, 1.1754943508222875e-38f);
+            const float is = 1.0f / scl;
+            const int col = h * (int)a.o_h + 32 * j;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                int pk = __builtin_amdgcn_cvt_pk_fp8_f32(v[k * 4] * is, v[k * 4 + 1] * is, 0, false);
+                pk = __builtin_amdgcn_cvt_pk_fp8_f32(v[k * 4 + 2] * is, v[k * 4 + 3] * is, pk, true);
+                *(uint32_t*)(a.o8 + ro + col + k * 16 + 4 * g) = (uint32_t)pk;
+            }
+            if (g == 0) a.o8mx[((size_t)(col >> 7) * a.o8_rows + (size_t)(ro / a.o_t)) * 4 + ((col >> 5) & 3)] = (uint8_t)((__builtin_bit_cast(uint32_t, scl) >> 23) & 0xffu);
+        }
+        return;
+    }
+    if (a.so_o) {
+        if (g == 0) {
+            a.so_ml[srow * 2] = m_run;
+            a.so_ml[srow * 2 + 1] = l_run;
+        }
+        float* so = a.so_o + srow * D + 4 * g;
+#pragma unroll
+        for (int db = 0; db < DB; ++db) *(float4*)(so + db * 16) = make_float4(oacc[db][0] * inv, oacc[db][1] * inv, oacc[db][2] * inv, oacc[db][3] * inv);
+        return;
+    }
+    bf16_t* op = a.out + (long long)b * a.o_b + (long long)t * a.o_t + (long long)h * a.o_h + 4 * g;
+#pragma unroll
+    for (int db = 0; db < DB; ++db) {
+        uint2 v;
+        v.x = pack_bf2(oacc[db][0] * inv, oacc[db][1] * inv);
+        v.y = pack_bf2(oacc[db][2] * inv, oacc[db][3] * inv);
+        *(uint2*)(op + db * 16) = v;
+    }
+}
+// when launch_d takes the workgroup-shared form: MHA at D = 128, length masks, enough query rows per (batch entry, head) to share the keys, enough
+// workgroups to fill the chip (COVER_ATTN_SHARED=0: never)
+static bool attn_shared_ok(const cover_attn_args* x) {
+    static const char* env = getenv("COVER_ATTN_SHARED");
+    if (env && env[0] == '0') return false;
+    if (x->D != 128 || x->Hq != x->Hkv || x->Tq < 48 || x->n_seg < 1 || x->n_seg > 3) return false;
+    for (int i = 0; i < x->n_seg; ++i)
+        if (x->seg[i].mask_mode != COVER_MASK_LEN) return false;
+    return (long long)((x->Tq + 63) / 64) * x->Hq * x->B >= 128;
+}
+
 template <int D, bool KSPLIT, int NWS = 4, bool MXO = false>
 __global__ __launch_bounds__((KSPLIT && D > 128) ? 64 * NWS : 512) void attn_kernel(AttnDev a) {
     attn_body<D, KSPLIT, NWS, MXO>(a, blockIdx.x, blockIdx.y, blockIdx.z);
@@ -363,6 +618,12 @@ static hipError_t launch_d(const AttnDev& a, hipStream_t st) {
     // tiles over ~280 keys) is a chain of ~10 dependent key tiles per wave: split the keys over the block's waves there too
     // (config 5: 24.7 -> see profiles/ us per layer)
     if (a.si_o != nullptr && !e_max && D <= 128) ks_max = 4095;
+    if (a.shared) {
+        dim3 grid((a.Tq + 63) / 64, a.Hq, a.B);
+        if (a.o8) hipLaunchKernelGGL((attn_shared_k<true>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((attn_shared_k<false>), grid, dim3(256), 0, st, a);
+        return hipGetLastError();
+    }
     if (a.o8) {   // block-scaled output: the key-split kernel with four waves at D = 128 only (attention_mx_ok below says when)
         if constexpr (D == 128) {
             if (qtiles > ks_max) return hipErrorInvalidValue;
@@ -399,7 +660,7 @@ bool attention_mx_ok(const cover_attn_args* x) {
     static const char* e_max = getenv("COVER_ATTN_KSPLIT_MAX");
     const long long ks_max = (x->state_in_o != nullptr && !e_max) ? 4095 : (e_max ? atoll(e_max) : 1023);
     const long long qtiles = (long long)((x->Tq + 15) / 16) * x->Hkv * x->B;
-    return qtiles <= ks_max;
+    return qtiles <= ks_max || attn_shared_ok(x);
 }
 
 static hipError_t build_attn_dev(const cover_attn_args* x, AttnDev& a) {
@@ -418,6 +679,7 @@ static hipError_t build_attn_dev(const cover_attn_args* x, AttnDev& a) {
     a.o8 = (uint8_t*)x->out8; a.o8mx = (uint8_t*)x->out8_mx; a.o8_rows = x->out8_rows;
     if (!a.o8 || !a.o8mx) { a.o8 = nullptr; a.o8mx = nullptr; }
     if (a.o8 && !attention_mx_ok(x)) return hipErrorInvalidValue;
+    a.shared = attn_shared_ok(x);
     for (int i = 0; i < x->n_seg; ++i) {
         const cover_kv_segment& s = x->seg[i];
         SegDev& d = a.seg[i];

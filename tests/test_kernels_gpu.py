@@ -2,12 +2,15 @@
 restatement of the same op on the CPU. bf16 kernels: inputs are rounded to bf16 first, the reference computes in
 fp32 and the comparison allows bf16 output rounding. fp32 kernels: atol/rtol 2e-5. Index outputs: exact."""
 import math
+import os
+import sys
 
 import numpy as np
 import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 from cover_vla_amd import ops  # noqa: E402
 
@@ -631,6 +634,38 @@ def test_score_select(dev, N, gs):
     s[7] = s[10] = 1.0
     r, _ = ops.group_argmax(s.to(dev), 3)
     assert r.cpu().tolist()[:3] == [7, 2, 1]
+
+
+def test_attention_shared_keys_form_equals_the_per_tile_form(dev, tmp_path):
+    """attn_shared_k (64 query rows of a (batch entry, head) share one LDS-staged copy of every K / V^T tile; the large-N decode pass) against (1) the per-tile
+    kernel it replaces there (COVER_ATTN_SHARED=0 in a child process: the knob is read once) -- within 5e-3 rel-L2 (the key-split merge sums in another order; the
+    non-split per-tile form is the same arithmetic in the same order) -- and (2) an fp32 softmax over [shared keys | own-entry keys] without the resumed state."""
+    import subprocess
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    outs = {}
+    for knob in ("1", "0"):
+        f = str(tmp_path / f"o{knob}.pt")
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_attn_shared_child.py"), f], env=dict(os.environ, COVER_ATTN_SHARED=knob, PYTHONPATH=ROOT),
+                           capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        outs[knob] = torch.load(f)
+    a, b = outs["1"]["resumed"].float(), outs["0"]["resumed"].float()        # 1 024 query tiles resumed from a state: the per-tile form runs key-split
+    assert ((a - b).norm() / b.norm()).item() < 5e-3
+    # without a state the per-tile form runs un-split: one wave walks a tile's keys in order, as a wave of the shared form does -- identical bits
+    assert torch.equal(outs["1"]["plain"].view(torch.int16), outs["0"]["plain"].view(torch.int16))
+    from _attn_shared_child import problem
+    P, S, H, D, q, segs, state, (k0, v0, k1, v1, len1, T0) = problem(torch.device("cpu"))
+    qq = q.float().view(P, S, 3, H, D)[:, :, 0]                                      # [P, S, H, D]
+    ref = torch.empty(P, S, H, D)
+    for pi in range(P):
+        L1 = int(len1[pi])
+        kk = torch.cat([k0[0, :T0].float(), k1[pi, :L1].float()], 0)                 # [T, H, D]
+        vv = torch.cat([v0[0, :, :, :T0].float().permute(2, 0, 1), v1[pi, :, :, :L1].float().permute(2, 0, 1)], 0)
+        sc = torch.einsum("shd,thd->hst", qq[pi], kk) * D ** -0.5
+        pr = torch.softmax(sc, -1).to(torch.bfloat16).float()
+        ref[pi] = torch.einsum("hst,thd->shd", pr, vv)
+    got = outs["1"]["plain"].float().view(P, S, H, D)
+    assert ((got - ref).norm() / ref.norm()).item() < 1.2e-2
 
 
 def test_attention_state_chaining_decode(dev):

@@ -5,8 +5,49 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 import numpy as np, torch
 from cover_vla_amd import ops, _lib as L
 dev = torch.device("cuda:0")
-fn = L.lib().cover_at_debug
-fn.argtypes = [C.c_void_p]
+try:
+    fn = L.lib().cover_at_debug          # (-DCOVER_AT_DEBUG builds only)
+    fn.argtypes = [C.c_void_p]
+except AttributeError:
+    fn = None
+def report(tag):
+    if fn is None:
+        print(tag, flush=True)
+        return
+    buf = np.zeros(4096, dtype=np.uint64); fn(buf.ctypes.data)
+    t = buf.reshape(512, 8).astype(np.float64) / 100.0
+    t = t[t[:, 0] > 0]
+    t0 = t[:, 0].min()
+    qq = lambda x: f"{np.percentile(x - t0, 5):5.1f}/{np.median(x - t0):5.1f}/{(x - t0).max():5.1f}"
+    print(f"{tag}: blocks {len(t)}  start {qq(t[:,0])}  Q {qq(t[:,1])}  firstK {qq(t[:,2])}  tiles {qq(t[:,3])}  merged {qq(t[:,4])}  end {qq(t[:,5])}  (p5/median/max us)", flush=True)
+
+
+if os.environ.get("SHAPE") == "c5":
+    # the attention pass of a config-5 decode layer: 8 prompts x 64 samples, 32 heads (MHA) at D = 128 over [shared prefix 257 keys | prompt text <= 24 keys],
+    # resumed from the own-token state; bf16 output and the block-scaled output (the first 512 of the 1024 workgroups are stamped)
+    P, S, H, D, T0, LT = 8, 64, 32, 128, 257, 24
+    N = P * S
+    q = torch.randn(N, 3 * H * D, device=dev).bfloat16()
+    cap0 = 288
+    k0 = torch.randn(1, cap0, H, D, device=dev).bfloat16(); v0 = torch.randn(1, H, D, cap0, device=dev).bfloat16()
+    k1 = torch.randn(P, 32, H, D, device=dev).bfloat16(); v1 = torch.randn(P, H, D, 32, device=dev).bfloat16()
+    zero = torch.zeros(P, dtype=torch.int32, device=dev)
+    len1 = (9 + (torch.arange(P, device=dev) * 5) % 16).to(torch.int32)
+    segs = [ops.Segment(k0, v0, (cap0 * H * D, H * D, D), (H * D * cap0, D * cap0, cap0), length=T0, slot_of_batch=zero),
+            ops.Segment(k1, v1, (32 * H * D, H * D, D), (H * D * 32, D * 32, 32), length=LT, len_of_batch=len1)]
+    state = (torch.randn(N, H, D, device=dev) * 0.3, torch.stack([torch.randn(N, H, device=dev), torch.rand(N, H, device=dev) + 0.5], -1).contiguous())
+    out = torch.empty(N, H * D, dtype=torch.bfloat16, device=dev)
+    o8 = torch.empty(N, H * D, dtype=torch.uint8, device=dev); omx = torch.empty(H * D // 128, N, 4, dtype=torch.uint8, device=dev)
+    for tag, kw in (("bf16 out", dict()), ("MX out  ", dict(out8=(o8, omx)))):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for rep in range(3):
+            e0.record()
+            ops.attention(q, (S * 3 * H * D, 3 * H * D, D), None if kw else out, (S * H * D, H * D, D), P, S, H, H, D, D ** -0.5, segs, state_in=state, **kw)
+            e1.record()
+            torch.cuda.synchronize()
+        report(f"config-5 decode attention, {tag} ({e0.elapsed_time(e1) * 1e3:.1f} us launch to launch)")
+    sys.exit(0)
+
 Hq, Hkv, Tq = 8, 1, 5
 for D, B, Tp in ((256, 40, 328), (256, 40, 32), (64, 40, 32)):
     q = torch.randn(B, Tq, Hq, D, device=dev).bfloat16()
