@@ -48,12 +48,18 @@ constexpr int DA_NW = 16;
 __device__ unsigned long long g_da_dbg[512 * 8];   // per block: start, phase 1 done (LDS hand-off), tile phase done, end
 extern "C" int cover_da_debug(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_da_dbg), sizeof(g_da_dbg)); }
 #define DAT(slot) do { if (threadIdx.x == 0) g_da_dbg[(((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) & 511) * 8 + (slot)] = wall_clock64(); } while (0)
+// per WAVE of one workgroup (tile 1, head 7, value block 2): 0 reached the phase-1 barrier, 1 passed it, 2 first tile folded, 3 all tiles folded, 4 role, 5 tiles, 6 kernel start
+__device__ unsigned long long g_da_wave[16 * 8];
+extern "C" int cover_da_debug_waves(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_da_wave), sizeof(g_da_wave)); }
+#define DAW(slot, val) do { if ((threadIdx.x & 63) == 0 && blockIdx.x == 1 && blockIdx.y == 7 && blockIdx.z == 2) g_da_wave[(threadIdx.x >> 6) * 8 + (slot)] = (val); } while (0)
 #else
 #define DAT(slot) do { } while (0)
+#define DAW(slot, val) do { } while (0)
 #endif
 template <int D, int VS>
 __global__ __launch_bounds__(1024) void decode_attn_fused_k(DecAttnDev a) {
     DAT(0);
+    DAW(6, wall_clock64());
     constexpr int KS = D / 32, DB = D / 16 / VS, HALF = D / 2, DV = D / VS;
     constexpr int OW = DB * 4 * 64;                    // floats of one wave's O state
     constexpr int IPW = (DB * 4 + DA_NW - 1) / DA_NW;  // (db, e) output items merged per wave
@@ -86,7 +92,6 @@ __global__ __launch_bounds__(1024) void decode_attn_fused_k(DecAttnDev a) {
         if (a.rope_mode != 0) ppos = a.positions[pcand];
         if (a.slot2) pslot2 = a.slot2[pcand];
     }
-
 #ifdef COVER_DA_DEBUG   // (timeline builds only: in the product the slab loads below go out BEHIND the index loads without waiting for them --
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   //  only cos / sin chain on the position -- one round trip less in front of phase 1b)
 #endif
@@ -305,10 +310,13 @@ __global__ __launch_bounds__(1024) void decode_attn_fused_k(DecAttnDev a) {
     DAT(6);
     bool have = next_tile();
     if (have) load_tile();
+    DAW(0, wall_clock64());
+    DAW(4, (unsigned long long)role);
     // LDS-only barrier: q / k_new / v_new are exchanged through LDS, so neither the cache stores nor the tile loads
     // still in flight are waited for here
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     DAT(1);
+    DAW(1, wall_clock64());
     // k_new / v_new -> the candidate's own cache segment, BEHIND the barrier: the V^T stores touch one 128-byte line per lane (d-major rows),
     // a block issues ~2 000 of them, and in front of the barrier their ISSUE time (per-block timelines: the last wave reached the barrier
     // 2 us after the first) was on every wave's critical path; here it runs under the flight time of the first tiles' loads. Nobody reads
@@ -328,6 +336,9 @@ __global__ __launch_bounds__(1024) void decode_attn_fused_k(DecAttnDev a) {
     // of the same wave (rare: more tiles than waves in the pool) is folded into the slot. No O accumulator lives across
     // tiles, which keeps the kernel inside the 128-register budget of a 16-wave block with K and V of a tile in flight.
     bool first = true;
+#ifdef COVER_DA_DEBUG
+    int dbg_tiles = 0;
+#endif
     int sw = w;                                        // state slot this wave is writing
 #pragma clang loop unroll(disable)
     while (have) {
@@ -417,10 +428,18 @@ __global__ __launch_bounds__(1024) void decode_attn_fused_k(DecAttnDev a) {
             sm[sw * 16 + r] = m;
             sl[sw * 16 + r] = l;
         }
+#ifdef COVER_DA_DEBUG
+        if (first) DAW(2, wall_clock64());
+        dbg_tiles++;
+#endif
         first = false;
         have = next_tile();
         if (have) load_tile();
     }
+#ifdef COVER_DA_DEBUG
+    DAW(3, wall_clock64());
+    DAW(5, (unsigned long long)dbg_tiles);
+#endif
     if (first && sw == w) {   // a wave without a tile contributes the empty state
 #pragma unroll
         for (int i = 0; i < DB * 4; ++i) so[w * OW + i * 64 + lane] = 0.f;

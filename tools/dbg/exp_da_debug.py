@@ -46,4 +46,14 @@ for rep in range(3):
     t = t[t[:, 0] > 0]
     t0 = t[:, 0].min()
     q = lambda x: f"{np.percentile(x - t0, 5):5.1f}/{np.median(x - t0):5.1f}/{(x - t0).max():5.1f}"
+    try:
+        fw = L.lib().cover_da_debug_waves
+        fw.argtypes = [C.c_void_p]
+        wb = np.zeros(128, dtype=np.uint64); fw(wb.ctypes.data)
+        wv = wb.reshape(16, 8).astype(np.float64)
+        w0 = wv[:, 6].min() / 100.0
+        print("   waves of workgroup (tile 1, head 7, value block 2) -- role: at barrier / past barrier / first tile folded / all folded (tiles), us from the workgroup's start:")
+        print("   " + "  ".join(f"w{i}[{'ABC'[int(wv[i, 4])]}] {wv[i, 0] / 100.0 - w0:4.1f}/{wv[i, 1] / 100.0 - w0:4.1f}/{wv[i, 2] / 100.0 - w0:4.1f}/{wv[i, 3] / 100.0 - w0:4.1f}({int(wv[i, 5])})" for i in range(16)))
+    except AttributeError:
+        pass
     print(f"{mode} rep {rep}: blocks {len(t)}  start {q(t[:,0])}  idx {q(t[:,4])}  partials {q(t[:,5])}  lds-written {q(t[:,6])}  phase1 {q(t[:,1])}  tiles {q(t[:,2])}  end {q(t[:,3])}  (p5/median/max us)")
