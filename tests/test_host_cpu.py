@@ -501,3 +501,37 @@ def test_sampled_pick_decided_is_the_exact_worst_case():
             n_und += int(flipped)
             assert flipped or near < 0.05 + 2.5 * err, (case, t, picks, u, err, near)
     assert n_dec > 50 and n_und > 50, (n_dec, n_und)
+
+
+def test_oracle_mx_block_quantiser_follows_its_rule():
+    """oracle/cover_ref/blocks.py::fake_quant_blocks_e4m3 (the restatement of cover_quantize_act_fp8_mx the config-5 oracle uses at the inputs of o_proj / down_proj): one
+    power-of-two scale per 32 consecutive elements -- the smallest 2^e with amax / 2^e <= 448, 2^0 for an all-zero block -- RNE to e4m3, de-quantised. Checked element by
+    element against a loop over the blocks, on a block amax exactly at a power-of-two boundary, an all-zero block, and blocks five decades apart inside one row (where one scale
+    per row -- fake_quant_rows_e4m3 -- flushes the small block to the subnormal grid and the block scales do not)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    from cover_ref import blocks as Bk
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(3, 128, generator=g)
+    x[0, :32] *= 1e-5                       # a block five decades below its neighbours
+    x[1, 32:64] = 0.0                       # an all-zero block
+    x[2, 64] = 448.0 * 2.0 ** -5            # amax / 448 exactly 2^-5 -> scale 2^-5, the element maps to 448
+    x[2, 65:96] = x[2, 65:96].clamp(-10, 10)
+    x = x.bfloat16()
+    got = Bk.fake_quant_blocks_e4m3(x).float()
+    want = torch.empty_like(got)
+    for m in range(3):
+        for b in range(4):
+            blk = x[m, 32 * b: 32 * b + 32].float()
+            amax = float(blk.abs().max())
+            e = 0 if amax == 0 else int(np.ceil(np.log2(amax / 448.0)))
+            s = 2.0 ** e
+            assert amax / s <= 448.0 and (amax == 0 or amax / (s / 2) > 448.0)
+            want[m, 32 * b: 32 * b + 32] = (blk / s).to(torch.float8_e4m3fn).float() * s
+    assert torch.equal(got, want)
+    assert float(got[2, 64]) == float(x[2, 64])                       # 448 x 2^-5 is exactly representable
+    assert torch.equal(got[1, 32:64], torch.zeros(32))
+    # the small block keeps e4m3's relative precision under block scales, and loses it under one scale per row
+    small = x[0, :32].float()
+    rel_blocks = ((got[0, :32] - small).norm() / small.norm()).item()
+    rel_rows = ((Bk.fake_quant_rows_e4m3(x)[0, :32].float() - small).norm() / small.norm()).item()
+    assert rel_blocks < 0.04 and rel_rows > 0.2, (rel_blocks, rel_rows)
