@@ -342,6 +342,7 @@ __global__ __launch_bounds__(256) void attn_shared_k(AttnDev a) {
     constexpr int D = 128, KS = D / 32, DB = D / 16;
     constexpr int KT_BYTES = 32 * 256, VT_BYTES = D * 64, ST_BYTES = KT_BYTES + VT_BYTES, NST = 4, DIST = 3;
     __shared__ __attribute__((aligned(16))) char smem[NST * ST_BYTES];   // 64 KiB
+    ATT(0);
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15, g = lane >> 4;
@@ -482,6 +483,7 @@ __global__ __launch_bounds__(256) void attn_shared_k(AttnDev a) {
 #pragma unroll
         for (int i = 0; i < DIST; ++i) issue_next();   // tiles 0 .. DIST - 1
     }
+    ATT(1);   // (timeline builds: segment table read, first DMA batch issued)
     // Q fragments and the resumed state AFTER the first DMA batch: the compiler's wait for them then covers pieces that are needed at the first tile anyway
     {
         const bf16_t* qp = a.q + (long long)b * a.q_b + (long long)tc * a.q_t + (long long)h * a.q_h + g * 8;
@@ -507,12 +509,14 @@ __global__ __launch_bounds__(256) void attn_shared_k(AttnDev a) {
 #pragma unroll
     for (int db = 0; db < DB; ++db) asm volatile("" : "+v"(oacc[db]));
     asm volatile("" : "+v"(m_run), "+v"(l_run));
+    ATT(2);   // (Q fragments and the resumed state landed)
     if (iseg < 3) {
         for (int t0 = 0; t0 < len0; t0 += 32) tile(len0, t0);
         for (int t0 = 0; t0 < len1; t0 += 32) tile(len1, t0);
         for (int t0 = 0; t0 < len2; t0 += 32) tile(len2, t0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the surplus re-loads of the tail)
     }
+    ATT(3);   // (tiles done)
     if (!q_ok) return;
     const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
     if constexpr (MXO) {
@@ -547,6 +551,7 @@ __global__ __launch_bounds__(256) void attn_shared_k(AttnDev a) {
             }
             if (g == 0) a.o8mx[((size_t)(col >> 7) * a.o8_rows + (size_t)(ro / a.o_t)) * 4 + ((col >> 5) & 3)] = (uint8_t)((__builtin_bit_cast(uint32_t, scl) >> 23) & 0xffu);
         }
+        ATT(5);
         return;
     }
     if (a.so_o) {
@@ -567,6 +572,7 @@ __global__ __launch_bounds__(256) void attn_shared_k(AttnDev a) {
         v.y = pack_bf2(oacc[db][2] * inv, oacc[db][3] * inv);
         *(uint2*)(op + db * 16) = v;
     }
+    ATT(5);
 }
 // when launch_d takes the workgroup-shared form: MHA at D = 128, length masks, enough query rows per (batch entry, head) to share the keys, enough
 // workgroups to fill the chip (COVER_ATTN_SHARED=0: never)

@@ -19,7 +19,8 @@ def report(tag):
     t = t[t[:, 0] > 0]
     t0 = t[:, 0].min()
     qq = lambda x: f"{np.percentile(x - t0, 5):5.1f}/{np.median(x - t0):5.1f}/{(x - t0).max():5.1f}"
-    print(f"{tag}: blocks {len(t)}  start {qq(t[:,0])}  Q {qq(t[:,1])}  firstK {qq(t[:,2])}  tiles {qq(t[:,3])}  merged {qq(t[:,4])}  end {qq(t[:,5])}  (p5/median/max us)", flush=True)
+    print(f"{tag}: blocks {len(t)}  start {qq(t[:,0])}  Q {qq(t[:,1])}  firstK {qq(t[:,2])}  tiles {qq(t[:,3])}  merged {qq(t[:,4])}  end {qq(t[:,5])}  (p5/median/max us; attn_shared_k: "
+          f"'Q' = first DMA batch issued, 'firstK' = Q + state landed, 'merged' unused)", flush=True)
 
 
 if os.environ.get("SHAPE") == "c5":
