@@ -419,10 +419,22 @@ __global__ __launch_bounds__(256) void attn_shared_k(AttnDev a) {
         }
     };
     int cstage = 0;
+#ifdef COVER_AT_DEBUG   // where a tile's time goes (thread 0 of every workgroup; 100 MHz ticks summed over the tiles): wait | barrier | DMA issue | S^T | softmax | PV
+    unsigned long long seg_t[6] = {0, 0, 0, 0, 0, 0}, tp = 0;
+#define TSEG(i) do { const unsigned long long tn_ = wall_clock64(); seg_t[i] += tn_ - tp; tp = tn_; } while (0)
+#else
+#define TSEG(i) do { } while (0)
+#endif
     auto tile = [&](int vis, int t0) __attribute__((always_inline)) {
+#ifdef COVER_AT_DEBUG
+        tp = wall_clock64();
+#endif
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (DIST - 1)) : "memory");   // this thread's pieces of the tile have landed ...
+        TSEG(0);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");          // ... everybody's have, and everybody is done with the previous tile's stage
+        TSEG(1);
         issue_next();                                                           // tile + DIST, into the stage of tile - 1
+        TSEG(2);
         const char* ks_ = smem + cstage * ST_BYTES;
         const char* vs_ = ks_ + KT_BYTES;
         const int k0 = 8 * (r >> 2) + (r & 3), k1 = k0 + 4;
@@ -435,6 +447,10 @@ __global__ __launch_bounds__(256) void attn_shared_k(AttnDev a) {
             s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(kr0), qf[ksi], s0, 0, 0, 0);
             s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(kr1), qf[ksi], s1, 0, 0, 0);
         }
+#ifdef COVER_AT_DEBUG
+        asm volatile("" : "+v"(s0), "+v"(s1));
+        TSEG(3);
+#endif
         float sc[8];
         float tmax = -INFINITY;
 #pragma unroll
@@ -470,6 +486,10 @@ __global__ __launch_bounds__(256) void attn_shared_k(AttnDev a) {
         pp.z = pack_bf2(p[4], p[5]);
         pp.w = pack_bf2(p[6], p[7]);
         const bf16x8 pf = as_bf16x8(pp);
+#ifdef COVER_AT_DEBUG
+        asm volatile("" : "+v"(pp.x), "+v"(pp.y), "+v"(pp.z), "+v"(pp.w));
+        TSEG(4);
+#endif
 #pragma unroll
         for (int db = 0; db < DB; ++db) {
             const bf16x8 vf = as_bf16x8(*(const uint4*)(vs_ + (db * 16 + r) * 64 + ((g ^ (r >> 2)) << 4)));
@@ -477,6 +497,11 @@ __global__ __launch_bounds__(256) void attn_shared_k(AttnDev a) {
             o[0] *= alpha; o[1] *= alpha; o[2] *= alpha; o[3] *= alpha;
             oacc[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, o, 0, 0, 0);
         }
+#ifdef COVER_AT_DEBUG
+#pragma unroll
+        for (int db = 0; db < DB; ++db) asm volatile("" : "+v"(oacc[db]));
+        TSEG(5);
+#endif
         cstage = cstage == NST - 1 ? 0 : cstage + 1;
     };
     if (iseg < 3) {
@@ -517,6 +542,13 @@ __global__ __launch_bounds__(256) void attn_shared_k(AttnDev a) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the surplus re-loads of the tail)
     }
     ATT(3);   // (tiles done)
+#ifdef COVER_AT_DEBUG
+    if (threadIdx.x == 0) {   // slots 6, 7 of the block's record: (wait | barrier | issue) and (S^T | softmax | PV) ticks, 16 bits each
+        const unsigned bi = (((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) & 511) * 8;
+        g_at_dbg[bi + 6] = (seg_t[0] & 0xffff) | ((seg_t[1] & 0xffff) << 16) | ((seg_t[2] & 0xffff) << 32);
+        g_at_dbg[bi + 7] = (seg_t[3] & 0xffff) | ((seg_t[4] & 0xffff) << 16) | ((seg_t[5] & 0xffff) << 32);
+    }
+#endif
     if (!q_ok) return;
     const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
     if constexpr (MXO) {

@@ -19,6 +19,11 @@ def report(tag):
     t = t[t[:, 0] > 0]
     t0 = t[:, 0].min()
     qq = lambda x: f"{np.percentile(x - t0, 5):5.1f}/{np.median(x - t0):5.1f}/{(x - t0).max():5.1f}"
+    raw = buf.reshape(512, 8)
+    raw = raw[raw[:, 0] > 0]
+    if (raw[:, 7] != 0).any():   # attn_shared_k: ticks of thread 0 summed over the tiles, per phase of a tile
+        f = lambda col, sh: np.median((raw[:, col] >> np.uint64(sh)) & np.uint64(0xffff)) / 100.0
+        print(f"   tile phases (us summed over the tiles, median over workgroups): wait {f(6, 0):.2f} | barrier {f(6, 16):.2f} | DMA issue {f(6, 32):.2f} | S^T {f(7, 0):.2f} | softmax {f(7, 16):.2f} | PV {f(7, 32):.2f}")
     print(f"{tag}: blocks {len(t)}  start {qq(t[:,0])}  Q {qq(t[:,1])}  firstK {qq(t[:,2])}  tiles {qq(t[:,3])}  merged {qq(t[:,4])}  end {qq(t[:,5])}  (p5/median/max us; attn_shared_k: "
           f"'Q' = first DMA batch issued, 'firstK' = Q + state landed, 'merged' unused)", flush=True)
 
